@@ -1,0 +1,199 @@
+/* ipcfp.h — C ABI of the MI355X-native batch AMT/HAMT Merkle-witness engine.
+ *
+ * This header is the drop-in boundary.  The reference
+ * (consensus-shipyard/ipc-filecoin-proofs, Rust) has no FFI of its own: its seam
+ * is the `fvm_ipld_blockstore::Blockstore` trait plus four free functions.  Each
+ * entry point below names the reference interface it replaces (paths relative to
+ * /root/reference/).  A Rust host binds these with `extern "C"`
+ * (bindings/rust/ffi.rs).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch/Rust types cross the ABI.
+ *   - every function returns 0 (IPCFP_OK) or a negative IPCFP_E_* code; the text of
+ *     the last failure on a context is available from ipcfp_last_error().
+ *   - "host" pointers are ordinary process memory, BORROWED for the duration of
+ *     the call.  "device" pointers (suffix _d / functions named *_device) are HBM
+ *     addresses on the context's GPU (e.g. a hipMalloc'ed buffer or
+ *     torch.Tensor.data_ptr()).
+ *   - a context is thread-compatible (external synchronisation), owns one HIP
+ *     stream, and all calls are synchronous unless named *_async.
+ *   - per-proof outcomes are STATUS BYTES (ipcfp_status_t), because the reference
+ *     distinguishes Ok(true) / Ok(false) / Err.  The wrapper maps
+ *     the lowest-index ERR_* of a batch to `Err(..)`, exactly as the reference's
+ *     first-error-aborts loop does (src/proofs/events/verifier.rs:62-71,
+ *     src/proofs/verifier.rs:19-28).
+ */
+#ifndef IPCFP_H
+#define IPCFP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPCFP_ABI_VERSION 1
+
+/* ---- return codes ------------------------------------------------------- */
+#define IPCFP_OK 0
+#define IPCFP_E_INVALID (-1)     /* bad argument (null pointer, size mismatch …)      */
+#define IPCFP_E_NO_DEVICE (-2)   /* no gfx950 device / HIP runtime unusable           */
+#define IPCFP_E_HIP (-3)         /* a HIP call failed; see ipcfp_last_error()         */
+#define IPCFP_E_NOMEM (-4)       /* host or device allocation failed                  */
+#define IPCFP_E_UNSUPPORTED (-5) /* e.g. a witness CID longer than IPCFP_CID_SLOT     */
+#define IPCFP_E_PARSE (-6)       /* a CID / hex string could not be parsed (host side)*/
+
+/* ---- CIDs --------------------------------------------------------------- */
+/* Binary CIDs cross the ABI in fixed 40-byte slots, zero padded on the right.
+ * The Filecoin chain CID (CIDv1, dag-cbor 0x71, blake2b-256 0xb220, 32-byte
+ * digest) is 38 bytes: 01 71 a0 e4 02 20 ‖ digest.  A binary CID is
+ * self-delimiting, so zero padding is unambiguous.  Replaces `cid::Cid` values
+ * (src/proofs/common/bundle.rs:12, src/proofs/common/witness.rs:60-72). */
+#define IPCFP_CID_SLOT 40
+#define IPCFP_CID_BLAKE2B_LEN 38
+
+/* ---- per-item status bytes ---------------------------------------------- */
+typedef uint8_t ipcfp_status_t;
+enum {
+    IPCFP_ST_FALSE = 0, /* Ok(false) — generic                                        */
+    IPCFP_ST_TRUE = 1,  /* Ok(true)                                                   */
+    /* Ok(false) with a reason (values 2..63)                                         */
+    IPCFP_ST_FALSE_UNTRUSTED_PARENT = 2,   /* events/verifier.rs:134                  */
+    IPCFP_ST_FALSE_UNTRUSTED_CHILD = 3,    /* events/verifier.rs:139, storage/verifier.rs:87 */
+    IPCFP_ST_FALSE_PARENTS_MISMATCH = 4,   /* events/verifier.rs:161                  */
+    IPCFP_ST_FALSE_CHILD_EPOCH = 5,        /* events/verifier.rs:166                  */
+    IPCFP_ST_FALSE_PARENT_EPOCH = 6,       /* events/verifier.rs:176                  */
+    IPCFP_ST_FALSE_MSG_NOT_IN_EXEC = 7,    /* events/verifier.rs:194                  */
+    IPCFP_ST_FALSE_EXEC_INDEX = 8,         /* events/verifier.rs:199                  */
+    IPCFP_ST_FALSE_NO_RECEIPT = 9,         /* events/verifier.rs:224                  */
+    IPCFP_ST_FALSE_NO_EVENTS_ROOT = 10,    /* events/verifier.rs:229                  */
+    IPCFP_ST_FALSE_NO_EVENT = 11,          /* events/verifier.rs:237                  */
+    IPCFP_ST_FALSE_EMITTER = 12,           /* events/verifier.rs:262                  */
+    IPCFP_ST_FALSE_NOT_EVM_LOG = 13,       /* events/verifier.rs:267                  */
+    IPCFP_ST_FALSE_TOPIC_COUNT = 14,       /* events/verifier.rs:272                  */
+    IPCFP_ST_FALSE_TOPIC = 15,             /* events/verifier.rs:276-281              */
+    IPCFP_ST_FALSE_DATA = 16,              /* events/verifier.rs:284-287              */
+    IPCFP_ST_FALSE_FILTER = 17,            /* events/verifier.rs:247-251              */
+    IPCFP_ST_FALSE_STATE_ROOT = 18,        /* storage/verifier.rs:110                 */
+    IPCFP_ST_FALSE_ACTOR_STATE = 19,       /* storage/verifier.rs:126                 */
+    IPCFP_ST_FALSE_STORAGE_ROOT = 20,      /* storage/verifier.rs:144                 */
+    IPCFP_ST_FALSE_VALUE = 21,             /* storage/verifier.rs:169                 */
+    IPCFP_ST_NOT_FOUND = 32,               /* primitive gets: Ok(None)                */
+    /* Err(..) (values >= 64)                                                         */
+    IPCFP_ST_ERR = 64,                     /* generic Err                             */
+    IPCFP_ST_ERR_MISSING_BLOCK = 65,       /* a CID the walk needs is not in the witness */
+    IPCFP_ST_ERR_DECODE = 66,              /* DAG-CBOR shape the reference's serde rejects */
+    IPCFP_ST_ERR_TXMETA_MISMATCH = 67,     /* events/utils.rs:66-72                   */
+    IPCFP_ST_ERR_ACTOR_NOT_FOUND = 68,     /* common/decode.rs:39                     */
+    IPCFP_ST_ERR_BAD_CLAIM = 69,           /* unparsable CID / hex string in the claim */
+    IPCFP_ST_ERR_MAX_DEPTH = 70,           /* HAMT hash bits exhausted                */
+    IPCFP_ST_ERR_EMPTY_PARENTS = 71        /* events/verifier.rs:172 `parent_cids[0]` panics */
+};
+#define IPCFP_ST_IS_ERR(s) ((s) >= 64)
+
+/* per-block CID check outcome (ipcfp_witness_verify_cids) */
+enum {
+    IPCFP_CID_MISMATCH = 0,   /* bytes do not hash to the claimed CID                   */
+    IPCFP_CID_OK = 1,         /* Blake2b-256(bytes) == digest carried by the CID        */
+    IPCFP_CID_UNCHECKED = 2   /* CID is not (v1, *, blake2b-256, 32): not hashed here   */
+};
+
+/* ---- context ------------------------------------------------------------ */
+typedef struct ipcfp_ctx ipcfp_ctx_t;
+
+/* Binds one GPU (HIP device ordinal) and creates the context's stream.
+ * Fails with IPCFP_E_NO_DEVICE when no HIP device is usable: there is NO CPU
+ * fallback anywhere behind this ABI. */
+int ipcfp_ctx_create(int device, ipcfp_ctx_t** out);
+void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx);
+const char* ipcfp_last_error(const ipcfp_ctx_t* ctx);
+const char* ipcfp_strerror(int rc);
+int ipcfp_abi_version(void);
+/* The context's hipStream_t (as void*), so a host can record its own events on
+ * the stream the kernels are launched on. */
+void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx);
+int ipcfp_ctx_sync(ipcfp_ctx_t* ctx);
+/* Device properties used by the benchmarks: name (≤ 63 chars), CU count, HBM bytes. */
+int ipcfp_ctx_device_info(ipcfp_ctx_t* ctx, char name[64], int* cu_count, uint64_t* hbm_bytes);
+
+/* Per-kernel timing with HIP events on the context's stream.  While enabled,
+ * every launch of a profiled kernel is bracketed by an event pair;
+ * ipcfp_profile_read() synchronises and returns the launch count and the summed
+ * duration for one kernel id since the last reset. */
+enum {
+    IPCFP_K_BLAKE2B_CID = 0,
+    IPCFP_K_KECCAK256 = 1,
+    IPCFP_K_SHA256 = 2,
+    IPCFP_K_CID_INDEX = 3,
+    IPCFP_K_AMT_GET = 4,
+    IPCFP_K_EVENT_SCAN = 5,
+    IPCFP_K_HAMT_GET = 6,
+    IPCFP_K_REPLAY = 7,
+    IPCFP_K_EVENT_VERIFY = 8,
+    IPCFP_K_STORAGE_VERIFY = 9,
+    IPCFP_K_EXEC_ORDER = 10,
+    IPCFP_K_BLAKE2B_RAW = 11,
+    IPCFP_K_COUNT = 16
+};
+int ipcfp_profile_enable(ipcfp_ctx_t* ctx, int on);
+int ipcfp_profile_reset(ipcfp_ctx_t* ctx);
+int ipcfp_profile_read(ipcfp_ctx_t* ctx, int kernel_id, uint64_t* launches, double* total_ms);
+
+/* ---- witness store -------------------------------------------------------
+ * Replaces `MemoryBlockstore` + `load_witness_store`
+ * (src/proofs/events/verifier.rs:79-89, src/proofs/storage/verifier.rs:68-78): the
+ * CID → bytes map every verifier call walks.  The engine keeps the whole witness
+ * resident in HBM as a structure of arrays:
+ *     bytes[]            all block payloads, each block 16-byte aligned
+ *     off[n], len[n]     the coalesced offset/length table
+ *     cids[n][40]        claimed CIDs
+ *     open-addressing hash table  CID → block id  (duplicate CID: last one wins,
+ *                        as HashMap::insert does)
+ * `bytes`/`off`/`len`/`cids` are borrowed host memory; the witness owns its
+ * device copy.  Block i is bytes[off[i] .. off[i]+len[i]).                      */
+typedef struct ipcfp_witness ipcfp_witness_t;
+
+int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                         const uint32_t* len, const uint8_t* cids40, uint64_t n, ipcfp_witness_t** out);
+/* Same, but the four arrays are already resident in HBM on the context's device
+ * (the timed benchmarks use this: inputs resident before the clock starts).     */
+int ipcfp_witness_create_device(ipcfp_ctx_t* ctx, const void* bytes_d, uint64_t nbytes, const void* off_d,
+                                const void* len_d, const void* cids40_d, uint64_t n, ipcfp_witness_t** out);
+void ipcfp_witness_destroy(ipcfp_witness_t* w);
+uint64_t ipcfp_witness_block_count(const ipcfp_witness_t* w);
+uint64_t ipcfp_witness_byte_count(const ipcfp_witness_t* w);
+
+/* K1 — Blake2b-256 CID check of every witness block.
+ * Replaces `Block::cid` / `put_cbor(.., Code::Blake2b256)` (src/proofs/events/utils.rs:65-72;
+ * README.md:401 "CID verification").  The reference's MemoryBlockstore never
+ * hashes witness blocks, so this is reported BESIDE the verdicts:
+ *   status[i] ∈ {IPCFP_CID_MISMATCH, IPCFP_CID_OK, IPCFP_CID_UNCHECKED}   (host, n bytes, nullable)
+ *   *n_bad    = number of IPCFP_CID_MISMATCH blocks                         (nullable)            */
+int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* status, uint64_t* n_bad);
+/* Launch-only form: results stay in HBM; read them with the accessors below
+ * after ipcfp_ctx_sync().                                                      */
+int ipcfp_witness_verify_cids_async(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);
+/* Device pointers owned by the witness: the ⌈n/32⌉-word OK bitmap (bit i of
+ * word i/32 set ⇔ block i is IPCFP_CID_OK) — the buffer a multi-GPU host
+ * all-gathers — and the n status bytes.                                        */
+void* ipcfp_witness_cid_bitmap_device(ipcfp_witness_t* w);
+void* ipcfp_witness_cid_status_device(ipcfp_witness_t* w);
+
+/* ---- batch hashes (host buffers in, host digests out) --------------------
+ * message i = bytes[off[i] .. off[i]+len[i]); out32 receives n × 32 bytes.
+ *   blake2b256 : multihash-codetable Code::Blake2b256       (events/utils.rs:65)
+ *   keccak256  : sha3::Keccak256 — hash_event_signature / keccak256
+ *                (common/evm.rs:62-69, 81-88)
+ *   sha256     : fvm_ipld_hamt's key hasher (common/decode.rs:29-39)            */
+int ipcfp_blake2b256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                           const uint32_t* len, uint64_t n, uint8_t* out32);
+int ipcfp_keccak256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                          const uint32_t* len, uint64_t n, uint8_t* out32);
+int ipcfp_sha256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                       const uint32_t* len, uint64_t n, uint8_t* out32);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+#endif /* IPCFP_H */

@@ -1,0 +1,23 @@
+"""ipc-filecoin-proofs_amd — MI355X-native batch AMT/HAMT Merkle-witness engine.
+
+The product is ``libipcfp.so`` (hand-written HIP kernels for gfx950 + a C++ host,
+behind the C ABI of ``include/ipcfp.h``).  This Python package is only the thin
+``ctypes`` binding the tests and ``bench.py`` drive it through; it contains no
+compute and NO CPU fallback: if the shared library or a GPU is missing, loading /
+context creation fails loudly.
+
+(The directory name contains a hyphen, so ``import ipc_filecoin_proofs_amd`` — a
+two-line shim package at the repo root — is the importable spelling.)
+"""
+from .binding import (  # noqa: F401
+    Engine,
+    EngineError,
+    Witness,
+    lib_path,
+    load_library,
+    ST,
+    CID_OK,
+    CID_MISMATCH,
+    CID_UNCHECKED,
+    KERNEL_IDS,
+)

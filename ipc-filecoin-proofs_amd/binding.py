@@ -1,0 +1,338 @@
+"""ctypes binding of ``libipcfp.so`` (C ABI: ``include/ipcfp.h``).
+
+Plumbing only.  Every method forwards to one C entry point; numpy arrays carry the
+host buffers.  No algorithm lives here and nothing falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+__all__ = [
+    "Engine",
+    "EngineError",
+    "Witness",
+    "lib_path",
+    "load_library",
+    "ST",
+    "CID_OK",
+    "CID_MISMATCH",
+    "CID_UNCHECKED",
+    "KERNEL_IDS",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+CID_MISMATCH, CID_OK, CID_UNCHECKED = 0, 1, 2
+CID_SLOT = 40
+
+KERNEL_IDS = {
+    "blake2b_cid": 0,
+    "keccak256": 1,
+    "sha256": 2,
+    "cid_index": 3,
+    "amt_get": 4,
+    "event_scan": 5,
+    "hamt_get": 6,
+    "replay": 7,
+    "event_verify": 8,
+    "storage_verify": 9,
+    "exec_order": 10,
+    "blake2b_raw": 11,
+}
+
+
+class ST:
+    """ipcfp_status_t values (include/ipcfp.h)."""
+
+    FALSE = 0
+    TRUE = 1
+    FALSE_UNTRUSTED_PARENT = 2
+    FALSE_UNTRUSTED_CHILD = 3
+    FALSE_PARENTS_MISMATCH = 4
+    FALSE_CHILD_EPOCH = 5
+    FALSE_PARENT_EPOCH = 6
+    FALSE_MSG_NOT_IN_EXEC = 7
+    FALSE_EXEC_INDEX = 8
+    FALSE_NO_RECEIPT = 9
+    FALSE_NO_EVENTS_ROOT = 10
+    FALSE_NO_EVENT = 11
+    FALSE_EMITTER = 12
+    FALSE_NOT_EVM_LOG = 13
+    FALSE_TOPIC_COUNT = 14
+    FALSE_TOPIC = 15
+    FALSE_DATA = 16
+    FALSE_FILTER = 17
+    FALSE_STATE_ROOT = 18
+    FALSE_ACTOR_STATE = 19
+    FALSE_STORAGE_ROOT = 20
+    FALSE_VALUE = 21
+    NOT_FOUND = 32
+    ERR = 64
+    ERR_MISSING_BLOCK = 65
+    ERR_DECODE = 66
+    ERR_TXMETA_MISMATCH = 67
+    ERR_ACTOR_NOT_FOUND = 68
+    ERR_BAD_CLAIM = 69
+    ERR_MAX_DEPTH = 70
+    ERR_EMPTY_PARENTS = 71
+
+    @staticmethod
+    def is_err(s: int) -> bool:
+        return s >= 64
+
+    @staticmethod
+    def is_true(s: int) -> bool:
+        return s == 1
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get("IPCFP_LIB", os.path.join(_HERE, "libipcfp.so"))
+
+
+_lib = None
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def load_library() -> C.CDLL:
+    """Load libipcfp.so.  Raises EngineError if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EngineError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This engine has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise EngineError(f"cannot load {path}: {e}") from e
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    sigs = {
+        "ipcfp_abi_version": (i32, []),
+        "ipcfp_strerror": (C.c_char_p, [i32]),
+        "ipcfp_ctx_create": (i32, [i32, C.POINTER(vp)]),
+        "ipcfp_ctx_destroy": (None, [vp]),
+        "ipcfp_last_error": (C.c_char_p, [vp]),
+        "ipcfp_ctx_stream": (vp, [vp]),
+        "ipcfp_ctx_sync": (i32, [vp]),
+        "ipcfp_ctx_device_info": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(u64)]),
+        "ipcfp_profile_enable": (i32, [vp, i32]),
+        "ipcfp_profile_reset": (i32, [vp]),
+        "ipcfp_profile_read": (i32, [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
+        "ipcfp_witness_create": (i32, [vp, vp, u64, vp, vp, vp, u64, C.POINTER(vp)]),
+        "ipcfp_witness_create_device": (i32, [vp, vp, u64, vp, vp, vp, u64, C.POINTER(vp)]),
+        "ipcfp_witness_destroy": (None, [vp]),
+        "ipcfp_witness_block_count": (u64, [vp]),
+        "ipcfp_witness_byte_count": (u64, [vp]),
+        "ipcfp_witness_verify_cids": (i32, [vp, vp, vp, C.POINTER(u64)]),
+        "ipcfp_witness_verify_cids_async": (i32, [vp, vp]),
+        "ipcfp_witness_cid_bitmap_device": (vp, [vp]),
+        "ipcfp_witness_cid_status_device": (vp, [vp]),
+        "ipcfp_blake2b256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
+        "ipcfp_keccak256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
+        "ipcfp_sha256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _table(blocks):
+    """list[bytes] → (bytes u8[], off u64[], len u32[]) packed back to back."""
+    lens = np.fromiter((len(b) for b in blocks), dtype=np.uint32, count=len(blocks))
+    off = np.zeros(len(blocks), dtype=np.uint64)
+    if len(blocks):
+        off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    data = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy() if len(blocks) else np.zeros(0, np.uint8)
+    return data, off, lens
+
+
+class Engine:
+    """One GPU context (``ipcfp_ctx_t``)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.ipcfp_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"ipcfp_ctx_create(device={device}) failed: {self.lib.ipcfp_strerror(rc).decode()}")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ipcfp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- helpers ---------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.ipcfp_last_error(self.h).decode(errors="replace")
+            raise EngineError(f"{what}: {self.lib.ipcfp_strerror(rc).decode()} ({rc}) {msg}")
+
+    def sync(self):
+        self._check(self.lib.ipcfp_ctx_sync(self.h), "sync")
+
+    @property
+    def stream_ptr(self) -> int:
+        return int(self.lib.ipcfp_ctx_stream(self.h) or 0)
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        cus = C.c_int()
+        mem = C.c_uint64()
+        self._check(self.lib.ipcfp_ctx_device_info(self.h, name, C.byref(cus), C.byref(mem)), "device_info")
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
+
+    # -- profiling ---------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.ipcfp_profile_enable(self.h, 1 if on else 0), "profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.ipcfp_profile_reset(self.h), "profile_reset")
+
+    def profile_read(self, kernel: str):
+        n = C.c_uint64()
+        ms = C.c_double()
+        self._check(self.lib.ipcfp_profile_read(self.h, KERNEL_IDS[kernel], C.byref(n), C.byref(ms)), "profile_read")
+        return n.value, ms.value
+
+    # -- batch hashes ------------------------------------------------------------
+    def _hash(self, fn, data, off, lens):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(off)
+        out = np.zeros((n, 32), dtype=np.uint8)
+        self._check(fn(self.h, _p(data), data.size, _p(off), _p(lens), n, _p(out)), fn.__name__)
+        return out
+
+    def blake2b256(self, data, off, lens):
+        return self._hash(self.lib.ipcfp_blake2b256_batch, data, off, lens)
+
+    def keccak256(self, data, off, lens):
+        return self._hash(self.lib.ipcfp_keccak256_batch, data, off, lens)
+
+    def sha256(self, data, off, lens):
+        return self._hash(self.lib.ipcfp_sha256_batch, data, off, lens)
+
+    def blake2b256_list(self, msgs):
+        return self.blake2b256(*_table(msgs))
+
+    def keccak256_list(self, msgs):
+        return self.keccak256(*_table(msgs))
+
+    def sha256_list(self, msgs):
+        return self.sha256(*_table(msgs))
+
+    # -- witness -------------------------------------------------------------------
+    def witness(self, data, off, lens, cids40) -> "Witness":
+        return Witness(self, data, off, lens, cids40)
+
+    def witness_from_blocks(self, blocks, cids) -> "Witness":
+        """blocks: list[bytes]; cids: list[bytes] binary CIDs (≤ 40 B each)."""
+        data, off, lens = _table(blocks)
+        return Witness(self, data, off, lens, pack_cids(cids))
+
+    def witness_device(self, bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n) -> "Witness":
+        return Witness(self, None, None, None, None, device=(bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n))
+
+
+def pack_cids(cids) -> np.ndarray:
+    out = np.zeros((len(cids), CID_SLOT), dtype=np.uint8)
+    for i, c in enumerate(cids):
+        if len(c) > CID_SLOT:
+            raise EngineError(f"CID {i} is {len(c)} bytes; the ABI slot is {CID_SLOT}")
+        out[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
+    return out
+
+
+class Witness:
+    """HBM-resident witness store (``ipcfp_witness_t``)."""
+
+    def __init__(self, eng: Engine, data, off, lens, cids40, device=None):
+        self.eng = eng
+        self.lib = eng.lib
+        h = C.c_void_p()
+        if device is None:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            off = np.ascontiguousarray(off, dtype=np.uint64)
+            lens = np.ascontiguousarray(lens, dtype=np.uint32)
+            cids40 = np.ascontiguousarray(cids40, dtype=np.uint8).reshape(-1, CID_SLOT)
+            n = len(off)
+            if len(lens) != n or len(cids40) != n:
+                raise EngineError("off/len/cids length mismatch")
+            rc = self.lib.ipcfp_witness_create(eng.h, _p(data), data.size, _p(off), _p(lens), _p(cids40), n, C.byref(h))
+        else:
+            bp, nbytes, op, lp, cp, n = device
+            rc = self.lib.ipcfp_witness_create_device(eng.h, bp, nbytes, op, lp, cp, n, C.byref(h))
+        eng._check(rc, "witness_create")
+        self.h = h
+        self.n = int(n)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ipcfp_witness_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def block_count(self) -> int:
+        return int(self.lib.ipcfp_witness_block_count(self.h))
+
+    def verify_cids(self):
+        """K1.  Returns (status u8[n], n_bad)."""
+        st = np.zeros(self.n, dtype=np.uint8)
+        bad = C.c_uint64()
+        self.eng._check(self.lib.ipcfp_witness_verify_cids(self.eng.h, self.h, _p(st), C.byref(bad)), "verify_cids")
+        return st, int(bad.value)
+
+    def verify_cids_async(self):
+        self.eng._check(self.lib.ipcfp_witness_verify_cids_async(self.eng.h, self.h), "verify_cids_async")
+
+    @property
+    def cid_bitmap_ptr(self) -> int:
+        return int(self.lib.ipcfp_witness_cid_bitmap_device(self.h) or 0)
+
+    @property
+    def cid_status_ptr(self) -> int:
+        return int(self.lib.ipcfp_witness_cid_status_device(self.h) or 0)

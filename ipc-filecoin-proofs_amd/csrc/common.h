@@ -1,0 +1,105 @@
+// csrc/common.h — internal declarations shared by the host side and the kernel
+// launchers of libipcfp.so.  Nothing here crosses the C ABI (include/ipcfp.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "ipcfp.h"
+
+namespace ipcfp {
+
+struct ProfiledLaunch {
+    int kernel_id;
+    hipEvent_t start, stop;
+};
+
+}  // namespace ipcfp
+
+// The opaque context of the C ABI.
+struct ipcfp_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    hipDeviceProp_t props{};
+    // --- tuning knobs (env IPCFP_B2B_MODE / IPCFP_B2B_WG; defaults are the measured best) ---
+    int b2b_mode = 0;        // 0: hipcc-chosen u64 adds, 1: explicit add_co/addc pairs
+    uint32_t b2b_wg = 64;    // K1 workgroup size (multiple of 64, <= 256)
+    // --- per-kernel HIP-event timing (ipcfp_profile_*) ---
+    bool profiling = false;
+    std::vector<ipcfp::ProfiledLaunch> launches;   // recorded, not yet read
+    std::vector<hipEvent_t> free_events;           // recycled events
+    uint64_t prof_count[IPCFP_K_COUNT] = {};
+    double prof_ms[IPCFP_K_COUNT] = {};
+};
+
+namespace ipcfp {
+
+int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...);
+
+#define IPCFP_HIP(ctx, call)                                                                    \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return ::ipcfp::set_error((ctx), IPCFP_E_HIP, "%s failed: %s (%s:%d)", #call,       \
+                                      hipGetErrorString(_e), __FILE__, __LINE__);               \
+    } while (0)
+
+// RAII bracket: records an event pair around a kernel launch when profiling is on.
+struct ProfileScope {
+    ipcfp_ctx* ctx;
+    int kernel_id;
+    hipEvent_t start = nullptr, stop = nullptr;
+    ProfileScope(ipcfp_ctx* c, int id);
+    ~ProfileScope();
+};
+
+// A device allocation owned by the engine.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t count = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        count = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        count = n;
+        if (n == 0) n = 1;
+        return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+    }
+    size_t bytes() const { return count * sizeof(T); }
+};
+
+inline uint32_t div_up(uint64_t a, uint64_t b) { return uint32_t((a + b - 1) / b); }
+
+}  // namespace ipcfp
+
+// The opaque witness of the C ABI: the whole witness resident in HBM as SoA.
+struct ipcfp_witness {
+    ipcfp_ctx* ctx = nullptr;
+    uint64_t n = 0;        // blocks
+    uint64_t nbytes = 0;   // payload bytes (sum of len)
+    uint64_t arena_bytes = 0;
+    ipcfp::DevBuf<uint8_t> arena;     // 16-byte aligned blocks + 256 B tail slack
+    ipcfp::DevBuf<uint64_t> off;      // n
+    ipcfp::DevBuf<uint32_t> len;      // n
+    ipcfp::DevBuf<uint8_t> cids;      // n × 40
+    ipcfp::DevBuf<uint32_t> order;    // n: block ids sorted by 128-byte chunk count (K1 lane schedule)
+    ipcfp::DevBuf<uint32_t> ok_bits;  // ceil(n/32)
+    ipcfp::DevBuf<uint8_t> cid_status;  // n
+    ipcfp::DevBuf<unsigned long long> counters;  // [0] = mismatches
+    // CID → block-id index (K4)
+    ipcfp::DevBuf<uint32_t> index_slots;  // table of block ids, 0xffffffff = empty
+    uint32_t index_mask = 0;
+    bool uniform_chunks = false;  // every block has the same chunk count → identity order
+};

@@ -1,0 +1,170 @@
+// csrc/host/context.cpp — context lifecycle, error text and HIP-event kernel timing.
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+#include "../common.h"
+
+namespace ipcfp {
+
+int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return rc;
+}
+
+static hipEvent_t take_event(ipcfp_ctx* ctx) {
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfileScope::ProfileScope(ipcfp_ctx* c, int id) : ctx(c), kernel_id(id) {
+    if (!ctx->profiling) return;
+    start = take_event(ctx);
+    stop = take_event(ctx);
+    if (start && stop) (void)hipEventRecord(start, ctx->stream);
+}
+
+ProfileScope::~ProfileScope() {
+    if (!ctx->profiling || !start || !stop) return;
+    (void)hipEventRecord(stop, ctx->stream);
+    ctx->launches.push_back({kernel_id, start, stop});
+}
+
+// fold every recorded launch into the per-kernel sums (synchronises the stream)
+static int drain_launches(ipcfp_ctx* ctx) {
+    if (ctx->launches.empty()) return IPCFP_OK;
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& l : ctx->launches) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, l.start, l.stop) == hipSuccess && l.kernel_id >= 0 &&
+            l.kernel_id < IPCFP_K_COUNT) {
+            ctx->prof_count[l.kernel_id] += 1;
+            ctx->prof_ms[l.kernel_id] += ms;
+        }
+        ctx->free_events.push_back(l.start);
+        ctx->free_events.push_back(l.stop);
+    }
+    ctx->launches.clear();
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp
+
+using namespace ipcfp;
+
+extern "C" {
+
+int ipcfp_abi_version(void) { return IPCFP_ABI_VERSION; }
+
+const char* ipcfp_strerror(int rc) {
+    switch (rc) {
+        case IPCFP_OK: return "ok";
+        case IPCFP_E_INVALID: return "invalid argument";
+        case IPCFP_E_NO_DEVICE: return "no usable HIP device (this engine has no CPU fallback)";
+        case IPCFP_E_HIP: return "HIP runtime error";
+        case IPCFP_E_NOMEM: return "out of memory";
+        case IPCFP_E_UNSUPPORTED: return "unsupported input";
+        case IPCFP_E_PARSE: return "parse error";
+        default: return "unknown error";
+    }
+}
+
+int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
+    if (!out) return IPCFP_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return IPCFP_E_NO_DEVICE;
+    if (device < 0 || device >= count) return IPCFP_E_INVALID;
+    ipcfp_ctx* ctx = new (std::nothrow) ipcfp_ctx();
+    if (!ctx) return IPCFP_E_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->props, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return IPCFP_E_NO_DEVICE;
+    }
+    if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = std::atoi(e) == 1 ? 1 : 0;
+    if (const char* e = std::getenv("IPCFP_B2B_WG")) {
+        const int wg = std::atoi(e);
+        if (wg == 64 || wg == 128 || wg == 192 || wg == 256) ctx->b2b_wg = uint32_t(wg);
+    }
+    *out = ctx;
+    return IPCFP_OK;
+}
+
+void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& l : ctx->launches) {
+        (void)hipEventDestroy(l.start);
+        (void)hipEventDestroy(l.stop);
+    }
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* ipcfp_last_error(const ipcfp_ctx_t* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
+    if (!ctx) return IPCFP_E_INVALID;
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+
+int ipcfp_ctx_device_info(ipcfp_ctx_t* ctx, char name[64], int* cu_count, uint64_t* hbm_bytes) {
+    if (!ctx) return IPCFP_E_INVALID;
+    if (name) {
+        std::strncpy(name, ctx->props.name, 63);
+        name[63] = 0;
+    }
+    if (cu_count) *cu_count = ctx->props.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->props.totalGlobalMem;
+    return IPCFP_OK;
+}
+
+int ipcfp_profile_enable(ipcfp_ctx_t* ctx, int on) {
+    if (!ctx) return IPCFP_E_INVALID;
+    if (!on) {
+        int rc = drain_launches(ctx);
+        if (rc) return rc;
+    }
+    ctx->profiling = on != 0;
+    return IPCFP_OK;
+}
+
+int ipcfp_profile_reset(ipcfp_ctx_t* ctx) {
+    if (!ctx) return IPCFP_E_INVALID;
+    int rc = drain_launches(ctx);
+    if (rc) return rc;
+    for (int k = 0; k < IPCFP_K_COUNT; ++k) {
+        ctx->prof_count[k] = 0;
+        ctx->prof_ms[k] = 0.0;
+    }
+    return IPCFP_OK;
+}
+
+int ipcfp_profile_read(ipcfp_ctx_t* ctx, int kernel_id, uint64_t* launches, double* total_ms) {
+    if (!ctx || kernel_id < 0 || kernel_id >= IPCFP_K_COUNT) return IPCFP_E_INVALID;
+    int rc = drain_launches(ctx);
+    if (rc) return rc;
+    if (launches) *launches = ctx->prof_count[kernel_id];
+    if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
+    return IPCFP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// csrc/host/witness.cpp — the HBM-resident witness store and the K1 entry points.
+//
+// Reference counterpart: `load_witness_store` → `MemoryBlockstore`
+// (src/proofs/events/verifier.rs:79-89, src/proofs/storage/verifier.rs:68-78), rebuilt
+// per storage proof by the reference (src/proofs/verifier.rs:19-28); here it is built
+// once per bundle and stays resident.
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "../common.h"
+#include "../kernels/launch.h"
+
+using namespace ipcfp;
+
+namespace ipcfp {
+int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w);  // cid_index.hip
+}
+
+namespace {
+
+constexpr uint64_t kTailSlack = 256;  // K1 may read one 128-byte chunk past a block's padded end
+
+// Shared tail of both constructors: `raw_bytes_d/raw_off_d` hold the caller's layout on
+// the device; build the aligned arena (adopting nothing: the witness owns its copy),
+// the lane schedule and the CID index.
+int finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
+                  const uint32_t* len_d_src, const uint8_t* cids_d_src, bool src_is_device_owned_copy) {
+    (void)src_is_device_owned_copy;
+    const uint32_t n = uint32_t(w->n);
+    IPCFP_HIP(ctx, w->off.alloc(n));
+    IPCFP_HIP(ctx, w->len.alloc(n));
+    IPCFP_HIP(ctx, w->cids.alloc(size_t(n) * IPCFP_CID_SLOT));
+    IPCFP_HIP(ctx, w->order.alloc(n));
+    IPCFP_HIP(ctx, w->ok_bits.alloc(div_up(n, 32)));
+    IPCFP_HIP(ctx, w->cid_status.alloc(n));
+    IPCFP_HIP(ctx, w->counters.alloc(8));
+    IPCFP_HIP(ctx, hipMemcpyAsync(w->len.p, len_d_src, size_t(n) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(w->cids.p, cids_d_src, size_t(n) * IPCFP_CID_SLOT, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(w->counters.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(w->ok_bits.p, 0, w->ok_bits.bytes() ? w->ok_bits.bytes() : 4, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(w->cid_status.p, 0, n ? n : 1, ctx->stream));
+
+    // aligned offsets + arena size
+    DevBuf<uint64_t> scratch;
+    IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
+    uint64_t* total_d = scratch.p + div_up(n, 1024) + 1;
+    int rc = launch_aligned_offsets(ctx, w->len.p, n, w->off.p, total_d, scratch.p);
+    if (rc) return rc;
+    uint64_t total = 0;
+    IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    w->arena_bytes = total + kTailSlack;
+    IPCFP_HIP(ctx, w->arena.alloc(w->arena_bytes));
+    IPCFP_HIP(ctx, hipMemsetAsync(w->arena.p + total, 0, kTailSlack, ctx->stream));
+    rc = launch_repack(ctx, raw_bytes_d, raw_off_d, w->len.p, w->off.p, n, w->arena.p);
+    if (rc) return rc;
+
+    // K1 lane schedule (block ids by chunk count, longest first)
+    DevBuf<uint32_t> bins;
+    IPCFP_HIP(ctx, bins.alloc(256));
+    rc = launch_chunk_order(ctx, w->len.p, n, bins.p, w->order.p);
+    if (rc) return rc;
+
+    rc = witness_build_index(ctx, w);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                         const uint32_t* len, const uint8_t* cids40, uint64_t n, ipcfp_witness_t** out) {
+    if (!ctx || !out) return IPCFP_E_INVALID;
+    *out = nullptr;
+    if (n && (!off || !len || !cids40)) return set_error(ctx, IPCFP_E_INVALID, "null table pointer");
+    if (nbytes && !bytes) return set_error(ctx, IPCFP_E_INVALID, "null bytes pointer");
+    if (n >= 0xffffffffull) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
+    uint64_t payload = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (off[i] > nbytes || uint64_t(len[i]) > nbytes - off[i])
+            return set_error(ctx, IPCFP_E_INVALID, "block %llu [%llu,+%u) lies outside the %llu-byte buffer",
+                             (unsigned long long)i, (unsigned long long)off[i], len[i], (unsigned long long)nbytes);
+        payload += len[i];
+    }
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<ipcfp_witness> w(new (std::nothrow) ipcfp_witness());
+    if (!w) return IPCFP_E_NOMEM;
+    w->ctx = ctx;
+    w->n = n;
+    w->nbytes = payload;
+
+    DevBuf<uint8_t> raw_bytes, raw_cids;
+    DevBuf<uint64_t> raw_off;
+    DevBuf<uint32_t> raw_len;
+    IPCFP_HIP(ctx, raw_bytes.alloc(nbytes));
+    IPCFP_HIP(ctx, raw_off.alloc(n));
+    IPCFP_HIP(ctx, raw_len.alloc(n));
+    IPCFP_HIP(ctx, raw_cids.alloc(n * IPCFP_CID_SLOT));
+    if (nbytes) IPCFP_HIP(ctx, hipMemcpyAsync(raw_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (n) {
+        IPCFP_HIP(ctx, hipMemcpyAsync(raw_off.p, off, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        IPCFP_HIP(ctx, hipMemcpyAsync(raw_len.p, len, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        IPCFP_HIP(ctx, hipMemcpyAsync(raw_cids.p, cids40, n * IPCFP_CID_SLOT, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = finish_create(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p, true);
+    if (rc) return rc;
+    *out = w.release();
+    return IPCFP_OK;
+}
+
+int ipcfp_witness_create_device(ipcfp_ctx_t* ctx, const void* bytes_d, uint64_t nbytes, const void* off_d,
+                                const void* len_d, const void* cids40_d, uint64_t n, ipcfp_witness_t** out) {
+    if (!ctx || !out) return IPCFP_E_INVALID;
+    *out = nullptr;
+    if (n && (!off_d || !len_d || !cids40_d)) return set_error(ctx, IPCFP_E_INVALID, "null table pointer");
+    if (n >= 0xffffffffull) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<ipcfp_witness> w(new (std::nothrow) ipcfp_witness());
+    if (!w) return IPCFP_E_NOMEM;
+    w->ctx = ctx;
+    w->n = n;
+    w->nbytes = nbytes;  // upper bound; the device path does not sum lengths on the host
+    int rc = finish_create(ctx, w.get(), static_cast<const uint8_t*>(bytes_d), static_cast<const uint64_t*>(off_d),
+                           static_cast<const uint32_t*>(len_d), static_cast<const uint8_t*>(cids40_d), false);
+    if (rc) return rc;
+    *out = w.release();
+    return IPCFP_OK;
+}
+
+void ipcfp_witness_destroy(ipcfp_witness_t* w) {
+    if (!w) return;
+    if (w->ctx) {
+        (void)hipSetDevice(w->ctx->device);
+        (void)hipStreamSynchronize(w->ctx->stream);
+    }
+    delete w;
+}
+
+uint64_t ipcfp_witness_block_count(const ipcfp_witness_t* w) { return w ? w->n : 0; }
+uint64_t ipcfp_witness_byte_count(const ipcfp_witness_t* w) { return w ? w->nbytes : 0; }
+
+int ipcfp_witness_verify_cids_async(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
+    if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_blake2b256_cid(ctx, w->arena.p, w->off.p, w->len.p, w->cids.p, w->order.p, uint32_t(w->n),
+                                 w->ok_bits.p, w->cid_status.p, w->counters.p);
+}
+
+int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* status, uint64_t* n_bad) {
+    int rc = ipcfp_witness_verify_cids_async(ctx, w);
+    if (rc) return rc;
+    unsigned long long bad = 0;
+    if (status && w->n)
+        IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(&bad, w->counters.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_bad) *n_bad = bad;
+    return IPCFP_OK;
+}
+
+void* ipcfp_witness_cid_bitmap_device(ipcfp_witness_t* w) { return w ? w->ok_bits.p : nullptr; }
+void* ipcfp_witness_cid_status_device(ipcfp_witness_t* w) { return w ? w->cid_status.p : nullptr; }
+
+// ---- batch hashes ---------------------------------------------------------
+namespace {
+enum HashKind { H_B2B, H_KECCAK, H_SHA256 };
+
+int hash_batch(ipcfp_ctx_t* ctx, HashKind kind, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+               const uint32_t* len, uint64_t n, uint8_t* out32) {
+    if (!ctx) return IPCFP_E_INVALID;
+    if (n == 0) return IPCFP_OK;
+    if (!off || !len || !out32 || (nbytes && !bytes)) return set_error(ctx, IPCFP_E_INVALID, "null pointer");
+    if (n >= 0xffffffffull) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 messages");
+    for (uint64_t i = 0; i < n; ++i)
+        if (off[i] > nbytes || uint64_t(len[i]) > nbytes - off[i])
+            return set_error(ctx, IPCFP_E_INVALID, "message %llu outside the buffer", (unsigned long long)i);
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint8_t> b, o;
+    DevBuf<uint64_t> off_d;
+    DevBuf<uint32_t> len_d;
+    IPCFP_HIP(ctx, b.alloc(nbytes + kTailSlack));
+    IPCFP_HIP(ctx, off_d.alloc(n));
+    IPCFP_HIP(ctx, len_d.alloc(n));
+    IPCFP_HIP(ctx, o.alloc(n * 32));
+    if (nbytes) IPCFP_HIP(ctx, hipMemcpyAsync(b.p, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(off_d.p, off, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(len_d.p, len, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = IPCFP_OK;
+    if (kind == H_B2B) {
+        // Blake2b wants 16-byte aligned blocks: re-lay out on the device, then hash in chunk-count order.
+        DevBuf<uint64_t> new_off, scratch;
+        DevBuf<uint32_t> order, bins;
+        DevBuf<uint8_t> arena;
+        IPCFP_HIP(ctx, new_off.alloc(n));
+        IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
+        IPCFP_HIP(ctx, order.alloc(n));
+        IPCFP_HIP(ctx, bins.alloc(256));
+        uint64_t* total_d = scratch.p + div_up(n, 1024) + 1;
+        rc = launch_aligned_offsets(ctx, len_d.p, uint32_t(n), new_off.p, total_d, scratch.p);
+        if (rc) return rc;
+        uint64_t total = 0;
+        IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d, 8, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, arena.alloc(total + kTailSlack));
+        rc = launch_repack(ctx, b.p, off_d.p, len_d.p, new_off.p, uint32_t(n), arena.p);
+        if (rc) return rc;
+        rc = launch_chunk_order(ctx, len_d.p, uint32_t(n), bins.p, order.p);
+        if (rc) return rc;
+        rc = launch_blake2b256_raw(ctx, arena.p, new_off.p, len_d.p, order.p, uint32_t(n), o.p);
+        if (rc) return rc;
+        IPCFP_HIP(ctx, hipMemcpyAsync(out32, o.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return IPCFP_OK;
+    }
+    rc = (kind == H_KECCAK) ? launch_keccak256(ctx, b.p, off_d.p, len_d.p, uint32_t(n), o.p)
+                            : launch_sha256(ctx, b.p, off_d.p, len_d.p, uint32_t(n), o.p);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipMemcpyAsync(out32, o.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+}  // namespace
+
+int ipcfp_blake2b256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                           const uint32_t* len, uint64_t n, uint8_t* out32) {
+    return hash_batch(ctx, H_B2B, bytes, nbytes, off, len, n, out32);
+}
+int ipcfp_keccak256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                          const uint32_t* len, uint64_t n, uint8_t* out32) {
+    return hash_batch(ctx, H_KECCAK, bytes, nbytes, off, len, n, out32);
+}
+int ipcfp_sha256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
+                       const uint32_t* len, uint64_t n, uint8_t* out32) {
+    return hash_batch(ctx, H_SHA256, bytes, nbytes, off, len, n, out32);
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// csrc/kernels/cid_index.hip — K4: the CID → block-id index of the witness store.
+//
+// Replaces `MemoryBlockstore::put_keyed` into a `HashMap<Cid, Vec<u8>>`
+// (src/proofs/events/verifier.rs:82-86, src/proofs/storage/verifier.rs:69-75).  Same
+// observable semantics: no hashing of the data on insert and a
+// duplicate CID keeps the LAST block inserted (HashMap::insert overwrites).
+//
+// Layout: power-of-two open-addressing table of u32 block ids, load factor ≤ 0.5,
+// linear probing; keys are compared against the cids[] array (5 × u64 per CID).
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "launch.h"
+#include "witness_dev.h"
+
+namespace ipcfp {
+
+__global__ __launch_bounds__(256) void k_index_insert(const uint8_t* __restrict__ cids, uint32_t n,
+                                                      uint32_t* __restrict__ slots, uint32_t mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CidKey key = load_cid_slot(cids, i);
+    uint32_t s = cid_hash(key) & mask;
+    for (;;) {
+        uint32_t cur = slots[s];
+        if (cur == kNoBlock) {
+            cur = atomicCAS(&slots[s], kNoBlock, i);
+            if (cur == kNoBlock) return;  // claimed an empty slot
+        }
+        // slot owned by block `cur` (its CID identity never changes once claimed)
+        if (cid_equal(load_cid_slot(cids, cur), key)) {
+            atomicMax(&slots[s], i);  // duplicate CID: last block wins
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
+    const uint32_t n = uint32_t(w->n);
+    uint32_t size = 64;
+    while (size < 2ull * n) size <<= 1;
+    IPCFP_HIP(ctx, w->index_slots.alloc(size));
+    w->index_mask = size - 1;
+    IPCFP_HIP(ctx, hipMemsetAsync(w->index_slots.p, 0xff, size_t(size) * 4, ctx->stream));
+    if (n == 0) return IPCFP_OK;
+    {
+        ProfileScope prof(ctx, IPCFP_K_CID_INDEX);
+        hipLaunchKernelGGL(k_index_insert, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n,
+                           w->index_slots.p, w->index_mask);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

@@ -1,0 +1,34 @@
+// csrc/kernels/launch.h — host-callable launchers of the HIP kernels.  Every
+// launcher enqueues on ctx->stream and returns without synchronising.
+#pragma once
+#include <cstdint>
+
+#include "../common.h"
+
+namespace ipcfp {
+
+// --- blake2b_cid.hip (K1) ---
+int launch_chunk_order(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint32_t* bins_d, uint32_t* order_d);
+int launch_blake2b256_cid(ipcfp_ctx* ctx, const uint8_t* arena, const uint64_t* off, const uint32_t* len,
+                          const uint8_t* cids40, const uint32_t* order, uint32_t n, uint32_t* ok_bits,
+                          uint8_t* status, unsigned long long* counters);
+int launch_blake2b256_raw(ipcfp_ctx* ctx, const uint8_t* arena, const uint64_t* off, const uint32_t* len,
+                          const uint32_t* order, uint32_t n, uint8_t* out32);
+
+// --- repack.hip ---
+// new_off[i] = exclusive prefix sum of round_up(len[i], 16); *total_d receives the arena size.
+int launch_aligned_offsets(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint64_t* new_off_d,
+                           uint64_t* total_d, uint64_t* scratch_d /* >= div_up(n,1024)+1 */);
+// dst[new_off[i] .. +len[i]) = src[old_off[i] .. +len[i]); pad bytes up to the next 16 are zeroed.
+int launch_repack(ipcfp_ctx* ctx, const uint8_t* src, const uint64_t* old_off, const uint32_t* len,
+                  const uint64_t* new_off, uint32_t n, uint8_t* dst);
+// *flag_d |= 1 if any off[i] % 16 != 0
+int launch_check_aligned(ipcfp_ctx* ctx, const uint64_t* off_d, uint32_t n, uint32_t* flag_d);
+
+// --- hash_short.hip (K2 Keccak-256, K3 SHA-256) ---
+int launch_keccak256(ipcfp_ctx* ctx, const uint8_t* bytes, const uint64_t* off, const uint32_t* len, uint32_t n,
+                     uint8_t* out32);
+int launch_sha256(ipcfp_ctx* ctx, const uint8_t* bytes, const uint64_t* off, const uint32_t* len, uint32_t n,
+                  uint8_t* out32);
+
+}  // namespace ipcfp

@@ -1,0 +1,81 @@
+// csrc/kernels/witness_dev.h — device-side view of the HBM-resident witness and the
+// CID → block-id lookup every walk kernel uses instead of `Blockstore::get`
+// (trait impls: src/proofs/common/blockstore.rs:26-39; MemoryBlockstore:
+// src/proofs/events/verifier.rs:82-86).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ipcfp {
+
+constexpr uint32_t kNoBlock = 0xffffffffu;
+
+struct WitnessView {
+    const uint8_t* arena;    // 16-byte aligned blocks
+    const uint64_t* off;     // n
+    const uint32_t* len;     // n
+    const uint8_t* cids;     // n × 40, zero padded
+    const uint32_t* slots;   // open-addressing table of block ids (kNoBlock = empty)
+    uint32_t mask;           // table size - 1 (power of two)
+    uint32_t n;
+    // K8 recording: when non-null, every lookup of a CID present in the witness sets
+    // bit `block id` (RecordingBlockStore::get, src/proofs/common/blockstore.rs:26-30)
+    uint32_t* touched;
+};
+
+struct CidKey {
+    uint64_t w[5];  // 40-byte slot as little-endian words
+};
+
+__device__ __forceinline__ uint32_t cid_hash(const CidKey& k) {
+    uint64_t x = k.w[0] ^ ((k.w[1] << 13) | (k.w[1] >> 51)) ^ ((k.w[2] << 27) | (k.w[2] >> 37)) ^
+                 ((k.w[3] << 41) | (k.w[3] >> 23)) ^ k.w[4];
+    x *= 0x9E3779B97F4A7C15ULL;
+    return uint32_t(x >> 32);
+}
+
+__device__ __forceinline__ CidKey load_cid_slot(const uint8_t* cids, uint32_t i) {
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(cids + 40ull * i);
+    CidKey k;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) k.w[j] = p[j];
+    return k;
+}
+
+__device__ __forceinline__ bool cid_equal(const CidKey& a, const CidKey& b) {
+    return ((a.w[0] ^ b.w[0]) | (a.w[1] ^ b.w[1]) | (a.w[2] ^ b.w[2]) | (a.w[3] ^ b.w[3]) | (a.w[4] ^ b.w[4])) == 0;
+}
+
+// Build a key from `n` CID bytes at an arbitrary address (n ≤ 40; longer CIDs
+// cannot be witness keys — ipcfp.h IPCFP_CID_SLOT).
+__device__ __forceinline__ CidKey cid_key_from_bytes(const uint8_t* p, uint32_t n) {
+    CidKey k;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint32_t idx = 8u * j + b;
+            if (idx < n) v |= uint64_t(p[idx]) << (8 * b);
+        }
+        k.w[j] = v;
+    }
+    return k;
+}
+
+// Blockstore::get → block id, or kNoBlock when the CID is not in the witness.
+__device__ __forceinline__ uint32_t witness_find(const WitnessView& w, const CidKey& key) {
+    uint32_t s = cid_hash(key) & w.mask;
+    for (;;) {
+        const uint32_t b = w.slots[s];
+        if (b == kNoBlock) return kNoBlock;
+        if (cid_equal(load_cid_slot(w.cids, b), key)) {
+            if (w.touched) atomicOr(&w.touched[b >> 5], 1u << (b & 31));
+            return b;
+        }
+        s = (s + 1) & w.mask;
+    }
+}
+
+}  // namespace ipcfp

@@ -1,0 +1,37 @@
+"""pytest configuration: the `gpu` marker and shared fixtures.
+
+`-m "not gpu"` runs here (no GPU): oracle vs known answers, host logic, ABI symbol
+checks.  `-m gpu` runs on an MI355X: HIP path vs oracle, through the C ABI.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One engine context on cuda:0.  Fails loudly (no CPU fallback) if the HIP
+    library or the device is missing."""
+    import ipc_filecoin_proofs_amd as ipcfp
+
+    eng = ipcfp.Engine(0)
+    yield eng
+    eng.close()
