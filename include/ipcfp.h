@@ -193,6 +193,75 @@ int ipcfp_keccak256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbyte
 int ipcfp_sha256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
                        const uint32_t* len, uint64_t n, uint8_t* out32);
 
+/* ---- proof claims (string form, exactly the reference's structs) ----------
+ * CIDs and hex values are NUL-terminated strings, as in the reference's serde
+ * structs; the host parses them once per batch (src/proofs/common/witness.rs:60-72).
+ * An unparsable string is not an ABI error: it yields the per-proof status the
+ * reference's `?` would produce at the point it parses that field.             */
+
+/* `EventProof` + `EventData` (src/proofs/events/bundle.rs:5-23) */
+typedef struct ipcfp_event_proof {
+    int64_t parent_epoch;
+    int64_t child_epoch;
+    const char* const* parent_tipset_cids; /* ordered tipset key of H */
+    uint32_t n_parent_tipset_cids;
+    const char* child_block_cid;
+    const char* message_cid;
+    uint64_t exec_index;
+    uint64_t event_index;
+    /* event_data */
+    uint64_t emitter;
+    const char* const* topics; /* "0x…" hex strings */
+    uint32_t n_topics;
+    const char* data; /* "0x…" hex string */
+} ipcfp_event_proof_t;
+
+/* `StorageProof` (src/proofs/storage/bundle.rs:5-14) */
+typedef struct ipcfp_storage_proof {
+    int64_t child_epoch;
+    const char* child_block_cid;
+    const char* parent_state_root;
+    uint64_t actor_id;
+    const char* actor_state_cid;
+    const char* storage_root;
+    const char* slot;  /* "0x" + 64 hex */
+    const char* value; /* "0x" + 64 hex */
+} ipcfp_storage_proof_t;
+
+/* The closure `create_event_filter(event_sig, subnet_id)` returns
+ * (src/proofs/events/verifier.rs:28-39): topics.len() >= 2 && t[0]==topic0 && t[1]==topic1. */
+typedef struct ipcfp_event_filter {
+    uint8_t topic0[32]; /* Keccak-256(event signature) */
+    uint8_t topic1[32]; /* ascii_to_bytes32(subnet id)  */
+} ipcfp_event_filter_t;
+
+/* topic0 = Keccak-256(event_sig) is computed ON THE DEVICE (K2); topic1 is the
+ * zero-padded ASCII of subnet_id (src/proofs/common/evm.rs:62-78).               */
+int ipcfp_create_event_filter(ipcfp_ctx_t* ctx, const char* event_sig, const char* subnet_id,
+                              ipcfp_event_filter_t* out);
+
+/* `TrustPolicy` (src/proofs/trust/mod.rs:8-16,53-78): the predicate is evaluated on the
+ * host, before the device call, because it is a pure function of (epoch, cid).  */
+typedef struct ipcfp_trust_policy {
+    int kind;           /* 0 = AcceptAll, 1 = F3Certificate epoch range (cert.rs:52-64) */
+    int ec_chain_empty; /* kind 1: certificate with an empty EC chain ⇒ nothing is trusted */
+    int64_t min_epoch;  /* kind 1: first EC-chain epoch */
+    int64_t max_epoch;  /* kind 1: last EC-chain epoch  */
+} ipcfp_trust_policy_t;
+
+/* `verify_event_proof` (src/proofs/events/verifier.rs:51-74) over a batch.
+ *   status[i]            per-proof ipcfp_status_t (n bytes, host)
+ *   filter               nullable — the built-in `check_event` closure form
+ * The reference aborts at the first Err; callers reproduce that by scanning status[]
+ * for the lowest index with IPCFP_ST_IS_ERR (bindings/rust/ffi.rs does).          */
+int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
+                              const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                              ipcfp_status_t* status);
+
+/* `verify_storage_proof` (src/proofs/storage/verifier.rs:24-63) over a batch. */
+int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_storage_proof_t* proofs,
+                                uint64_t n, const ipcfp_trust_policy_t* trust, ipcfp_status_t* status);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -1,0 +1,143 @@
+// oracle/amt.cpp — TEST INFRASTRUCTURE (see amt.hpp for provenance).
+#include "amt.hpp"
+
+namespace orc {
+
+namespace {
+
+struct Node {
+    uint32_t width = 0;
+    std::vector<uint8_t> bmap;
+    bool is_link = false;            // links non-empty
+    std::vector<Cid> links;          // compacted
+    std::vector<ValueLoc> values;    // compacted
+    bool bit(uint32_t i) const { return bmap[i / 8] & (1u << (i % 8)); }
+    uint32_t rank(uint32_t i) const {  // set bits below i
+        uint32_t r = 0;
+        for (uint32_t k = 0; k < i; ++k) r += bit(k) ? 1 : 0;
+        return r;
+    }
+};
+
+// Decode `[bmap, links, values]` at r (CollapsedNode) and expand-check it.
+Node read_node(Reader& r, const Bytes* block, uint32_t bw, const ValueChecker& check) {
+    Node nd;
+    nd.width = 1u << bw;
+    r.expect_array(3);
+    nd.bmap = r.read_bytes_vec();
+    const uint64_t nlinks = r.read_array();
+    for (uint64_t i = 0; i < nlinks; ++i) nd.links.push_back(read_cid(r));
+    const uint64_t nvals = r.read_array();
+    for (uint64_t i = 0; i < nvals; ++i) {
+        ValueLoc v;
+        v.block = block;
+        v.off = r.pos;
+        check(r);
+        v.len = r.pos - v.off;
+        nd.values.push_back(v);
+    }
+    if (!nd.links.empty() && !nd.values.empty()) decode_err("AMT node has both links and values");
+    if (nd.bmap.size() != (nd.width + 7) / 8) decode_err("AMT bitmap has the wrong length");
+    uint32_t pop = 0;
+    for (uint32_t i = 0; i < nd.width; ++i) pop += nd.bit(i) ? 1 : 0;
+    // bits of the last byte beyond `width` (bit_width < 3) are ignored, as the crate's loop does
+    nd.is_link = !nd.links.empty();
+    const size_t have = nd.is_link ? nd.links.size() : nd.values.size();
+    if (have != pop) decode_err("AMT node entry count does not match its bitmap");
+    return nd;
+}
+
+uint64_t nodes_for_height(uint32_t bw, uint64_t height) {
+    const uint64_t shift = uint64_t(bw) * height;
+    return shift >= 64 ? UINT64_MAX : (1ull << shift);
+}
+
+Node load_child(const Blockstore& bs, const Cid& c, uint32_t bw, const ValueChecker& check) {
+    const Bytes& raw = must_get(bs, c, "AMT node");
+    Reader r(raw);
+    Node nd = read_node(r, &raw, bw, check);
+    r.finish();
+    return nd;
+}
+
+bool node_get(const Blockstore& bs, const Node& nd, uint64_t height, uint32_t bw, uint64_t i,
+              const ValueChecker& check, ValueLoc& loc) {
+    if (!nd.is_link) {
+        // Node::Leaf: `vals.get(i)`
+        if (i >= nd.width || !nd.bit(uint32_t(i))) return false;
+        loc = nd.values[nd.rank(uint32_t(i))];
+        return true;
+    }
+    if (height == 0) decode_err("AMT link node at height 0");
+    const uint64_t span = nodes_for_height(bw, height);
+    const uint64_t sub = i / span;
+    if (sub >= nd.width || !nd.bit(uint32_t(sub))) return false;
+    Node child = load_child(bs, nd.links[nd.rank(uint32_t(sub))], bw, check);
+    return node_get(bs, child, height - 1, bw, i % span, check, loc);
+}
+
+void node_for_each(const Blockstore& bs, const Node& nd, uint64_t height, uint32_t bw, uint64_t base,
+                   const ValueChecker& check, const std::function<void(uint64_t, const ValueLoc&)>& f) {
+    if (!nd.is_link) {
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < nd.width; ++i)
+            if (nd.bit(i)) f(base + i, nd.values[k++]);
+        return;
+    }
+    if (height == 0) decode_err("AMT link node at height 0");
+    const uint64_t span = nodes_for_height(bw, height);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < nd.width; ++i) {
+        if (!nd.bit(i)) continue;
+        Node child = load_child(bs, nd.links[k++], bw, check);
+        node_for_each(bs, child, height - 1, bw, base + uint64_t(i) * span, check, f);
+    }
+}
+
+Node root_node(const AmtRoot& root, const ValueChecker& check) {
+    Reader r(*root.block);
+    r.pos = root.node_off;
+    return read_node(r, root.block, root.bit_width, check);
+}
+
+}  // namespace
+
+AmtRoot amt_load(const Blockstore& bs, const Cid& c, int version, const ValueChecker& check) {
+    const Bytes& raw = must_get(bs, c, "AMT root");
+    Reader r(raw);
+    AmtRoot root;
+    root.block = &raw;
+    if (version == 0) {
+        r.expect_array(3);
+        root.bit_width = 3;
+    } else {
+        r.expect_array(4);
+        const uint64_t bw = r.read_uint();
+        if (bw < 1 || bw > kAmtMaxBitWidth) decode_err("AMT bit width out of the supported range");
+        root.bit_width = uint32_t(bw);
+    }
+    root.height = r.read_uint();
+    root.count = r.read_uint();
+    root.node_off = r.pos;
+    (void)read_node(r, &raw, root.bit_width, check);
+    r.finish();
+    // `if root.height > MAX_HEIGHT { return Err(MaxHeight) }`, MAX_HEIGHT = 64 / bit_width
+    if (root.height > 64 / root.bit_width) decode_err("AMT height above the maximum");
+    return root;
+}
+
+bool amt_get(const Blockstore& bs, const AmtRoot& root, uint64_t index, const ValueChecker& check, ValueLoc& loc) {
+    // `if i > MAX_INDEX` (u64::MAX - 1) → Err(OutOfRange)
+    if (index == UINT64_MAX) throw Err(IPCFP_ST_ERR, "AMT index out of range");
+    if (index >= nodes_for_height(root.bit_width, root.height + 1)) return false;
+    Node nd = root_node(root, check);
+    return node_get(bs, nd, root.height, root.bit_width, index, check, loc);
+}
+
+void amt_for_each(const Blockstore& bs, const AmtRoot& root, const ValueChecker& check,
+                  const std::function<void(uint64_t, const ValueLoc&)>& f) {
+    Node nd = root_node(root, check);
+    node_for_each(bs, nd, root.height, root.bit_width, 0, check, f);
+}
+
+}  // namespace orc

@@ -1,0 +1,46 @@
+// oracle/verify.hpp — TEST INFRASTRUCTURE.  The reference's verifiers and the event scan, restated.
+#pragma once
+#include "hamt.hpp"
+#include "types.hpp"
+
+namespace orc {
+
+// TrustPolicy::{verify_parent_tipset, verify_child_header} (src/proofs/trust/mod.rs:53-78,
+// src/cert.rs:52-64) with `.unwrap_or(false)` applied (src/proofs/verifier.rs:21-25,38-49).
+bool trusted(const ipcfp_trust_policy_t* t, int64_t epoch);
+
+// reconstruct_execution_order (src/proofs/events/utils.rs:16-30) → collect_exec_list(verify_txmeta = true) (:48-94)
+std::vector<Cid> reconstruct_execution_order(const Blockstore& bs, const std::vector<Cid>& parent_hdr_cids);
+
+// verify_single_proof (src/proofs/events/verifier.rs:92-121) → status byte; Err is thrown.
+uint8_t verify_event_proof_one(const Blockstore& bs, const ipcfp_event_proof_t& p, const ipcfp_trust_policy_t* trust,
+                               const ipcfp_event_filter_t* filter);
+
+// verify_storage_proof steps 2-6 (src/proofs/storage/verifier.rs:24-63) over an already loaded store.
+uint8_t verify_storage_proof_one(const Blockstore& bs, const ipcfp_storage_proof_t& p,
+                                 const ipcfp_trust_policy_t* trust);
+
+// read_storage_slot (src/proofs/storage/decode.rs:36-97); true ⇒ Some(value)
+bool read_storage_slot(const Blockstore& bs, const Cid& root, const uint8_t slot[32], Bytes& value);
+
+// get_actor_state (src/proofs/common/decode.rs:17-42)
+ActorState get_actor_state(const Blockstore& bs, const Cid& state_root, uint64_t actor_id);
+
+// Address::new_id(id).to_bytes()
+Bytes id_address_bytes(uint64_t id);
+
+struct ScanMatch {
+    uint64_t exec_index, event_index, emitter;
+    std::vector<std::array<uint8_t, 32>> topics;
+    Bytes data;
+};
+// find_matching_events (src/proofs/events/generator.rs:180-307) with the RPC receipt list replaced by
+// the receipts AMT itself (for_each order).  `receipt_has_match[i]` = pass-1 verdict per receipt index;
+// `matches` = pass-2 (exec_index, event_index, EventData) in emission order; `touched` (nullable) = the
+// union of every RecordingBlockStore's take_seen() that generate_event_proof feeds to the collector
+// for this step (rec_events per matching receipt + rec_receipts), sorted in `Cid: Ord`.
+void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_event_filter_t& filter, bool has_actor,
+                 uint64_t actor, std::vector<uint8_t>& receipt_has_match, std::vector<ScanMatch>& matches,
+                 std::vector<Cid>* touched);
+
+}  // namespace orc

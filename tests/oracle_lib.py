@@ -29,6 +29,29 @@ class Oracle:
         lib.orc_hash_batch.argtypes = [C.c_int, vp, vp, vp, u64, vp]
         lib.orc_blake2b256_verify.restype = u64
         lib.orc_blake2b256_verify.argtypes = [vp, vp, vp, vp, u64, vp]
+        lib.orc_cid_to_string.restype = C.c_int
+        lib.orc_cid_to_string.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+        lib.orc_cid_from_string.restype = C.c_int
+        lib.orc_cid_from_string.argtypes = [C.c_char_p, vp]
+        lib.orc_cid_for_block.restype = None
+        lib.orc_cid_for_block.argtypes = [C.c_char_p, u64, vp]
+        lib.orc_store_create.restype = vp
+        lib.orc_store_create.argtypes = [vp, vp, vp, vp, u64]
+        lib.orc_store_destroy.restype = None
+        lib.orc_store_destroy.argtypes = [vp]
+        lib.orc_amt_get.restype = None
+        lib.orc_amt_get.argtypes = [vp, vp, C.c_int, C.c_int, vp, u64, vp, vp, C.c_uint32, vp]
+        lib.orc_hamt_get.restype = None
+        lib.orc_hamt_get.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp, vp, u64, vp, vp, C.c_uint32, vp]
+        lib.orc_exec_order.restype = C.c_uint8
+        lib.orc_exec_order.argtypes = [vp, vp, C.c_uint32, vp, u64, C.POINTER(u64)]
+        lib.orc_scan_events.restype = C.c_uint8
+        lib.orc_scan_events.argtypes = [vp, vp, vp, C.c_int, u64, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64),
+                                        vp, u64, C.POINTER(u64)]
+        lib.orc_verify_event_proofs.restype = None
+        lib.orc_verify_event_proofs.argtypes = [vp, vp, u64, vp, vp, vp, C.c_int, C.c_int]
+        lib.orc_verify_storage_proofs.restype = None
+        lib.orc_verify_storage_proofs.argtypes = [vp, vp, u64, vp, vp, C.c_int, C.c_int]
 
     def _one(self, fn, data: bytes) -> bytes:
         out = np.zeros(32, dtype=np.uint8)
@@ -43,6 +66,26 @@ class Oracle:
 
     def sha256(self, data: bytes) -> bytes:
         return self._one(self.lib.orc_sha256, data)
+
+    # ---- CIDs ----
+    def cid_to_string(self, cid: bytes) -> str:
+        buf = C.create_string_buffer(256)
+        n = self.lib.orc_cid_to_string(cid, len(cid), buf, 256)
+        assert n >= 0
+        return buf.value.decode()
+
+    def cid_from_string(self, s: str):
+        out = np.zeros(40, dtype=np.uint8)
+        n = self.lib.orc_cid_from_string(s.encode(), _p(out))
+        return None if n < 0 else out.tobytes()[:n]
+
+    def cid_for_block(self, data: bytes) -> bytes:
+        out = np.zeros(40, dtype=np.uint8)
+        self.lib.orc_cid_for_block(data, len(data), _p(out))
+        return out.tobytes()[:38]
+
+    def store(self, data, off, lens, cids40):
+        return OracleStore(self, data, off, lens, cids40)
 
     def hash_batch(self, kind: str, data, off, lens):
         k = {"blake2b256": 0, "keccak256": 1, "sha256": 2}[kind]
@@ -61,6 +104,80 @@ class Oracle:
         ok = np.zeros(len(off), dtype=np.uint8)
         good = self.lib.orc_blake2b256_verify(_p(data), _p(off), _p(lens), _p(expect32), len(off), _p(ok))
         return ok, int(good)
+
+
+VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "vec_u8": 4, "any": 5}
+
+
+class OracleStore:
+    """MemoryBlockstore over a witness table (keeps the arrays alive)."""
+
+    def __init__(self, orc: Oracle, data, off, lens, cids40):
+        self.orc = orc
+        self.lib = orc.lib
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.off = np.ascontiguousarray(off, dtype=np.uint64)
+        self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.cids = np.ascontiguousarray(cids40, dtype=np.uint8).reshape(-1, 40)
+        self.h = self.lib.orc_store_create(_p(self.data), _p(self.off), _p(self.lens), _p(self.cids), len(self.off))
+
+    def close(self):
+        if self.h:
+            self.lib.orc_store_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def amt_get(self, root40: bytes, version: int, kind: str, indices, cap=1024):
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        n = len(idx)
+        st = np.zeros(n, dtype=np.uint8)
+        out = np.zeros((n, cap), dtype=np.uint8)
+        ol = np.zeros(n, dtype=np.uint32)
+        root = np.frombuffer(root40.ljust(40, b"\0"), dtype=np.uint8).copy()
+        self.lib.orc_amt_get(self.h, _p(root), version, VALUE_KINDS[kind], _p(idx), n, _p(st), _p(out), cap, _p(ol))
+        return st, [out[i, : ol[i]].tobytes() for i in range(n)]
+
+    def hamt_get(self, root40: bytes, bit_width: int, kind: str, keys, cap=1024):
+        n = len(keys)
+        kl = np.array([len(k) for k in keys], dtype=np.uint32)
+        ko = np.zeros(n, dtype=np.uint32)
+        if n:
+            ko[1:] = np.cumsum(kl[:-1])
+        kb = np.frombuffer(b"".join(keys), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+        st = np.zeros(n, dtype=np.uint8)
+        out = np.zeros((n, cap), dtype=np.uint8)
+        ol = np.zeros(n, dtype=np.uint32)
+        root = np.frombuffer(root40.ljust(40, b"\0"), dtype=np.uint8).copy()
+        self.lib.orc_hamt_get(self.h, _p(root), bit_width, VALUE_KINDS[kind], _p(kb), _p(ko), _p(kl), n, _p(st),
+                              _p(out), cap, _p(ol))
+        return st, [out[i, : ol[i]].tobytes() for i in range(n)]
+
+    def exec_order(self, parent_cids, cap=1 << 21):
+        pc = np.zeros((len(parent_cids), 40), dtype=np.uint8)
+        for i, c in enumerate(parent_cids):
+            pc[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
+        out = np.zeros((cap, 40), dtype=np.uint8)
+        cnt = C.c_uint64()
+        st = self.lib.orc_exec_order(self.h, _p(pc), len(parent_cids), _p(out), cap, C.byref(cnt))
+        return int(st), out[: min(cnt.value, cap)]
+
+    def scan_events(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor=None, cap_receipts=1 << 21,
+                    cap_matches=1 << 20, cap_touched=1 << 21, want_touched=True):
+        filt = np.frombuffer(topic0 + topic1, dtype=np.uint8).copy()
+        root = np.frombuffer(receipts_root.ljust(40, b"\0"), dtype=np.uint8).copy()
+        has = np.zeros(cap_receipts, dtype=np.uint8)
+        trip = np.zeros((cap_matches, 3), dtype=np.uint64)
+        touched = np.zeros((cap_touched, 40), dtype=np.uint8) if want_touched else None
+        nr, nm, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        st = self.lib.orc_scan_events(self.h, _p(root), _p(filt), 0 if actor is None else 1, 0 if actor is None else actor,
+                                      _p(has), cap_receipts, C.byref(nr), _p(trip), cap_matches, C.byref(nm),
+                                      _p(touched), cap_touched, C.byref(nt))
+        return int(st), has[: nr.value], trip[: nm.value], (touched[: nt.value] if want_touched else None)
 
 
 _cached = None
