@@ -157,6 +157,21 @@ class OracleStore:
                               _p(out), cap, _p(ol))
         return st, [out[i, : ol[i]].tobytes() for i in range(n)]
 
+    def verify_event_proofs(self, claims, trust=None, filt=None, mode=0, threads=0):
+        st = np.zeros(claims.n, dtype=np.uint8)
+        self.lib.orc_verify_event_proofs(self.h, C.cast(claims.arr, C.c_void_p), claims.n,
+                                         C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+                                         C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None,
+                                         _p(st), mode, threads)
+        return st
+
+    def verify_storage_proofs(self, claims, trust=None, mode=0, threads=0):
+        st = np.zeros(claims.n, dtype=np.uint8)
+        self.lib.orc_verify_storage_proofs(self.h, C.cast(claims.arr, C.c_void_p), claims.n,
+                                           C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+                                           _p(st), mode, threads)
+        return st
+
     def exec_order(self, parent_cids, cap=1 << 21):
         pc = np.zeros((len(parent_cids), 40), dtype=np.uint8)
         for i, c in enumerate(parent_cids):
