@@ -193,6 +193,39 @@ int ipcfp_keccak256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbyte
 int ipcfp_sha256_batch(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
                        const uint32_t* len, uint64_t n, uint8_t* out32);
 
+/* ---- path-walk primitives --------------------------------------------------
+ * A located value: the CBOR item of block `block` at [off, off+len).  `block` indexes the
+ * witness's blocks in the order they were passed to ipcfp_witness_create.            */
+typedef struct ipcfp_value_loc {
+    uint32_t block; /* 0xffffffff when no value was located */
+    uint32_t off;
+    uint32_t len;
+} ipcfp_value_loc_t;
+
+/* element type an AMT / HAMT is opened with (decides how every value of a visited node is
+ * type-checked, as serde does when it decodes the node) */
+enum {
+    IPCFP_V_CID = 0,           /* Amtv0<Cid>            events/utils.rs:76,84            */
+    IPCFP_V_RECEIPT = 1,       /* Amtv0<Receipt>        events/verifier.rs:220           */
+    IPCFP_V_STAMPED_EVENT = 2, /* Amt<StampedEvent>     events/verifier.rs:234           */
+    IPCFP_V_ACTOR_STATE = 3,   /* Hamt<_, ActorState>   common/decode.rs:29              */
+    IPCFP_V_VEC_U8 = 4,        /* Hamt<_, Vec<u8>>      storage/decode.rs:79,86,92       */
+    IPCFP_V_ANY = 5            /* any well-formed item                                    */
+};
+
+/* K5 — `Amt::load(root).get(index[i])` for a batch of indices (version 0 = Amtv0, 3 = Amt).
+ * status[i] ∈ {IPCFP_ST_TRUE, IPCFP_ST_NOT_FOUND, IPCFP_ST_ERR_*}; loc nullable.
+ * Replaces src/proofs/events/verifier.rs:220-226,234-239; src/proofs/events/generator.rs:249. */
+int ipcfp_amt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid40, int version, int value_kind,
+                  const uint64_t* index, uint64_t n, ipcfp_status_t* status, ipcfp_value_loc_t* loc);
+
+/* K7 — `Hamt::load_with_bit_width(root, bit_width).get(key_i)`; key i = keys[key_off[i] .. +key_len[i]).
+ * The SHA-256 key hash (K3) is computed in the same kernel.
+ * Replaces src/proofs/common/decode.rs:29-39; src/proofs/storage/decode.rs:79-96.          */
+int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid40, uint32_t bit_width,
+                   int value_kind, const uint8_t* keys, const uint32_t* key_off, const uint32_t* key_len, uint64_t n,
+                   ipcfp_status_t* status, ipcfp_value_loc_t* loc);
+
 /* ---- proof claims (string form, exactly the reference's structs) ----------
  * CIDs and hex values are NUL-terminated strings, as in the reference's serde
  * structs; the host parses them once per batch (src/proofs/common/witness.rs:60-72).

@@ -89,6 +89,10 @@ class ST:
         return s == 1
 
 
+VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "vec_u8": 4, "any": 5}
+LOC_DTYPE = np.dtype([("block", np.uint32), ("off", np.uint32), ("len", np.uint32)])
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -144,6 +148,11 @@ def load_library() -> C.CDLL:
         "ipcfp_blake2b256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
         "ipcfp_keccak256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
         "ipcfp_sha256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
+        "ipcfp_amt_get": (i32, [vp, vp, vp, i32, i32, vp, u64, vp, vp]),
+        "ipcfp_hamt_get": (i32, [vp, vp, vp, C.c_uint32, i32, vp, vp, vp, u64, vp, vp]),
+        "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
+        "ipcfp_verify_storage_proofs": (i32, [vp, vp, vp, u64, vp, vp]),
+        "ipcfp_verify_event_proofs": (i32, [vp, vp, vp, u64, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -253,6 +262,13 @@ class Engine:
     def sha256_list(self, msgs):
         return self.sha256(*_table(msgs))
 
+    def create_event_filter(self, event_sig: str, subnet_id: str):
+        """(topic0, topic1) of create_event_filter; topic0 is hashed on the device."""
+        out = np.zeros(64, dtype=np.uint8)
+        self._check(self.lib.ipcfp_create_event_filter(self.h, event_sig.encode(), subnet_id.encode(), _p(out)),
+                    "create_event_filter")
+        return out[:32].tobytes(), out[32:].tobytes()
+
     # -- witness -------------------------------------------------------------------
     def witness(self, data, off, lens, cids40) -> "Witness":
         return Witness(self, data, off, lens, cids40)
@@ -328,6 +344,49 @@ class Witness:
 
     def verify_cids_async(self):
         self.eng._check(self.lib.ipcfp_witness_verify_cids_async(self.eng.h, self.h), "verify_cids_async")
+
+    # -- path-walk primitives ---------------------------------------------------------
+    def amt_get(self, root_cid: bytes, version: int, kind: str, indices):
+        """K5.  Returns (status u8[n], loc structured[n] with fields block/off/len)."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        n = len(idx)
+        st = np.zeros(n, dtype=np.uint8)
+        loc = np.zeros(n, dtype=LOC_DTYPE)
+        root = np.frombuffer(bytes(root_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        self.eng._check(self.lib.ipcfp_amt_get(self.eng.h, self.h, _p(root), version, VALUE_KINDS[kind], _p(idx), n,
+                                               _p(st), _p(loc)), "amt_get")
+        return st, loc
+
+    def hamt_get(self, root_cid: bytes, bit_width: int, kind: str, keys):
+        """K7.  keys: list[bytes]."""
+        n = len(keys)
+        kl = np.array([len(k) for k in keys], dtype=np.uint32)
+        ko = np.zeros(n, dtype=np.uint32)
+        if n:
+            ko[1:] = np.cumsum(kl[:-1])
+        kb = np.frombuffer(b"".join(keys), dtype=np.uint8).copy() if n and kl.sum() else np.zeros(1, np.uint8)
+        st = np.zeros(n, dtype=np.uint8)
+        loc = np.zeros(n, dtype=LOC_DTYPE)
+        root = np.frombuffer(bytes(root_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        self.eng._check(self.lib.ipcfp_hamt_get(self.eng.h, self.h, _p(root), bit_width, VALUE_KINDS[kind], _p(kb),
+                                                _p(ko), _p(kl), n, _p(st), _p(loc)), "hamt_get")
+        return st, loc
+
+    # -- verifiers (claim arrays are ctypes arrays of the ipcfp.h structs) -------------------
+    def verify_storage_proofs(self, claims_arr, n, trust=None):
+        st = np.zeros(n, dtype=np.uint8)
+        self.eng._check(self.lib.ipcfp_verify_storage_proofs(
+            self.eng.h, self.h, C.cast(claims_arr, C.c_void_p), n,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None, _p(st)), "verify_storage_proofs")
+        return st
+
+    def verify_event_proofs(self, claims_arr, n, trust=None, filt=None):
+        st = np.zeros(n, dtype=np.uint8)
+        self.eng._check(self.lib.ipcfp_verify_event_proofs(
+            self.eng.h, self.h, C.cast(claims_arr, C.c_void_p), n,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st)), "verify_event_proofs")
+        return st
 
     @property
     def cid_bitmap_ptr(self) -> int:

@@ -1,0 +1,90 @@
+// csrc/host/primitives.cpp — C-ABI entry points of the batch path-walk primitives.
+#include <cstring>
+
+#include "../common.h"
+#include "../kernels/launch.h"
+
+using namespace ipcfp;
+
+namespace ipcfp {
+
+WitnessView witness_view(const ipcfp_witness* w, uint32_t* touched_bits) {
+    WitnessView v;
+    v.arena = w->arena.p;
+    v.off = w->off.p;
+    v.len = w->len.p;
+    v.cids = w->cids.p;
+    v.slots = w->index_slots.p;
+    v.mask = w->index_mask;
+    v.n = uint32_t(w->n);
+    v.touched = touched_bits;
+    return v;
+}
+
+CidKey key_from_slot(const uint8_t* slot40) {
+    CidKey k;
+    std::memcpy(k.w, slot40, 40);
+    return k;
+}
+
+}  // namespace ipcfp
+
+extern "C" {
+
+int ipcfp_amt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid40, int version, int value_kind,
+                  const uint64_t* index, uint64_t n, ipcfp_status_t* status, ipcfp_value_loc_t* loc) {
+    if (!ctx || !w || w->ctx != ctx || !root_cid40 || (n && (!index || !status))) return IPCFP_E_INVALID;
+    if (version != 0 && version != 3) return set_error(ctx, IPCFP_E_INVALID, "AMT version must be 0 or 3");
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    if (n == 0) return IPCFP_OK;
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint64_t> idx;
+    DevBuf<uint8_t> st;
+    DevBuf<ipcfp_value_loc_t> lc;
+    IPCFP_HIP(ctx, idx.alloc(n));
+    IPCFP_HIP(ctx, st.alloc(n));
+    IPCFP_HIP(ctx, lc.alloc(n));
+    IPCFP_HIP(ctx, hipMemcpyAsync(idx.p, index, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_amt_get(ctx, witness_view(w), key_from_slot(root_cid40), version, value_kind, idx.p, uint32_t(n),
+                            st.p, lc.p);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipMemcpyAsync(status, st.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (loc) IPCFP_HIP(ctx, hipMemcpyAsync(loc, lc.p, n * sizeof(ipcfp_value_loc_t), hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+
+int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid40, uint32_t bit_width,
+                   int value_kind, const uint8_t* keys, const uint32_t* key_off, const uint32_t* key_len, uint64_t n,
+                   ipcfp_status_t* status, ipcfp_value_loc_t* loc) {
+    if (!ctx || !w || w->ctx != ctx || !root_cid40 || (n && (!keys || !key_off || !key_len || !status)))
+        return IPCFP_E_INVALID;
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    if (n == 0) return IPCFP_OK;
+    uint64_t kbytes = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t end = uint64_t(key_off[i]) + key_len[i];
+        if (end > kbytes) kbytes = end;
+    }
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf<uint8_t> kb, st;
+    DevBuf<uint32_t> ko, kl;
+    DevBuf<ipcfp_value_loc_t> lc;
+    IPCFP_HIP(ctx, kb.alloc(kbytes + 16));
+    IPCFP_HIP(ctx, ko.alloc(n));
+    IPCFP_HIP(ctx, kl.alloc(n));
+    IPCFP_HIP(ctx, st.alloc(n));
+    IPCFP_HIP(ctx, lc.alloc(n));
+    if (kbytes) IPCFP_HIP(ctx, hipMemcpyAsync(kb.p, keys, kbytes, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(ko.p, key_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(kl.p, key_len, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_hamt_get(ctx, witness_view(w), key_from_slot(root_cid40), bit_width, value_kind, kb.p, ko.p, kl.p,
+                             uint32_t(n), st.p, lc.p);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipMemcpyAsync(status, st.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    if (loc) IPCFP_HIP(ctx, hipMemcpyAsync(loc, lc.p, n * sizeof(ipcfp_value_loc_t), hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+
+}  // extern "C"

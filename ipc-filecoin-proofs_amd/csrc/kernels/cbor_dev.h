@@ -1,0 +1,387 @@
+// csrc/kernels/cbor_dev.h — strict DAG-CBOR reader for gfx950 device code.
+//
+// Device counterpart of every `serde_ipld_dagcbor::from_slice` /
+// `fvm_ipld_encoding::from_slice` the reference performs on witness blocks
+// (src/proofs/common/decode.rs:26,81,90,122; src/proofs/storage/decode.rs:46-85;
+// src/proofs/events/utils.rs:25,61; src/proofs/events/verifier.rs:158,174,217) and of
+// the typed values fvm_ipld_amt / fvm_ipld_hamt decode inside nodes.
+//
+// Rules (identical to oracle/cbor.hpp so parity is well defined):
+// definite lengths only; tag 42 only, payload a byte string starting 0x00 holding ONE
+// well-formed CID; text must be UTF-8; simple values false/true/null; floats 64-bit only;
+// non-minimal integer encodings accepted; trailing bytes after the top-level item are an
+// error (finish()).
+//
+// Error model: the reader is STICKY — the first violation stores a status code in
+// `err` (IPCFP_ST_ERR_DECODE) and every later call is a no-op returning 0, so walk code
+// reads straight-line and checks `err` where the reference's `?` would return.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ipcfp.h"
+#include "witness_dev.h"
+
+namespace ipcfp {
+
+struct Rd {
+    const uint8_t* p;
+    uint32_t n;
+    uint32_t pos;
+    uint32_t err;
+
+    __device__ __forceinline__ void init(const uint8_t* data, uint32_t len) {
+        p = data;
+        n = len;
+        pos = 0;
+        err = 0;
+    }
+    __device__ __forceinline__ void fail() {
+        if (!err) err = IPCFP_ST_ERR_DECODE;
+    }
+    __device__ __forceinline__ bool ok() const { return err == 0; }
+
+    // next byte without consuming; 0xff (never a valid start we rely on) when failed / at end
+    __device__ __forceinline__ uint32_t peek() {
+        if (err) return 0xff;
+        if (pos >= n) {
+            fail();
+            return 0xff;
+        }
+        return p[pos];
+    }
+
+    // item header → major type, argument
+    __device__ __forceinline__ void head(uint32_t& major, uint64_t& arg) {
+        major = 8;  // invalid
+        arg = 0;
+        if (err) return;
+        if (pos >= n) return fail();
+        const uint32_t b = p[pos++];
+        const uint32_t m = b >> 5, ai = b & 31u;
+        if (ai < 24) {
+            if (m == 7 && !(ai >= 20 && ai <= 22)) return fail();
+            major = m;
+            arg = ai;
+            return;
+        }
+        if (m == 7 && ai != 27) return fail();
+        if (ai > 27) return fail();  // indefinite length / reserved
+        const uint32_t nb = 1u << (ai - 24);
+        if (nb > n - pos) return fail();
+        uint64_t v = 0;
+        for (uint32_t k = 0; k < nb; ++k) v = (v << 8) | p[pos + k];
+        pos += nb;
+        major = m;
+        arg = v;
+    }
+
+    __device__ __forceinline__ uint64_t read_uint() {
+        uint32_t m;
+        uint64_t a;
+        head(m, a);
+        if (err) return 0;
+        if (m != 0) {
+            fail();
+            return 0;
+        }
+        return a;
+    }
+    // i64 (major 0 or 1)
+    __device__ __forceinline__ long long read_int() {
+        uint32_t m;
+        uint64_t a;
+        head(m, a);
+        if (err) return 0;
+        if ((m != 0 && m != 1) || a > 0x7fffffffffffffffULL) {
+            fail();
+            return 0;
+        }
+        return m == 0 ? (long long)a : -1 - (long long)a;
+    }
+    // byte string → offset of its first byte (relative to p) and length
+    __device__ __forceinline__ void read_bytes(uint32_t& off, uint32_t& len) {
+        off = len = 0;
+        uint32_t m;
+        uint64_t a;
+        head(m, a);
+        if (err) return;
+        if (m != 2 || a > uint64_t(n - pos)) return fail();
+        off = pos;
+        len = uint32_t(a);
+        pos += len;
+    }
+    // NOTE: deliberately NOT inlined.  With this loop inlined into read_text, hipcc 7.2
+    // (AMD clang 22.0.0git) mis-structurises the caller's control flow on gfx950: the success
+    // path of read_text picks up the zero that the failure paths assign to `off`
+    // (reproduced stand-alone; the LLVM IR is correct, the emitted ISA is not).  Keeping the
+    // loop out of line keeps the callers' CFG simple; text items are short map/entry keys.
+    __device__ __noinline__ bool utf8_ok(uint32_t off, uint32_t len) const {
+        uint32_t i = 0;
+        while (i < len) {
+            const uint32_t c = p[off + i];
+            if (c < 0x80) {
+                ++i;
+                continue;
+            }
+            uint32_t need, cp;
+            if ((c & 0xE0) == 0xC0) { need = 1; cp = c & 0x1F; }
+            else if ((c & 0xF0) == 0xE0) { need = 2; cp = c & 0x0F; }
+            else if ((c & 0xF8) == 0xF0) { need = 3; cp = c & 0x07; }
+            else return false;
+            if (need > len - i - 1) return false;
+            for (uint32_t k = 1; k <= need; ++k) {
+                const uint32_t cc = p[off + i + k];
+                if ((cc & 0xC0) != 0x80) return false;
+                cp = (cp << 6) | (cc & 0x3F);
+            }
+            if (need == 1 && cp < 0x80) return false;
+            if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) return false;
+            if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) return false;
+            i += need + 1;
+        }
+        return true;
+    }
+    __device__ __forceinline__ void read_text(uint32_t& off, uint32_t& len) {
+        off = len = 0;
+        uint32_t m;
+        uint64_t a;
+        head(m, a);
+        if (err) return;
+        if (m != 3 || a > uint64_t(n - pos)) return fail();
+        if (!utf8_ok(pos, uint32_t(a))) return fail();
+        off = pos;
+        len = uint32_t(a);
+        pos += len;
+    }
+    __device__ __forceinline__ uint64_t read_array() {
+        uint32_t m;
+        uint64_t a;
+        head(m, a);
+        if (err) return 0;
+        if (m != 4) {
+            fail();
+            return 0;
+        }
+        return a;
+    }
+    __device__ __forceinline__ void expect_array(uint64_t len) {
+        const uint64_t a = read_array();
+        if (!err && a != len) fail();
+    }
+    __device__ __forceinline__ uint64_t read_map() {
+        uint32_t m;
+        uint64_t a;
+        head(m, a);
+        if (err) return 0;
+        if (m != 5) {
+            fail();
+            return 0;
+        }
+        return a;
+    }
+    __device__ __forceinline__ bool at_null() { return !err && pos < n && p[pos] == 0xf6; }
+    __device__ __forceinline__ void read_null() {
+        if (err) return;
+        if (pos >= n || p[pos] != 0xf6) return fail();
+        ++pos;
+    }
+
+    // one well-formed binary CID in p[off, off+len)?  (oracle/cid.hpp cid_parse_binary)
+    __device__ __forceinline__ bool cid_ok(uint32_t off, uint32_t len) const {
+        if (len == 34 && p[off] == 0x12 && p[off + 1] == 0x20) return true;  // CIDv0
+        uint32_t q = off;
+        const uint32_t end = off + len;
+        uint64_t field[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            uint64_t v = 0;
+            bool done = false;
+            for (int shift = 0; shift < 63; shift += 7) {
+                if (q >= end) return false;
+                const uint32_t c = p[q++];
+                v |= uint64_t(c & 0x7f) << shift;
+                if (!(c & 0x80)) {
+                    if (c == 0 && shift > 0) return false;  // non-minimal varint
+                    done = true;
+                    break;
+                }
+            }
+            if (!done) return false;
+            field[f] = v;
+        }
+        if (field[0] != 1) return false;        // version
+        if (field[3] > 64) return false;        // multihash size
+        return uint64_t(end - q) == field[3];   // digest fills the rest exactly
+    }
+    // tag-42 link → offset/len of the CID bytes (without the 0x00 prefix)
+    __device__ __forceinline__ void read_link(uint32_t& off, uint32_t& len) {
+        off = len = 0;
+        uint32_t m;
+        uint64_t a;
+        head(m, a);
+        if (err) return;
+        if (m != 6 || a != 42) return fail();
+        uint32_t bo, bl;
+        read_bytes(bo, bl);
+        if (err) return;
+        if (bl < 1 || p[bo] != 0x00) return fail();
+        if (!cid_ok(bo + 1, bl - 1)) return fail();
+        off = bo + 1;
+        len = bl - 1;
+    }
+    // the link as a witness key (CIDs longer than the 40-byte slot cannot be witness keys:
+    // they are still VALID links, but can never be found → the caller sees kNoBlock)
+    __device__ __forceinline__ bool read_link_key(CidKey& key) {
+        uint32_t off, len;
+        read_link(off, len);
+        if (err) return false;
+        if (len > 40) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) key.w[j] = ~0ULL;  // not a possible key (slot bytes 38..39 are zero)
+            return true;
+        }
+        key = cid_key_from_bytes(p + off, len);
+        return true;
+    }
+
+    // IgnoredAny: skip exactly one well-formed item (iterative; maps count 2 items per pair)
+    __device__ __forceinline__ void skip() {
+        uint64_t todo = 1;
+        while (todo && !err) {
+            --todo;
+            uint32_t m;
+            uint64_t a;
+            head(m, a);
+            if (err) return;
+            switch (m) {
+                case 0:
+                case 1:
+                case 7:
+                    break;
+                case 2:
+                    if (a > uint64_t(n - pos)) return fail();
+                    pos += uint32_t(a);
+                    break;
+                case 3:
+                    if (a > uint64_t(n - pos)) return fail();
+                    if (!utf8_ok(pos, uint32_t(a))) return fail();
+                    pos += uint32_t(a);
+                    break;
+                case 4:
+                    if (a > uint64_t(n - pos)) return fail();
+                    todo += a;
+                    break;
+                case 5:
+                    if (a > uint64_t(n - pos) / 2) return fail();
+                    todo += 2 * a;
+                    break;
+                case 6: {
+                    if (a != 42) return fail();
+                    uint32_t bo, bl;
+                    read_bytes(bo, bl);
+                    if (err) return;
+                    if (bl < 1 || p[bo] != 0x00 || !cid_ok(bo + 1, bl - 1)) return fail();
+                    break;
+                }
+                default:
+                    return fail();
+            }
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (!err && pos != n) fail();
+    }
+};
+
+// ---- typed value checks (what serde does when it decodes Vec<V> / bucket values) ----
+enum ValueKind : int { VK_CID = 0, VK_RECEIPT = 1, VK_STAMPED_EVENT = 2, VK_ACTOR_STATE = 3, VK_VEC_U8 = 4, VK_ANY = 5 };
+
+__device__ __forceinline__ void check_receipt(Rd& r) {  // fvm_shared Receipt
+    r.expect_array(4);
+    if (r.read_uint() > 0xffffffffULL) r.fail();  // exit_code: u32
+    uint32_t o, l;
+    r.read_bytes(o, l);
+    (void)r.read_uint();
+    if (r.at_null()) r.read_null();
+    else r.read_link(o, l);
+}
+
+__device__ __forceinline__ void check_stamped_event(Rd& r) {
+    r.expect_array(2);
+    (void)r.read_uint();
+    const uint64_t ne = r.read_array();
+    for (uint64_t i = 0; i < ne && r.ok(); ++i) {
+        uint32_t o, l;
+        r.expect_array(4);
+        (void)r.read_uint();
+        r.read_text(o, l);
+        (void)r.read_uint();
+        r.read_bytes(o, l);
+    }
+}
+
+__device__ __forceinline__ void check_address(Rd& r, uint32_t off, uint32_t n) {  // Address::from_bytes shape
+    if (n < 1) return r.fail();
+    const uint8_t* p = r.p + off;
+    const uint32_t proto = p[0];
+    if (proto == 0 || proto == 4) {
+        uint32_t pos = 1;
+        bool term = false;
+        for (int k = 0; k < 10; ++k) {
+            if (pos >= n) return r.fail();
+            if (!(p[pos++] & 0x80)) {
+                term = true;
+                break;
+            }
+        }
+        if (!term) return r.fail();
+        if (proto == 0) {
+            if (pos != n) r.fail();
+        } else if (n - pos > 54) {
+            r.fail();
+        }
+    } else if (proto == 1 || proto == 2) {
+        if (n != 21) r.fail();
+    } else if (proto == 3) {
+        if (n != 49) r.fail();
+    } else {
+        r.fail();
+    }
+}
+
+__device__ __forceinline__ void check_actor_state(Rd& r) {
+    uint32_t o, l;
+    r.expect_array(5);
+    r.read_link(o, l);
+    r.read_link(o, l);
+    (void)r.read_uint();
+    r.read_bytes(o, l);  // TokenAmount: sign byte 0|1 + magnitude, ≤ 128 bytes
+    if (r.ok() && (l > 128 || (l > 0 && r.p[o] > 1))) r.fail();
+    if (r.at_null()) r.read_null();
+    else {
+        r.read_bytes(o, l);
+        if (r.ok()) check_address(r, o, l);
+    }
+}
+
+__device__ __forceinline__ void check_vec_u8(Rd& r) {  // serde Vec<u8> = array of u8
+    const uint64_t n = r.read_array();
+    for (uint64_t i = 0; i < n && r.ok(); ++i)
+        if (r.read_uint() > 255) r.fail();
+}
+
+__device__ __forceinline__ void check_value(Rd& r, int kind) {
+    uint32_t o, l;
+    switch (kind) {
+        case VK_CID: r.read_link(o, l); break;
+        case VK_RECEIPT: check_receipt(r); break;
+        case VK_STAMPED_EVENT: check_stamped_event(r); break;
+        case VK_ACTOR_STATE: check_actor_state(r); break;
+        case VK_VEC_U8: check_vec_u8(r); break;
+        default: r.skip(); break;
+    }
+}
+
+}  // namespace ipcfp

@@ -4,6 +4,7 @@
 #include <cstdint>
 
 #include "../common.h"
+#include "witness_dev.h"
 
 namespace ipcfp {
 
@@ -30,5 +31,20 @@ int launch_keccak256(ipcfp_ctx* ctx, const uint8_t* bytes, const uint64_t* off, 
                      uint8_t* out32);
 int launch_sha256(ipcfp_ctx* ctx, const uint8_t* bytes, const uint64_t* off, const uint32_t* len, uint32_t n,
                   uint8_t* out32);
+
+// --- walk.hip (K5 amt_get, K7 hamt_get) ---
+int launch_amt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, int version, int vkind,
+                   const uint64_t* index_d, uint32_t n, uint8_t* status_d, void* loc_d);
+int launch_hamt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
+                    const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
+                    uint8_t* status_d, void* loc_d);
+
+// --- verify_storage.hip ---
+struct StorageClaimPacked;
+int launch_verify_storage(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,
+                          const ipcfp_trust_policy_t& trust, uint8_t* status_d);
+
+// device view of a witness (host helper, witness.cpp)
+WitnessView witness_view(const ipcfp_witness* w, uint32_t* touched_bits = nullptr);
 
 }  // namespace ipcfp

@@ -1,0 +1,121 @@
+// csrc/kernels/types_dev.h — typed DAG-CBOR decodes of the chain objects on the hot path
+// (device side; same shapes as oracle/types.cpp).
+#pragma once
+#include "walk_dev.h"
+
+namespace ipcfp {
+
+constexpr uint32_t kMaxParents = 16;  // tipset keys are small (mainnet: ≤ ~10 blocks); engine limit, see DESIGN.md
+
+// HeaderLite (src/proofs/common/decode.rs:100-118): 16-tuple; fields 5,7,8,9,10,12,14 typed.
+struct HeaderLite {
+    uint32_t parents_off;  // offset of the first parent link item (after the array header)
+    uint32_t n_parents;
+    long long height;
+    CidKey parent_state_root, parent_message_receipts, messages;
+};
+
+// from_slice::<HeaderLite>(raw): TRUE or ERR_DECODE
+__device__ __forceinline__ uint32_t decode_header(Rd& r, HeaderLite& h) {
+    r.expect_array(16);
+    for (int i = 0; i < 5; ++i) r.skip();
+    const uint64_t np = r.read_array();
+    h.parents_off = r.pos;
+    h.n_parents = np > 0xffffffffULL ? 0xffffffffu : uint32_t(np);
+    for (uint64_t i = 0; i < np && r.ok(); ++i) {
+        uint32_t o, l;
+        r.read_link(o, l);
+    }
+    r.skip();
+    h.height = r.read_int();
+    r.read_link_key(h.parent_state_root);
+    r.read_link_key(h.parent_message_receipts);
+    r.read_link_key(h.messages);
+    r.skip();
+    (void)r.read_uint();
+    r.skip();
+    (void)r.read_uint();
+    r.skip();
+    r.finish();
+    return r.ok() ? IPCFP_ST_TRUE : IPCFP_ST_ERR_DECODE;
+}
+
+// `bs.get(cid)?.ok_or(..)?` + from_slice::<HeaderLite>
+__device__ __forceinline__ uint32_t load_header(const WitnessView& w, const CidKey& cid, HeaderLite& h, uint32_t& block) {
+    block = witness_find(w, cid);
+    if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+    Rd r = open_block(w, block);
+    return decode_header(r, h);
+}
+
+// Address::new_id(id).to_bytes() = 00 ‖ uvarint(id)  (≤ 11 bytes)
+__device__ __forceinline__ uint32_t id_address_bytes(uint64_t id, uint8_t out[12]) {
+    uint32_t n = 0;
+    out[n++] = 0;
+    do {
+        uint8_t c = id & 0x7f;
+        id >>= 7;
+        if (id) c |= 0x80;
+        out[n++] = c;
+    } while (id);
+    return n;
+}
+
+// get_actor_state (src/proofs/common/decode.rs:17-42) → the actor's `state` CID.
+__device__ __forceinline__ uint32_t get_actor_state(const WitnessView& w, const CidKey& state_root, uint64_t actor_id,
+                                                    CidKey& actor_state) {
+    const uint32_t b = witness_find(w, state_root);
+    if (b == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;  // decode.rs:23-25
+    Rd r = open_block(w, b);
+    r.expect_array(3);  // StateRoot [version, actors, info]   decode.rs:26
+    if (r.read_uint() > 5) r.fail();
+    CidKey actors, info;
+    r.read_link_key(actors);
+    r.read_link_key(info);
+    r.finish();
+    if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+    uint8_t key[12];
+    const uint32_t kl = id_address_bytes(actor_id, key);  // decode.rs:34
+    ValueLoc loc;
+    const uint32_t st = hamt_get(w, actors, 5, VK_ACTOR_STATE, key, kl, loc);  // decode.rs:29-37
+    if (st == IPCFP_ST_NOT_FOUND) return IPCFP_ST_ERR_ACTOR_NOT_FOUND;          // decode.rs:39
+    if (st != IPCFP_ST_TRUE) return st;
+    Rd v;
+    v.init(w.arena + w.off[loc.block] + loc.off, loc.len);
+    CidKey code;
+    v.expect_array(5);
+    v.read_link_key(code);
+    v.read_link_key(actor_state);
+    return v.ok() ? IPCFP_ST_TRUE : IPCFP_ST_ERR_DECODE;
+}
+
+// one attempt of parse_evm_state: `fields`-tuple [bytecode cid, bytecode_hash bytes(32), contract_state cid,
+// (reserved?), nonce u64, tombstone?]
+__device__ __forceinline__ bool try_evm_state(const WitnessView& w, uint32_t block, int fields, CidKey& contract_state) {
+    Rd r = open_block(w, block);
+    CidKey bytecode;
+    r.expect_array(uint64_t(fields));
+    r.read_link_key(bytecode);
+    uint32_t o, l;
+    r.read_bytes(o, l);
+    if (r.ok() && l != 32) r.fail();
+    r.read_link_key(contract_state);
+    if (fields == 6) {
+        if (r.at_null()) r.read_null();
+        else r.skip();
+    }
+    (void)r.read_uint();
+    if (r.at_null()) r.read_null();
+    else r.skip();
+    r.finish();
+    return r.ok();
+}
+
+// parse_evm_state (src/proofs/common/decode.rs:79-97): V6 first, then V5
+__device__ __forceinline__ uint32_t parse_evm_state(const WitnessView& w, uint32_t block, CidKey& contract_state) {
+    if (try_evm_state(w, block, 6, contract_state)) return IPCFP_ST_TRUE;
+    if (try_evm_state(w, block, 5, contract_state)) return IPCFP_ST_TRUE;
+    return IPCFP_ST_ERR_DECODE;
+}
+
+}  // namespace ipcfp

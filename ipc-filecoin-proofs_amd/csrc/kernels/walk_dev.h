@@ -1,0 +1,299 @@
+// csrc/kernels/walk_dev.h — AMT / HAMT path walks on the HBM-resident witness, one query
+// per lane.
+//
+// Device counterparts of (crates fvm_ipld_amt 0.7.4 / fvm_ipld_hamt 0.10.4, restated in
+// oracle/amt.cpp, oracle/hamt.cpp):
+//   Amtv0::<V>::load(root).get(i)   src/proofs/events/verifier.rs:220-226
+//   Amt::<V>::load(root).get(i)     src/proofs/events/verifier.rs:234-239
+//   Hamt::load_with_bit_width(root, bw).get(key)
+//                                   src/proofs/common/decode.rs:29-39, src/proofs/storage/decode.rs:79-96
+// Semantics kept exact: `load` reads and fully decodes the root block; every visited node
+// is decoded COMPLETELY (all links are valid CIDs, all values type-check, counts match the
+// bitmap) before the next link is followed; a missing child block is Err, a clear bit is
+// None.  Node bitmaps are tiny (1-4 bytes for AMT, ≤ 4 for a bit-width-5 HAMT), so the
+// child select is a mask + popcount in registers.
+#pragma once
+#include "cbor_dev.h"
+#include "sha256_dev.h"
+
+namespace ipcfp {
+
+struct ValueLoc {
+    uint32_t block;  // witness block id
+    uint32_t off;    // byte offset of the value's CBOR item inside the block
+    uint32_t len;    // its encoded length
+};
+
+__device__ __forceinline__ Rd open_block(const WitnessView& w, uint32_t b) {
+    Rd r;
+    r.init(w.arena + w.off[b], w.len[b]);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// AMT
+// ---------------------------------------------------------------------------
+constexpr uint32_t kAmtMaxBitWidth = 8;
+
+struct AmtNode {
+    uint32_t width;       // 1 << bit_width
+    uint32_t bmap[8];     // up to 256 bits, bit i ⇔ bmap[i/32] >> (i%32)  (LSB-first bytes ⇒ same bit order)
+    uint32_t nlinks, nvalues;
+    // position bookkeeping for the entry the caller asked for
+    uint32_t want;        // ordinal (rank) of the wanted link/value, or ~0u
+    uint32_t want_off, want_len;  // value: item offset/len; link: CID bytes offset/len
+    __device__ __forceinline__ bool bit(uint32_t i) const { return (bmap[i >> 5] >> (i & 31)) & 1u; }
+    __device__ __forceinline__ uint32_t rank(uint32_t i) const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t lo = uint32_t(k) * 32u;
+            if (i >= lo + 32) r += __popc(bmap[k]);
+            else if (i > lo) r += __popc(bmap[k] & ((1u << (i - lo)) - 1u));
+        }
+        return r;
+    }
+    __device__ __forceinline__ uint32_t popcount() const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r += __popc(bmap[k]);
+        return r;
+    }
+};
+
+// Decode `[bmap, [links…], [values…]]` at r (CollapsedNode) and apply the expand() checks.
+// PASS 1 (sub == ~0u): only decode/validate.  With sub != ~0u the ordinal rank(sub) entry's
+// location is recorded (link CID bytes or value item).
+__device__ __forceinline__ void amt_read_node(Rd& r, uint32_t bw, int vkind, uint32_t sub, AmtNode& nd) {
+    nd.width = 1u << bw;
+    nd.nlinks = nd.nvalues = 0;
+    nd.want = ~0u;
+    nd.want_off = nd.want_len = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nd.bmap[k] = 0;
+    r.expect_array(3);
+    uint32_t bo, bl;
+    r.read_bytes(bo, bl);
+    if (!r.ok()) return;
+    const uint32_t need = (nd.width + 7) / 8;
+    const bool bmap_len_ok = bl == need;
+    // keep the bits we can hold; a wrong length is an error AFTER links/values decode (order is
+    // irrelevant: every failure here is ERR_DECODE)
+    for (uint32_t k = 0; k < bl && k < 32; ++k) nd.bmap[k >> 2] |= uint32_t(r.p[bo + k]) << (8 * (k & 3));
+    if (nd.width < 32) nd.bmap[0] &= (1u << nd.width) - 1u;  // bits ≥ width are ignored (bw < 3)
+    if (bmap_len_ok && sub != ~0u && sub < nd.width && nd.bit(sub)) nd.want = nd.rank(sub);
+    const uint64_t nl = r.read_array();
+    if (!r.ok()) return;
+    for (uint64_t i = 0; i < nl && r.ok(); ++i) {
+        uint32_t o, l;
+        r.read_link(o, l);
+        if (i == nd.want) {
+            nd.want_off = o;
+            nd.want_len = l;
+        }
+    }
+    const uint64_t nv = r.read_array();
+    if (!r.ok()) return;
+    for (uint64_t i = 0; i < nv && r.ok(); ++i) {
+        const uint32_t start = r.pos;
+        check_value(r, vkind);
+        if (i == nd.want) {
+            nd.want_off = start;
+            nd.want_len = r.pos - start;
+        }
+    }
+    if (!r.ok()) return;
+    nd.nlinks = nl > 0xffffffffULL ? 0xffffffffu : uint32_t(nl);
+    nd.nvalues = nv > 0xffffffffULL ? 0xffffffffu : uint32_t(nv);
+    if (nl && nv) return r.fail();    // LinksAndValues
+    if (!bmap_len_ok) return r.fail();
+    const uint64_t have = nl ? nl : nv;
+    if (have != nd.popcount()) return r.fail();
+}
+
+struct AmtRootInfo {
+    uint32_t block;
+    uint32_t node_off;  // offset of the inline root node
+    uint32_t bit_width;
+    uint64_t height, count;
+};
+
+// Amt::load / Amtv0::load.  Returns a status: TRUE on success, ERR_* otherwise.
+__device__ __forceinline__ uint32_t amt_load(const WitnessView& w, const CidKey& root, int version, int vkind,
+                                             AmtRootInfo& info) {
+    const uint32_t b = witness_find(w, root);
+    if (b == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+    Rd r = open_block(w, b);
+    info.block = b;
+    if (version == 0) {
+        r.expect_array(3);
+        info.bit_width = 3;
+    } else {
+        r.expect_array(4);
+        const uint64_t bw = r.read_uint();
+        if (r.ok() && (bw < 1 || bw > kAmtMaxBitWidth)) r.fail();
+        info.bit_width = uint32_t(bw);
+    }
+    info.height = r.read_uint();
+    info.count = r.read_uint();
+    info.node_off = r.pos;
+    if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+    AmtNode nd;
+    amt_read_node(r, info.bit_width, vkind, ~0u, nd);
+    r.finish();
+    if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+    if (info.height > 64 / info.bit_width) return IPCFP_ST_ERR_DECODE;  // MaxHeight
+    return IPCFP_ST_TRUE;
+}
+
+__device__ __forceinline__ uint64_t amt_span(uint32_t bw, uint64_t height) {
+    const uint64_t shift = uint64_t(bw) * height;
+    return shift >= 64 ? ~0ULL : (1ULL << shift);
+}
+
+// Amt::get(index) on a loaded root.  TRUE ⇒ loc set; NOT_FOUND ⇒ None; ERR_*.
+__device__ __forceinline__ uint32_t amt_get(const WitnessView& w, const AmtRootInfo& root, int vkind, uint64_t index,
+                                            ValueLoc& loc) {
+    if (index == ~0ULL) return IPCFP_ST_ERR;  // > MAX_INDEX
+    if (index >= amt_span(root.bit_width, root.height + 1)) return IPCFP_ST_NOT_FOUND;
+    uint32_t block = root.block;
+    uint32_t node_off = root.node_off;
+    uint64_t height = root.height;
+    uint64_t i = index;
+    const uint32_t bw = root.bit_width;
+    for (;;) {
+        Rd r = open_block(w, block);
+        r.pos = node_off;
+        const uint64_t span = amt_span(bw, height);
+        // which entry of this node do we need?  (decided before parsing so one pass finds it)
+        // Leaf: entry i; Link node: entry i / span.  The node kind is known only after parsing
+        // (links non-empty), so parse with the link-candidate and re-derive for leaves.
+        const uint64_t sub64 = i / span;
+        const uint32_t sub_link = sub64 < 256 ? uint32_t(sub64) : 0xfffffffeu;
+        const uint32_t sub_leaf = i < 256 ? uint32_t(i) : 0xfffffffeu;
+        AmtNode nd;
+        // First assume a link node unless height == 0 (span == 1 makes both candidates equal).
+        amt_read_node(r, bw, vkind, height == 0 ? sub_leaf : sub_link, nd);
+        if (node_off == 0) r.finish();  // a child block holds exactly one node; the root's tail was checked by load
+        if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+        if (nd.nlinks == 0) {
+            // Node::Leaf — `vals.get(i)`; at height > 0 the wanted ordinal must be re-derived for i
+            if (i >= nd.width || !nd.bit(uint32_t(i))) return IPCFP_ST_NOT_FOUND;
+            if (height != 0) {
+                Rd r2 = open_block(w, block);
+                r2.pos = node_off;
+                amt_read_node(r2, bw, vkind, uint32_t(i), nd);
+            }
+            loc.block = block;
+            loc.off = nd.want_off;
+            loc.len = nd.want_len;
+            return IPCFP_ST_TRUE;
+        }
+        if (height == 0) return IPCFP_ST_ERR_DECODE;  // link node at height 0
+        if (sub64 >= nd.width || !nd.bit(uint32_t(sub64))) return IPCFP_ST_NOT_FOUND;
+        const CidKey key = nd.want_len <= 40 ? cid_key_from_bytes(r.p + nd.want_off, nd.want_len)
+                                             : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+        const uint32_t child = witness_find(w, key);
+        if (child == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+        block = child;
+        node_off = 0;
+        i = i % span;
+        height -= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// HAMT
+// ---------------------------------------------------------------------------
+// Hamt::load_with_bit_width(root, bw).get(key): TRUE ⇒ loc set; NOT_FOUND; ERR_*.
+__device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
+                                             const uint8_t* key, uint32_t key_len, ValueLoc& loc) {
+    if (bit_width < 1 || bit_width > 8) return IPCFP_ST_ERR_DECODE;
+    uint32_t h[8];
+    sha256::hash_bytes(key, key_len, h);
+    uint32_t consumed = 0;
+    uint32_t block = witness_find(w, root);
+    if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+    for (;;) {
+        Rd r = open_block(w, block);
+        // HashBits::next happens after the node is decoded; compute idx first only when bits remain
+        const bool depth_ok = consumed + bit_width <= 256;
+        const uint32_t idx = depth_ok ? sha256::take_bits(h, consumed, bit_width) : 0;
+        // ---- decode the whole node: [bitfield bytes, [pointer…]] ----
+        r.expect_array(2);
+        uint32_t bo, bl;
+        r.read_bytes(bo, bl);
+        if (r.ok() && bl > 32) r.fail();
+        if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+        // big-endian integer, leading zeros stripped: byte k (from the END) holds bits 8k..8k+7
+        bool bit_set = false;
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < bl; ++k) {
+            const uint32_t byte = r.p[bo + bl - 1 - k];
+            const uint32_t lo = 8 * k;
+            if (idx >= lo + 8) rank += __popc(byte);
+            else if (idx >= lo) {
+                rank += __popc(byte & ((1u << (idx - lo)) - 1u));
+                bit_set = (byte >> (idx - lo)) & 1u;
+            }
+        }
+        const uint64_t np = r.read_array();
+        if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+        // outcome of the wanted pointer, filled while scanning
+        bool ptr_is_link = false;
+        uint32_t link_off = 0, link_len = 0;
+        bool found = false;
+        ValueLoc hit{};
+        for (uint64_t pi = 0; pi < np && r.ok(); ++pi) {
+            const bool wanted = bit_set && pi == rank;
+            const uint32_t b0 = r.peek();
+            if ((b0 >> 5) == 6) {
+                uint32_t o, l;
+                r.read_link(o, l);
+                if (wanted) {
+                    ptr_is_link = true;
+                    link_off = o;
+                    link_len = l;
+                }
+            } else if ((b0 >> 5) == 4) {
+                const uint64_t nkv = r.read_array();
+                for (uint64_t k = 0; k < nkv && r.ok(); ++k) {
+                    r.expect_array(2);
+                    uint32_t ko, kl;
+                    r.read_bytes(ko, kl);
+                    const uint32_t vstart = r.pos;
+                    check_value(r, vkind);
+                    if (wanted && r.ok() && !found && kl == key_len) {
+                        bool eq = true;
+                        for (uint32_t c = 0; c < kl; ++c) eq &= r.p[ko + c] == key[c];
+                        if (eq) {
+                            found = true;
+                            hit.block = block;
+                            hit.off = vstart;
+                            hit.len = r.pos - vstart;
+                        }
+                    }
+                }
+            } else {
+                r.fail();
+            }
+        }
+        r.finish();
+        if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+        if (!depth_ok) return IPCFP_ST_ERR_MAX_DEPTH;
+        consumed += bit_width;
+        if (!bit_set) return IPCFP_ST_NOT_FOUND;
+        if (uint64_t(rank) >= np) return IPCFP_ST_ERR_DECODE;
+        if (!ptr_is_link) {
+            if (!found) return IPCFP_ST_NOT_FOUND;
+            loc = hit;
+            return IPCFP_ST_TRUE;
+        }
+        const CidKey ck = link_len <= 40 ? cid_key_from_bytes(r.p + link_off, link_len)
+                                         : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+        block = witness_find(w, ck);
+        if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+    }
+}
+
+}  // namespace ipcfp

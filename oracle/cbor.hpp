@@ -63,6 +63,42 @@ inline bool utf8_valid(const uint8_t* s, size_t n) {
     return true;
 }
 
+// ---- binary CID structure (cid 0.11 `Cid::read_bytes`; see oracle/cid.hpp) ----
+inline bool read_varint(const uint8_t* p, size_t n, size_t& pos, uint64_t& v) {
+    v = 0;
+    for (int shift = 0; shift < 63; shift += 7) {
+        if (pos >= n) return false;
+        const uint8_t c = p[pos++];
+        v |= uint64_t(c & 0x7f) << shift;
+        if (!(c & 0x80)) {
+            if (c == 0 && shift > 0) return false;  // unsigned-varint: non-minimal encoding rejected
+            return true;
+        }
+    }
+    return false;
+}
+
+struct CidParts {
+    uint64_t version = 0, codec = 0, mh_code = 0, mh_size = 0;
+    const uint8_t* digest = nullptr;
+};
+
+// Validate the binary form; true iff `p[0..n)` is exactly one well-formed CID.
+inline bool cid_parse_binary(const uint8_t* p, size_t n, CidParts& out) {
+    if (n == 34 && p[0] == 0x12 && p[1] == 0x20) {
+        out.version = 0; out.codec = 0x70; out.mh_code = 0x12; out.mh_size = 32; out.digest = p + 2;
+        return true;
+    }
+    size_t pos = 0;
+    if (!read_varint(p, n, pos, out.version) || out.version != 1) return false;
+    if (!read_varint(p, n, pos, out.codec)) return false;
+    if (!read_varint(p, n, pos, out.mh_code)) return false;
+    if (!read_varint(p, n, pos, out.mh_size) || out.mh_size > 64) return false;
+    if (n - pos != out.mh_size) return false;
+    out.digest = p + pos;
+    return true;
+}
+
 struct Reader {
     const uint8_t* p;
     size_t n;
@@ -210,6 +246,8 @@ struct Reader {
                     const uint8_t* q; size_t l;
                     read_bytes(q, l);
                     if (l < 1 || q[0] != 0x00) decode_err("CID link must start with 0x00");
+                    CidParts parts;  // deserialize_any on tag 42 builds a Cid, so the bytes must parse
+                    if (!cid_parse_binary(q + 1, l - 1, parts)) decode_err("malformed CID in link");
                     break;
                 }
                 case 7: break;  // false/true/null/f64: validated by head()

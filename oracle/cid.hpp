@@ -31,41 +31,6 @@ struct Cid {
     bool operator<(const Cid& o) const;
 };
 
-inline bool read_varint(const uint8_t* p, size_t n, size_t& pos, uint64_t& v) {
-    v = 0;
-    for (int shift = 0; shift < 63; shift += 7) {
-        if (pos >= n) return false;
-        const uint8_t c = p[pos++];
-        v |= uint64_t(c & 0x7f) << shift;
-        if (!(c & 0x80)) {
-            if (c == 0 && shift > 0) return false;  // unsigned-varint: non-minimal encoding rejected
-            return true;
-        }
-    }
-    return false;
-}
-
-struct CidParts {
-    uint64_t version = 0, codec = 0, mh_code = 0, mh_size = 0;
-    const uint8_t* digest = nullptr;
-};
-
-// Validate the binary form; true iff `p[0..n)` is exactly one well-formed CID.
-inline bool cid_parse_binary(const uint8_t* p, size_t n, CidParts& out) {
-    if (n == 34 && p[0] == 0x12 && p[1] == 0x20) {
-        out.version = 0; out.codec = 0x70; out.mh_code = 0x12; out.mh_size = 32; out.digest = p + 2;
-        return true;
-    }
-    size_t pos = 0;
-    if (!read_varint(p, n, pos, out.version) || out.version != 1) return false;
-    if (!read_varint(p, n, pos, out.codec)) return false;
-    if (!read_varint(p, n, pos, out.mh_code)) return false;
-    if (!read_varint(p, n, pos, out.mh_size) || out.mh_size > 64) return false;
-    if (n - pos != out.mh_size) return false;
-    out.digest = p + pos;
-    return true;
-}
-
 inline bool Cid::operator<(const Cid& o) const {
     CidParts x, y;
     if (!cid_parse_binary(b.data(), b.size(), x) || !cid_parse_binary(o.b.data(), o.b.size(), y)) return b < o.b;
