@@ -226,6 +226,16 @@ int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid
                    int value_kind, const uint8_t* keys, const uint32_t* key_off, const uint32_t* key_len, uint64_t n,
                    ipcfp_status_t* status, ipcfp_value_loc_t* loc);
 
+/* `reconstruct_execution_order(bs, parent_hdr_cids)` (src/proofs/events/utils.rs:16-30 →
+ * collect_exec_list(verify_txmeta = true), :48-94): per parent header the TxMeta is loaded and
+ * re-hashed (Blake2b-256 of its canonical encoding must reproduce the header's `messages` CID),
+ * then the BLS and secp message AMTs are walked; a CID seen before is skipped.
+ *   *status_out  IPCFP_ST_TRUE, or the ERR_* the reference's `?` would surface first
+ *   *count       number of messages in execution order
+ *   out_cids40   receives min(*count, cap) message CIDs in execution order (nullable)        */
+int ipcfp_exec_order(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                     ipcfp_status_t* status_out, uint8_t* out_cids40, uint64_t cap, uint64_t* count);
+
 /* ---- proof claims (string form, exactly the reference's structs) ----------
  * CIDs and hex values are NUL-terminated strings, as in the reference's serde
  * structs; the host parses them once per batch (src/proofs/common/witness.rs:60-72).

@@ -150,6 +150,7 @@ def load_library() -> C.CDLL:
         "ipcfp_sha256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
         "ipcfp_amt_get": (i32, [vp, vp, vp, i32, i32, vp, u64, vp, vp]),
         "ipcfp_hamt_get": (i32, [vp, vp, vp, C.c_uint32, i32, vp, vp, vp, u64, vp, vp]),
+        "ipcfp_exec_order": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
         "ipcfp_verify_storage_proofs": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_verify_event_proofs": (i32, [vp, vp, vp, u64, vp, vp, vp]),
@@ -371,6 +372,23 @@ class Witness:
         self.eng._check(self.lib.ipcfp_hamt_get(self.eng.h, self.h, _p(root), bit_width, VALUE_KINDS[kind], _p(kb),
                                                 _p(ko), _p(kl), n, _p(st), _p(loc)), "hamt_get")
         return st, loc
+
+    def exec_order(self, parent_cids, cap=None):
+        """reconstruct_execution_order → (status, cids u8[count, 40])."""
+        pc = np.zeros((max(len(parent_cids), 1), CID_SLOT), dtype=np.uint8)
+        for i, c in enumerate(parent_cids):
+            pc[i, : len(c)] = np.frombuffer(bytes(c), dtype=np.uint8)
+        st = np.zeros(1, dtype=np.uint8)
+        cnt = C.c_uint64()
+        # first call: count only
+        self.eng._check(self.lib.ipcfp_exec_order(self.eng.h, self.h, _p(pc), len(parent_cids), _p(st), None, 0,
+                                                  C.byref(cnt)), "exec_order")
+        n = int(cnt.value) if cap is None else min(int(cnt.value), cap)
+        out = np.zeros((n, CID_SLOT), dtype=np.uint8)
+        if n:
+            self.eng._check(self.lib.ipcfp_exec_order(self.eng.h, self.h, _p(pc), len(parent_cids), _p(st), _p(out), n,
+                                                      C.byref(cnt)), "exec_order")
+        return int(st[0]), out
 
     # -- verifiers (claim arrays are ctypes arrays of the ipcfp.h structs) -------------------
     def verify_storage_proofs(self, claims_arr, n, trust=None):

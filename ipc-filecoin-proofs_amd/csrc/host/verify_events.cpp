@@ -1,7 +1,274 @@
-// csrc/host/verify_events.cpp — placeholder until the event path lands (next commit).
+// csrc/host/verify_events.cpp — `verify_event_proof` batches and `reconstruct_execution_order`.
+//
+// Host side of src/proofs/events/verifier.rs:51-74: parse the claim strings once, group the
+// proofs by tipset context (parent_tipset_cids, child_block_cid), prepare each context on the
+// device (header facts + execution order — both recomputed PER PROOF by the reference,
+// events/verifier.rs:105,115,190), then verify the whole batch with one kernel.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
 #include "../common.h"
+#include "../kernels/claims_dev.h"
+#include "../kernels/exec_order.h"
+#include "../kernels/launch.h"
+#include "cidstr.h"
+
 using namespace ipcfp;
-extern "C" int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t*, const ipcfp_event_proof_t*, uint64_t,
-                                         const ipcfp_trust_policy_t*, const ipcfp_event_filter_t*, ipcfp_status_t*) {
-    return set_error(ctx, IPCFP_E_UNSUPPORTED, "ipcfp_verify_event_proofs: not built yet");
+
+namespace ipcfp {
+
+void parse_cid_claim(const char* s, CidKey& key, bool& parsed, bool& canonical);
+CidKey key_from_slot(const uint8_t* slot40);
+
+// device buffers of one context's execution order
+struct ExecState {
+    DevBuf<CidKey> keys;        // raw for_each sequence
+    DevBuf<uint32_t> slots;     // hash table → first raw position
+    DevBuf<uint32_t> first;     // 1 where the raw position is a first occurrence
+    DevBuf<uint32_t> pos;       // exclusive scan of `first` → execution index
+    uint32_t mask = 0;
+    uint64_t raw_len = 0, exec_len = 0;
+    uint32_t status = IPCFP_ST_ERR;
+};
+
+// Reconstruct the execution order of the context stored at ctx_d (device) on the device.
+int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
+                     ExecState& ex) {
+    DevBuf<AmtRootSpec> roots;
+    DevBuf<unsigned long long> err;
+    IPCFP_HIP(ctx, roots.alloc(2 * size_t(n_parents) + 1));
+    IPCFP_HIP(ctx, err.alloc(1));
+    int rc = launch_exec_roots(ctx, view, ctx_d, roots.p, err.p);
+    if (rc) return rc;
+    AmtEnumResult en;
+    rc = amt_enumerate(ctx, view, roots.p, 2 * n_parents, VK_CID, err.p, en);
+    if (rc) return rc;
+    unsigned long long e = kNoEnumError;
+    IPCFP_HIP(ctx, hipMemcpyAsync(&e, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ex.status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
+    ex.raw_len = ex.exec_len = 0;
+    if (ex.status != IPCFP_ST_TRUE) return IPCFP_OK;
+    const uint32_t n = uint32_t(en.n_leaves);
+    ex.raw_len = n;
+    uint32_t size = 64;
+    while (size < 2ull * n) size <<= 1;
+    ex.mask = size - 1;
+    IPCFP_HIP(ctx, ex.keys.alloc(n));
+    IPCFP_HIP(ctx, ex.slots.alloc(size));
+    IPCFP_HIP(ctx, ex.first.alloc(n));
+    IPCFP_HIP(ctx, ex.pos.alloc(n));
+    IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 4, ctx->stream));
+    rc = launch_exec_dedup(ctx, view, en.leaves.p, n, ex.keys.p, ex.slots.p, ex.mask, ex.first.p);
+    if (rc) return rc;
+    DevBuf<uint64_t> scratch, total;
+    IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
+    IPCFP_HIP(ctx, total.alloc(1));
+    rc = launch_scan_u32(ctx, ex.first.p, n, ex.pos.p, total.p, scratch.p);
+    if (rc) return rc;
+    uint64_t distinct = 0;
+    IPCFP_HIP(ctx, hipMemcpyAsync(&distinct, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `en.leaves` alive until the kernels are done
+    ex.exec_len = distinct;
+    return IPCFP_OK;
 }
+
+}  // namespace ipcfp
+
+namespace {
+
+const ipcfp_trust_policy_t kAcceptAllEv = {0, 0, 0, 0};
+
+bool parse_hex0x(const char* s, bool allow_upper_x, std::vector<uint8_t>& out) {
+    // the reference formats "0x" + lowercase hex and compares ignoring ASCII case, so a claimed
+    // string matches iff it is '0' 'x'|'X' followed by hex digits of the same bytes
+    if (!s || s[0] != '0' || !(s[1] == 'x' || (allow_upper_x && s[1] == 'X'))) return false;
+    return hex_decode(s + 2, std::strlen(s + 2), out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
+                              const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                              ipcfp_status_t* status) {
+    if (!ctx || !w || w->ctx != ctx || (n && (!proofs || !status))) return IPCFP_E_INVALID;
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    if (n == 0) return IPCFP_OK;
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+
+    // ---- parse claims, group by tipset context ----
+    std::vector<EventClaimPacked> packed(n);
+    std::vector<uint8_t> blob;
+    std::vector<TipsetCtxDev> tcs;
+    std::unordered_map<std::string, uint32_t> ctx_index;
+    const char* const* last_parents = nullptr;
+    const char* last_child = nullptr;
+    uint32_t last_np = 0, last_ctx = 0;
+    bool have_last = false;
+    for (uint64_t i = 0; i < n; ++i) {
+        const ipcfp_event_proof_t& p = proofs[i];
+        EventClaimPacked& c = packed[i];
+        std::memset(&c, 0, sizeof c);
+        c.parent_epoch = p.parent_epoch;
+        c.child_epoch = p.child_epoch;
+        c.exec_index = p.exec_index;
+        c.event_index = p.event_index;
+        c.emitter = p.emitter;
+        // context
+        uint32_t ci;
+        if (have_last && p.parent_tipset_cids == last_parents && p.child_block_cid == last_child &&
+            p.n_parent_tipset_cids == last_np) {
+            ci = last_ctx;  // same string arrays as the previous proof
+        } else {
+            std::string key;
+            for (uint32_t k = 0; k < p.n_parent_tipset_cids; ++k) {
+                key += p.parent_tipset_cids[k] ? p.parent_tipset_cids[k] : "";
+                key.push_back('\n');
+            }
+            key.push_back('|');
+            key += p.child_block_cid ? p.child_block_cid : "";
+            auto it = ctx_index.find(key);
+            if (it == ctx_index.end()) {
+                if (p.n_parent_tipset_cids > kMaxParents)
+                    return set_error(ctx, IPCFP_E_UNSUPPORTED, "proof %llu names %u parent blocks (engine limit %u)",
+                                     (unsigned long long)i, p.n_parent_tipset_cids, kMaxParents);
+                TipsetCtxDev tc;
+                std::memset(&tc, 0, sizeof tc);
+                tc.n_parents = p.n_parent_tipset_cids;
+                bool all = true;
+                for (uint32_t k = 0; k < tc.n_parents; ++k) {
+                    bool parsed, canon;
+                    parse_cid_claim(p.parent_tipset_cids[k], tc.parents[k], parsed, canon);
+                    all = all && parsed;
+                }
+                if (all) tc.flags |= TC_PARENTS_PARSED;
+                bool parsed, canon;
+                parse_cid_claim(p.child_block_cid, tc.child, parsed, canon);
+                if (parsed) tc.flags |= TC_CHILD_PARSED;
+                ci = uint32_t(tcs.size());
+                tcs.push_back(tc);
+                ctx_index.emplace(std::move(key), ci);
+            } else {
+                ci = it->second;
+            }
+            last_parents = p.parent_tipset_cids;
+            last_child = p.child_block_cid;
+            last_np = p.n_parent_tipset_cids;
+            last_ctx = ci;
+            have_last = true;
+        }
+        c.context = ci;
+        bool parsed, canon;
+        parse_cid_claim(p.message_cid, c.message, parsed, canon);
+        if (parsed) c.flags |= EC_MSG_PARSED;
+        // topics: n × [matchable, 32 bytes]
+        c.n_topics = p.n_topics;
+        c.topics_off = uint32_t(blob.size());
+        for (uint32_t k = 0; k < p.n_topics; ++k) {
+            std::vector<uint8_t> t;
+            const bool ok = parse_hex0x(p.topics ? p.topics[k] : nullptr, true, t) && t.size() == 32;
+            blob.push_back(ok ? 1 : 0);
+            const size_t at = blob.size();
+            blob.resize(at + 32, 0);
+            if (ok) std::memcpy(blob.data() + at, t.data(), 32);
+        }
+        std::vector<uint8_t> d;
+        if (parse_hex0x(p.data, true, d)) {
+            c.flags |= EC_DATA_MATCHABLE;
+            c.data_off = uint32_t(blob.size());
+            c.data_len = uint32_t(d.size());
+            blob.insert(blob.end(), d.begin(), d.end());
+        }
+        if (blob.size() >= 0xf0000000ULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "claim blob too large");
+    }
+
+    // ---- contexts on the device ----
+    const WitnessView view = witness_view(w);
+    DevBuf<TipsetCtxDev> tcs_d;
+    IPCFP_HIP(ctx, tcs_d.alloc(tcs.size()));
+    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
+                                  ctx->stream));
+    int rc = launch_ctx_headers(ctx, view, tcs_d.p, uint32_t(tcs.size()));
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipMemcpyAsync(tcs.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
+    for (size_t k = 0; k < tcs.size(); ++k) {
+        TipsetCtxDev& tc = tcs[k];
+        tc.exec_status = IPCFP_ST_ERR_BAD_CLAIM;
+        tc.exec_slots = nullptr;
+        // the execution order is only reached when steps 1-2 can pass for some proof of this context
+        const bool reachable = (tc.flags & TC_PARENTS_PARSED) && (tc.flags & TC_CHILD_PARSED) &&
+                               tc.child_status == IPCFP_ST_TRUE && tc.parents_match && tc.n_parents > 0 &&
+                               tc.parent0_status == IPCFP_ST_TRUE;
+        if (!reachable) continue;
+        execs[k].reset(new ExecState());
+        rc = build_exec_order(ctx, view, tcs_d.p + k, tc.n_parents, *execs[k]);
+        if (rc) return rc;
+        tc.exec_status = execs[k]->status;
+        tc.exec_mask = execs[k]->mask;
+        tc.exec_slots = execs[k]->slots.p;
+        tc.exec_keys = execs[k]->keys.p;
+        tc.exec_pos = execs[k]->pos.p;
+        tc.exec_len = execs[k]->exec_len;
+    }
+    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
+                                  ctx->stream));
+
+    // ---- the batch ----
+    DevBuf<EventClaimPacked> cd;
+    DevBuf<uint8_t> bd, sd;
+    IPCFP_HIP(ctx, cd.alloc(n));
+    IPCFP_HIP(ctx, bd.alloc(blob.size() + 64));
+    IPCFP_HIP(ctx, sd.alloc(n));
+    IPCFP_HIP(ctx, hipMemcpyAsync(cd.p, packed.data(), n * sizeof(EventClaimPacked), hipMemcpyHostToDevice, ctx->stream));
+    if (!blob.empty())
+        IPCFP_HIP(ctx, hipMemcpyAsync(bd.p, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_verify_events(ctx, view, cd.p, uint32_t(n), tcs_d.p, bd.p, trust ? *trust : kAcceptAllEv, filter, sd.p);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+
+// reconstruct_execution_order(bs, parent_hdr_cids) (src/proofs/events/utils.rs:16-30).
+//   *status_out  IPCFP_ST_TRUE or the ERR_* the reference's `?` would surface first
+//   *count       number of messages in execution order
+//   out_cids40   receives min(*count, cap) CIDs (40-byte slots), nullable
+int ipcfp_exec_order(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                     ipcfp_status_t* status_out, uint8_t* out_cids40, uint64_t cap, uint64_t* count) {
+    if (!ctx || !w || w->ctx != ctx || !status_out || !count || (n_parents && !parent_cids40)) return IPCFP_E_INVALID;
+    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    TipsetCtxDev tc;
+    std::memset(&tc, 0, sizeof tc);
+    tc.n_parents = n_parents;
+    tc.flags = TC_PARENTS_PARSED | TC_CHILD_PARSED;
+    for (uint32_t k = 0; k < n_parents; ++k) tc.parents[k] = key_from_slot(parent_cids40 + IPCFP_CID_SLOT * k);
+    DevBuf<TipsetCtxDev> tc_d;
+    IPCFP_HIP(ctx, tc_d.alloc(1));
+    IPCFP_HIP(ctx, hipMemcpyAsync(tc_d.p, &tc, sizeof tc, hipMemcpyHostToDevice, ctx->stream));
+    ExecState ex;
+    int rc = build_exec_order(ctx, witness_view(w), tc_d.p, n_parents, ex);
+    if (rc) return rc;
+    *status_out = ipcfp_status_t(ex.status);
+    *count = ex.status == IPCFP_ST_TRUE ? ex.exec_len : 0;
+    if (ex.status == IPCFP_ST_TRUE && out_cids40 && ex.exec_len) {
+        DevBuf<CidKey> out;
+        IPCFP_HIP(ctx, out.alloc(ex.exec_len));
+        rc = launch_exec_compact(ctx, ex.keys.p, uint32_t(ex.raw_len), ex.first.p, ex.pos.p, out.p);
+        if (rc) return rc;
+        const uint64_t take = ex.exec_len < cap ? ex.exec_len : cap;
+        IPCFP_HIP(ctx, hipMemcpyAsync(out_cids40, out.p, take * IPCFP_CID_SLOT, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return IPCFP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// csrc/kernels/amt_enum.h — level-synchronous `Amt::for_each` over the HBM-resident witness.
+//
+// The reference walks the big AMTs sequentially and depth-first
+// (`bls_amt.for_each`, `secp_amt.for_each` src/proofs/events/utils.rs:76-90; the receipts list that
+// drives `find_matching_events`, src/proofs/events/generator.rs:199-239).  Here every node of a level
+// is decoded by its own lane, children are placed with a prefix sum so ascending-index order is
+// preserved, and each node is decoded exactly once per pass.  Several AMTs (e.g. the BLS and secp
+// trees of every parent block) are enumerated TOGETHER: roots lower than the tallest tree ride along
+// as pass-through entries until their level comes up, so the output is the concatenation of the
+// for_each sequences in root order.
+//
+// Errors: `for_each` aborts at the first failing node in depth-first order.  Every failure here is
+// recorded as (sequence number, base index of the failing node, status code) packed into one u64
+// and combined with atomicMin — the minimum IS the first failure in depth-first order, because a
+// failing node has no descendants and every node with a smaller base index is visited earlier.
+#pragma once
+#include <cstdint>
+
+#include "../common.h"
+#include "walk_dev.h"
+
+namespace ipcfp {
+
+struct AmtRootSpec {
+    CidKey root;
+    uint32_t version;  // 0 | 3
+    uint32_t seq;      // error-ordering sequence number of this AMT (ascending in traversal order)
+    uint32_t skip;     // 1 ⇒ do not load (an earlier stage already failed for it)
+    uint32_t pad;
+};
+
+// one frontier entry
+struct EnumNode {
+    uint32_t block;     // kNoBlock ⇒ dead entry (contributes nothing)
+    uint32_t node_off;  // offset of the node inside the block
+    uint64_t base;      // index of the node's first slot
+    uint32_t seq;
+    uint16_t height;    // node height (0 = leaf level)
+    uint8_t bit_width;
+    uint8_t leaf_ready; // a Leaf node met above height 0: carried down unchanged
+};
+
+// one enumerated value, in for_each order
+struct LeafRef {
+    uint32_t block, off, len;
+    uint32_t seq;
+    uint64_t index;
+};
+
+constexpr uint64_t kNoEnumError = ~0ULL;
+__host__ __device__ inline uint64_t pack_enum_error(uint32_t seq, uint64_t base, uint32_t code) {
+    return (uint64_t(seq & 0xffffu) << 48) | ((base & 0xffffffffffULL) << 8) | (code & 0xffu);
+}
+__host__ __device__ inline uint32_t enum_error_code(uint64_t e) { return e == kNoEnumError ? 0u : uint32_t(e & 0xffu); }
+
+}  // namespace ipcfp
+
+struct ipcfp_ctx;
+struct ipcfp_witness;
+
+namespace ipcfp {
+
+// Host-side driver state: device buffers reused across levels.
+struct AmtEnumResult {
+    DevBuf<LeafRef> leaves;
+    uint64_t n_leaves = 0;
+    uint64_t error = kNoEnumError;  // packed first error (after the final sync)
+};
+
+// Enumerate `n_roots` AMTs (device array `roots_d`) whose values have type `vkind`.
+// `err_d` is a device u64 initialised by the caller (kNoEnumError or earlier-stage errors); the
+// enumerator atomicMin's into it.  Synchronises the stream twice (tree height, value count).
+int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
+                  unsigned long long* err_d, AmtEnumResult& out);
+
+}  // namespace ipcfp

@@ -1,0 +1,221 @@
+// csrc/kernels/amt_enum.hip — level-synchronous `Amt::for_each` (see amt_enum.h).
+#include "amt_enum.h"
+
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "launch.h"
+
+namespace ipcfp {
+
+__device__ __forceinline__ void enum_error(unsigned long long* err, uint32_t seq, uint64_t base, uint32_t code) {
+    atomicMin(err, (unsigned long long)pack_enum_error(seq, base, code));
+}
+
+// roots → frontier (one entry per root, in root order)
+__global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootSpec* __restrict__ roots, uint32_t n,
+                                                   int vkind, EnumNode* __restrict__ frontier,
+                                                   uint32_t* __restrict__ max_height,
+                                                   unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const AmtRootSpec spec = roots[t];
+    EnumNode e{kNoBlock, 0, 0, spec.seq, 0, 0, 0};
+    if (!spec.skip) {
+        AmtRootInfo info;
+        const uint32_t st = amt_load(w, spec.root, int(spec.version), vkind, info);
+        if (st != IPCFP_ST_TRUE) {
+            enum_error(err, spec.seq, 0, st);
+        } else {
+            e.block = info.block;
+            e.node_off = info.node_off;
+            e.height = uint16_t(info.height);
+            e.bit_width = uint8_t(info.bit_width);
+            atomicMax(max_height, uint32_t(info.height));
+        }
+    }
+    frontier[t] = e;
+}
+
+// decode the node of entry e (validating it completely); false ⇒ decode error
+__device__ __forceinline__ bool enum_read_node(const WitnessView& w, const EnumNode& e, int vkind, AmtNode& nd) {
+    Rd r = open_block(w, e.block);
+    r.pos = e.node_off;
+    amt_read_node(r, e.bit_width, vkind, ~0u, nd);
+    if (e.node_off == 0) r.finish();
+    return r.ok();
+}
+
+// interior level L ≥ 1: how many entries does each frontier entry contribute to the next level?
+__global__ __launch_bounds__(256) void k_enum_count(WitnessView w, const EnumNode* __restrict__ frontier, uint32_t n,
+                                                    uint32_t level, int vkind, uint32_t* __restrict__ counts,
+                                                    unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const EnumNode e = frontier[t];
+    uint32_t c = 0;
+    if (e.block != kNoBlock) {
+        if (e.leaf_ready || e.height < level) {
+            c = 1;  // rides along
+        } else {
+            AmtNode nd;
+            if (!enum_read_node(w, e, vkind, nd)) enum_error(err, e.seq, e.base, IPCFP_ST_ERR_DECODE);
+            else c = nd.nlinks ? nd.nlinks : 1;  // a Leaf above height 0 is carried down as-is
+        }
+    }
+    counts[t] = c;
+}
+
+__global__ __launch_bounds__(256) void k_enum_expand(WitnessView w, const EnumNode* __restrict__ frontier, uint32_t n,
+                                                     uint32_t level, int vkind, const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ offsets,
+                                                     EnumNode* __restrict__ next,
+                                                     unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (counts[t] == 0) return;
+    EnumNode e = frontier[t];
+    const uint32_t o = offsets[t];
+    if (e.leaf_ready || e.height < level) {
+        next[o] = e;
+        return;
+    }
+    // re-walk the (already validated) node to reach its links
+    Rd r = open_block(w, e.block);
+    r.pos = e.node_off;
+    r.expect_array(3);
+    uint32_t bo, bl;
+    r.read_bytes(bo, bl);
+    const uint64_t nl = r.read_array();
+    if (nl == 0) {
+        e.leaf_ready = 1;
+        next[o] = e;
+        return;
+    }
+    const uint64_t span = amt_span(e.bit_width, e.height);
+    uint32_t sub = 0;
+    for (uint64_t j = 0; j < nl; ++j) {
+        while (!((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;  // j-th set bit (bitmap validated: popcount == nl)
+        CidKey key;
+        r.read_link_key(key);
+        EnumNode c{kNoBlock, 0, e.base + uint64_t(sub) * span, e.seq, uint16_t(e.height - 1), e.bit_width, 0};
+        const uint32_t b = witness_find(w, key);
+        if (b == kNoBlock) enum_error(err, e.seq, c.base, IPCFP_ST_ERR_MISSING_BLOCK);
+        else c.block = b;
+        next[o + uint32_t(j)] = c;
+        ++sub;
+    }
+}
+
+// leaf level: number of values per entry
+__global__ __launch_bounds__(256) void k_enum_count_leaf(WitnessView w, const EnumNode* __restrict__ frontier,
+                                                         uint32_t n, int vkind, uint32_t* __restrict__ counts,
+                                                         unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const EnumNode e = frontier[t];
+    uint32_t c = 0;
+    if (e.block != kNoBlock) {
+        AmtNode nd;
+        if (!enum_read_node(w, e, vkind, nd)) enum_error(err, e.seq, e.base, IPCFP_ST_ERR_DECODE);
+        else if (nd.nlinks) enum_error(err, e.seq, e.base, IPCFP_ST_ERR_DECODE);  // link node at height 0
+        else c = nd.nvalues;
+    }
+    counts[t] = c;
+}
+
+__global__ __launch_bounds__(256) void k_enum_emit(WitnessView w, const EnumNode* __restrict__ frontier, uint32_t n,
+                                                   int vkind, const uint32_t* __restrict__ counts,
+                                                   const uint32_t* __restrict__ offsets,
+                                                   LeafRef* __restrict__ leaves) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (counts[t] == 0) return;
+    const EnumNode e = frontier[t];
+    const uint32_t o = offsets[t];
+    Rd r = open_block(w, e.block);
+    r.pos = e.node_off;
+    r.expect_array(3);
+    uint32_t bo, bl;
+    r.read_bytes(bo, bl);
+    (void)r.read_array();  // no links in a leaf
+    const uint64_t nv = r.read_array();
+    uint32_t sub = 0;
+    for (uint64_t j = 0; j < nv; ++j) {
+        while (!((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;
+        const uint32_t start = r.pos;
+        check_value(r, vkind);
+        leaves[o + uint32_t(j)] = LeafRef{e.block, start, r.pos - start, e.seq, e.base + sub};
+        ++sub;
+    }
+}
+
+int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* out_d, uint64_t* total_d,
+                    uint64_t* scratch_d);
+
+int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
+                  unsigned long long* err_d, AmtEnumResult& out) {
+    out.n_leaves = 0;
+    out.error = kNoEnumError;
+    out.leaves.release();
+    if (n_roots == 0) return IPCFP_OK;
+    ProfileScope prof(ctx, IPCFP_K_EXEC_ORDER);
+    DevBuf<EnumNode> cur, nxt;
+    DevBuf<uint32_t> counts, offsets, small;
+    DevBuf<uint64_t> scratch, total_d;
+    IPCFP_HIP(ctx, cur.alloc(n_roots));
+    IPCFP_HIP(ctx, small.alloc(4));
+    IPCFP_HIP(ctx, total_d.alloc(2));
+    IPCFP_HIP(ctx, hipMemsetAsync(small.p, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_enum_roots, dim3(div_up(n_roots, 64)), dim3(64), 0, ctx->stream, view, roots_d, n_roots, vkind,
+                       cur.p, small.p, err_d);
+    uint32_t max_height = 0;
+    IPCFP_HIP(ctx, hipMemcpyAsync(&max_height, small.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t n = n_roots;
+    for (uint32_t level = max_height;; --level) {
+        IPCFP_HIP(ctx, counts.alloc(n));
+        IPCFP_HIP(ctx, offsets.alloc(n));
+        IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
+        if (level >= 1)
+            hipLaunchKernelGGL(k_enum_count, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
+                               vkind, counts.p, err_d);
+        else
+            hipLaunchKernelGGL(k_enum_count_leaf, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n,
+                               vkind, counts.p, err_d);
+        int rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total_d.p, scratch.p);
+        if (rc) return rc;
+        uint64_t total = 0;
+        IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (total >= 0x7fffffffULL)
+            return set_error(ctx, IPCFP_E_UNSUPPORTED, "AMT enumeration expands to %llu entries",
+                             (unsigned long long)total);
+        if (level >= 1) {
+            IPCFP_HIP(ctx, nxt.alloc(total));
+            if (total)
+                hipLaunchKernelGGL(k_enum_expand, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
+                                   vkind, counts.p, offsets.p, nxt.p, err_d);
+            IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cur is released below
+            std::swap(cur.p, nxt.p);
+            std::swap(cur.count, nxt.count);
+            n = uint32_t(total);
+            if (n == 0) break;
+        } else {
+            IPCFP_HIP(ctx, out.leaves.alloc(total));
+            out.n_leaves = total;
+            if (total)
+                hipLaunchKernelGGL(k_enum_emit, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, vkind,
+                                   counts.p, offsets.p, out.leaves.p);
+            break;
+        }
+    }
+    unsigned long long e = kNoEnumError;
+    IPCFP_HIP(ctx, hipMemcpyAsync(&e, err_d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, hipGetLastError());
+    out.error = e;
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

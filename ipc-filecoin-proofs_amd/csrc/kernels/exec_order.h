@@ -1,0 +1,37 @@
+// csrc/kernels/exec_order.h — device state of one tipset context: everything `verify_single_proof`
+// derives from (parent_tipset_cids, child_block_cid) alone — header consistency facts
+// (src/proofs/events/verifier.rs:147-181) and the reconstructed execution order
+// (src/proofs/events/utils.rs:16-30,48-94) — computed ONCE per distinct pair instead of once per
+// proof (the reference recomputes it for every proof: events/verifier.rs:190).
+#pragma once
+#include <cstdint>
+
+#include "amt_enum.h"
+#include "types_dev.h"
+
+namespace ipcfp {
+
+struct TipsetCtxDev {
+    // inputs
+    uint32_t flags;      // TC_* (claims_dev.h)
+    uint32_t n_parents;
+    CidKey child;
+    CidKey parents[kMaxParents];
+    // header facts (k_ctx_headers)
+    uint32_t child_status;     // TRUE or ERR_* of `get(child)` + HeaderLite decode
+    uint32_t parents_match;    // child_hdr.parents == parent_cids
+    long long child_height;
+    CidKey receipts_root;      // child_hdr.parent_message_receipts
+    uint32_t parent0_status;   // TRUE or ERR_* for parent_cids[0]
+    uint32_t pad0;
+    long long parent0_height;
+    // execution order (filled by the host after the enumeration)
+    uint32_t exec_status;      // TRUE or the first ERR_* of reconstruct_execution_order
+    uint32_t exec_mask;        // hash-table size - 1
+    const uint32_t* exec_slots;   // open addressing over message CIDs → FIRST position in the raw sequence
+    const CidKey* exec_keys;      // raw for_each sequence (with duplicates)
+    const uint32_t* exec_pos;     // raw position → execution index (valid where the position is a first occurrence)
+    uint64_t exec_len;            // number of distinct messages
+};
+
+}  // namespace ipcfp

@@ -44,6 +44,26 @@ struct StorageClaimPacked;
 int launch_verify_storage(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,
                           const ipcfp_trust_policy_t& trust, uint8_t* status_d);
 
+// --- scan.hip ---
+int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* out_d, uint64_t* total_d,
+                    uint64_t* scratch_d);
+
+// --- verify_events.hip ---
+struct TipsetCtxDev;
+struct AmtRootSpec;
+struct LeafRef;
+struct EventClaimPacked;
+int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n);
+int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
+                      unsigned long long* err_d);
+int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,
+                      uint32_t* slots_d, uint32_t mask, uint32_t* first_d);
+int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const uint32_t* first_d,
+                        const uint32_t* pos_d, CidKey* out_d);
+int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
+                         const TipsetCtxDev* ctxs_d, const uint8_t* blob_d, const ipcfp_trust_policy_t& trust,
+                         const ipcfp_event_filter_t* filter, uint8_t* status_d);
+
 // device view of a witness (host helper, witness.cpp)
 WitnessView witness_view(const ipcfp_witness* w, uint32_t* touched_bits = nullptr);
 

@@ -1,0 +1,375 @@
+// csrc/kernels/verify_events.hip — batch `verify_event_proof`: tipset-context preparation,
+// execution-order reconstruction, and one proof per lane.
+//
+// Replaces src/proofs/events/verifier.rs:51-290 and src/proofs/events/utils.rs:16-30,48-94.
+// Check order and every Ok(false)/Err outcome follow SURVEY.md A.10; the status byte names the
+// reference line that decided.
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "blake2b_dev.h"
+#include "claims_dev.h"
+#include "events_dev.h"
+#include "exec_order.h"
+#include "launch.h"
+
+namespace ipcfp {
+
+// ---------------------------------------------------------------------------
+// Blake2b-256 of a short byte buffer on one lane (the TxMeta re-hash, events/utils.rs:65)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void blake2b256_small(const uint8_t* buf, uint32_t len, uint64_t out[4]) {
+    uint64_t h[8];
+    b2b::init256(h);
+    uint32_t done = 0;
+    uint64_t t = 0;
+    for (;;) {
+        const uint32_t left = len - done;
+        const bool last = left <= 128;
+        const uint32_t take = last ? left : 128;
+        uint64_t m[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t idx = 8u * w + b;
+                if (idx < take) v |= uint64_t(buf[done + idx]) << (8 * b);
+            }
+            m[w] = v;
+        }
+        t += take;
+        b2b::compress<0>(h, m, t, last);
+        done += take;
+        if (last) break;
+    }
+    out[0] = h[0];
+    out[1] = h[1];
+    out[2] = h[2];
+    out[3] = h[3];
+}
+
+// ---------------------------------------------------------------------------
+// context headers: one thread per context
+// ---------------------------------------------------------------------------
+__global__ void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    TipsetCtxDev& c = ctxs[t];
+    c.child_status = IPCFP_ST_ERR_BAD_CLAIM;
+    c.parents_match = 0;
+    c.child_height = 0;
+    c.parent0_status = IPCFP_ST_ERR_BAD_CLAIM;
+    c.parent0_height = 0;
+    if ((c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) != (TC_PARENTS_PARSED | TC_CHILD_PARSED)) return;
+    HeaderLite h;
+    uint32_t hb;
+    c.child_status = load_header(w, c.child, h, hb);  // events/verifier.rs:155-158
+    if (c.child_status == IPCFP_ST_TRUE) {
+        c.child_height = h.height;
+        c.receipts_root = h.parent_message_receipts;
+        // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
+        bool same = h.n_parents == c.n_parents;
+        if (same) {
+            Rd r = open_block(w, hb);
+            r.pos = h.parents_off;
+            for (uint32_t i = 0; i < c.n_parents && same; ++i) {
+                CidKey k;
+                r.read_link_key(k);
+                same = r.ok() && cid_equal(k, c.parents[i]);
+            }
+        }
+        c.parents_match = same ? 1u : 0u;
+    }
+    if (c.n_parents > 0) {
+        HeaderLite ph;
+        uint32_t pb;
+        c.parent0_status = load_header(w, c.parents[0], ph, pb);  // :171-174
+        if (c.parent0_status == IPCFP_ST_TRUE) c.parent0_height = ph.height;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// execution order, stage 1 (one thread): parent headers → TxMeta → AMT roots
+//   error sequence numbers: parent header b → b;  TxMeta of block b → P + 3b;
+//   its BLS AMT → P + 3b + 1;  its secp AMT → P + 3b + 2   (traversal order of utils.rs)
+// ---------------------------------------------------------------------------
+__global__ void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx, AmtRootSpec* __restrict__ roots,
+                             unsigned long long* __restrict__ err) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const uint32_t P = ctx->n_parents;
+    unsigned long long first = kNoEnumError;
+    auto fail = [&](uint32_t seq, uint32_t code) {
+        const unsigned long long e = pack_enum_error(seq, 0, code);
+        if (e < first) first = e;
+    };
+    // reconstruct_execution_order (utils.rs:20-27): every parent header is decoded first
+    CidKey tx[kMaxParents];
+    bool have_tx[kMaxParents];
+    for (uint32_t b = 0; b < P; ++b) {
+        HeaderLite h;
+        uint32_t hb;
+        const uint32_t st = load_header(w, ctx->parents[b], h, hb);
+        have_tx[b] = st == IPCFP_ST_TRUE;
+        if (have_tx[b]) tx[b] = h.messages;
+        else fail(b, st);
+    }
+    // collect_exec_list (utils.rs:56-91)
+    for (uint32_t b = 0; b < P; ++b) {
+        const uint32_t seq = P + 3 * b;
+        AmtRootSpec bls{}, secp{};
+        bls.version = secp.version = 0;
+        bls.seq = seq + 1;
+        secp.seq = seq + 2;
+        bls.skip = secp.skip = 1;
+        if (have_tx[b]) {
+            const uint32_t tb = witness_find(w, tx[b]);  // :58-60
+            if (tb == kNoBlock) {
+                fail(seq, IPCFP_ST_ERR_MISSING_BLOCK);
+            } else {
+                Rd r = open_block(w, tb);
+                uint32_t o0, l0, o1, l1;
+                r.expect_array(2);  // (Cid, Cid)  :61
+                r.read_link(o0, l0);
+                r.read_link(o1, l1);
+                r.finish();
+                if (!r.ok()) {
+                    fail(seq, IPCFP_ST_ERR_DECODE);
+                } else {
+                    // put_cbor(&(bls_root, secp_root), Blake2b256): canonical re-encoding, hashed (:65-72)
+                    uint8_t enc[200];
+                    uint32_t n = 0;
+                    enc[n++] = 0x82;
+                    const uint32_t offs[2] = {o0, o1}, lens[2] = {l0, l1};
+                    for (int k = 0; k < 2; ++k) {
+                        enc[n++] = 0xd8;
+                        enc[n++] = 0x2a;
+                        const uint32_t bl = lens[k] + 1;
+                        if (bl < 24) enc[n++] = uint8_t(0x40 | bl);
+                        else { enc[n++] = 0x58; enc[n++] = uint8_t(bl); }
+                        enc[n++] = 0x00;
+                        for (uint32_t i = 0; i < lens[k]; ++i) enc[n++] = r.p[offs[k] + i];
+                    }
+                    uint64_t d[4];
+                    blake2b256_small(enc, n, d);
+                    CidKey re;
+                    re.w[0] = 0x00002002e4a07101ULL | (d[0] << 48);
+                    re.w[1] = (d[0] >> 16) | (d[1] << 48);
+                    re.w[2] = (d[1] >> 16) | (d[2] << 48);
+                    re.w[3] = (d[2] >> 16) | (d[3] << 48);
+                    re.w[4] = d[3] >> 16;
+                    if (!cid_equal(re, tx[b])) {
+                        fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
+                    } else {
+                        bls.root = lens[0] <= 40 ? cid_key_from_bytes(r.p + o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        secp.root = lens[1] <= 40 ? cid_key_from_bytes(r.p + o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        bls.skip = secp.skip = 0;
+                    }
+                }
+            }
+        }
+        roots[2 * b] = bls;
+        roots[2 * b + 1] = secp;
+    }
+    *err = first;
+}
+
+// stage 2: leaf values (tag-42 links, already validated) → message CID keys
+__global__ __launch_bounds__(256) void k_exec_keys(WitnessView w, const LeafRef* __restrict__ leaves, uint32_t n,
+                                                   CidKey* __restrict__ keys) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const LeafRef l = leaves[t];
+    Rd r;
+    r.init(w.arena + w.off[l.block] + l.off, l.len);
+    CidKey k;
+    r.read_link_key(k);
+    keys[t] = k;
+}
+
+// stage 3: `seen.insert(c)` — the table keeps, per distinct CID, the SMALLEST raw position
+__global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ keys, uint32_t n,
+                                                     uint32_t* __restrict__ slots, uint32_t mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CidKey key = keys[i];
+    uint32_t s = cid_hash(key) & mask;
+    for (;;) {
+        uint32_t cur = slots[s];
+        if (cur == kNoBlock) {
+            cur = atomicCAS(&slots[s], kNoBlock, i);
+            if (cur == kNoBlock) return;
+        }
+        if (cid_equal(keys[cur], key)) {
+            atomicMin(&slots[s], i);
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t exec_find(const uint32_t* slots, uint32_t mask, const CidKey* keys,
+                                              const CidKey& key) {
+    uint32_t s = cid_hash(key) & mask;
+    for (;;) {
+        const uint32_t cur = slots[s];
+        if (cur == kNoBlock) return kNoBlock;
+        if (cid_equal(keys[cur], key)) return cur;
+        s = (s + 1) & mask;
+    }
+}
+
+// stage 4: first[i] = 1 iff position i is the first occurrence of its CID (`if seen.insert(*c) { out.push(*c) }`)
+__global__ __launch_bounds__(256) void k_exec_first(const CidKey* __restrict__ keys, uint32_t n,
+                                                    const uint32_t* __restrict__ slots, uint32_t mask,
+                                                    uint32_t* __restrict__ first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    first[i] = exec_find(slots, mask, keys, keys[i]) == i ? 1u : 0u;
+}
+
+// the distinct CIDs in execution order (ipcfp_exec_order)
+__global__ __launch_bounds__(256) void k_exec_compact(const CidKey* __restrict__ keys, uint32_t n,
+                                                      const uint32_t* __restrict__ first,
+                                                      const uint32_t* __restrict__ pos, CidKey* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (first[i]) out[pos[i]] = keys[i];
+}
+
+// ---------------------------------------------------------------------------
+// one proof per lane
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool ev_trusted(const ipcfp_trust_policy_t& t, long long epoch) {
+    if (t.kind == 0) return true;
+    if (t.ec_chain_empty) return false;
+    return epoch >= t.min_epoch && epoch <= t.max_epoch;
+}
+
+__device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const EventClaimPacked& c,
+                                                     const TipsetCtxDev& tc, const uint8_t* __restrict__ blob,
+                                                     const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter) {
+    // Step 1: verify_trust_anchors (events/verifier.rs:124-144)
+    if (!(tc.flags & TC_PARENTS_PARSED) || !(tc.flags & TC_CHILD_PARSED)) return IPCFP_ST_ERR_BAD_CLAIM;  // :130-131
+    if (!ev_trusted(trust, c.parent_epoch)) return IPCFP_ST_FALSE_UNTRUSTED_PARENT;                          // :134
+    if (!ev_trusted(trust, c.child_epoch)) return IPCFP_ST_FALSE_UNTRUSTED_CHILD;                            // :139
+    // Step 2: verify_header_consistency (:147-181)
+    if (tc.child_status != IPCFP_ST_TRUE) return tc.child_status;                                             // :155-158
+    if (!tc.parents_match) return IPCFP_ST_FALSE_PARENTS_MISMATCH;                                            // :161
+    if (tc.child_height != c.child_epoch) return IPCFP_ST_FALSE_CHILD_EPOCH;                                  // :166
+    if (tc.n_parents == 0) return IPCFP_ST_ERR_EMPTY_PARENTS;                                                 // :172 (panic)
+    if (tc.parent0_status != IPCFP_ST_TRUE) return tc.parent0_status;                                         // :171-174
+    if (tc.parent0_height != c.parent_epoch) return IPCFP_ST_FALSE_PARENT_EPOCH;                              // :176
+    // Step 3: verify_execution_order (:184-204)
+    if (tc.exec_status != IPCFP_ST_TRUE) return tc.exec_status;                                               // :190
+    if (!(c.flags & EC_MSG_PARSED)) return IPCFP_ST_ERR_BAD_CLAIM;                                            // :193
+    const uint32_t raw = tc.exec_slots ? exec_find(tc.exec_slots, tc.exec_mask, tc.exec_keys, c.message) : kNoBlock;
+    if (raw == kNoBlock) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                                               // :194
+    if (uint64_t(tc.exec_pos[raw]) != c.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;                         // :199
+    // Step 4: verify_receipt_and_event (:207-254)
+    AmtRootInfo receipts;
+    uint32_t st = amt_load(w, tc.receipts_root, 0, VK_RECEIPT, receipts);                                     // :220
+    if (st != IPCFP_ST_TRUE) return st;
+    ValueLoc rloc;
+    st = amt_get(w, receipts, VK_RECEIPT, c.exec_index, rloc);                                                // :224
+    if (st == IPCFP_ST_NOT_FOUND) return IPCFP_ST_FALSE_NO_RECEIPT;
+    if (st != IPCFP_ST_TRUE) return st;
+    Rd rr;
+    rr.init(w.arena + w.off[rloc.block] + rloc.off, rloc.len);
+    uint32_t o, l;
+    rr.expect_array(4);
+    (void)rr.read_uint();
+    rr.read_bytes(o, l);
+    (void)rr.read_uint();
+    if (rr.at_null()) return IPCFP_ST_FALSE_NO_EVENTS_ROOT;                                                   // :229
+    CidKey events_root;
+    rr.read_link_key(events_root);
+    AmtRootInfo events;
+    st = amt_load(w, events_root, 3, VK_STAMPED_EVENT, events);                                               // :234
+    if (st != IPCFP_ST_TRUE) return st;
+    ValueLoc eloc;
+    st = amt_get(w, events, VK_STAMPED_EVENT, c.event_index, eloc);                                           // :237
+    if (st == IPCFP_ST_NOT_FOUND) return IPCFP_ST_FALSE_NO_EVENT;
+    if (st != IPCFP_ST_TRUE) return st;
+    // verify_event_data_matches (:257-290)
+    Rd er;
+    er.init(w.arena + w.off[eloc.block] + eloc.off, eloc.len);
+    uint64_t emitter;
+    EvmLogLoc log;
+    decode_event_log(er, emitter, log);
+    if (emitter != c.emitter) return IPCFP_ST_FALSE_EMITTER;                                                  // :262
+    if (!log.is_log) return IPCFP_ST_FALSE_NOT_EVM_LOG;                                                       // :267
+    if (log.n_topics != c.n_topics) return IPCFP_ST_FALSE_TOPIC_COUNT;                                        // :272
+    for (uint32_t i = 0; i < log.n_topics; ++i) {                                                             // :276-281
+        const uint8_t* claimed = blob + c.topics_off + 33u * i;
+        if (!claimed[0]) return IPCFP_ST_FALSE_TOPIC;  // the claimed string is not "0x" + 64 hex digits
+        if (!bytes32_equal(er.p + log.topic_at(i), claimed + 1)) return IPCFP_ST_FALSE_TOPIC;
+    }
+    if (!(c.flags & EC_DATA_MATCHABLE) || c.data_len != log.data.len) return IPCFP_ST_FALSE_DATA;             // :284-287
+    for (uint32_t i = 0; i < c.data_len; ++i)
+        if (blob[c.data_off + i] != er.p[log.data.off + i]) return IPCFP_ST_FALSE_DATA;
+    if (filter && !log_matches(er, log, *filter)) return IPCFP_ST_FALSE_FILTER;                               // :247-251
+    return IPCFP_ST_TRUE;
+}
+
+__global__ __launch_bounds__(256) void k_verify_events(WitnessView w, const EventClaimPacked* __restrict__ claims,
+                                                       uint32_t n, const TipsetCtxDev* __restrict__ ctxs,
+                                                       const uint8_t* __restrict__ blob, ipcfp_trust_policy_t trust,
+                                                       ipcfp_event_filter_t filter, int has_filter,
+                                                       uint8_t* __restrict__ status) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const EventClaimPacked& c = claims[t];
+    status[t] = uint8_t(verify_event_one(w, c, ctxs[c.context], blob, trust, has_filter ? &filter : nullptr));
+}
+
+// ------------------------------ launchers -----------------------------------
+int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_ctx_headers, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, w, ctxs_d, n);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
+                      unsigned long long* err_d) {
+    hipLaunchKernelGGL(k_exec_roots, dim3(1), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,
+                      uint32_t* slots_d, uint32_t mask, uint32_t* first_d) {
+    if (n == 0) return IPCFP_OK;
+    const dim3 g(div_up(n, 256)), b(256);
+    hipLaunchKernelGGL(k_exec_keys, g, b, 0, ctx->stream, w, leaves_d, n, keys_d);
+    hipLaunchKernelGGL(k_exec_insert, g, b, 0, ctx->stream, keys_d, n, slots_d, mask);
+    hipLaunchKernelGGL(k_exec_first, g, b, 0, ctx->stream, keys_d, n, slots_d, mask, first_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const uint32_t* first_d,
+                        const uint32_t* pos_d, CidKey* out_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_exec_compact, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, keys_d, n, first_d, pos_d,
+                       out_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
+                         const TipsetCtxDev* ctxs_d, const uint8_t* blob_d, const ipcfp_trust_policy_t& trust,
+                         const ipcfp_event_filter_t* filter, uint8_t* status_d) {
+    if (n == 0) return IPCFP_OK;
+    ipcfp_event_filter_t f{};
+    if (filter) f = *filter;
+    {
+        ProfileScope prof(ctx, IPCFP_K_EVENT_VERIFY);
+        hipLaunchKernelGGL(k_verify_events, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, claims_d, n, ctxs_d,
+                           blob_d, trust, f, filter ? 1 : 0, status_d);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

@@ -1,0 +1,160 @@
+"""GPU: execution-order reconstruction and the event-proof verifier vs the CPU oracle on seeded
+synthetic tipsets — bit-exact statuses through the C ABI, including every Ok(false)/Err branch
+of SURVEY.md A.10 that a claim or a tampered witness can reach."""
+import numpy as np
+import pytest
+
+import claims
+from tools.synth import Tipset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tip():
+    return Tipset(n_receipts=4000, n_parents=3, dup_permille=80, n_planted=9, variety=1, max_events=6,
+                  no_events_permille=150)
+
+
+@pytest.fixture(scope="module")
+def both(tip, engine, oracle):
+    w = engine.witness(tip.data, tip.off, tip.lens, tip.cids)
+    st = oracle.store(tip.data, tip.off, tip.lens, tip.cids)
+    yield w, st
+    w.close()
+    st.close()
+
+
+def test_exec_order(tip, both):
+    w, st = both
+    gs, gc = w.exec_order(tip.parent_cids)
+    os_, oc = st.exec_order(tip.parent_cids)
+    assert gs == os_ == 1
+    assert np.array_equal(gc, oc) and np.array_equal(gc, tip.exec_order)
+    # a subset / permutation of the parents gives a different (but still agreed) order
+    for parents in ([tip.parent_cids[1]], [tip.parent_cids[2], tip.parent_cids[0]], []):
+        gs, gc = w.exec_order(parents)
+        os_, oc = st.exec_order(parents)
+        assert gs == os_ and np.array_equal(gc, oc)
+    # a CID that is not a header / not in the witness
+    for parents in ([tip.receipts_root], [tip.parent_cids[0], b"\x01\x71\xa0\xe4\x02\x20" + bytes(32)]):
+        gs, _ = w.exec_order(parents)
+        os_, _ = st.exec_order(parents)
+        assert gs == os_ and gs >= 64
+
+
+def test_event_proofs_honest(tip, both):
+    w, st = both
+    ec = claims.EventClaims(tip)
+    got = w.verify_event_proofs(ec.arr, ec.n)
+    want = st.verify_event_proofs(ec, mode=1)
+    assert np.array_equal(got, want)
+    assert set(np.unique(got).tolist()) <= {1, 13}  # TRUE, or the claim describes a non-EVM event
+    assert (got == 1).sum() > ec.n // 2
+    filt = claims.make_filter(tip.topic0, tip.topic1)
+    got = w.verify_event_proofs(ec.arr, ec.n, filt=filt)
+    want = st.verify_event_proofs(ec, filt=filt, mode=1)
+    assert np.array_equal(got, want)
+    assert 17 in got and 1 in got or len(tip.planted) == 0
+
+
+def test_event_proofs_adversarial(tip, both, oracle):
+    w, st = both
+    good = [i for i in range(len(tip.claim_exec)) if tip.claim_ntopics[i] >= 2][:40]
+    ec = claims.EventClaims(tip, indices=good)
+    other = claims.cid_str(oracle.cid_for_block(b"x"))
+    ec.arr[0].exec_index += 1                                   # message at another position → FALSE_EXEC_INDEX
+    ec.set_str(1, "message_cid", other)                         # → FALSE_MSG_NOT_IN_EXEC
+    ec.set_str(2, "message_cid", "zzz")                         # → Err
+    ec.arr[3].event_index = 999                                 # → FALSE_NO_EVENT
+    ec.arr[4].emitter += 1                                      # → FALSE_EMITTER
+    ec.set_topics(5, [ec.arr[5].topics[0].decode()])            # → FALSE_TOPIC_COUNT
+    t = [ec.arr[6].topics[k].decode() for k in range(ec.arr[6].n_topics)]
+    ec.set_topics(6, [t[0], "0x" + "11" * 32] + t[2:])          # → FALSE_TOPIC
+    ec.set_topics(7, [x.upper().replace("0X", "0x") for x in
+                      [ec.arr[7].topics[k].decode() for k in range(ec.arr[7].n_topics)]])  # case-insensitive → TRUE
+    ec.set_str(8, "data", ec.arr[8].data.decode() + "00")       # → FALSE_DATA
+    ec.set_str(9, "data", ec.arr[9].data.decode()[2:])          # no 0x prefix → FALSE_DATA
+    ec.arr[10].child_epoch += 1                                 # → FALSE_CHILD_EPOCH
+    ec.arr[11].parent_epoch -= 1                                # → FALSE_PARENT_EPOCH
+    ec.set_parents(12, [claims.cid_str(c) for c in tip.parent_cids[::-1]])   # order matters → FALSE_PARENTS_MISMATCH
+    ec.set_parents(13, [claims.cid_str(c) for c in tip.parent_cids[:-1]])    # → FALSE_PARENTS_MISMATCH
+    ec.set_parents(14, [])                                      # → FALSE_PARENTS_MISMATCH (count differs first)
+    ec.set_parents(15, ["nonsense"])                            # → Err
+    ec.set_str(16, "child_block_cid", other)                    # → Err (missing child header)
+    ec.set_str(17, "child_block_cid", claims.cid_str(tip.parent_cids[0]))   # a header whose parents differ
+    ec.set_str(18, "child_block_cid", "???")                    # → Err
+    ec.arr[19].exec_index = 10 ** 9                             # position mismatch comes first → FALSE_EXEC_INDEX
+    ec.set_topics(20, [x.replace("0x", "0X") for x in
+                       [ec.arr[20].topics[k].decode() for k in range(ec.arr[20].n_topics)]])  # "0X" ignoring case → TRUE
+    got = w.verify_event_proofs(ec.arr, ec.n)
+    want = st.verify_event_proofs(ec, mode=0)
+    assert np.array_equal(got, want), (got.tolist(), want.tolist())
+    exp = {0: 8, 1: 7, 2: 69, 3: 11, 4: 12, 5: 14, 6: 15, 7: 1, 8: 16, 9: 16, 10: 5, 11: 6, 12: 4, 13: 4, 14: 4,
+           15: 69, 16: 65, 17: 4, 18: 69, 19: 8, 20: 1}
+    for k, v in exp.items():
+        assert got[k] == v, (k, got[k], v)
+    assert (got[21:] == 1).all()
+    # trust policies
+    for tp in (claims.TrustPolicy(1, 0, tip.parent_epoch, tip.parent_epoch),       # child epoch outside → untrusted child
+               claims.TrustPolicy(1, 0, tip.child_epoch, tip.child_epoch + 5),     # parent epoch outside
+               claims.TrustPolicy(1, 1, 0, 10 ** 9),                                # empty EC chain
+               claims.TrustPolicy(1, 0, tip.parent_epoch, tip.child_epoch)):        # both inside
+        got = w.verify_event_proofs(ec.arr, ec.n, trust=tp)
+        want = st.verify_event_proofs(ec, trust=tp, mode=0)
+        assert np.array_equal(got, want)
+
+
+def tampered(tip, mutate):
+    """Copy of the witness tables with one block's bytes changed (CIDs untouched: the reference's
+    MemoryBlockstore never re-hashes witness blocks)."""
+    data = tip.data.copy()
+    mutate(data)
+    return data
+
+
+def test_event_proofs_on_broken_witness(tip, engine, oracle):
+    """Missing / undecodable blocks on the path must give the same Err on both sides, and the
+    first error in traversal order must win."""
+    ec = claims.EventClaims(tip, indices=np.arange(0, 60))
+    # (a) drop the child's receipts-AMT root, (b) drop one TxMeta, (c) corrupt a message-AMT node
+    hdr_parent1 = tip.block(tip.find_block(tip.parent_cids[1]))
+    cases = []
+    keep = np.ones(tip.n_blocks, dtype=bool)
+    keep[tip.find_block(tip.receipts_root)] = False
+    cases.append(("no receipts root", keep, None))
+    # TxMeta of parent 1: the `messages` link is the 3rd link after `height`; find it via the oracle-free route:
+    # it is the only 87-byte block whose CID appears in that header
+    lens87 = [i for i in range(tip.n_blocks) if tip.lens[i] == 87 and tip.cids[i, :38].tobytes() in hdr_parent1]
+    assert len(lens87) == 1
+    keep = np.ones(tip.n_blocks, dtype=bool)
+    keep[lens87[0]] = False
+    cases.append(("no txmeta", keep, None))
+
+    def corrupt_txmeta(data):
+        o = int(tip.off[lens87[0]])
+        data[o + 10] ^= 0x01  # flips a digest byte inside the first link: still valid CBOR, different CID
+
+    cases.append(("txmeta mismatch", np.ones(tip.n_blocks, dtype=bool), corrupt_txmeta))
+
+    def corrupt_header(data):
+        o = int(tip.off[tip.find_block(tip.parent_cids[2])])
+        data[o] = 0x8F  # 15-tuple: HeaderLite arity error
+
+    cases.append(("bad parent header", np.ones(tip.n_blocks, dtype=bool), corrupt_header))
+    for name, keep, mut in cases:
+        data = tip.data.copy()
+        if mut:
+            mut(data)
+        idx = np.nonzero(keep)[0]
+        w = engine.witness(data, tip.off[idx], tip.lens[idx], tip.cids[idx])
+        st = oracle.store(data, tip.off[idx], tip.lens[idx], tip.cids[idx])
+        got = w.verify_event_proofs(ec.arr, ec.n)
+        want = st.verify_event_proofs(ec, mode=0)
+        assert np.array_equal(got, want), (name, got.tolist()[:10], want.tolist()[:10])
+        assert (got >= 64).all(), name
+        gs, _ = w.exec_order(tip.parent_cids)
+        os_, _ = st.exec_order(tip.parent_cids)
+        assert gs == os_, name
+        w.close()
+        st.close()
