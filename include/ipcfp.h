@@ -236,6 +236,38 @@ int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid
 int ipcfp_exec_order(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
                      ipcfp_status_t* status_out, uint8_t* out_cids40, uint64_t cap, uint64_t* count);
 
+/* The closure `create_event_filter(event_sig, subnet_id)` returns
+ * (src/proofs/events/verifier.rs:28-39): topics.len() >= 2 && t[0]==topic0 && t[1]==topic1. */
+typedef struct ipcfp_event_filter {
+    uint8_t topic0[32]; /* Keccak-256(event signature) */
+    uint8_t topic1[32]; /* ascii_to_bytes32(subnet id)  */
+} ipcfp_event_filter_t;
+
+/* K6 + K8 — `find_matching_events` (src/proofs/events/generator.rs:180-307) over the resident tipset.
+ * The receipt list the reference obtains over RPC is the receipts AMT (Amtv0<Receipt>) walked in
+ * index order.  PASS 1 marks every receipt that has at least one event passing the emitter filter
+ * (`actor_id_filter`) and `matches_log`; PASS 2 emits one match per such event in
+ * (exec_index, event_index) order — the fields an `EventProof` is built from.
+ *   *status_out        IPCFP_ST_TRUE or the first ERR_* in traversal order
+ *   receipt_has_match  one byte per receipt index (nullable); *n_receipts = number of indices
+ *   matches            (nullable) up to cap_matches records; *n_matches = total
+ *   touched_bits       (nullable) ⌈block_count/32⌉ words: bit b set ⇔ witness block b is in the union
+ *                      of the RecordingBlockStores generate_event_proof collects for this step
+ *                      (`take_seen`, src/proofs/common/blockstore.rs:21-30): rec_receipts plus one
+ *                      rec_events per matching receipt.                                          */
+typedef struct ipcfp_event_match {
+    uint64_t exec_index;
+    uint64_t event_index;
+    uint64_t emitter;
+    ipcfp_value_loc_t event; /* the StampedEvent item */
+    uint32_t reserved;
+} ipcfp_event_match_t;
+
+int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* receipts_root40,
+                      const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
+                      uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
+                      ipcfp_event_match_t* matches, uint64_t cap_matches, uint64_t* n_matches, uint32_t* touched_bits);
+
 /* ---- proof claims (string form, exactly the reference's structs) ----------
  * CIDs and hex values are NUL-terminated strings, as in the reference's serde
  * structs; the host parses them once per batch (src/proofs/common/witness.rs:60-72).
@@ -270,13 +302,6 @@ typedef struct ipcfp_storage_proof {
     const char* slot;  /* "0x" + 64 hex */
     const char* value; /* "0x" + 64 hex */
 } ipcfp_storage_proof_t;
-
-/* The closure `create_event_filter(event_sig, subnet_id)` returns
- * (src/proofs/events/verifier.rs:28-39): topics.len() >= 2 && t[0]==topic0 && t[1]==topic1. */
-typedef struct ipcfp_event_filter {
-    uint8_t topic0[32]; /* Keccak-256(event signature) */
-    uint8_t topic1[32]; /* ascii_to_bytes32(subnet id)  */
-} ipcfp_event_filter_t;
 
 /* topic0 = Keccak-256(event_sig) is computed ON THE DEVICE (K2); topic1 is the
  * zero-padded ASCII of subnet_id (src/proofs/common/evm.rs:62-78).               */

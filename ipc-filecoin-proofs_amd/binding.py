@@ -91,6 +91,8 @@ class ST:
 
 VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "vec_u8": 4, "any": 5}
 LOC_DTYPE = np.dtype([("block", np.uint32), ("off", np.uint32), ("len", np.uint32)])
+MATCH_DTYPE = np.dtype([("exec_index", np.uint64), ("event_index", np.uint64), ("emitter", np.uint64),
+                        ("block", np.uint32), ("off", np.uint32), ("len", np.uint32), ("reserved", np.uint32)])
 
 
 class EngineError(RuntimeError):
@@ -151,6 +153,7 @@ def load_library() -> C.CDLL:
         "ipcfp_amt_get": (i32, [vp, vp, vp, i32, i32, vp, u64, vp, vp]),
         "ipcfp_hamt_get": (i32, [vp, vp, vp, C.c_uint32, i32, vp, vp, vp, u64, vp, vp]),
         "ipcfp_exec_order": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, C.POINTER(u64)]),
+        "ipcfp_scan_events": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
         "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
         "ipcfp_verify_storage_proofs": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_verify_event_proofs": (i32, [vp, vp, vp, u64, vp, vp, vp]),
@@ -389,6 +392,30 @@ class Witness:
             self.eng._check(self.lib.ipcfp_exec_order(self.eng.h, self.h, _p(pc), len(parent_cids), _p(st), _p(out), n,
                                                       C.byref(cnt)), "exec_order")
         return int(st[0]), out
+
+    def scan_events(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor=None, want_touched=True):
+        """K6/K8.  Returns (status, has_match u8[n_receipts], matches structured[n], touched block ids)."""
+        root = np.frombuffer(bytes(receipts_root).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        filt = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
+        st = np.zeros(1, dtype=np.uint8)
+        nr, nm = C.c_uint64(), C.c_uint64()
+        words = (self.n + 31) // 32
+        touched = np.zeros(max(words, 1), dtype=np.uint32) if want_touched else None
+        a = (0, 0) if actor is None else (1, int(actor))
+        # sizing call, then the real one
+        self.eng._check(self.lib.ipcfp_scan_events(self.eng.h, self.h, _p(root), _p(filt), a[0], a[1], _p(st), None, 0,
+                                                   C.byref(nr), None, 0, C.byref(nm), None), "scan_events")
+        has = np.zeros(int(nr.value), dtype=np.uint8)
+        m = np.zeros(int(nm.value), dtype=MATCH_DTYPE)
+        if st[0] == 1:
+            self.eng._check(self.lib.ipcfp_scan_events(self.eng.h, self.h, _p(root), _p(filt), a[0], a[1], _p(st),
+                                                       _p(has), len(has), C.byref(nr), _p(m), len(m), C.byref(nm),
+                                                       _p(touched)), "scan_events")
+        ids = None
+        if want_touched:
+            bits = np.unpackbits(touched.view(np.uint8), bitorder="little")[: self.n]
+            ids = np.nonzero(bits)[0]
+        return int(st[0]), has, m, ids
 
     # -- verifiers (claim arrays are ctypes arrays of the ipcfp.h structs) -------------------
     def verify_storage_proofs(self, claims_arr, n, trust=None):

@@ -1,0 +1,105 @@
+// csrc/host/scan_events.cpp — `find_matching_events` over the HBM-resident tipset
+// (src/proofs/events/generator.rs:180-307): enumerate the receipts AMT, PASS 1, prefix-sum, PASS 2.
+#include <cstring>
+#include <vector>
+
+#include "../common.h"
+#include "../kernels/amt_enum.h"
+#include "../kernels/launch.h"
+
+using namespace ipcfp;
+
+namespace ipcfp {
+CidKey key_from_slot(const uint8_t* slot40);
+}
+
+extern "C" {
+
+int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* receipts_root40,
+                      const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
+                      uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
+                      ipcfp_event_match_t* matches, uint64_t cap_matches, uint64_t* n_matches, uint32_t* touched_bits) {
+    if (!ctx || !w || w->ctx != ctx || !receipts_root40 || !filter || !status_out || !n_receipts || !n_matches)
+        return IPCFP_E_INVALID;
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    *n_receipts = *n_matches = 0;
+    *status_out = IPCFP_ST_ERR;
+    const WitnessView view = witness_view(w);
+    const CidKey root = key_from_slot(receipts_root40);
+
+    DevBuf<AmtRootSpec> roots;
+    DevBuf<unsigned long long> err;
+    IPCFP_HIP(ctx, roots.alloc(1));
+    IPCFP_HIP(ctx, err.alloc(1));
+    AmtRootSpec spec{};
+    spec.root = root;
+    spec.version = 0;
+    spec.seq = 0;
+    unsigned long long e0 = kNoEnumError;
+    IPCFP_HIP(ctx, hipMemcpyAsync(roots.p, &spec, sizeof spec, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(err.p, &e0, 8, hipMemcpyHostToDevice, ctx->stream));
+    AmtEnumResult en;
+    int rc = amt_enumerate(ctx, view, roots.p, 1, VK_RECEIPT, err.p, en);
+    if (rc) return rc;
+    if (en.error != kNoEnumError) {
+        *status_out = ipcfp_status_t(enum_error_code(en.error));
+        return IPCFP_OK;
+    }
+    const uint32_t n = uint32_t(en.n_leaves);
+    // receipt indices are ascending: the last leaf gives the size of the per-index byte map
+    uint64_t n_idx = 0;
+    if (n) {
+        LeafRef last;
+        IPCFP_HIP(ctx, hipMemcpyAsync(&last, en.leaves.p + (n - 1), sizeof last, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        n_idx = last.index + 1;
+    }
+    DevBuf<uint32_t> counts, offsets, touched;
+    DevBuf<uint64_t> scratch, total;
+    DevBuf<uint8_t> has;
+    IPCFP_HIP(ctx, counts.alloc(n));
+    IPCFP_HIP(ctx, offsets.alloc(n));
+    IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
+    IPCFP_HIP(ctx, total.alloc(1));
+    IPCFP_HIP(ctx, has.alloc(n_idx));
+    if (n_idx) IPCFP_HIP(ctx, hipMemsetAsync(has.p, 0, n_idx, ctx->stream));
+    rc = launch_scan_pass1(ctx, view, en.leaves.p, n, *filter, has_actor, actor, counts.p, err.p);
+    if (rc) return rc;
+    rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total.p, scratch.p);
+    if (rc) return rc;
+    uint64_t nm = 0;
+    unsigned long long e1 = kNoEnumError;
+    IPCFP_HIP(ctx, hipMemcpyAsync(&nm, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(&e1, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (e1 != kNoEnumError) {
+        *status_out = ipcfp_status_t(enum_error_code(e1));
+        return IPCFP_OK;
+    }
+    DevBuf<ipcfp_event_match_t> md;
+    IPCFP_HIP(ctx, md.alloc(nm));
+    const uint32_t words = div_up(w->n, 32);
+    WitnessView rec = view;
+    if (touched_bits) {
+        IPCFP_HIP(ctx, touched.alloc(words));
+        IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, size_t(words) * 4, ctx->stream));
+        rec.touched = touched.p;
+    }
+    rc = launch_scan_pass2(ctx, rec, root, en.leaves.p, n, *filter, has_actor, actor, counts.p, offsets.p, md.p, has.p,
+                           n_idx);
+    if (rc) return rc;
+    *n_receipts = n_idx;
+    *n_matches = nm;
+    if (receipt_has_match && n_idx)
+        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match, has.p, n_idx < cap_receipts ? n_idx : cap_receipts,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    if (matches && nm)
+        IPCFP_HIP(ctx, hipMemcpyAsync(matches, md.p, (nm < cap_matches ? nm : cap_matches) * sizeof(ipcfp_event_match_t),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+    if (touched_bits) IPCFP_HIP(ctx, hipMemcpyAsync(touched_bits, touched.p, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *status_out = IPCFP_ST_TRUE;
+    return IPCFP_OK;
+}
+
+}  // extern "C"

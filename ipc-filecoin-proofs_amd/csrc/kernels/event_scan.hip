@@ -1,0 +1,218 @@
+// csrc/kernels/event_scan.hip — K6: the two-pass event-filter scan, one receipt per lane.
+//
+// Replaces find_matching_events (src/proofs/events/generator.rs:180-307):
+//   PASS 1 (:209-239)  for every receipt with an events_root: Amt::<StampedEvent>::load + for_each,
+//                      emitter filter (:220-224), extract_evm_log (common/evm.rs:13-59),
+//                      EventMatcher::matches_log (:38-40)  →  has_matching per receipt
+//   PASS 2 (:242-301)  for matching receipts only: r_amt.get(i) (records the receipt path), the events
+//                      AMT walked again on a recorder, one EventProof per matching event in index order.
+// The receipt list the reference takes from RPC (:199-204) is the receipts AMT enumerated in index
+// order (amt_enum.hip).  K8: with `touched` set in the WitnessView, PASS 2 marks exactly the blocks
+// the reference's RecordingBlockStores see (rec_receipts + one rec_events per matching receipt,
+// src/proofs/common/blockstore.rs:26-30); PASS 1 runs untracked, like the throw-away recorder.
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "amt_enum.h"
+#include "events_dev.h"
+#include "launch.h"
+
+namespace ipcfp {
+
+struct EventMatch {  // == ipcfp_event_match_t
+    uint64_t exec_index, event_index, emitter;
+    ValueLoc event;
+    uint32_t pad;
+};
+
+// Amt::for_each on one lane (depth-first, explicit stack).  `f(index, block, off, len)` is called for
+// every value in ascending index order.  Returns TRUE or the first ERR_* in traversal order.
+template <typename F>
+__device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, const AmtRootInfo& root, int vkind, F&& f) {
+    constexpr int kMaxDepth = 14;  // height ≤ 64 / bit_width, bit_width ≥ 5 for FVM event AMTs; deeper trees are rejected
+    if (root.height >= kMaxDepth) return IPCFP_ST_ERR_DECODE;
+    uint32_t blk[kMaxDepth], noff[kMaxDepth], next_sub[kMaxDepth];
+    uint64_t base[kMaxDepth];
+    int depth = 0;
+    blk[0] = root.block;
+    noff[0] = root.node_off;
+    next_sub[0] = 0;
+    base[0] = 0;
+    const uint32_t bw = root.bit_width;
+    while (depth >= 0) {
+        const uint64_t height = root.height - uint64_t(depth);
+        Rd r = open_block(w, blk[depth]);
+        r.pos = noff[depth];
+        if (next_sub[depth] == 0) {  // first visit: decode the whole node (CollapsedNode::expand checks)
+            AmtNode nd;
+            Rd v = r;
+            amt_read_node(v, bw, vkind, ~0u, nd);
+            if (noff[depth] == 0) v.finish();
+            if (!v.ok()) return IPCFP_ST_ERR_DECODE;
+            if (nd.nlinks && height == 0) return IPCFP_ST_ERR_DECODE;
+        }
+        r.expect_array(3);
+        uint32_t bo, bl;
+        r.read_bytes(bo, bl);
+        const uint64_t nl = r.read_array();
+        const uint32_t width = 1u << bw;
+        if (nl == 0) {  // Leaf: every value, ascending
+            const uint64_t nv = r.read_array();
+            uint32_t sub = 0;
+            for (uint64_t j = 0; j < nv; ++j) {
+                while (!((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;
+                const uint32_t start = r.pos;
+                check_value(r, vkind);
+                f(base[depth] + sub, blk[depth], start, r.pos - start);
+                ++sub;
+            }
+            --depth;
+            continue;
+        }
+        // Link node: next set bit at or after next_sub
+        uint32_t sub = next_sub[depth];
+        uint32_t ordinal = 0;
+        for (uint32_t i = 0; i < sub && i < width; ++i) ordinal += (r.p[bo + (i >> 3)] >> (i & 7)) & 1u;
+        while (sub < width && !((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;
+        if (sub >= width) {
+            --depth;
+            continue;
+        }
+        next_sub[depth] = sub + 1;
+        CidKey key;
+        for (uint32_t k = 0; k <= ordinal; ++k) r.read_link_key(key);  // the ordinal-th link
+        const uint32_t child = witness_find(w, key);
+        if (child == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+        const uint64_t span = amt_span(bw, height);
+        base[depth + 1] = base[depth] + uint64_t(sub) * span;
+        ++depth;
+        blk[depth] = child;
+        noff[depth] = 0;
+        next_sub[depth] = 0;
+    }
+    return IPCFP_ST_TRUE;
+}
+
+// decode a receipt value; returns false when events_root is null
+__device__ __forceinline__ bool receipt_events_root(const WitnessView& w, const LeafRef& l, CidKey& root) {
+    Rd r;
+    r.init(w.arena + w.off[l.block] + l.off, l.len);
+    uint32_t o, n;
+    r.expect_array(4);
+    (void)r.read_uint();
+    r.read_bytes(o, n);
+    (void)r.read_uint();
+    if (r.at_null()) return false;
+    r.read_link_key(root);
+    return true;
+}
+
+struct ScanParams {
+    ipcfp_event_filter_t filter;
+    uint64_t actor;
+    uint32_t has_actor;
+    uint32_t pad;
+};
+
+// PASS 1: counts[t] = number of matching events of receipt leaf t
+__global__ __launch_bounds__(256) void k_scan_pass1(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+                                                    ScanParams sp, uint32_t* __restrict__ counts,
+                                                    unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t c = 0;
+    CidKey ev_root;
+    if (receipt_events_root(w, receipts[t], ev_root)) {
+        AmtRootInfo info;
+        uint32_t st = amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info);  // generator.rs:215
+        if (st == IPCFP_ST_TRUE)
+            st = amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t, uint32_t b, uint32_t off, uint32_t len) {
+                Rd er;
+                er.init(w.arena + w.off[b] + off, len);
+                uint64_t emitter;
+                EvmLogLoc log;
+                decode_event_log(er, emitter, log);
+                if (sp.has_actor && emitter != sp.actor) return;  // :220-224
+                if (log_matches(er, log, sp.filter)) ++c;         // :227-231
+            });
+        if (st != IPCFP_ST_TRUE) {
+            atomicMin(err, (unsigned long long)pack_enum_error(1, t, st));
+            c = 0;
+        }
+    }
+    counts[t] = c;
+}
+
+// PASS 2: matching receipts write their matches in order; the recorded blocks are marked in w.touched
+__global__ __launch_bounds__(256) void k_scan_pass2(WitnessView w, CidKey receipts_root,
+                                                    const LeafRef* __restrict__ receipts, uint32_t n, ScanParams sp,
+                                                    const uint32_t* __restrict__ counts,
+                                                    const uint32_t* __restrict__ offsets,
+                                                    EventMatch* __restrict__ matches,
+                                                    uint8_t* __restrict__ has_match, uint64_t has_cap) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {  // `Amtv0::load(&receipts_root, &rec_receipts)` records the root even without matches (:195-196)
+        AmtRootInfo info;
+        (void)amt_load(w, receipts_root, 0, VK_RECEIPT, info);
+    }
+    if (t >= n) return;
+    const LeafRef leaf = receipts[t];
+    const uint32_t c = counts[t];
+    if (leaf.index < has_cap) has_match[leaf.index] = c ? 1 : 0;
+    if (c == 0) return;
+    // `r_amt.get(i)` on the recorder (:249): marks the receipt's path
+    AmtRootInfo rinfo;
+    if (amt_load(w, receipts_root, 0, VK_RECEIPT, rinfo) == IPCFP_ST_TRUE) {
+        ValueLoc rl;
+        (void)amt_get(w, rinfo, VK_RECEIPT, leaf.index, rl);
+    }
+    CidKey ev_root;
+    if (!receipt_events_root(w, leaf, ev_root)) return;
+    AmtRootInfo info;
+    if (amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info) != IPCFP_ST_TRUE) return;  // :259
+    uint32_t k = 0;
+    const uint32_t o = offsets[t];
+    (void)amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t j, uint32_t b, uint32_t off, uint32_t len) {
+        Rd er;
+        er.init(w.arena + w.off[b] + off, len);
+        uint64_t emitter;
+        EvmLogLoc log;
+        decode_event_log(er, emitter, log);
+        if (sp.has_actor && emitter != sp.actor) return;
+        if (!log_matches(er, log, sp.filter)) return;
+        if (matches && k < c) matches[o + k] = EventMatch{leaf.index, j, emitter, ValueLoc{b, off, len}, 0};
+        ++k;
+    });
+}
+
+int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                      const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, uint32_t* counts_d,
+                      unsigned long long* err_d) {
+    if (n == 0) return IPCFP_OK;
+    ScanParams sp{filter, actor, has_actor ? 1u : 0u, 0};
+    {
+        ProfileScope prof(ctx, IPCFP_K_EVENT_SCAN);
+        hipLaunchKernelGGL(k_scan_pass1, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n, sp, counts_d,
+                           err_d);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
+                      uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
+                      const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint8_t* has_match_d,
+                      uint64_t has_cap) {
+    ScanParams sp{filter, actor, has_actor ? 1u : 0u, 0};
+    const uint32_t threads = n ? n : 1;
+    {
+        ProfileScope prof(ctx, IPCFP_K_REPLAY);
+        hipLaunchKernelGGL(k_scan_pass2, dim3(div_up(threads, 256)), dim3(256), 0, ctx->stream, w, receipts_root,
+                           receipts_d, n, sp, counts_d, offsets_d, static_cast<EventMatch*>(matches_d), has_match_d,
+                           has_cap);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

@@ -64,6 +64,15 @@ int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimP
                          const TipsetCtxDev* ctxs_d, const uint8_t* blob_d, const ipcfp_trust_policy_t& trust,
                          const ipcfp_event_filter_t* filter, uint8_t* status_d);
 
+// --- event_scan.hip (K6 scan, K8 replay bitmap) ---
+int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                      const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, uint32_t* counts_d,
+                      unsigned long long* err_d);
+int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
+                      uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
+                      const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint8_t* has_match_d,
+                      uint64_t has_cap);
+
 // device view of a witness (host helper, witness.cpp)
 WitnessView witness_view(const ipcfp_witness* w, uint32_t* touched_bits = nullptr);
 

@@ -158,3 +158,61 @@ def test_event_proofs_on_broken_witness(tip, engine, oracle):
         assert gs == os_, name
         w.close()
         st.close()
+
+
+def sorted_cids(tip, ids):
+    c = sorted({tip.cids[i, :38].tobytes() for i in ids}, key=lambda b: b[6:])
+    return c
+
+
+@pytest.mark.parametrize("actor", ["filter", None])
+def test_scan_events(tip, both, actor):
+    """K6 + K8: has-match map, (exec_index, event_index, emitter) list in emission order and the
+    recorded-block set must equal find_matching_events restated on the CPU."""
+    w, st = both
+    a = tip.filter_actor if actor == "filter" else None
+    gs, ghas, gm, gids = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=a)
+    os_, ohas, otrip, otouched = st.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=a)
+    assert gs == os_ == 1
+    assert np.array_equal(ghas, ohas)
+    got = np.stack([gm["exec_index"], gm["event_index"], gm["emitter"]], axis=1) if len(gm) else np.zeros((0, 3), np.uint64)
+    assert np.array_equal(got, otrip)
+    assert sorted_cids(tip, gids) == [bytes(c[:38]) for c in otouched]
+    if a is not None:
+        assert sorted(set(gm["exec_index"].tolist())) == sorted(set(tip.planted.tolist()))
+    # each match locates a StampedEvent whose bytes start with the 2-tuple header and the emitter
+    for m in gm[:20]:
+        o = int(tip.off[m["block"]]) + int(m["off"])
+        assert tip.data[o] == 0x82
+
+
+def test_scan_events_other_filters(tip, both, engine):
+    w, st = both
+    t0, t1 = engine.create_event_filter("Transfer(address,address,uint256)", "calib-subnet-3")
+    for a in (None, 1500):
+        gs, ghas, gm, gids = w.scan_events(tip.receipts_root, t0, t1, actor=a)
+        os_, ohas, otrip, otouched = st.scan_events(tip.receipts_root, t0, t1, actor=a)
+        assert gs == os_ and np.array_equal(ghas, ohas) and len(gm) == len(otrip)
+        assert sorted_cids(tip, gids) == [bytes(c[:38]) for c in otouched]
+    # a root that is not an AMT / is missing
+    for root in (tip.child_cid, b"\x01\x71\xa0\xe4\x02\x20" + bytes(32)):
+        gs, _, _, _ = w.scan_events(root, t0, t1)
+        os_, _, _, _ = st.scan_events(root, t0, t1)
+        assert gs == os_ and gs >= 64
+
+
+def test_scan_events_deep_event_amts(engine, oracle):
+    """Events AMTs with bit width 2 are several levels deep: exercises the per-lane depth-first walk."""
+    tip2 = Tipset(n_receipts=300, n_planted=6, variety=1, max_events=40, events_bit_width=2, seed=77)
+    w = engine.witness(tip2.data, tip2.off, tip2.lens, tip2.cids)
+    st = oracle.store(tip2.data, tip2.off, tip2.lens, tip2.cids)
+    gs, ghas, gm, gids = w.scan_events(tip2.receipts_root, tip2.topic0, tip2.topic1, actor=tip2.filter_actor)
+    os_, ohas, otrip, otouched = st.scan_events(tip2.receipts_root, tip2.topic0, tip2.topic1, actor=tip2.filter_actor)
+    assert gs == os_ == 1 and np.array_equal(ghas, ohas)
+    got = np.stack([gm["exec_index"], gm["event_index"], gm["emitter"]], axis=1)
+    assert np.array_equal(got, otrip) and len(otrip) >= 6
+    assert sorted_cids(tip2, gids) == [bytes(c[:38]) for c in otouched]
+    ec = claims.EventClaims(tip2)
+    assert np.array_equal(w.verify_event_proofs(ec.arr, ec.n), st.verify_event_proofs(ec, mode=1))
+    w.close()
+    st.close()
