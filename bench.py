@@ -1,15 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X Merkle-witness engine.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
-driver launches one rank per GPU through torch.distributed.run (RCCL).  W untimed
-warm-up steps, then exactly K timed steps bracketed by barrier +
-torch.cuda.synchronize() on both sides, MAX over ranks; rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches
+one rank per GPU through torch.distributed.run (RCCL).  W untimed warm-up steps, then exactly K
+timed steps bracketed by barrier + torch.cuda.synchronize() on both sides, MAX over ranks; rank 0
+prints ONE JSON line.
 
-Workload selection: see WORKLOADS below and DESIGN.md §Measurement.  A "step" is one
-pass of the hot path over one batch of synthetic input that is already resident in
-HBM when the clock starts.  torch is plumbing only (device sync, torch.distributed);
-every kernel that is timed is launched by libipcfp.so through its C ABI.
+Workload (BASELINE.json `metric`: "Merkle proofs verified/sec + HBM GB/s, 1M-receipt synthetic
+tipset"): configs[2]'s tipset — 1 000 000 receipts under an Amtv0<Receipt>, one events AMT
+(v3, bit width 5) per receipt, 5 parent headers with TxMeta + BLS/secp message AMTs, ≈1.29 M witness
+blocks ≈ 0.44 GB — and one EventProof claim per receipt.  A "step" is one full verification pass of
+that tipset with every input already resident in HBM:
+    K4  rebuild the CID → block index            (load_witness_store)
+    K1  Blake2b-256 CID check of every block     (the kernel the roofline is quoted on)
+    K6  two-pass event-filter scan of all receipts (topic0 + topic1 + actor_id_filter)
+        exec-order reconstruction (TxMeta re-hash + message AMT walks + first-seen dedupe)
+        verify_event_proof for every claim (receipt AMT walk + events AMT walk + event compare)
+`value` = claims verified per second.  Multi-GPU: the proof batch is sharded by receipt index — rank r
+owns the receipts, events and claims of its own 1M-receipt shard (weak scaling) — with no data-path
+collective; one RCCL all-gather of the per-shard verdict bytes + CID bitmaps closes each step.
+
+torch is plumbing only (HBM residency of inputs, device sync, torch.distributed); every timed
+kernel is launched by libipcfp.so through its C ABI.  DESIGN.md §Measurement has the byte accounting.
 """
 from __future__ import annotations
 
@@ -24,36 +36,30 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec HBM3E peak (guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md §Chip-level parameters)
+METRIC = "Merkle proofs verified/sec + HBM GB/s, 1M-receipt synthetic tipset, 1/2/4/8 GPU"
 
 
 class DevView:
     """Expose a raw device pointer to torch through __cuda_array_interface__."""
 
     def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {
-            "shape": (nbytes,),
-            "typestr": "|u1",
-            "data": (ptr, False),
-            "version": 3,
-        }
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
 
 def splitmix64(seed: int, n: int) -> np.ndarray:
-    """n 64-bit words of SplitMix64 (SURVEY.md §8d PRNG), vectorised."""
     idx = np.arange(1, n + 1, dtype=np.uint64)
-    z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
     return z ^ (z >> np.uint64(31))
 
 
 def make_cfg2(n: int, seed: int):
-    """BASELINE.json configs[1]: n blocks of exactly 1024 B = DAG-CBOR byte-string
-    header 59 03 FD + 1021 PRNG bytes."""
-    with np.errstate(over="ignore"):
-        words = splitmix64(seed, n * 128)
-    data = words.view(np.uint8).reshape(n, 1024).copy()
+    """BASELINE.json configs[1]: n blocks of exactly 1024 B = DAG-CBOR byte-string header 59 03 FD +
+    1021 PRNG bytes (used by tools/tune_b2b.py and `--workload cid`)."""
+    data = splitmix64(seed, n * 128).view(np.uint8).reshape(n, 1024).copy()
     data[:, 0] = 0x59
     data[:, 1] = 0x03
     data[:, 2] = 0xFD
@@ -65,10 +71,10 @@ def make_cfg2(n: int, seed: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=100_000, help="witness blocks per GPU (config 2: 100k)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--receipts", type=int, default=1_000_000, help="receipts per GPU shard")
+    ap.add_argument("--cpu-sample", type=int, default=50_000, help="claims verified by the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -84,46 +90,56 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
 
     import ipc_filecoin_proofs_amd as ipcfp
+    from tools.synth import SEED_BASE, Tipset
 
     eng = ipcfp.Engine(local_rank)
     info = eng.device_info()
 
-    # ---- synthetic input: this rank's shard (weak scaling: fixed blocks per GPU) ----
-    n = args.blocks
-    seed = 0x1BC0F11EC0150000 + 2 + (rank << 20)
-    data, off, lens = make_cfg2(n, seed)
-    # expected CIDs: true digests (computed once, untimed, by the engine's raw-digest
-    # kernel; tests/ pin that kernel bit-exact to the oracle), one bit flipped in every
-    # block with i % 1024 == 7 so the verdict bitmap is non-trivial
-    dig = eng.blake2b256(data, off, lens)
-    cids = np.zeros((n, 40), dtype=np.uint8)
-    cids[:, :6] = np.frombuffer(bytes.fromhex("0171a0e40220"), dtype=np.uint8)
-    cids[:, 6:38] = dig
-    bad_idx = np.arange(7, n, 1024)
-    cids[bad_idx, 6] ^= 1
+    # ---- this rank's shard of the tipset (weak scaling: a fixed number of receipts per GPU) ----
+    t_gen = time.perf_counter()
+    tip = Tipset(seed=SEED_BASE + 3 + (rank << 24), n_receipts=args.receipts, n_parents=5, dup_permille=20,
+                 n_planted=max(1, args.receipts // 1000), max_events=4, no_events_permille=0, variety=0)
+    n_claims = len(tip.claim_exec)
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec, tip.claim_event,
+        tip.claim_emitter, tip.exec_order[tip.claim_exec.astype(np.int64)], tip.claim_ntopics, tip.claim_topics,
+        tip.claim_datalen, tip.claim_data)
+    t_gen = time.perf_counter() - t_gen
 
-    # inputs resident in HBM before the clock starts
-    t_bytes = torch.from_numpy(data).cuda()
-    t_off = torch.from_numpy(off.view(np.int64)).cuda()
-    t_len = torch.from_numpy(lens.view(np.int32)).cuda()
-    t_cids = torch.from_numpy(cids.reshape(-1)).cuda()
+    # ---- inputs resident in HBM before the clock starts ----
+    t_bytes = torch.from_numpy(tip.data).to(dev)
+    t_off = torch.from_numpy(tip.off.view(np.int64)).to(dev)
+    t_len = torch.from_numpy(tip.lens.view(np.int32)).to(dev)
+    t_cids = torch.from_numpy(tip.cids.reshape(-1)).to(dev)
+    t_claims = torch.from_numpy(cl.view(np.uint8).reshape(-1)).to(dev)
+    t_blob = torch.from_numpy(blob).to(dev)
+    t_status = torch.zeros(n_claims, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    w = eng.witness_device(t_bytes.data_ptr(), data.size, t_off.data_ptr(), t_len.data_ptr(), t_cids.data_ptr(), n)
-    bitmap_bytes = ((n + 31) // 32) * 4
-    t_bitmap = torch.as_tensor(DevView(w.cid_bitmap_ptr, bitmap_bytes), device=f"cuda:{local_rank}")
-    gathered = torch.empty(world * bitmap_bytes, dtype=torch.uint8, device=f"cuda:{local_rank}") if world > 1 else None
+    w = eng.witness_device(t_bytes.data_ptr(), tip.data.size, t_off.data_ptr(), t_len.data_ptr(), t_cids.data_ptr(),
+                           tip.n_blocks)
+    bitmap_bytes = ((tip.n_blocks + 31) // 32) * 4
+    t_bitmap = torch.as_tensor(DevView(w.cid_bitmap_ptr, bitmap_bytes), device=dev)
+    payload = torch.empty(bitmap_bytes + n_claims, dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty(world * (bitmap_bytes + n_claims), dtype=torch.uint8, device=dev) if world > 1 else None
+    scan_result = {}
 
     def step():
-        w.verify_cids_async()
+        w.rebuild_index()                                                               # K4
+        w.verify_cids_async()                                                           # K1
+        st, _, m, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                    want_touched=False, counts_only=True)               # K6
+        scan_result["status"], scan_result["matches"] = st, m
+        w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len,
+                                     t_status.data_ptr())                               # exec order + verify
         if world > 1:
-            eng.sync()  # engine stream → visible to the RCCL stream
-            dist.all_gather_into_tensor(gathered, t_bitmap)
+            payload[:bitmap_bytes].copy_(t_bitmap)
+            payload[bitmap_bytes:].copy_(t_status)
+            dist.all_gather_into_tensor(gathered, payload)                               # the one collective
 
     def fence():
         if world > 1:
@@ -144,28 +160,34 @@ def main():
     eng.profile_enable(False)
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- correctness of what was timed (self-check; parity proper lives in tests/) ----
-    st, nbad = w.verify_cids()
-    want = np.ones(n, dtype=np.uint8)
-    want[bad_idx] = 0
-    if not (np.array_equal(st, want) and nbad == len(bad_idx)):
-        raise SystemExit("bench self-check failed: verdicts differ from the planted mismatches")
+    # ---- what was timed must be right (self-check; parity proper lives in tests/) ----
+    status = t_status.cpu().numpy()
+    cid_status, n_bad = w.verify_cids()
+    if n_bad or not (cid_status == 1).all():
+        raise SystemExit("bench self-check failed: a witness CID did not verify")
+    if not (status == 1).all():
+        raise SystemExit(f"bench self-check failed: {int((status != 1).sum())} honest claims did not verify")
+    if scan_result["status"] != 1 or scan_result["matches"] < len(tip.planted):
+        raise SystemExit("bench self-check failed: the scan missed planted matches")
 
-    launches, k_ms = eng.profile_read("blake2b_cid")
-    k_avg_ms = k_ms / max(launches, 1)
-    algo_bytes = float(lens.astype(np.float64).sum() + n * (40 + 12 + 4))
+    kern = {}
+    for k in ("blake2b_cid", "cid_index", "event_scan", "replay", "event_verify", "exec_order"):
+        cnt, ms = eng.profile_read(k)
+        kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
+    k_launches, k_ms = eng.profile_read("blake2b_cid")
+    k_avg_ms = k_ms / max(k_launches, 1)
+    # algorithmic bytes of one K1 launch: every block's payload + its 40-byte claimed CID + (off, len) + order
+    algo_bytes = float(tip.lens.astype(np.float64).sum() + tip.n_blocks * (40 + 12 + 4))
     achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
 
     if rank == 0:
-        units = n * world * args.steps
-        value = units / elapsed
         out = {
-            "metric": "Merkle proofs verified/sec + HBM GB/s, 1M-receipt synthetic tipset, 1/2/4/8 GPU",
-            "value": value,
+            "metric": METRIC,
+            "value": n_claims * world * args.steps / elapsed,
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -177,14 +199,20 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "config2: Blake2b-256 CID verification of %d x 1 KiB DAG-CBOR witness blocks per GPU"
-                % n,
-                "blocks_per_gpu": n,
-                "block_bytes": 1024,
-                "sharding": "block index range per rank; one RCCL all-gather of the per-shard OK bitmaps per step"
-                if world > 1
-                else "single GPU",
+                "workload": "config3 tipset: %d receipts per GPU (Amtv0<Receipt> + one Amt<StampedEvent> each, 5 parent "
+                            "headers with TxMeta and message AMTs), %d witness blocks, %.3f GB; one EventProof claim per "
+                            "receipt; step = CID index + Blake2b-256 CID check of every block + event-filter scan + "
+                            "exec-order reconstruction + verify_event_proof of every claim" %
+                            (args.receipts, tip.n_blocks, tip.stats["payload_bytes"] / 1e9),
+                "receipts_per_gpu": args.receipts,
+                "claims_per_gpu": n_claims,
+                "witness_blocks_per_gpu": tip.n_blocks,
+                "witness_bytes_per_gpu": tip.stats["payload_bytes"],
+                "scan_matches": int(scan_result["matches"]),
+                "sharding": ("receipt-index shard per rank; one RCCL all-gather of verdict bytes + CID bitmaps per step"
+                             if world > 1 else "single GPU"),
                 "device": info["name"],
+                "setup_seconds_untimed": round(t_gen, 2),
             },
             "roofline": {
                 "bound": "hbm",
@@ -195,12 +223,14 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "kernel_avg_ms": k_avg_ms,
-                "launches": launches,
+                "launches": k_launches,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "note": "VALU-bound on gfx950 (≈19 int ops/byte; profiles/r01_ubench_valu_rates.log): see DESIGN.md §K1",
             },
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kern.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(data, off, lens, cids, want, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(tip, status, args.cpu_sample)
         print(json.dumps(out))
     w.close()
     eng.close()
@@ -208,35 +238,58 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(data, off, lens, cids, want, budget_s):
-    """The scalar C++ oracle (a restatement of the reference path — the Rust binary
-    cannot be built here) timed on this box's host cores on a bounded sample of the
-    same workload.  Also used as the checker for the sample."""
+def cpu_baseline(tip, gpu_status, sample):
+    """The scalar C++ oracle — a restatement of the reference path; the Rust reference cannot be built in
+    this image — timed on this box's host cores.  Variant B2 of BASELINE.md §2: witness store and
+    execution order built once (the as-written reference rebuilds the execution order per proof, which
+    is quadratic and cannot finish at this size).  The fixed parts of the step run on the FULL tipset;
+    the per-claim verifier runs on a bounded sample and is scaled linearly to all claims.  The sample's
+    verdicts double as a check of the GPU's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import claims as claims_mod
     import oracle_lib
 
     orc = oracle_lib.load()
-    n = len(off)
-    expect = np.ascontiguousarray(cids[:, 6:38])
-    # size the sample from a short probe so the leg takes ~budget_s
-    probe = min(n, 2000)
+    n = len(tip.claim_exec)
+    sample = min(sample, n)
     t0 = time.perf_counter()
-    orc.blake2b256_verify(data, off[:probe], lens[:probe], expect[:probe])
-    per = (time.perf_counter() - t0) / probe
-    sample = int(max(1000, min(n, budget_s / max(per, 1e-9))))
+    st = orc.store(tip.data, tip.off, tip.lens, tip.cids)
+    t_store = time.perf_counter() - t0
     t0 = time.perf_counter()
-    ok, _ = orc.blake2b256_verify(data, off[:sample], lens[:sample], expect[:sample])
-    dt = time.perf_counter() - t0
-    if not np.array_equal(ok, want[:sample]):
-        raise SystemExit("cpu_baseline: oracle verdicts differ from the GPU's on the sample")
+    ok, good = orc.blake2b256_verify(tip.data, tip.off, tip.lens, np.ascontiguousarray(tip.cids[:, 6:38]))
+    t_cid = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s, has, trip, _ = st.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                     want_touched=False)
+    t_scan = time.perf_counter() - t0
+    ec1 = claims_mod.EventClaims(tip, indices=np.arange(1))
+    ecs = claims_mod.EventClaims(tip, indices=np.arange(sample))
+    t0 = time.perf_counter()
+    st.verify_event_proofs(ec1, mode=1, threads=1)  # builds the execution-order cache: the fixed part
+    t_exec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s1 = st.verify_event_proofs(ecs, mode=1, threads=1)
+    t_sample = max(time.perf_counter() - t0 - t_exec, 1e-9)
+    t0 = time.perf_counter()
+    sall = st.verify_event_proofs(ecs, mode=1, threads=0)
+    t_sample_mt = max(time.perf_counter() - t0 - t_exec, 1e-9)
+    if good != tip.n_blocks or s != 1 or not np.array_equal(s1, gpu_status[:sample]) or not np.array_equal(s1, sall):
+        raise SystemExit("cpu_baseline: the oracle's verdicts differ from the GPU's on the sample")
+    fixed = t_store + t_cid + t_scan + t_exec
+    t_step_1 = fixed + t_sample * (n / sample)
+    t_step_mt = fixed + t_sample_mt * (n / sample)
     return {
-        "value": sample / dt,
+        "value": n / t_step_1,
         "unit": "proofs/s",
         "cores": 1,
         "kind": "port",
-        "sample": "first %d of the %d blocks of this workload, scalar C++ oracle (restatement of the "
-        "reference path; the Rust reference cannot be built in this image), 1 thread, -O3" % (sample, n),
-        "gbps": float(lens[:sample].astype(np.float64).sum()) / dt / 1e9,
+        "sample": "scalar C++ oracle (restatement of the reference; the Rust crate cannot be built here), -O3, 1 thread: "
+                  "store build + Blake2b CID check + event scan + exec-order on the FULL %d-receipt tipset, "
+                  "verify_event_proof on the first %d of %d claims scaled linearly; exec order cached per tipset "
+                  "(BASELINE.md variant B2)" % (tip.params["n_receipts"], sample, n),
+        "seconds": {"store_build": t_store, "cid_check": t_cid, "event_scan": t_scan, "exec_order": t_exec,
+                    "verify_sample": t_sample, "verify_sample_all_threads": t_sample_mt, "step_1_thread": t_step_1},
+        "value_verify_all_host_threads": n / t_step_mt,
         "host_cpus": os.cpu_count(),
     }
 

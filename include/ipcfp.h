@@ -330,6 +330,51 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
 int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_storage_proof_t* proofs,
                                 uint64_t n, const ipcfp_trust_policy_t* trust, ipcfp_status_t* status);
 
+/* ---- packed (binary) claims: the device-resident fast path -----------------------------
+ * The string entry points above parse each claim once and lower it to these structs; a host that
+ * already holds binary CIDs (or verifies the same bundle repeatedly) can build them itself and keep
+ * them in HBM.  Semantics are identical: the flags record what `Cid::try_from(str)?` and the
+ * hex compares of the reference would have observed for the original strings.               */
+#define IPCFP_MAX_PARENTS 16 /* parent blocks per tipset key (engine limit) */
+
+#define IPCFP_TIPSET_PARENTS_PARSED 1u /* every parent_tipset_cids[i] parses (events/verifier.rs:130) */
+#define IPCFP_TIPSET_CHILD_PARSED 2u   /* child_block_cid parses (:131)                               */
+typedef struct ipcfp_tipset_ref {
+    uint32_t flags;
+    uint32_t n_parents;
+    uint8_t child[IPCFP_CID_SLOT];
+    uint8_t parents[IPCFP_MAX_PARENTS][IPCFP_CID_SLOT];
+} ipcfp_tipset_ref_t;
+
+#define IPCFP_CLAIM_MSG_PARSED 1u     /* message_cid parses (events/verifier.rs:193)                   */
+#define IPCFP_CLAIM_DATA_MATCHABLE 2u /* event_data.data is "0x" + an even number of hex digits        */
+typedef struct ipcfp_event_claim {
+    int64_t parent_epoch;
+    int64_t child_epoch;
+    uint64_t exec_index;
+    uint64_t event_index;
+    uint64_t emitter;
+    uint8_t message_cid[IPCFP_CID_SLOT];
+    uint32_t tipset;     /* index into the ipcfp_tipset_ref_t table                                    */
+    uint32_t flags;      /* IPCFP_CLAIM_*                                                               */
+    uint32_t n_topics;   /* claimed topic count                                                        */
+    uint32_t topics_off; /* blob offset of n_topics × 33 bytes: [1 if the string was "0x"+64 hex, topic[32]] */
+    uint32_t data_off;   /* blob offset of the claimed data bytes                                      */
+    uint32_t data_len;
+} ipcfp_event_claim_t;
+
+/* verify_event_proof over packed claims resident in HBM.  `tipsets` is a small HOST table;
+ * claims_d / blob_d / status_d are DEVICE pointers (n claims, blob_len bytes, n status bytes).
+ * Synchronous: returns after the status bytes are written.                                   */
+int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets,
+                                     uint32_t n_tipsets, const void* claims_d, uint64_t n, const void* blob_d,
+                                     uint64_t blob_len, const ipcfp_trust_policy_t* trust,
+                                     const ipcfp_event_filter_t* filter, void* status_d);
+
+/* Rebuild the CID → block index of an existing witness in place (K4), e.g. once per verification
+ * pass when the index build is to be charged to that pass.  No allocation.                    */
+int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

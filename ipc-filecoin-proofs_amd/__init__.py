@@ -20,4 +20,10 @@ from .binding import (  # noqa: F401
     CID_MISMATCH,
     CID_UNCHECKED,
     KERNEL_IDS,
+    pack_event_claims,
+    pack_cids,
+    CLAIM_DTYPE,
+    TIPSET_DTYPE,
+    LOC_DTYPE,
+    MATCH_DTYPE,
 )

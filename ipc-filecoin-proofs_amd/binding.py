@@ -22,6 +22,12 @@ __all__ = [
     "CID_MISMATCH",
     "CID_UNCHECKED",
     "KERNEL_IDS",
+    "pack_event_claims",
+    "pack_cids",
+    "CLAIM_DTYPE",
+    "TIPSET_DTYPE",
+    "LOC_DTYPE",
+    "MATCH_DTYPE",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -91,6 +97,13 @@ class ST:
 
 VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "vec_u8": 4, "any": 5}
 LOC_DTYPE = np.dtype([("block", np.uint32), ("off", np.uint32), ("len", np.uint32)])
+MAX_PARENTS = 16
+TIPSET_DTYPE = np.dtype([("flags", np.uint32), ("n_parents", np.uint32), ("child", np.uint8, (CID_SLOT,)),
+                         ("parents", np.uint8, (MAX_PARENTS, CID_SLOT))])
+CLAIM_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), ("exec_index", np.uint64),
+                        ("event_index", np.uint64), ("emitter", np.uint64), ("message_cid", np.uint8, (CID_SLOT,)),
+                        ("tipset", np.uint32), ("flags", np.uint32), ("n_topics", np.uint32),
+                        ("topics_off", np.uint32), ("data_off", np.uint32), ("data_len", np.uint32)])
 MATCH_DTYPE = np.dtype([("exec_index", np.uint64), ("event_index", np.uint64), ("emitter", np.uint64),
                         ("block", np.uint32), ("off", np.uint32), ("len", np.uint32), ("reserved", np.uint32)])
 
@@ -154,6 +167,8 @@ def load_library() -> C.CDLL:
         "ipcfp_hamt_get": (i32, [vp, vp, vp, C.c_uint32, i32, vp, vp, vp, u64, vp, vp]),
         "ipcfp_exec_order": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_scan_events": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
+        "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
+        "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
         "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
         "ipcfp_verify_storage_proofs": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_verify_event_proofs": (i32, [vp, vp, vp, u64, vp, vp, vp]),
@@ -286,6 +301,56 @@ class Engine:
         return Witness(self, None, None, None, None, device=(bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n))
 
 
+def pack_event_claims(parent_cids, child_cid, parent_epoch, child_epoch, exec_index, event_index, emitter,
+                      message_cids40, n_topics, topics, data_len, data):
+    """Lower binary event claims of ONE tipset to the packed ABI form (ipcfp_tipset_ref_t[1],
+    ipcfp_event_claim_t[n], blob).  topics: u8[n, 4, 32]; data: u8[n, dmax].  All flags are set: binary
+    inputs correspond to strings that parsed."""
+    n = len(exec_index)
+    ts = np.zeros(1, dtype=TIPSET_DTYPE)
+    ts["flags"] = 3
+    ts["n_parents"] = len(parent_cids)
+    ts["child"][0, : len(child_cid)] = np.frombuffer(bytes(child_cid), dtype=np.uint8)
+    for k, c in enumerate(parent_cids):
+        ts["parents"][0, k, : len(c)] = np.frombuffer(bytes(c), dtype=np.uint8)
+    cl = np.zeros(n, dtype=CLAIM_DTYPE)
+    cl["parent_epoch"] = parent_epoch
+    cl["child_epoch"] = child_epoch
+    cl["exec_index"] = exec_index
+    cl["event_index"] = event_index
+    cl["emitter"] = emitter
+    cl["message_cid"] = message_cids40
+    cl["flags"] = 3
+    cl["n_topics"] = n_topics
+    # blob: per claim n_topics × [1, topic(32)] then data
+    nt = np.asarray(n_topics, dtype=np.int64)
+    dl = np.asarray(data_len, dtype=np.int64)
+    sizes = nt * 33 + dl
+    starts = np.zeros(n, dtype=np.int64)
+    if n:
+        starts[1:] = np.cumsum(sizes[:-1])
+    total = int(sizes.sum())
+    blob = np.zeros(total + 64, dtype=np.uint8)
+    cl["topics_off"] = starts
+    cl["data_off"] = starts + nt * 33
+    cl["data_len"] = dl
+    for t in range(topics.shape[1]):
+        sel = np.nonzero(nt > t)[0]
+        if len(sel) == 0:
+            continue
+        base = starts[sel] + 33 * t
+        blob[base] = 1
+        idx = base[:, None] + 1 + np.arange(32)[None, :]
+        blob[idx] = topics[sel, t]
+    dmax = data.shape[1]
+    for j in range(dmax):
+        sel = np.nonzero(dl > j)[0]
+        if len(sel) == 0:
+            break
+        blob[starts[sel] + nt[sel] * 33 + j] = data[sel, j]
+    return ts, cl, blob[: total + 64], total
+
+
 def pack_cids(cids) -> np.ndarray:
     out = np.zeros((len(cids), CID_SLOT), dtype=np.uint8)
     for i, c in enumerate(cids):
@@ -393,8 +458,10 @@ class Witness:
                                                       C.byref(cnt)), "exec_order")
         return int(st[0]), out
 
-    def scan_events(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor=None, want_touched=True):
-        """K6/K8.  Returns (status, has_match u8[n_receipts], matches structured[n], touched block ids)."""
+    def scan_events(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor=None, want_touched=True,
+                    counts_only=False):
+        """K6/K8.  Returns (status, has_match u8[n_receipts], matches structured[n], touched block ids);
+        with counts_only: (status, n_receipts, n_matches, None) and nothing is copied back."""
         root = np.frombuffer(bytes(receipts_root).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
         filt = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
         st = np.zeros(1, dtype=np.uint8)
@@ -405,6 +472,8 @@ class Witness:
         # sizing call, then the real one
         self.eng._check(self.lib.ipcfp_scan_events(self.eng.h, self.h, _p(root), _p(filt), a[0], a[1], _p(st), None, 0,
                                                    C.byref(nr), None, 0, C.byref(nm), None), "scan_events")
+        if counts_only:
+            return int(st[0]), int(nr.value), int(nm.value), None
         has = np.zeros(int(nr.value), dtype=np.uint8)
         m = np.zeros(int(nm.value), dtype=MATCH_DTYPE)
         if st[0] == 1:
@@ -432,6 +501,19 @@ class Witness:
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st)), "verify_event_proofs")
         return st
+
+    def rebuild_index(self):
+        """K4 again, in place (no allocation)."""
+        self.eng._check(self.lib.ipcfp_witness_rebuild_index(self.eng.h, self.h), "rebuild_index")
+
+    def verify_event_claims_device(self, tipsets: np.ndarray, claims_ptr: int, n: int, blob_ptr: int, blob_len: int,
+                                   status_ptr: int, trust=None, filt=None):
+        """Packed claims resident in HBM (ipcfp_event_claim_t[n]); status bytes are written to status_ptr."""
+        tipsets = np.ascontiguousarray(tipsets, dtype=TIPSET_DTYPE)
+        self.eng._check(self.lib.ipcfp_verify_event_claims_device(
+            self.eng.h, self.h, _p(tipsets), len(tipsets), claims_ptr, n, blob_ptr, blob_len,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, status_ptr), "verify_event_claims_device")
 
     @property
     def cid_bitmap_ptr(self) -> int:

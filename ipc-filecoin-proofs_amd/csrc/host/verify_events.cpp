@@ -76,11 +76,54 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     return IPCFP_OK;
 }
 
+
+// Shared device path of the string and the packed entry points: prepare every tipset context
+// (header facts, execution order) and verify the batch.  `claims_d`, `blob_d`, `status_d` are device.
+int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
+                  uint32_t n, const uint8_t* blob_d, const ipcfp_trust_policy_t* trust,
+                  const ipcfp_event_filter_t* filter, uint8_t* status_d) {
+    static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
+    const WitnessView view = witness_view(w);
+    DevBuf<TipsetCtxDev> tcs_d;
+    IPCFP_HIP(ctx, tcs_d.alloc(tcs.size()));
+    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
+                                  ctx->stream));
+    int rc = launch_ctx_headers(ctx, view, tcs_d.p, uint32_t(tcs.size()));
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipMemcpyAsync(tcs.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
+    for (size_t k = 0; k < tcs.size(); ++k) {
+        TipsetCtxDev& tc = tcs[k];
+        tc.exec_status = IPCFP_ST_ERR_BAD_CLAIM;
+        tc.exec_slots = nullptr;
+        // the execution order is only reached when steps 1-2 can pass for some proof of this context
+        const bool reachable = (tc.flags & TC_PARENTS_PARSED) && (tc.flags & TC_CHILD_PARSED) &&
+                               tc.child_status == IPCFP_ST_TRUE && tc.parents_match && tc.n_parents > 0 &&
+                               tc.parent0_status == IPCFP_ST_TRUE;
+        if (!reachable) continue;
+        execs[k].reset(new ExecState());
+        rc = build_exec_order(ctx, view, tcs_d.p + k, tc.n_parents, *execs[k]);
+        if (rc) return rc;
+        tc.exec_status = execs[k]->status;
+        tc.exec_mask = execs[k]->mask;
+        tc.exec_slots = execs[k]->slots.p;
+        tc.exec_keys = execs[k]->keys.p;
+        tc.exec_pos = execs[k]->pos.p;
+        tc.exec_len = execs[k]->exec_len;
+    }
+    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
+                                  ctx->stream));
+    rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, blob_d, trust ? *trust : accept_all, filter, status_d);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // contexts / exec tables are released on return
+    return IPCFP_OK;
+}
+
 }  // namespace ipcfp
 
 namespace {
-
-const ipcfp_trust_policy_t kAcceptAllEv = {0, 0, 0, 0};
 
 bool parse_hex0x(const char* s, bool allow_upper_x, std::vector<uint8_t>& out) {
     // the reference formats "0x" + lowercase hex and compares ignoring ASCII case, so a claimed
@@ -187,41 +230,7 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
         if (blob.size() >= 0xf0000000ULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "claim blob too large");
     }
 
-    // ---- contexts on the device ----
-    const WitnessView view = witness_view(w);
-    DevBuf<TipsetCtxDev> tcs_d;
-    IPCFP_HIP(ctx, tcs_d.alloc(tcs.size()));
-    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
-                                  ctx->stream));
-    int rc = launch_ctx_headers(ctx, view, tcs_d.p, uint32_t(tcs.size()));
-    if (rc) return rc;
-    IPCFP_HIP(ctx, hipMemcpyAsync(tcs.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), hipMemcpyDeviceToHost,
-                                  ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
-    for (size_t k = 0; k < tcs.size(); ++k) {
-        TipsetCtxDev& tc = tcs[k];
-        tc.exec_status = IPCFP_ST_ERR_BAD_CLAIM;
-        tc.exec_slots = nullptr;
-        // the execution order is only reached when steps 1-2 can pass for some proof of this context
-        const bool reachable = (tc.flags & TC_PARENTS_PARSED) && (tc.flags & TC_CHILD_PARSED) &&
-                               tc.child_status == IPCFP_ST_TRUE && tc.parents_match && tc.n_parents > 0 &&
-                               tc.parent0_status == IPCFP_ST_TRUE;
-        if (!reachable) continue;
-        execs[k].reset(new ExecState());
-        rc = build_exec_order(ctx, view, tcs_d.p + k, tc.n_parents, *execs[k]);
-        if (rc) return rc;
-        tc.exec_status = execs[k]->status;
-        tc.exec_mask = execs[k]->mask;
-        tc.exec_slots = execs[k]->slots.p;
-        tc.exec_keys = execs[k]->keys.p;
-        tc.exec_pos = execs[k]->pos.p;
-        tc.exec_len = execs[k]->exec_len;
-    }
-    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
-                                  ctx->stream));
-
-    // ---- the batch ----
+    // ---- upload, then the shared device path ----
     DevBuf<EventClaimPacked> cd;
     DevBuf<uint8_t> bd, sd;
     IPCFP_HIP(ctx, cd.alloc(n));
@@ -230,9 +239,34 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     IPCFP_HIP(ctx, hipMemcpyAsync(cd.p, packed.data(), n * sizeof(EventClaimPacked), hipMemcpyHostToDevice, ctx->stream));
     if (!blob.empty())
         IPCFP_HIP(ctx, hipMemcpyAsync(bd.p, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_verify_events(ctx, view, cd.p, uint32_t(n), tcs_d.p, bd.p, trust ? *trust : kAcceptAllEv, filter, sd.p);
+    int rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, trust, filter, sd.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+
+int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets,
+                                     uint32_t n_tipsets, const void* claims_d, uint64_t n, const void* blob_d,
+                                     uint64_t blob_len, const ipcfp_trust_policy_t* trust,
+                                     const ipcfp_event_filter_t* filter, void* status_d) {
+    (void)blob_len;
+    if (!ctx || !w || w->ctx != ctx || (n && (!claims_d || !status_d || !tipsets))) return IPCFP_E_INVALID;
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    if (n == 0) return IPCFP_OK;
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<TipsetCtxDev> tcs(n_tipsets);
+    for (uint32_t k = 0; k < n_tipsets; ++k) {
+        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
+        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
+        tcs[k].flags = tipsets[k].flags;
+        tcs[k].n_parents = tipsets[k].n_parents;
+        tcs[k].child = key_from_slot(tipsets[k].child);
+        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
+    }
+    int rc = verify_packed(ctx, w, tcs, static_cast<const EventClaimPacked*>(claims_d), uint32_t(n),
+                           static_cast<const uint8_t*>(blob_d), trust, filter, static_cast<uint8_t*>(status_d));
+    if (rc) return rc;
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IPCFP_OK;
 }

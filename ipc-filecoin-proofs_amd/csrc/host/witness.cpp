@@ -163,6 +163,12 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
     return IPCFP_OK;
 }
 
+int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
+    if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    return witness_build_index(ctx, w);
+}
+
 void* ipcfp_witness_cid_bitmap_device(ipcfp_witness_t* w) { return w ? w->ok_bits.p : nullptr; }
 void* ipcfp_witness_cid_status_device(ipcfp_witness_t* w) { return w ? w->cid_status.p : nullptr; }
 

@@ -40,7 +40,7 @@ int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
     const uint32_t n = uint32_t(w->n);
     uint32_t size = 64;
     while (size < 2ull * n) size <<= 1;
-    IPCFP_HIP(ctx, w->index_slots.alloc(size));
+    if (w->index_slots.count != size) IPCFP_HIP(ctx, w->index_slots.alloc(size));  // rebuilds reuse the table
     w->index_mask = size - 1;
     IPCFP_HIP(ctx, hipMemsetAsync(w->index_slots.p, 0xff, size_t(size) * 4, ctx->stream));
     if (n == 0) return IPCFP_OK;

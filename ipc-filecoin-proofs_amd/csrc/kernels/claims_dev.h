@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 
+#include "ipcfp.h"
 #include "witness_dev.h"
 
 namespace ipcfp {
@@ -45,7 +46,7 @@ enum : uint32_t {
     TC_CHILD_PARSED = 1u << 1,        // child CID string parses (:131)
 };
 
-struct EventClaimPacked {
+struct EventClaimPacked {   // layout == ipcfp_event_claim_t (include/ipcfp.h)
     long long parent_epoch, child_epoch;
     uint64_t exec_index, event_index, emitter;
     CidKey message;
@@ -56,5 +57,8 @@ struct EventClaimPacked {
     uint32_t data_off;      // blob offset of the claimed data bytes
     uint32_t data_len;
 };
+static_assert(sizeof(EventClaimPacked) == sizeof(ipcfp_event_claim_t), "packed claim layout");
+static_assert(EC_MSG_PARSED == IPCFP_CLAIM_MSG_PARSED && EC_DATA_MATCHABLE == IPCFP_CLAIM_DATA_MATCHABLE, "flags");
+static_assert(TC_PARENTS_PARSED == IPCFP_TIPSET_PARENTS_PARSED && TC_CHILD_PARSED == IPCFP_TIPSET_CHILD_PARSED, "flags");
 
 }  // namespace ipcfp

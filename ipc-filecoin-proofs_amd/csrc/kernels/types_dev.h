@@ -5,7 +5,7 @@
 
 namespace ipcfp {
 
-constexpr uint32_t kMaxParents = 16;  // tipset keys are small (mainnet: ≤ ~10 blocks); engine limit, see DESIGN.md
+constexpr uint32_t kMaxParents = IPCFP_MAX_PARENTS;  // tipset keys are small (mainnet: ≤ ~10 blocks); engine limit, see DESIGN.md
 
 // HeaderLite (src/proofs/common/decode.rs:100-118): 16-tuple; fields 5,7,8,9,10,12,14 typed.
 struct HeaderLite {

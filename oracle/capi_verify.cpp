@@ -77,10 +77,33 @@ void orc_verify_event_proofs(void* store, const ipcfp_event_proof_t* proofs, uin
             status[i] = guarded([&] { return verify_event_proof_one(s->bs, proofs[i], trust, filter); });
         return;
     }
+    // one ExecCache per distinct tipset key (the strings of parent_tipset_cids)
+    std::unordered_map<std::string, ExecCache> caches;
+    std::vector<const ExecCache*> which(n, nullptr);
+    for (uint64_t i = 0; i < n; ++i) {
+        std::string key;
+        for (uint32_t k = 0; k < proofs[i].n_parent_tipset_cids; ++k) {
+            key += proofs[i].parent_tipset_cids[k] ? proofs[i].parent_tipset_cids[k] : "";
+            key.push_back('\n');
+        }
+        auto it = caches.find(key);
+        if (it == caches.end()) {
+            std::vector<Cid> parents;
+            bool parsed = true;
+            for (uint32_t k = 0; k < proofs[i].n_parent_tipset_cids && parsed; ++k) {
+                Cid c;
+                parsed = proofs[i].parent_tipset_cids[k] && cid_from_string(proofs[i].parent_tipset_cids[k], c);
+                parents.push_back(c);
+            }
+            // an unparsable key never reaches the execution order (Err at step 1): any cache will do
+            it = caches.emplace(key, parsed ? build_exec_cache(s->bs, parents) : ExecCache()).first;
+        }
+        which[i] = &it->second;
+    }
     if (threads > 0) omp_set_num_threads(threads);
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < int64_t(n); ++i)
-        status[i] = guarded([&] { return verify_event_proof_one(s->bs, proofs[i], trust, filter); });
+        status[i] = guarded([&] { return verify_event_proof_one(s->bs, proofs[i], trust, filter, which[i]); });
 }
 
 // mode 0: as written — the witness store is rebuilt for EVERY proof (verifier.rs:19-28 → storage/verifier.rs:30).

@@ -95,8 +95,21 @@ static bool eq_ignore_ascii_case(const std::string& a, const char* b) {
 }
 
 // ---- event proof ---------------------------------------------------------------
+ExecCache build_exec_cache(const Blockstore& bs, const std::vector<Cid>& parents) {
+    ExecCache c;
+    try {
+        std::vector<Cid> exec = reconstruct_execution_order(bs, parents);
+        c.index.reserve(exec.size() * 2);
+        for (size_t i = 0; i < exec.size(); ++i) c.index.emplace(exec[i].b, i);  // exec is already de-duplicated
+        c.ok = true;
+    } catch (const Err& e) {
+        c.err_status = e.status;
+    }
+    return c;
+}
+
 uint8_t verify_event_proof_one(const Blockstore& bs, const ipcfp_event_proof_t& p, const ipcfp_trust_policy_t* trust,
-                               const ipcfp_event_filter_t* filter) {
+                               const ipcfp_event_filter_t* filter, const ExecCache* exec_cache) {
     // Step 1: verify_trust_anchors (events/verifier.rs:124-144)
     std::vector<Cid> parent_cids = parse_claim_cids(p.parent_tipset_cids, p.n_parent_tipset_cids);  // :130
     Cid child_cid = parse_claim_cid(p.child_block_cid);                                                // :131
@@ -110,11 +123,19 @@ uint8_t verify_event_proof_one(const Blockstore& bs, const ipcfp_event_proof_t& 
     HeaderLite parent_hdr = decode_header(must_get(bs, parent_cids[0], "parent header"));               // :171-174
     if (parent_hdr.height != p.parent_epoch) return IPCFP_ST_FALSE_PARENT_EPOCH;                        // :176
     // Step 3: verify_execution_order (:184-204)
-    std::vector<Cid> exec = reconstruct_execution_order(bs, parent_cids);                               // :190
-    Cid msg = parse_claim_cid(p.message_cid);                                                           // :193
-    auto it = std::find(exec.begin(), exec.end(), msg);
-    if (it == exec.end()) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                                        // :194
-    if (uint64_t(it - exec.begin()) != p.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;                  // :199
+    if (exec_cache) {
+        if (!exec_cache->ok) throw Err(exec_cache->err_status, "reconstruct_execution_order failed");   // :190
+        Cid msg = parse_claim_cid(p.message_cid);                                                       // :193
+        auto hit = exec_cache->index.find(msg.b);
+        if (hit == exec_cache->index.end()) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                      // :194
+        if (hit->second != p.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;                              // :199
+    } else {
+        std::vector<Cid> exec = reconstruct_execution_order(bs, parent_cids);                           // :190
+        Cid msg = parse_claim_cid(p.message_cid);                                                       // :193
+        auto it = std::find(exec.begin(), exec.end(), msg);
+        if (it == exec.end()) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                                    // :194
+        if (uint64_t(it - exec.begin()) != p.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;              // :199
+    }
     // Step 4: verify_receipt_and_event (:207-254)
     HeaderLite ch = decode_header(must_get(bs, child_cid, "child header"));                             // :214-217
     AmtRoot receipts = amt_load(bs, ch.parent_message_receipts, 0, check_receipt);                      // :220

@@ -12,9 +12,19 @@ bool trusted(const ipcfp_trust_policy_t* t, int64_t epoch);
 // reconstruct_execution_order (src/proofs/events/utils.rs:16-30) → collect_exec_list(verify_txmeta = true) (:48-94)
 std::vector<Cid> reconstruct_execution_order(const Blockstore& bs, const std::vector<Cid>& parent_hdr_cids);
 
+// Baseline variant B2 ("fair"): the execution order of a tipset key computed once and
+// looked up through a hash map instead of being rebuilt and linearly searched per proof.
+struct ExecCache {
+    bool ok = false;
+    uint8_t err_status = 0;                                // Err of reconstruct_execution_order, if any
+    std::unordered_map<Bytes, uint64_t, BytesHash> index;  // message CID → execution index
+};
+
 // verify_single_proof (src/proofs/events/verifier.rs:92-121) → status byte; Err is thrown.
+// exec_cache == nullptr: exactly as written (execution order rebuilt for this proof, :190).
 uint8_t verify_event_proof_one(const Blockstore& bs, const ipcfp_event_proof_t& p, const ipcfp_trust_policy_t* trust,
-                               const ipcfp_event_filter_t* filter);
+                               const ipcfp_event_filter_t* filter, const ExecCache* exec_cache = nullptr);
+ExecCache build_exec_cache(const Blockstore& bs, const std::vector<Cid>& parents);
 
 // verify_storage_proof steps 2-6 (src/proofs/storage/verifier.rs:24-63) over an already loaded store.
 uint8_t verify_storage_proof_one(const Blockstore& bs, const ipcfp_storage_proof_t& p,

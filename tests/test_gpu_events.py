@@ -216,3 +216,36 @@ def test_scan_events_deep_event_amts(engine, oracle):
     assert np.array_equal(w.verify_event_proofs(ec.arr, ec.n), st.verify_event_proofs(ec, mode=1))
     w.close()
     st.close()
+
+
+def test_packed_device_claims_equal_string_claims(tip, both, engine):
+    """The device-resident packed path (what bench.py times) must give the same statuses as the
+    string path for the same claims."""
+    import ctypes
+    import torch
+
+    import ipc_filecoin_proofs_amd as ipcfp
+
+    w, st = both
+    ec = claims.EventClaims(tip)
+    want = st.verify_event_proofs(ec, mode=1)
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec, tip.claim_event,
+        tip.claim_emitter, tip.exec_order[tip.claim_exec.astype(np.int64)], tip.claim_ntopics, tip.claim_topics,
+        tip.claim_datalen, tip.claim_data)
+    # corrupt a few packed claims the same way the string test does
+    cl["exec_index"][0] += 1
+    cl["emitter"][1] += 1
+    ec.arr[0].exec_index += 1
+    ec.arr[1].emitter += 1
+    want = st.verify_event_proofs(ec, mode=1)
+    d_cl = torch.from_numpy(cl.view(np.uint8).reshape(-1)).cuda()
+    d_blob = torch.from_numpy(blob).cuda()
+    d_st = torch.zeros(len(cl), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    w.verify_event_claims_device(ts, d_cl.data_ptr(), len(cl), d_blob.data_ptr(), blob_len, d_st.data_ptr())
+    got = d_st.cpu().numpy()
+    assert np.array_equal(got, want)
+    w.rebuild_index()
+    w.verify_event_claims_device(ts, d_cl.data_ptr(), len(cl), d_blob.data_ptr(), blob_len, d_st.data_ptr())
+    assert np.array_equal(d_st.cpu().numpy(), want)
