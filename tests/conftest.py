@@ -30,6 +30,12 @@ def oracle():
 def engine():
     """One engine context on cuda:0.  Fails loudly (no CPU fallback) if the HIP
     library or the device is missing."""
+    # torch (its bundled HIP runtime) must come up before libipcfp.so creates its context when both are
+    # used in one process — the same order bench.py uses
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.init()
     import ipc_filecoin_proofs_amd as ipcfp
 
     eng = ipcfp.Engine(0)
