@@ -5,12 +5,28 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ipcfp.h"
 
 namespace ipcfp {
+
+// Caching device allocator, one per context.  hipMalloc/hipFree cost ≈100 µs each and serialise
+// the device; verification calls need a dozen scratch buffers, so freed buffers are kept and reused
+// (stream order on the context's single stream makes reuse safe; every entry point that hands
+// buffers back has synchronised the stream first).
+struct DevPool {
+    std::vector<std::pair<void*, size_t>> free_;  // (pointer, capacity in bytes)
+    size_t cached_bytes = 0;
+    hipError_t take(void** out, size_t bytes, size_t* cap);
+    void give(void* p, size_t cap);
+    void drain();
+    ~DevPool() { drain(); }
+};
+extern thread_local DevPool* g_tls_pool;
 
 struct ProfiledLaunch {
     int kernel_id;
@@ -25,6 +41,7 @@ struct ipcfp_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     hipDeviceProp_t props{};
+    ipcfp::DevPool pool;
     // --- tuning knobs (env IPCFP_B2B_MODE / IPCFP_B2B_WG; defaults are the measured best) ---
     int b2b_mode = 0;        // 0: hipcc-chosen u64 adds, 1: explicit add_co/addc pairs
     uint32_t b2b_wg = 64;    // K1 workgroup size (multiple of 64, <= 256)
@@ -62,26 +79,68 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t count = 0;
+    size_t cap = 0;          // capacity in bytes as handed out by the pool
+    DevPool* owner = nullptr;  // pool the buffer returns to (null: plain hipFree)
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (owner) owner->give(p, cap);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         count = 0;
+        cap = 0;
+        owner = nullptr;
     }
     hipError_t alloc(size_t n) {
         release();
         count = n;
-        if (n == 0) n = 1;
-        return hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        size_t bytes = (n ? n : 1) * sizeof(T);
+        if (g_tls_pool) {
+            owner = g_tls_pool;
+            return owner->take(reinterpret_cast<void**>(&p), bytes, &cap);
+        }
+        cap = bytes;
+        return hipMalloc(reinterpret_cast<void**>(&p), bytes);
     }
     size_t bytes() const { return count * sizeof(T); }
+    void swap(DevBuf& o) {
+        std::swap(p, o.p);
+        std::swap(count, o.count);
+        std::swap(cap, o.cap);
+        std::swap(owner, o.owner);
+    }
 };
+
+// Binds the calling thread to a context for the duration of one C-ABI call: device selection and
+// the allocation pool DevBufs draw from.
+struct CallScope {
+    DevPool* prev;
+    explicit CallScope(ipcfp_ctx* c) : prev(g_tls_pool) { g_tls_pool = &c->pool; }
+    ~CallScope() { g_tls_pool = prev; }
+};
+#define IPCFP_ENTER(ctx)                                 \
+    IPCFP_HIP((ctx), hipSetDevice((ctx)->device));       \
+    ::ipcfp::CallScope _ipcfp_call_scope(ctx)
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return uint32_t((a + b - 1) / b); }
 
+}  // namespace ipcfp
+
+namespace ipcfp {
+// A cached `Amt::for_each` enumeration of one AMT of the witness (amt_enum.hip): the leaf values in
+// index order.  Valid until the witness index is rebuilt.
+struct EnumCached {
+    uint64_t root[5];
+    int version = 0, vkind = 0;
+    DevBuf<uint8_t> leaves;  // LeafRef[n]
+    uint64_t n = 0;
+    uint64_t error = ~0ULL;  // packed first error, ~0 = none
+    bool dense = false;      // leaf i has index i for every i
+};
 }  // namespace ipcfp
 
 // The opaque witness of the C ABI: the whole witness resident in HBM as SoA.
@@ -102,4 +161,5 @@ struct ipcfp_witness {
     ipcfp::DevBuf<uint32_t> index_slots;  // table of block ids, 0xffffffff = empty
     uint32_t index_mask = 0;
     bool uniform_chunks = false;  // every block has the same chunk count → identity order
+    std::vector<std::unique_ptr<ipcfp::EnumCached>> enum_cache;
 };

@@ -17,6 +17,49 @@ int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...) {
     return rc;
 }
 
+thread_local DevPool* g_tls_pool = nullptr;
+
+hipError_t DevPool::take(void** out, size_t bytes, size_t* cap) {
+    const size_t want = (bytes + 255) & ~size_t(255);
+    // best fit among cached buffers that are not wastefully large
+    size_t best = free_.size();
+    for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].second >= want && free_[i].second <= 2 * want + (1u << 20) &&
+            (best == free_.size() || free_[i].second < free_[best].second))
+            best = i;
+    if (best != free_.size()) {
+        *out = free_[best].first;
+        *cap = free_[best].second;
+        cached_bytes -= free_[best].second;
+        free_[best] = free_.back();
+        free_.pop_back();
+        return hipSuccess;
+    }
+    *cap = want;
+    hipError_t e = hipMalloc(out, want);
+    if (e != hipSuccess && !free_.empty()) {  // give cached memory back and retry once
+        drain();
+        e = hipMalloc(out, want);
+    }
+    return e;
+}
+
+void DevPool::give(void* p, size_t cap) {
+    constexpr size_t kMaxCached = size_t(16) << 30;  // 288 GB of HBM: keeping 16 GB of scratch warm is cheap
+    if (cached_bytes + cap > kMaxCached) {
+        (void)hipFree(p);
+        return;
+    }
+    free_.emplace_back(p, cap);
+    cached_bytes += cap;
+}
+
+void DevPool::drain() {
+    for (auto& f : free_) (void)hipFree(f.first);
+    free_.clear();
+    cached_bytes = 0;
+}
+
 static hipEvent_t take_event(ipcfp_ctx* ctx) {
     if (!ctx->free_events.empty()) {
         hipEvent_t e = ctx->free_events.back();
@@ -112,6 +155,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
         (void)hipEventDestroy(l.stop);
     }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    ctx->pool.drain();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -37,7 +37,7 @@ int ipcfp_amt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid4
     if (version != 0 && version != 3) return set_error(ctx, IPCFP_E_INVALID, "AMT version must be 0 or 3");
     if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
     if (n == 0) return IPCFP_OK;
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     DevBuf<uint64_t> idx;
     DevBuf<uint8_t> st;
     DevBuf<ipcfp_value_loc_t> lc;
@@ -66,7 +66,7 @@ int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid
         const uint64_t end = uint64_t(key_off[i]) + key_len[i];
         if (end > kbytes) kbytes = end;
     }
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     DevBuf<uint8_t> kb, st;
     DevBuf<uint32_t> ko, kl;
     DevBuf<ipcfp_value_loc_t> lc;

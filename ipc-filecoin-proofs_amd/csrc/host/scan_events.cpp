@@ -21,36 +21,30 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
                       ipcfp_event_match_t* matches, uint64_t cap_matches, uint64_t* n_matches, uint32_t* touched_bits) {
     if (!ctx || !w || w->ctx != ctx || !receipts_root40 || !filter || !status_out || !n_receipts || !n_matches)
         return IPCFP_E_INVALID;
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     *n_receipts = *n_matches = 0;
     *status_out = IPCFP_ST_ERR;
     const WitnessView view = witness_view(w);
     const CidKey root = key_from_slot(receipts_root40);
 
-    DevBuf<AmtRootSpec> roots;
     DevBuf<unsigned long long> err;
-    IPCFP_HIP(ctx, roots.alloc(1));
     IPCFP_HIP(ctx, err.alloc(1));
-    AmtRootSpec spec{};
-    spec.root = root;
-    spec.version = 0;
-    spec.seq = 0;
     unsigned long long e0 = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemcpyAsync(roots.p, &spec, sizeof spec, hipMemcpyHostToDevice, ctx->stream));
     IPCFP_HIP(ctx, hipMemcpyAsync(err.p, &e0, 8, hipMemcpyHostToDevice, ctx->stream));
-    AmtEnumResult en;
-    int rc = amt_enumerate(ctx, view, roots.p, 1, VK_RECEIPT, err.p, en);
+    const EnumCached* en = nullptr;
+    int rc = amt_enumerate_cached(ctx, w, root, 0, VK_RECEIPT, &en);  // receipts in index order
     if (rc) return rc;
-    if (en.error != kNoEnumError) {
-        *status_out = ipcfp_status_t(enum_error_code(en.error));
+    if (en->error != kNoEnumError) {
+        *status_out = ipcfp_status_t(enum_error_code(en->error));
         return IPCFP_OK;
     }
-    const uint32_t n = uint32_t(en.n_leaves);
+    const LeafRef* leaves = reinterpret_cast<const LeafRef*>(en->leaves.p);
+    const uint32_t n = uint32_t(en->n);
     // receipt indices are ascending: the last leaf gives the size of the per-index byte map
     uint64_t n_idx = 0;
     if (n) {
         LeafRef last;
-        IPCFP_HIP(ctx, hipMemcpyAsync(&last, en.leaves.p + (n - 1), sizeof last, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, hipMemcpyAsync(&last, leaves + (n - 1), sizeof last, hipMemcpyDeviceToHost, ctx->stream));
         IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         n_idx = last.index + 1;
     }
@@ -63,7 +57,7 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
     IPCFP_HIP(ctx, total.alloc(1));
     IPCFP_HIP(ctx, has.alloc(n_idx));
     if (n_idx) IPCFP_HIP(ctx, hipMemsetAsync(has.p, 0, n_idx, ctx->stream));
-    rc = launch_scan_pass1(ctx, view, en.leaves.p, n, *filter, has_actor, actor, counts.p, err.p);
+    rc = launch_scan_pass1(ctx, view, leaves, n, *filter, has_actor, actor, counts.p, err.p);
     if (rc) return rc;
     rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total.p, scratch.p);
     if (rc) return rc;
@@ -85,7 +79,7 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
         IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, size_t(words) * 4, ctx->stream));
         rec.touched = touched.p;
     }
-    rc = launch_scan_pass2(ctx, rec, root, en.leaves.p, n, *filter, has_actor, actor, counts.p, offsets.p, md.p, has.p,
+    rc = launch_scan_pass2(ctx, rec, root, leaves, n, *filter, has_actor, actor, counts.p, offsets.p, md.p, has.p,
                            n_idx);
     if (rc) return rc;
     *n_receipts = n_idx;

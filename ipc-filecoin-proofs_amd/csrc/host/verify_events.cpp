@@ -98,6 +98,8 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         TipsetCtxDev& tc = tcs[k];
         tc.exec_status = IPCFP_ST_ERR_BAD_CLAIM;
         tc.exec_slots = nullptr;
+        tc.receipt_leaves = nullptr;
+        tc.n_receipt_leaves = 0;
         // the execution order is only reached when steps 1-2 can pass for some proof of this context
         const bool reachable = (tc.flags & TC_PARENTS_PARSED) && (tc.flags & TC_CHILD_PARSED) &&
                                tc.child_status == IPCFP_ST_TRUE && tc.parents_match && tc.n_parents > 0 &&
@@ -112,6 +114,14 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         tc.exec_keys = execs[k]->keys.p;
         tc.exec_pos = execs[k]->pos.p;
         tc.exec_len = execs[k]->exec_len;
+        // receipts AMT of this context: enumerate once (shared with ipcfp_scan_events through the witness cache)
+        const EnumCached* rc_enum = nullptr;
+        rc = amt_enumerate_cached(ctx, w, tc.receipts_root, 0, VK_RECEIPT, &rc_enum);
+        if (rc) return rc;
+        if (rc_enum->error == kNoEnumError && rc_enum->dense) {
+            tc.receipt_leaves = reinterpret_cast<const LeafRef*>(rc_enum->leaves.p);
+            tc.n_receipt_leaves = rc_enum->n;
+        }
     }
     IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
                                   ctx->stream));
@@ -142,7 +152,7 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     if (!ctx || !w || w->ctx != ctx || (n && (!proofs || !status))) return IPCFP_E_INVALID;
     if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
     if (n == 0) return IPCFP_OK;
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
 
     // ---- parse claims, group by tipset context ----
     std::vector<EventClaimPacked> packed(n);
@@ -254,7 +264,7 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
     if (!ctx || !w || w->ctx != ctx || (n && (!claims_d || !status_d || !tipsets))) return IPCFP_E_INVALID;
     if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
     if (n == 0) return IPCFP_OK;
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     std::vector<TipsetCtxDev> tcs(n_tipsets);
     for (uint32_t k = 0; k < n_tipsets; ++k) {
         if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
@@ -279,7 +289,7 @@ int ipcfp_exec_order(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent
                      ipcfp_status_t* status_out, uint8_t* out_cids40, uint64_t cap, uint64_t* count) {
     if (!ctx || !w || w->ctx != ctx || !status_out || !count || (n_parents && !parent_cids40)) return IPCFP_E_INVALID;
     if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     TipsetCtxDev tc;
     std::memset(&tc, 0, sizeof tc);
     tc.n_parents = n_parents;

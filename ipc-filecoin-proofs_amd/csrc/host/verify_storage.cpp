@@ -80,7 +80,7 @@ int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcf
             }
         }
     }
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     DevBuf<StorageClaimPacked> cd;
     DevBuf<uint8_t> sd;
     IPCFP_HIP(ctx, cd.alloc(n));

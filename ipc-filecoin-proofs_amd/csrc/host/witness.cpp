@@ -87,7 +87,7 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
                              (unsigned long long)i, (unsigned long long)off[i], len[i], (unsigned long long)nbytes);
         payload += len[i];
     }
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     std::unique_ptr<ipcfp_witness> w(new (std::nothrow) ipcfp_witness());
     if (!w) return IPCFP_E_NOMEM;
     w->ctx = ctx;
@@ -119,7 +119,7 @@ int ipcfp_witness_create_device(ipcfp_ctx_t* ctx, const void* bytes_d, uint64_t 
     *out = nullptr;
     if (n && (!off_d || !len_d || !cids40_d)) return set_error(ctx, IPCFP_E_INVALID, "null table pointer");
     if (n >= 0xffffffffull) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     std::unique_ptr<ipcfp_witness> w(new (std::nothrow) ipcfp_witness());
     if (!w) return IPCFP_E_NOMEM;
     w->ctx = ctx;
@@ -146,7 +146,7 @@ uint64_t ipcfp_witness_byte_count(const ipcfp_witness_t* w) { return w ? w->nbyt
 
 int ipcfp_witness_verify_cids_async(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     return launch_blake2b256_cid(ctx, w->arena.p, w->off.p, w->len.p, w->cids.p, w->order.p, uint32_t(w->n),
                                  w->ok_bits.p, w->cid_status.p, w->counters.p);
 }
@@ -165,7 +165,9 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
 
 int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    w->enum_cache.clear();  // enumerations are derived from the index
     return witness_build_index(ctx, w);
 }
 
@@ -185,7 +187,7 @@ int hash_batch(ipcfp_ctx_t* ctx, HashKind kind, const uint8_t* bytes, uint64_t n
     for (uint64_t i = 0; i < n; ++i)
         if (off[i] > nbytes || uint64_t(len[i]) > nbytes - off[i])
             return set_error(ctx, IPCFP_E_INVALID, "message %llu outside the buffer", (unsigned long long)i);
-    IPCFP_HIP(ctx, hipSetDevice(ctx->device));
+    IPCFP_ENTER(ctx);
     DevBuf<uint8_t> b, o;
     DevBuf<uint64_t> off_d;
     DevBuf<uint32_t> len_d;

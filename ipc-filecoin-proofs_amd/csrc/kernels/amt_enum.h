@@ -73,4 +73,9 @@ struct AmtEnumResult {
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
                   unsigned long long* err_d, AmtEnumResult& out);
 
+// Enumerate one AMT of the witness, or return the cached enumeration (owned by the witness; valid
+// until ipcfp_witness_rebuild_index).
+int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, int version, int vkind,
+                         const EnumCached** out);
+
 }  // namespace ipcfp

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "../common.h"
 #include "launch.h"
 
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(WitnessView w, const EnumNo
     const uint64_t span = amt_span(e.bit_width, e.height);
     uint32_t sub = 0;
     for (uint64_t j = 0; j < nl; ++j) {
-        while (!((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;  // j-th set bit (bitmap validated: popcount == nl)
+        while (!((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;  // j-th set bit (bitmap validated: popcount == nl)
         CidKey key;
         r.read_link_key(key);
         EnumNode c{kNoBlock, 0, e.base + uint64_t(sub) * span, e.seq, uint16_t(e.height - 1), e.bit_width, 0};
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_enum_emit(WitnessView w, const EnumNode
     const uint64_t nv = r.read_array();
     uint32_t sub = 0;
     for (uint64_t j = 0; j < nv; ++j) {
-        while (!((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;
+        while (!((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
         const uint32_t start = r.pos;
         check_value(r, vkind);
         leaves[o + uint32_t(j)] = LeafRef{e.block, start, r.pos - start, e.seq, e.base + sub};
@@ -197,8 +199,7 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                 hipLaunchKernelGGL(k_enum_expand, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
                                    vkind, counts.p, offsets.p, nxt.p, err_d);
             IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cur is released below
-            std::swap(cur.p, nxt.p);
-            std::swap(cur.count, nxt.count);
+            cur.swap(nxt);
             n = uint32_t(total);
             if (n == 0) break;
         } else {
@@ -215,6 +216,72 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     IPCFP_HIP(ctx, hipGetLastError());
     out.error = e;
+    return IPCFP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_check_dense(const LeafRef* __restrict__ leaves, uint32_t n,
+                                                     uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = i < n && leaves[i].index != uint64_t(i);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, int version, int vkind,
+                         const EnumCached** out) {
+    for (auto& e : w->enum_cache)
+        if (e->version == version && e->vkind == vkind && std::memcmp(e->root, root.w, 40) == 0) {
+            *out = e.get();
+            return IPCFP_OK;
+        }
+    std::unique_ptr<EnumCached> e(new EnumCached());
+    std::memcpy(e->root, root.w, 40);
+    e->version = version;
+    e->vkind = vkind;
+    WitnessView view;
+    view.arena = w->arena.p;
+    view.off = w->off.p;
+    view.len = w->len.p;
+    view.cids = w->cids.p;
+    view.slots = w->index_slots.p;
+    view.mask = w->index_mask;
+    view.n = uint32_t(w->n);
+    view.touched = nullptr;
+    DevBuf<AmtRootSpec> roots;
+    DevBuf<unsigned long long> err;
+    DevBuf<uint32_t> flag;
+    IPCFP_HIP(ctx, roots.alloc(1));
+    IPCFP_HIP(ctx, err.alloc(1));
+    IPCFP_HIP(ctx, flag.alloc(1));
+    AmtRootSpec spec{};
+    spec.root = root;
+    spec.version = uint32_t(version);
+    unsigned long long e0 = kNoEnumError;
+    IPCFP_HIP(ctx, hipMemcpyAsync(roots.p, &spec, sizeof spec, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemcpyAsync(err.p, &e0, 8, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(flag.p, 0, 4, ctx->stream));
+    AmtEnumResult en;
+    int rc = amt_enumerate(ctx, view, roots.p, 1, vkind, err.p, en);
+    if (rc) return rc;
+    e->n = en.n_leaves;
+    e->error = en.error;
+    uint32_t not_dense = 0;
+    if (en.n_leaves) {
+        const uint32_t n = uint32_t(en.n_leaves);
+        hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, flag.p);
+        IPCFP_HIP(ctx, hipMemcpyAsync(&not_dense, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    e->dense = !not_dense;
+    // move the leaves into the cache entry (byte-typed buffer)
+    e->leaves.p = reinterpret_cast<uint8_t*>(en.leaves.p);
+    e->leaves.count = en.leaves.count * sizeof(LeafRef);
+    e->leaves.cap = en.leaves.cap;
+    e->leaves.owner = en.leaves.owner;
+    en.leaves.p = nullptr;
+    en.leaves.count = en.leaves.cap = 0;
+    en.leaves.owner = nullptr;
+    *out = e.get();
+    w->enum_cache.push_back(std::move(e));
     return IPCFP_OK;
 }
 

@@ -25,17 +25,93 @@
 
 namespace ipcfp {
 
+// UTF-8 validity of a short text item.  A FREE function, deliberately NOT inlined: with this loop
+// inlined into Rd::read_text, hipcc 7.2 (AMD clang 22.0.0git) mis-structurises the caller's control
+// flow on gfx950 — the success path of read_text picks up the zero the failure paths assign to `off`
+// (reproduced stand-alone; the LLVM IR is correct, the emitted ISA is not).  Text items on this path
+// are short map / event-entry keys.
+__device__ __noinline__ bool utf8_ok_bytes(const uint8_t* s, uint32_t len) {
+    uint32_t i = 0;
+    while (i < len) {
+        const uint32_t c = s[i];
+        if (c < 0x80) {
+            ++i;
+            continue;
+        }
+        uint32_t need, cp;
+        if ((c & 0xE0) == 0xC0) { need = 1; cp = c & 0x1F; }
+        else if ((c & 0xF0) == 0xE0) { need = 2; cp = c & 0x0F; }
+        else if ((c & 0xF8) == 0xF0) { need = 3; cp = c & 0x07; }
+        else return false;
+        if (need > len - i - 1) return false;
+        for (uint32_t k = 1; k <= need; ++k) {
+            const uint32_t cc = s[i + k];
+            if ((cc & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (cc & 0x3F);
+        }
+        if (need == 1 && cp < 0x80) return false;
+        if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) return false;
+        if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) return false;
+        i += need + 1;
+    }
+    return true;
+}
+
 struct Rd {
     const uint8_t* p;
     uint32_t n;
     uint32_t pos;
     uint32_t err;
+    // Byte access goes through a one-word window: parsing is a chain of dependent loads, and a lane
+    // that fetches 8 aligned bytes at a time issues ≈6× fewer of them than one that fetches single
+    // bytes.  Blocks sit 16-byte aligned in the arena with tail slack, so the aligned word that holds
+    // the last byte of an item never leaves the arena.
+    const uint64_t* base8;  // p rounded down to 8 bytes
+    uint32_t bias;          // p - base8
+    uint32_t cwi;           // index of the cached word (~0u: none)
+    uint64_t cw;            // the cached word
 
     __device__ __forceinline__ void init(const uint8_t* data, uint32_t len) {
         p = data;
         n = len;
         pos = 0;
         err = 0;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(data);
+        base8 = reinterpret_cast<const uint64_t*>(a & ~uintptr_t(7));
+        bias = uint32_t(a & 7);
+        cwi = ~0u;
+        cw = 0;
+    }
+    // byte i of the item (i < n, or inside the block's padded tail)
+    __device__ __forceinline__ uint32_t at(uint32_t i) {
+        const uint32_t j = i + bias;
+        const uint32_t wi = j >> 3;
+        if (wi != cwi) {
+            cw = base8[wi];
+            cwi = wi;
+        }
+        return uint32_t(cw >> ((j & 7u) * 8u)) & 0xffu;
+    }
+    // the CID bytes [off, off+len) as a witness key (len ≤ 40)
+    __device__ __forceinline__ CidKey key_at(uint32_t off, uint32_t len) {
+        CidKey k;
+#pragma unroll
+        for (int w = 0; w < 5; ++w) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t idx = 8u * w + b;
+                if (idx < len) v |= uint64_t(at(off + idx)) << (8 * b);
+            }
+            k.w[w] = v;
+        }
+        return k;
+    }
+    // 32 bytes at `off` equal to q[0..32)?
+    __device__ __forceinline__ bool equal32(uint32_t off, const uint8_t* q) {
+        bool eq = true;
+        for (int i = 0; i < 32; ++i) eq &= at(off + i) == q[i];
+        return eq;
     }
     __device__ __forceinline__ void fail() {
         if (!err) err = IPCFP_ST_ERR_DECODE;
@@ -49,7 +125,7 @@ struct Rd {
             fail();
             return 0xff;
         }
-        return p[pos];
+        return at(pos);
     }
 
     // item header → major type, argument
@@ -58,7 +134,8 @@ struct Rd {
         arg = 0;
         if (err) return;
         if (pos >= n) return fail();
-        const uint32_t b = p[pos++];
+        const uint32_t b = at(pos);
+        ++pos;
         const uint32_t m = b >> 5, ai = b & 31u;
         if (ai < 24) {
             if (m == 7 && !(ai >= 20 && ai <= 22)) return fail();
@@ -71,7 +148,7 @@ struct Rd {
         const uint32_t nb = 1u << (ai - 24);
         if (nb > n - pos) return fail();
         uint64_t v = 0;
-        for (uint32_t k = 0; k < nb; ++k) v = (v << 8) | p[pos + k];
+        for (uint32_t k = 0; k < nb; ++k) v = (v << 8) | at(pos + k);
         pos += nb;
         major = m;
         arg = v;
@@ -112,36 +189,15 @@ struct Rd {
         len = uint32_t(a);
         pos += len;
     }
-    // NOTE: deliberately NOT inlined.  With this loop inlined into read_text, hipcc 7.2
-    // (AMD clang 22.0.0git) mis-structurises the caller's control flow on gfx950: the success
-    // path of read_text picks up the zero that the failure paths assign to `off`
-    // (reproduced stand-alone; the LLVM IR is correct, the emitted ISA is not).  Keeping the
-    // loop out of line keeps the callers' CFG simple; text items are short map/entry keys.
-    __device__ __noinline__ bool utf8_ok(uint32_t off, uint32_t len) const {
-        uint32_t i = 0;
-        while (i < len) {
-            const uint32_t c = p[off + i];
-            if (c < 0x80) {
-                ++i;
-                continue;
-            }
-            uint32_t need, cp;
-            if ((c & 0xE0) == 0xC0) { need = 1; cp = c & 0x1F; }
-            else if ((c & 0xF0) == 0xE0) { need = 2; cp = c & 0x0F; }
-            else if ((c & 0xF8) == 0xF0) { need = 3; cp = c & 0x07; }
-            else return false;
-            if (need > len - i - 1) return false;
-            for (uint32_t k = 1; k <= need; ++k) {
-                const uint32_t cc = p[off + i + k];
-                if ((cc & 0xC0) != 0x80) return false;
-                cp = (cp << 6) | (cc & 0x3F);
-            }
-            if (need == 1 && cp < 0x80) return false;
-            if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) return false;
-            if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) return false;
-            i += need + 1;
+    // UTF-8 validity of the text at [off, off+len): short ASCII keys ("t1", "d", "topics", "root" …)
+    // are settled from the window; anything else takes the out-of-line validator.
+    __device__ __forceinline__ bool text_ok(uint32_t off, uint32_t len) {
+        if (len <= 8) {
+            uint32_t hi = 0;
+            for (uint32_t i = 0; i < len; ++i) hi |= at(off + i);
+            if (hi < 0x80) return true;
         }
-        return true;
+        return utf8_ok_bytes(p + off, len);
     }
     __device__ __forceinline__ void read_text(uint32_t& off, uint32_t& len) {
         off = len = 0;
@@ -150,7 +206,7 @@ struct Rd {
         head(m, a);
         if (err) return;
         if (m != 3 || a > uint64_t(n - pos)) return fail();
-        if (!utf8_ok(pos, uint32_t(a))) return fail();
+        if (!text_ok(pos, uint32_t(a))) return fail();
         off = pos;
         len = uint32_t(a);
         pos += len;
@@ -181,16 +237,16 @@ struct Rd {
         }
         return a;
     }
-    __device__ __forceinline__ bool at_null() { return !err && pos < n && p[pos] == 0xf6; }
+    __device__ __forceinline__ bool at_null() { return !err && pos < n && at(pos) == 0xf6; }
     __device__ __forceinline__ void read_null() {
         if (err) return;
-        if (pos >= n || p[pos] != 0xf6) return fail();
+        if (pos >= n || at(pos) != 0xf6) return fail();
         ++pos;
     }
 
     // one well-formed binary CID in p[off, off+len)?  (oracle/cid.hpp cid_parse_binary)
-    __device__ __forceinline__ bool cid_ok(uint32_t off, uint32_t len) const {
-        if (len == 34 && p[off] == 0x12 && p[off + 1] == 0x20) return true;  // CIDv0
+    __device__ __forceinline__ bool cid_ok(uint32_t off, uint32_t len) {
+        if (len == 34 && at(off) == 0x12 && at(off + 1) == 0x20) return true;  // CIDv0
         uint32_t q = off;
         const uint32_t end = off + len;
         uint64_t field[4];
@@ -200,7 +256,8 @@ struct Rd {
             bool done = false;
             for (int shift = 0; shift < 63; shift += 7) {
                 if (q >= end) return false;
-                const uint32_t c = p[q++];
+                const uint32_t c = at(q);
+                ++q;
                 v |= uint64_t(c & 0x7f) << shift;
                 if (!(c & 0x80)) {
                     if (c == 0 && shift > 0) return false;  // non-minimal varint
@@ -226,7 +283,7 @@ struct Rd {
         uint32_t bo, bl;
         read_bytes(bo, bl);
         if (err) return;
-        if (bl < 1 || p[bo] != 0x00) return fail();
+        if (bl < 1 || at(bo) != 0x00) return fail();
         if (!cid_ok(bo + 1, bl - 1)) return fail();
         off = bo + 1;
         len = bl - 1;
@@ -242,7 +299,7 @@ struct Rd {
             for (int j = 0; j < 5; ++j) key.w[j] = ~0ULL;  // not a possible key (slot bytes 38..39 are zero)
             return true;
         }
-        key = cid_key_from_bytes(p + off, len);
+        key = key_at(off, len);
         return true;
     }
 
@@ -266,7 +323,7 @@ struct Rd {
                     break;
                 case 3:
                     if (a > uint64_t(n - pos)) return fail();
-                    if (!utf8_ok(pos, uint32_t(a))) return fail();
+                    if (!text_ok(pos, uint32_t(a))) return fail();
                     pos += uint32_t(a);
                     break;
                 case 4:
@@ -282,7 +339,7 @@ struct Rd {
                     uint32_t bo, bl;
                     read_bytes(bo, bl);
                     if (err) return;
-                    if (bl < 1 || p[bo] != 0x00 || !cid_ok(bo + 1, bl - 1)) return fail();
+                    if (bl < 1 || at(bo) != 0x00 || !cid_ok(bo + 1, bl - 1)) return fail();
                     break;
                 }
                 default:
@@ -324,14 +381,13 @@ __device__ __forceinline__ void check_stamped_event(Rd& r) {
 
 __device__ __forceinline__ void check_address(Rd& r, uint32_t off, uint32_t n) {  // Address::from_bytes shape
     if (n < 1) return r.fail();
-    const uint8_t* p = r.p + off;
-    const uint32_t proto = p[0];
+    const uint32_t proto = r.at(off);
     if (proto == 0 || proto == 4) {
         uint32_t pos = 1;
         bool term = false;
         for (int k = 0; k < 10; ++k) {
             if (pos >= n) return r.fail();
-            if (!(p[pos++] & 0x80)) {
+            if (!(r.at(off + pos++) & 0x80)) {
                 term = true;
                 break;
             }
@@ -358,7 +414,7 @@ __device__ __forceinline__ void check_actor_state(Rd& r) {
     r.read_link(o, l);
     (void)r.read_uint();
     r.read_bytes(o, l);  // TokenAmount: sign byte 0|1 + magnitude, ≤ 128 bytes
-    if (r.ok() && (l > 128 || (l > 0 && r.p[o] > 1))) r.fail();
+    if (r.ok() && (l > 128 || (l > 0 && r.at(o) > 1))) r.fail();
     if (r.at_null()) r.read_null();
     else {
         r.read_bytes(o, l);

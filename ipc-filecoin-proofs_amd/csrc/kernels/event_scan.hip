@@ -25,8 +25,10 @@ struct EventMatch {  // == ipcfp_event_match_t
     uint32_t pad;
 };
 
-// Amt::for_each on one lane (depth-first, explicit stack).  `f(index, block, off, len)` is called for
-// every value in ascending index order.  Returns TRUE or the first ERR_* in traversal order.
+// Amt::for_each on one lane (depth-first, explicit stack).  For every value in ascending index
+// order `f(index, block, r)` is called with the reader positioned on the value; f MUST consume
+// exactly that item, validating it as the AMT's value type (it is the type check serde performs).
+// Returns TRUE or the first ERR_* in traversal order.
 template <typename F>
 __device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, const AmtRootInfo& root, int vkind, F&& f) {
     constexpr int kMaxDepth = 14;  // height ≤ 64 / bit_width, bit_width ≥ 5 for FVM event AMTs; deeper trees are rejected
@@ -43,13 +45,13 @@ __device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, cons
         const uint64_t height = root.height - uint64_t(depth);
         Rd r = open_block(w, blk[depth]);
         r.pos = noff[depth];
-        if (next_sub[depth] == 0) {  // first visit: decode the whole node (CollapsedNode::expand checks)
+        if (next_sub[depth] == 0 && depth > 0) {  // first visit of a child: decode the whole node
+            // (CollapsedNode::expand checks; the root node was validated by amt_load)
             AmtNode nd;
             Rd v = r;
             amt_read_node(v, bw, vkind, ~0u, nd);
             if (noff[depth] == 0) v.finish();
             if (!v.ok()) return IPCFP_ST_ERR_DECODE;
-            if (nd.nlinks && height == 0) return IPCFP_ST_ERR_DECODE;
         }
         r.expect_array(3);
         uint32_t bo, bl;
@@ -60,20 +62,19 @@ __device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, cons
             const uint64_t nv = r.read_array();
             uint32_t sub = 0;
             for (uint64_t j = 0; j < nv; ++j) {
-                while (!((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;
-                const uint32_t start = r.pos;
-                check_value(r, vkind);
-                f(base[depth] + sub, blk[depth], start, r.pos - start);
+                while (!((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
+                f(base[depth] + sub, blk[depth], r);
                 ++sub;
             }
             --depth;
             continue;
         }
+        if (height == 0) return IPCFP_ST_ERR_DECODE;  // a link node at height 0
         // Link node: next set bit at or after next_sub
         uint32_t sub = next_sub[depth];
         uint32_t ordinal = 0;
-        for (uint32_t i = 0; i < sub && i < width; ++i) ordinal += (r.p[bo + (i >> 3)] >> (i & 7)) & 1u;
-        while (sub < width && !((r.p[bo + (sub >> 3)] >> (sub & 7)) & 1u)) ++sub;
+        for (uint32_t i = 0; i < sub && i < width; ++i) ordinal += (r.at(bo + (i >> 3)) >> (i & 7)) & 1u;
+        while (sub < width && !((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
         if (sub >= width) {
             --depth;
             continue;
@@ -126,12 +127,10 @@ __global__ __launch_bounds__(256) void k_scan_pass1(WitnessView w, const LeafRef
         AmtRootInfo info;
         uint32_t st = amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info);  // generator.rs:215
         if (st == IPCFP_ST_TRUE)
-            st = amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t, uint32_t b, uint32_t off, uint32_t len) {
-                Rd er;
-                er.init(w.arena + w.off[b] + off, len);
+            st = amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t, uint32_t, Rd& er) {
                 uint64_t emitter;
                 EvmLogLoc log;
-                decode_event_log(er, emitter, log);
+                decode_event_log(er, emitter, log);                // parses (and type-checks) the StampedEvent
                 if (sp.has_actor && emitter != sp.actor) return;  // :220-224
                 if (log_matches(er, log, sp.filter)) ++c;         // :227-231
             });
@@ -172,15 +171,14 @@ __global__ __launch_bounds__(256) void k_scan_pass2(WitnessView w, CidKey receip
     if (amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info) != IPCFP_ST_TRUE) return;  // :259
     uint32_t k = 0;
     const uint32_t o = offsets[t];
-    (void)amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t j, uint32_t b, uint32_t off, uint32_t len) {
-        Rd er;
-        er.init(w.arena + w.off[b] + off, len);
+    (void)amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t j, uint32_t b, Rd& er) {
+        const uint32_t start = er.pos;
         uint64_t emitter;
         EvmLogLoc log;
         decode_event_log(er, emitter, log);
         if (sp.has_actor && emitter != sp.actor) return;
         if (!log_matches(er, log, sp.filter)) return;
-        if (matches && k < c) matches[o + k] = EventMatch{leaf.index, j, emitter, ValueLoc{b, off, len}, 0};
+        if (matches && k < c) matches[o + k] = EventMatch{leaf.index, j, emitter, ValueLoc{b, start, er.pos - start}, 0};
         ++k;
     });
 }

@@ -42,7 +42,10 @@ __device__ __forceinline__ void decode_event_log(Rd& r, uint64_t& emitter, EvmLo
         (void)r.read_uint();
         r.read_bytes(vo, vl);
         if (!r.ok()) break;
-        const uint8_t* k = r.p + ko;
+        // keys that matter are at most 6 bytes: fetch them once
+        uint32_t k[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) k[q] = uint32_t(q) < kl ? r.at(ko + q) : 0u;
         const ByteRange v{vo, vl, true};
         if (kl == 1 && k[0] == 'd') d = v;
         else if (kl == 2 && k[0] == 't' && k[1] >= '1' && k[1] <= '4') {
@@ -94,9 +97,9 @@ __device__ __forceinline__ bool bytes32_equal(const uint8_t* a, const uint8_t* b
 }
 
 // matches_log / create_event_filter: topics.len() >= 2 && topics[0] == topic0 && topics[1] == topic1
-__device__ __forceinline__ bool log_matches(const Rd& r, const EvmLogLoc& log, const ipcfp_event_filter_t& f) {
+__device__ __forceinline__ bool log_matches(Rd& r, const EvmLogLoc& log, const ipcfp_event_filter_t& f) {
     if (!log.is_log || log.n_topics < 2) return false;
-    return bytes32_equal(r.p + log.topic_at(0), f.topic0) && bytes32_equal(r.p + log.topic_at(1), f.topic1);
+    return r.equal32(log.topic_at(0), f.topic0) && r.equal32(log.topic_at(1), f.topic1);
 }
 
 }  // namespace ipcfp

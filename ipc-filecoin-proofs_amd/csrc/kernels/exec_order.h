@@ -32,6 +32,10 @@ struct TipsetCtxDev {
     const CidKey* exec_keys;      // raw for_each sequence (with duplicates)
     const uint32_t* exec_pos;     // raw position → execution index (valid where the position is a first occurrence)
     uint64_t exec_len;            // number of distinct messages
+    // receipts AMT enumerated once per context (amt_enum.hip): when it decoded without error and is
+    // dense, `Amt::get(exec_index)` is a table lookup — every node on every path was already validated
+    const LeafRef* receipt_leaves;
+    uint64_t n_receipt_leaves;
 };
 
 }  // namespace ipcfp

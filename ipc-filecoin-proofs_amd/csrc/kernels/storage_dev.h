@@ -6,10 +6,10 @@
 
 namespace ipcfp {
 
-__device__ __forceinline__ bool text_is(const Rd& r, uint32_t off, uint32_t len, const char* s, uint32_t n) {
+__device__ __forceinline__ bool text_is(Rd& r, uint32_t off, uint32_t len, const char* s, uint32_t n) {
     if (len != n) return false;
     for (uint32_t i = 0; i < n; ++i)
-        if (r.p[off + i] != uint8_t(s[i])) return false;
+        if (r.at(off + i) != uint8_t(s[i])) return false;
     return true;
 }
 
@@ -39,7 +39,7 @@ __device__ __forceinline__ void read_small_map(Rd& r, const uint8_t* slot, bool 
                 r.read_bytes(bo, bl);
                 if (r.ok() && search && !hit.found && al == 32) {
                     bool eq = true;
-                    for (int c = 0; c < 32; ++c) eq &= r.p[ao + c] == slot[c];
+                    for (int c = 0; c < 32; ++c) eq &= r.at(ao + c) == slot[c];
                     if (eq) {
                         hit.found = true;
                         hit.off = bo;
@@ -55,12 +55,12 @@ __device__ __forceinline__ void read_small_map(Rd& r, const uint8_t* slot, bool 
 }
 
 // left_pad_32 of a byte range (len ≥ 32 keeps the LAST 32 bytes)
-__device__ __forceinline__ void left_pad_32_bytes(const uint8_t* p, uint32_t len, uint8_t out[32]) {
+__device__ __forceinline__ void left_pad_32_bytes(Rd& r, uint32_t off, uint32_t len, uint8_t out[32]) {
     for (int i = 0; i < 32; ++i) out[i] = 0;
     if (len >= 32) {
-        for (int i = 0; i < 32; ++i) out[i] = p[len - 32 + i];
+        for (int i = 0; i < 32; ++i) out[i] = uint8_t(r.at(off + len - 32 + i));
     } else {
-        for (uint32_t i = 0; i < len; ++i) out[32 - len + i] = p[i];
+        for (uint32_t i = 0; i < len; ++i) out[32 - len + i] = uint8_t(r.at(off + i));
     }
 }
 
@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t read_storage_slot_padded(const WitnessView& 
         for (uint64_t i = 0; i < n && r.ok(); ++i) read_small_map(r, slot, i == 0, hit);
         r.finish();
         if (r.ok() && n > 0) {
-            if (hit.found) left_pad_32_bytes(r.p + hit.off, hit.len, padded);
+            if (hit.found) left_pad_32_bytes(r, hit.off, hit.len, padded);
             return IPCFP_ST_TRUE;
         }
     }
@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t read_storage_slot_padded(const WitnessView& 
         read_small_map(r, slot, true, hit);
         r.finish();
         if (r.ok()) {
-            if (hit.found) left_pad_32_bytes(r.p + hit.off, hit.len, padded);
+            if (hit.found) left_pad_32_bytes(r, hit.off, hit.len, padded);
             return IPCFP_ST_TRUE;
         }
     }
@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t read_storage_slot_padded(const WitnessView& 
         read_small_map(r, slot, true, hit);
         r.finish();
         if (r.ok()) {
-            if (hit.found) left_pad_32_bytes(r.p + hit.off, hit.len, padded);
+            if (hit.found) left_pad_32_bytes(r, hit.off, hit.len, padded);
             return IPCFP_ST_TRUE;
         }
     }

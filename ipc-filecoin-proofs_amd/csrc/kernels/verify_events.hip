@@ -147,7 +147,7 @@ __global__ void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx
                         if (bl < 24) enc[n++] = uint8_t(0x40 | bl);
                         else { enc[n++] = 0x58; enc[n++] = uint8_t(bl); }
                         enc[n++] = 0x00;
-                        for (uint32_t i = 0; i < lens[k]; ++i) enc[n++] = r.p[offs[k] + i];
+                        for (uint32_t i = 0; i < lens[k]; ++i) enc[n++] = uint8_t(r.at(offs[k] + i));
                     }
                     uint64_t d[4];
                     blake2b256_small(enc, n, d);
@@ -160,8 +160,8 @@ __global__ void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx
                     if (!cid_equal(re, tx[b])) {
                         fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
                     } else {
-                        bls.root = lens[0] <= 40 ? cid_key_from_bytes(r.p + o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
-                        secp.root = lens[1] <= 40 ? cid_key_from_bytes(r.p + o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        bls.root = lens[0] <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        secp.root = lens[1] <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
                         bls.skip = secp.skip = 0;
                     }
                 }
@@ -266,13 +266,21 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     if (raw == kNoBlock) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                                               // :194
     if (uint64_t(tc.exec_pos[raw]) != c.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;                         // :199
     // Step 4: verify_receipt_and_event (:207-254)
-    AmtRootInfo receipts;
-    uint32_t st = amt_load(w, tc.receipts_root, 0, VK_RECEIPT, receipts);                                     // :220
-    if (st != IPCFP_ST_TRUE) return st;
+    uint32_t st;
     ValueLoc rloc;
-    st = amt_get(w, receipts, VK_RECEIPT, c.exec_index, rloc);                                                // :224
-    if (st == IPCFP_ST_NOT_FOUND) return IPCFP_ST_FALSE_NO_RECEIPT;
-    if (st != IPCFP_ST_TRUE) return st;
+    if (tc.receipt_leaves && c.exec_index < tc.n_receipt_leaves) {
+        // the receipts AMT was enumerated (and thereby fully validated) for this context: load + get
+        // of a present index cannot fail and yields exactly this leaf                                        // :220-224
+        const LeafRef l = tc.receipt_leaves[c.exec_index];
+        rloc = ValueLoc{l.block, l.off, l.len};
+    } else {
+        AmtRootInfo receipts;
+        st = amt_load(w, tc.receipts_root, 0, VK_RECEIPT, receipts);                                          // :220
+        if (st != IPCFP_ST_TRUE) return st;
+        st = amt_get(w, receipts, VK_RECEIPT, c.exec_index, rloc);                                            // :224
+        if (st == IPCFP_ST_NOT_FOUND) return IPCFP_ST_FALSE_NO_RECEIPT;
+        if (st != IPCFP_ST_TRUE) return st;
+    }
     Rd rr;
     rr.init(w.arena + w.off[rloc.block] + rloc.off, rloc.len);
     uint32_t o, l;
@@ -302,11 +310,11 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     for (uint32_t i = 0; i < log.n_topics; ++i) {                                                             // :276-281
         const uint8_t* claimed = blob + c.topics_off + 33u * i;
         if (!claimed[0]) return IPCFP_ST_FALSE_TOPIC;  // the claimed string is not "0x" + 64 hex digits
-        if (!bytes32_equal(er.p + log.topic_at(i), claimed + 1)) return IPCFP_ST_FALSE_TOPIC;
+        if (!er.equal32(log.topic_at(i), claimed + 1)) return IPCFP_ST_FALSE_TOPIC;
     }
     if (!(c.flags & EC_DATA_MATCHABLE) || c.data_len != log.data.len) return IPCFP_ST_FALSE_DATA;             // :284-287
     for (uint32_t i = 0; i < c.data_len; ++i)
-        if (blob[c.data_off + i] != er.p[log.data.off + i]) return IPCFP_ST_FALSE_DATA;
+        if (blob[c.data_off + i] != er.at(log.data.off + i)) return IPCFP_ST_FALSE_DATA;
     if (filter && !log_matches(er, log, *filter)) return IPCFP_ST_FALSE_FILTER;                               // :247-251
     return IPCFP_ST_TRUE;
 }

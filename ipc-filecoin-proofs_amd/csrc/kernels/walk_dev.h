@@ -79,7 +79,7 @@ __device__ __forceinline__ void amt_read_node(Rd& r, uint32_t bw, int vkind, uin
     const bool bmap_len_ok = bl == need;
     // keep the bits we can hold; a wrong length is an error AFTER links/values decode (order is
     // irrelevant: every failure here is ERR_DECODE)
-    for (uint32_t k = 0; k < bl && k < 32; ++k) nd.bmap[k >> 2] |= uint32_t(r.p[bo + k]) << (8 * (k & 3));
+    for (uint32_t k = 0; k < bl && k < 32; ++k) nd.bmap[k >> 2] |= r.at(bo + k) << (8 * (k & 3));
     if (nd.width < 32) nd.bmap[0] &= (1u << nd.width) - 1u;  // bits ≥ width are ignored (bw < 3)
     if (bmap_len_ok && sub != ~0u && sub < nd.width && nd.bit(sub)) nd.want = nd.rank(sub);
     const uint64_t nl = r.read_array();
@@ -191,7 +191,7 @@ __device__ __forceinline__ uint32_t amt_get(const WitnessView& w, const AmtRootI
         }
         if (height == 0) return IPCFP_ST_ERR_DECODE;  // link node at height 0
         if (sub64 >= nd.width || !nd.bit(uint32_t(sub64))) return IPCFP_ST_NOT_FOUND;
-        const CidKey key = nd.want_len <= 40 ? cid_key_from_bytes(r.p + nd.want_off, nd.want_len)
+        const CidKey key = nd.want_len <= 40 ? r.key_at(nd.want_off, nd.want_len)
                                              : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
         const uint32_t child = witness_find(w, key);
         if (child == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
@@ -229,7 +229,7 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
         bool bit_set = false;
         uint32_t rank = 0;
         for (uint32_t k = 0; k < bl; ++k) {
-            const uint32_t byte = r.p[bo + bl - 1 - k];
+            const uint32_t byte = r.at(bo + bl - 1 - k);
             const uint32_t lo = 8 * k;
             if (idx >= lo + 8) rank += __popc(byte);
             else if (idx >= lo) {
@@ -265,7 +265,7 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
                     check_value(r, vkind);
                     if (wanted && r.ok() && !found && kl == key_len) {
                         bool eq = true;
-                        for (uint32_t c = 0; c < kl; ++c) eq &= r.p[ko + c] == key[c];
+                        for (uint32_t c = 0; c < kl; ++c) eq &= r.at(ko + c) == key[c];
                         if (eq) {
                             found = true;
                             hit.block = block;
@@ -289,7 +289,7 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
             loc = hit;
             return IPCFP_ST_TRUE;
         }
-        const CidKey ck = link_len <= 40 ? cid_key_from_bytes(r.p + link_off, link_len)
+        const CidKey ck = link_len <= 40 ? r.key_at(link_off, link_len)
                                          : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
         block = witness_find(w, ck);
         if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
