@@ -198,8 +198,7 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             if (total)
                 hipLaunchKernelGGL(k_enum_expand, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
                                    vkind, counts.p, offsets.p, nxt.p, err_d);
-            IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cur is released below
-            cur.swap(nxt);
+            cur.swap(nxt);  // the old frontier returns to the pool; reuse is stream-ordered
             n = uint32_t(total);
             if (n == 0) break;
         } else {

@@ -93,36 +93,35 @@ __global__ void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, ui
 //   error sequence numbers: parent header b → b;  TxMeta of block b → P + 3b;
 //   its BLS AMT → P + 3b + 1;  its secp AMT → P + 3b + 2   (traversal order of utils.rs)
 // ---------------------------------------------------------------------------
+// One lane per parent block (the per-block work is independent; the error word orders the outcomes).
+// `err` must hold kNoEnumError on entry.
 __global__ void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx, AmtRootSpec* __restrict__ roots,
                              unsigned long long* __restrict__ err) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const uint32_t P = ctx->n_parents;
-    unsigned long long first = kNoEnumError;
-    auto fail = [&](uint32_t seq, uint32_t code) {
-        const unsigned long long e = pack_enum_error(seq, 0, code);
-        if (e < first) first = e;
-    };
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P) return;
+    auto fail = [&](uint32_t seq, uint32_t code) { atomicMin(err, (unsigned long long)pack_enum_error(seq, 0, code)); };
     // reconstruct_execution_order (utils.rs:20-27): every parent header is decoded first
-    CidKey tx[kMaxParents];
-    bool have_tx[kMaxParents];
-    for (uint32_t b = 0; b < P; ++b) {
+    CidKey tx[1];
+    bool have_tx[1];
+    {
         HeaderLite h;
         uint32_t hb;
         const uint32_t st = load_header(w, ctx->parents[b], h, hb);
-        have_tx[b] = st == IPCFP_ST_TRUE;
-        if (have_tx[b]) tx[b] = h.messages;
+        have_tx[0] = st == IPCFP_ST_TRUE;
+        if (have_tx[0]) tx[0] = h.messages;
         else fail(b, st);
     }
     // collect_exec_list (utils.rs:56-91)
-    for (uint32_t b = 0; b < P; ++b) {
+    {
         const uint32_t seq = P + 3 * b;
         AmtRootSpec bls{}, secp{};
         bls.version = secp.version = 0;
         bls.seq = seq + 1;
         secp.seq = seq + 2;
         bls.skip = secp.skip = 1;
-        if (have_tx[b]) {
-            const uint32_t tb = witness_find(w, tx[b]);  // :58-60
+        if (have_tx[0]) {
+            const uint32_t tb = witness_find(w, tx[0]);  // :58-60
             if (tb == kNoBlock) {
                 fail(seq, IPCFP_ST_ERR_MISSING_BLOCK);
             } else {
@@ -157,7 +156,7 @@ __global__ void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx
                     re.w[2] = (d[1] >> 16) | (d[2] << 48);
                     re.w[3] = (d[2] >> 16) | (d[3] << 48);
                     re.w[4] = d[3] >> 16;
-                    if (!cid_equal(re, tx[b])) {
+                    if (!cid_equal(re, tx[0])) {
                         fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
                     } else {
                         bls.root = lens[0] <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
@@ -170,7 +169,6 @@ __global__ void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx
         roots[2 * b] = bls;
         roots[2 * b + 1] = secp;
     }
-    *err = first;
 }
 
 // stage 2: leaf values (tag-42 links, already validated) → message CID keys
@@ -291,11 +289,8 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     if (rr.at_null()) return IPCFP_ST_FALSE_NO_EVENTS_ROOT;                                                   // :229
     CidKey events_root;
     rr.read_link_key(events_root);
-    AmtRootInfo events;
-    st = amt_load(w, events_root, 3, VK_STAMPED_EVENT, events);                                               // :234
-    if (st != IPCFP_ST_TRUE) return st;
     ValueLoc eloc;
-    st = amt_get(w, events, VK_STAMPED_EVENT, c.event_index, eloc);                                           // :237
+    st = amt_load_get(w, events_root, 3, VK_STAMPED_EVENT, c.event_index, eloc);                              // :234-237
     if (st == IPCFP_ST_NOT_FOUND) return IPCFP_ST_FALSE_NO_EVENT;
     if (st != IPCFP_ST_TRUE) return st;
     // verify_event_data_matches (:257-290)
@@ -340,6 +335,8 @@ int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_
 
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
                       unsigned long long* err_d) {
+    const unsigned long long none = kNoEnumError;
+    IPCFP_HIP(ctx, hipMemcpyAsync(err_d, &none, 8, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_exec_roots, dim3(1), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

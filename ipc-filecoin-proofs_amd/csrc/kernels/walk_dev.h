@@ -118,9 +118,11 @@ struct AmtRootInfo {
     uint64_t height, count;
 };
 
-// Amt::load / Amtv0::load.  Returns a status: TRUE on success, ERR_* otherwise.
+// Amt::load / Amtv0::load.  Returns a status: TRUE on success, ERR_* otherwise.  `hint` (optional)
+// names a slot of the ROOT node whose entry location is recorded in *root_node while the node is
+// being validated, so that a following get() on a height-0 tree need not parse the block again.
 __device__ __forceinline__ uint32_t amt_load(const WitnessView& w, const CidKey& root, int version, int vkind,
-                                             AmtRootInfo& info) {
+                                             AmtRootInfo& info, uint32_t hint = ~0u, AmtNode* root_node = nullptr) {
     const uint32_t b = witness_find(w, root);
     if (b == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
     Rd r = open_block(w, b);
@@ -139,10 +141,11 @@ __device__ __forceinline__ uint32_t amt_load(const WitnessView& w, const CidKey&
     info.node_off = r.pos;
     if (!r.ok()) return IPCFP_ST_ERR_DECODE;
     AmtNode nd;
-    amt_read_node(r, info.bit_width, vkind, ~0u, nd);
+    amt_read_node(r, info.bit_width, vkind, hint, nd);
     r.finish();
     if (!r.ok()) return IPCFP_ST_ERR_DECODE;
     if (info.height > 64 / info.bit_width) return IPCFP_ST_ERR_DECODE;  // MaxHeight
+    if (root_node) *root_node = nd;
     return IPCFP_ST_TRUE;
 }
 
@@ -200,6 +203,26 @@ __device__ __forceinline__ uint32_t amt_get(const WitnessView& w, const AmtRootI
         i = i % span;
         height -= 1;
     }
+}
+
+// Amt::load(root).get(index) in one go.  Identical outcomes to amt_load + amt_get; a height-0 tree
+// whose root is a leaf (the usual events AMT: ≤ 32 events) is parsed once instead of twice.
+__device__ __forceinline__ uint32_t amt_load_get(const WitnessView& w, const CidKey& root, int version, int vkind,
+                                                 uint64_t index, ValueLoc& loc) {
+    AmtRootInfo info;
+    AmtNode nd;
+    const uint32_t hint = index < 256 ? uint32_t(index) : 0xfffffffeu;
+    const uint32_t st = amt_load(w, root, version, vkind, info, hint, &nd);
+    if (st != IPCFP_ST_TRUE) return st;
+    if (info.height == 0 && nd.nlinks == 0) {
+        if (index == ~0ULL) return IPCFP_ST_ERR;
+        if (index >= nd.width || !nd.bit(uint32_t(index))) return IPCFP_ST_NOT_FOUND;
+        loc.block = info.block;
+        loc.off = nd.want_off;
+        loc.len = nd.want_len;
+        return IPCFP_ST_TRUE;
+    }
+    return amt_get(w, info, vkind, index, loc);
 }
 
 // ---------------------------------------------------------------------------
