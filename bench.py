@@ -180,9 +180,20 @@ def main():
         kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
     k_launches, k_ms = eng.profile_read("blake2b_cid")
     k_avg_ms = k_ms / max(k_launches, 1)
-    # algorithmic bytes of one K1 launch: every block's payload + its 40-byte claimed CID + (off, len) + order
-    algo_bytes = float(tip.lens.astype(np.float64).sum() + tip.n_blocks * (40 + 12 + 4))
+    # algorithmic bytes of one K1 launch: every block's payload + its 40-byte claimed CID + 16 B (offset, len, id)
+    algo_bytes = float(tip.lens.astype(np.float64).sum() + tip.n_blocks * (40 + 16))
     achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+    # HBM traffic of one K1 launch: FETCH_SIZE needs a rocprofv3 --pmc pass of its own, so the figure is
+    # the committed measurement of this very command (profiles/r01_k1_traffic.json) and only reported
+    # when the workload is the one that was profiled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_k1_traffic.json")) as f:
+            tr = json.load(f)
+        if tr["workload"]["witness_blocks"] == tip.n_blocks and tr["workload"]["payload_bytes"] == tip.stats["payload_bytes"]:
+            traffic = tr["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         out = {
@@ -221,7 +232,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel_avg_ms": k_avg_ms,
                 "launches": k_launches,
                 "algorithmic_bytes_per_launch": algo_bytes,

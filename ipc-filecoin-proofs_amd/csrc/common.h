@@ -39,6 +39,7 @@ struct ProfiledLaunch {
 struct ipcfp_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream_k1 = nullptr;  // K1 (VALU-bound hashing) runs beside the latency-bound walk kernels
     std::string last_error;
     hipDeviceProp_t props{};
     ipcfp::DevPool pool;
@@ -69,8 +70,9 @@ int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...);
 struct ProfileScope {
     ipcfp_ctx* ctx;
     int kernel_id;
+    hipStream_t stream;
     hipEvent_t start = nullptr, stop = nullptr;
-    ProfileScope(ipcfp_ctx* c, int id);
+    ProfileScope(ipcfp_ctx* c, int id, hipStream_t s = nullptr);
     ~ProfileScope();
 };
 
@@ -154,6 +156,8 @@ struct ipcfp_witness {
     ipcfp::DevBuf<uint32_t> len;      // n
     ipcfp::DevBuf<uint8_t> cids;      // n × 40
     ipcfp::DevBuf<uint32_t> order;    // n: block ids sorted by 128-byte chunk count (K1 lane schedule)
+    ipcfp::DevBuf<uint64_t> k1_meta;  // n × {arena offset u64, len u32, block id u32} in schedule order
+    ipcfp::DevBuf<uint8_t> k1_cids;   // n × 40: claimed CIDs in schedule order
     ipcfp::DevBuf<uint32_t> ok_bits;  // ceil(n/32)
     ipcfp::DevBuf<uint8_t> cid_status;  // n
     ipcfp::DevBuf<unsigned long long> counters;  // [0] = mismatches

@@ -71,16 +71,16 @@ static hipEvent_t take_event(ipcfp_ctx* ctx) {
     return e;
 }
 
-ProfileScope::ProfileScope(ipcfp_ctx* c, int id) : ctx(c), kernel_id(id) {
+ProfileScope::ProfileScope(ipcfp_ctx* c, int id, hipStream_t s) : ctx(c), kernel_id(id), stream(s ? s : c->stream) {
     if (!ctx->profiling) return;
     start = take_event(ctx);
     stop = take_event(ctx);
-    if (start && stop) (void)hipEventRecord(start, ctx->stream);
+    if (start && stop) (void)hipEventRecord(start, stream);
 }
 
 ProfileScope::~ProfileScope() {
     if (!ctx->profiling || !start || !stop) return;
-    (void)hipEventRecord(stop, ctx->stream);
+    (void)hipEventRecord(stop, stream);
     ctx->launches.push_back({kernel_id, start, stop});
 }
 
@@ -88,6 +88,7 @@ ProfileScope::~ProfileScope() {
 static int drain_launches(ipcfp_ctx* ctx) {
     if (ctx->launches.empty()) return IPCFP_OK;
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
     for (auto& l : ctx->launches) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, l.start, l.stop) == hipSuccess && l.kernel_id >= 0 &&
@@ -137,6 +138,13 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
         delete ctx;
         return IPCFP_E_NO_DEVICE;
     }
+    // K1 may run on a second stream (IPCFP_K1_STREAM=1).  Measured on the 1M-receipt tipset it does NOT
+    // pay: the VALU-bound hash kernel takes CUs from the latency-bound walk kernels, whose host-visible
+    // chain of levels then runs slower (step 4.95 → 5.59 ms), so the default is one stream.
+    ctx->stream_k1 = ctx->stream;
+    if (const char* e = std::getenv("IPCFP_K1_STREAM"))
+        if (std::atoi(e) == 1 && hipStreamCreateWithFlags(&ctx->stream_k1, hipStreamNonBlocking) != hipSuccess)
+            ctx->stream_k1 = ctx->stream;
     if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = std::atoi(e) == 1 ? 1 : 0;
     if (const char* e = std::getenv("IPCFP_B2B_WG")) {
         const int wg = std::atoi(e);
@@ -150,12 +158,14 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream_k1);
     for (auto& l : ctx->launches) {
         (void)hipEventDestroy(l.start);
         (void)hipEventDestroy(l.stop);
     }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     ctx->pool.drain();
+    if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -167,6 +177,7 @@ void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx) { return ctx ? reinterpret_cast<void*>(
 int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
     if (!ctx) return IPCFP_E_INVALID;
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
     return IPCFP_OK;
 }
 

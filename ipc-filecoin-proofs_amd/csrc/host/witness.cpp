@@ -42,11 +42,20 @@ int finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, 
     IPCFP_HIP(ctx, hipMemsetAsync(w->ok_bits.p, 0, w->ok_bits.bytes() ? w->ok_bits.bytes() : 4, ctx->stream));
     IPCFP_HIP(ctx, hipMemsetAsync(w->cid_status.p, 0, n ? n : 1, ctx->stream));
 
-    // aligned offsets + arena size
-    DevBuf<uint64_t> scratch;
+    // schedule (block ids by chunk count, longest first) → physical layout in schedule order
+    DevBuf<uint64_t> scratch, sched_off;
+    DevBuf<uint32_t> bins, sched_len;
     IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
+    IPCFP_HIP(ctx, bins.alloc(256));
+    IPCFP_HIP(ctx, sched_len.alloc(n));
+    IPCFP_HIP(ctx, sched_off.alloc(n));
+    IPCFP_HIP(ctx, w->k1_meta.alloc(size_t(n) * 2));
+    IPCFP_HIP(ctx, w->k1_cids.alloc(size_t(n) * IPCFP_CID_SLOT));
     uint64_t* total_d = scratch.p + div_up(n, 1024) + 1;
-    int rc = launch_aligned_offsets(ctx, w->len.p, n, w->off.p, total_d, scratch.p);
+    int rc = launch_k1_layout(ctx, w->len.p, n, bins.p, w->order.p, sched_len.p, sched_off.p, total_d, scratch.p,
+                              w->off.p, w->k1_meta.p);
+    if (rc) return rc;
+    rc = launch_gather_cids(ctx, w->order.p, w->cids.p, n, w->k1_cids.p);
     if (rc) return rc;
     uint64_t total = 0;
     IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
@@ -55,12 +64,6 @@ int finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, 
     IPCFP_HIP(ctx, w->arena.alloc(w->arena_bytes));
     IPCFP_HIP(ctx, hipMemsetAsync(w->arena.p + total, 0, kTailSlack, ctx->stream));
     rc = launch_repack(ctx, raw_bytes_d, raw_off_d, w->len.p, w->off.p, n, w->arena.p);
-    if (rc) return rc;
-
-    // K1 lane schedule (block ids by chunk count, longest first)
-    DevBuf<uint32_t> bins;
-    IPCFP_HIP(ctx, bins.alloc(256));
-    rc = launch_chunk_order(ctx, w->len.p, n, bins.p, w->order.p);
     if (rc) return rc;
 
     rc = witness_build_index(ctx, w);
@@ -137,6 +140,7 @@ void ipcfp_witness_destroy(ipcfp_witness_t* w) {
     if (w->ctx) {
         (void)hipSetDevice(w->ctx->device);
         (void)hipStreamSynchronize(w->ctx->stream);
+        (void)hipStreamSynchronize(w->ctx->stream_k1);
     }
     delete w;
 }
@@ -147,8 +151,8 @@ uint64_t ipcfp_witness_byte_count(const ipcfp_witness_t* w) { return w ? w->nbyt
 int ipcfp_witness_verify_cids_async(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
     IPCFP_ENTER(ctx);
-    return launch_blake2b256_cid(ctx, w->arena.p, w->off.p, w->len.p, w->cids.p, w->order.p, uint32_t(w->n),
-                                 w->ok_bits.p, w->cid_status.p, w->counters.p);
+    return launch_blake2b256_cid(ctx, w->arena.p, w->k1_meta.p, w->k1_cids.p, uint32_t(w->n), w->ok_bits.p,
+                                 w->cid_status.p, w->counters.p);
 }
 
 int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* status, uint64_t* n_bad) {
@@ -156,9 +160,9 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
     if (rc) return rc;
     unsigned long long bad = 0;
     if (status && w->n)
-        IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipMemcpyAsync(&bad, w->counters.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream_k1));
+    IPCFP_HIP(ctx, hipMemcpyAsync(&bad, w->counters.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream_k1));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
     if (n_bad) *n_bad = bad;
     return IPCFP_OK;
 }
@@ -201,15 +205,19 @@ int hash_batch(ipcfp_ctx_t* ctx, HashKind kind, const uint8_t* bytes, uint64_t n
     int rc = IPCFP_OK;
     if (kind == H_B2B) {
         // Blake2b wants 16-byte aligned blocks: re-lay out on the device, then hash in chunk-count order.
-        DevBuf<uint64_t> new_off, scratch;
-        DevBuf<uint32_t> order, bins;
+        DevBuf<uint64_t> new_off, scratch, sched_off, meta;
+        DevBuf<uint32_t> order, bins, sched_len;
         DevBuf<uint8_t> arena;
         IPCFP_HIP(ctx, new_off.alloc(n));
         IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
         IPCFP_HIP(ctx, order.alloc(n));
         IPCFP_HIP(ctx, bins.alloc(256));
+        IPCFP_HIP(ctx, sched_len.alloc(n));
+        IPCFP_HIP(ctx, sched_off.alloc(n));
+        IPCFP_HIP(ctx, meta.alloc(n * 2));
         uint64_t* total_d = scratch.p + div_up(n, 1024) + 1;
-        rc = launch_aligned_offsets(ctx, len_d.p, uint32_t(n), new_off.p, total_d, scratch.p);
+        rc = launch_k1_layout(ctx, len_d.p, uint32_t(n), bins.p, order.p, sched_len.p, sched_off.p, total_d, scratch.p,
+                              new_off.p, meta.p);
         if (rc) return rc;
         uint64_t total = 0;
         IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -217,9 +225,7 @@ int hash_batch(ipcfp_ctx_t* ctx, HashKind kind, const uint8_t* bytes, uint64_t n
         IPCFP_HIP(ctx, arena.alloc(total + kTailSlack));
         rc = launch_repack(ctx, b.p, off_d.p, len_d.p, new_off.p, uint32_t(n), arena.p);
         if (rc) return rc;
-        rc = launch_chunk_order(ctx, len_d.p, uint32_t(n), bins.p, order.p);
-        if (rc) return rc;
-        rc = launch_blake2b256_raw(ctx, arena.p, new_off.p, len_d.p, order.p, uint32_t(n), o.p);
+        rc = launch_blake2b256_raw(ctx, arena.p, meta.p, uint32_t(n), o.p);
         if (rc) return rc;
         IPCFP_HIP(ctx, hipMemcpyAsync(out32, o.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
         IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));

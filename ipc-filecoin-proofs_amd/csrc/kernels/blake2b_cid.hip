@@ -5,17 +5,23 @@
 // witness block (README.md:401 "CID verification").
 //
 // Work mapping (gfx950): one hash per LANE, 64 independent hashes per wavefront
-// (see blake2b_dev.h for why not one hash per wavefront).  Lanes are scheduled
-// through `order[]`, the block ids sorted by 128-byte chunk count (longest
-// first), so the 64 lanes of a wavefront walk chunk chains of (almost) equal
-// length and exec-mask divergence is confined to bucket edges.
+// (see blake2b_dev.h for why not one hash per wavefront).  Lanes follow the
+// SCHEDULE: block ids sorted by 128-byte chunk count (longest first), so the 64
+// lanes of a wavefront walk chunk chains of (almost) equal length and exec-mask
+// divergence is confined to bucket edges.  The arena and K1's metadata are laid
+// out PHYSICALLY in schedule order: neighbouring lanes read neighbouring blocks,
+// so the 128-byte lines two blocks share are fetched once, and the per-lane
+// metadata (offset, length, id, claimed CID) is read coalesced.  (A length-sorted
+// schedule over an arrival-order arena re-fetched boundary lines and gathered
+// metadata: 970 MB of HBM traffic for 512 MB of algorithmic bytes on the tipset
+// witness — profiles/r01_rocprofv3_pmc_tipset.txt.)
 //
 // Memory: every lane streams its own block with 16-byte loads, eight per
 // 128-byte chunk; the next chunk is loaded into a second register set while the
 // current one is compressed, so the ≈900-cycle HBM latency hides under ≈5000
 // cycles of VALU work per chunk.  Each 128-byte line is fetched once and fully
-// used.  Algorithmic bytes per block: len + 40 (claimed CID) + 12 (off,len) + 4
-// (order) — DESIGN.md §K1.
+// used.  Algorithmic bytes per block: len + 40 (claimed CID) + 16 (offset, len,
+// id) — DESIGN.md §K1.
 #include <hip/hip_runtime.h>
 
 #include "../common.h"
@@ -52,31 +58,34 @@ __device__ __forceinline__ void hash_block(const uint8_t* __restrict__ arena, ui
     b2b::compress<MODE>(h, m, t, true);
 }
 
+// K1's per-lane metadata, stored in SCHEDULE order so a wavefront reads it coalesced.
+struct K1Meta {
+    uint64_t off;   // arena offset of the block
+    uint32_t len;
+    uint32_t id;    // block id (position in the caller's tables)
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_blake2b256_cid(const uint8_t* __restrict__ arena,
-                                                       const uint64_t* __restrict__ off,
-                                                       const uint32_t* __restrict__ len,
-                                                       const uint8_t* __restrict__ cids40,
-                                                       const uint32_t* __restrict__ order, uint32_t n,
+                                                       const K1Meta* __restrict__ meta,
+                                                       const uint8_t* __restrict__ sched_cids40, uint32_t n,
                                                        uint32_t* __restrict__ ok_bits,
                                                        uint8_t* __restrict__ status,
                                                        unsigned long long* __restrict__ counters) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const uint32_t i = order[t];
-    const uint64_t o = off[i];
-    const uint32_t L = len[i];
+    const K1Meta mt = meta[t];
+    const uint32_t i = mt.id;
 
     // claimed CID: 01 <codec> a0 e4 02 20 ‖ digest[32] ‖ 00 00   (40-byte slot)
-    const uint64_t* cw = reinterpret_cast<const uint64_t*>(cids40 + 40ull * i);
+    const uint64_t* cw = reinterpret_cast<const uint64_t*>(sched_cids40 + 40ull * t);
     const uint64_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3], w4 = cw[4];
     const bool is_b2b = ((w0 & 0x0000FFFFFFFF00FFULL) == 0x00002002e4a00001ULL) && ((w0 & 0x8000ULL) == 0) &&
                         ((w4 >> 48) == 0);
-    // wave-uniform early-out is not worth it: unchecked CIDs are rare; skip per lane
     uint8_t st = IPCFP_CID_UNCHECKED;
     if (is_b2b) {
         uint64_t h[8];
-        hash_block<MODE>(arena, o, L, h);
+        hash_block<MODE>(arena, mt.off, mt.len, h);
         const uint64_t e0 = (w0 >> 48) | (w1 << 16);
         const uint64_t e1 = (w1 >> 48) | (w2 << 16);
         const uint64_t e2 = (w2 >> 48) | (w3 << 16);
@@ -89,23 +98,46 @@ __global__ __launch_bounds__(256) void k_blake2b256_cid(const uint8_t* __restric
     status[i] = st;
 }
 
-// Raw digests (ipcfp_blake2b256_batch): out32[i] = Blake2b-256(block i).
+// Raw digests (ipcfp_blake2b256_batch): out32[id] = Blake2b-256(block).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_blake2b256_raw(const uint8_t* __restrict__ arena,
-                                                       const uint64_t* __restrict__ off,
-                                                       const uint32_t* __restrict__ len,
-                                                       const uint32_t* __restrict__ order, uint32_t n,
+                                                       const K1Meta* __restrict__ meta, uint32_t n,
                                                        uint64_t* __restrict__ out32) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const uint32_t i = order ? order[t] : t;
+    const K1Meta mt = meta[t];
     uint64_t h[8];
-    hash_block<MODE>(arena, off[i], len[i], h);
-    uint64_t* o = out32 + 4ull * i;
+    hash_block<MODE>(arena, mt.off, mt.len, h);
+    uint64_t* o = out32 + 4ull * mt.id;
     o[0] = h[0];
     o[1] = h[1];
     o[2] = h[2];
     o[3] = h[3];
+}
+
+// ---- physical layout in schedule order ----
+__global__ __launch_bounds__(256) void k_gather_len(const uint32_t* __restrict__ order, const uint32_t* __restrict__ len,
+                                                    uint32_t n, uint32_t* __restrict__ sched_len) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) sched_len[t] = len[order[t]];
+}
+
+__global__ __launch_bounds__(256) void k_place(const uint32_t* __restrict__ order, const uint32_t* __restrict__ sched_len,
+                                               const uint64_t* __restrict__ sched_off, uint32_t n,
+                                               uint64_t* __restrict__ off_by_id, K1Meta* __restrict__ meta) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t id = order[t];
+    off_by_id[id] = sched_off[t];
+    meta[t] = K1Meta{sched_off[t], sched_len[t], id};
+}
+
+__global__ __launch_bounds__(256) void k_gather_cids(const uint32_t* __restrict__ order, const uint8_t* __restrict__ cids,
+                                                     uint32_t n, uint8_t* __restrict__ sched_cids) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // one u64 word per thread: 5 words per CID
+    if (t >= n * 5u) return;
+    const uint32_t b = t / 5u, wd = t % 5u;
+    reinterpret_cast<uint64_t*>(sched_cids)[t] = reinterpret_cast<const uint64_t*>(cids)[uint64_t(order[b]) * 5u + wd];
 }
 
 // ---- lane schedule: counting sort of block ids by chunk count, longest first ----
@@ -178,38 +210,68 @@ int launch_chunk_order(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint32
     return IPCFP_OK;
 }
 
-int launch_blake2b256_cid(ipcfp_ctx* ctx, const uint8_t* arena, const uint64_t* off, const uint32_t* len,
-                          const uint8_t* cids40, const uint32_t* order, uint32_t n, uint32_t* ok_bits,
-                          uint8_t* status, unsigned long long* counters) {
-    IPCFP_HIP(ctx, hipMemsetAsync(ok_bits, 0, size_t(div_up(n, 32)) * 4, ctx->stream));
-    IPCFP_HIP(ctx, hipMemsetAsync(counters, 0, sizeof(unsigned long long), ctx->stream));
+// Lay the blocks out physically in schedule order: order[] from the counting sort, offsets from a
+// prefix sum over the schedule, off_by_id[] for every other kernel, K1's metadata coalesced.
+// sched_len_d / sched_off_d are scratch (n each); *total_d receives the arena payload size.
+int launch_k1_layout(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint32_t* bins_d, uint32_t* order_d,
+                     uint32_t* sched_len_d, uint64_t* sched_off_d, uint64_t* total_d, uint64_t* scan_scratch_d,
+                     uint64_t* off_by_id_d, void* meta_d) {
+    int rc = launch_chunk_order(ctx, len_d, n, bins_d, order_d);
+    if (rc) return rc;
+    if (n == 0) return launch_aligned_offsets(ctx, sched_len_d, 0, sched_off_d, total_d, scan_scratch_d);
+    const dim3 g(div_up(n, 256)), b(256);
+    hipLaunchKernelGGL(k_gather_len, g, b, 0, ctx->stream, order_d, len_d, n, sched_len_d);
+    rc = launch_aligned_offsets(ctx, sched_len_d, n, sched_off_d, total_d, scan_scratch_d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_place, g, b, 0, ctx->stream, order_d, sched_len_d, sched_off_d, n, off_by_id_d,
+                       static_cast<K1Meta*>(meta_d));
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_gather_cids(ipcfp_ctx* ctx, const uint32_t* order_d, const uint8_t* cids_d, uint32_t n, uint8_t* sched_cids_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_gather_cids, dim3(div_up(uint64_t(n) * 5, 256)), dim3(256), 0, ctx->stream, order_d, cids_d, n,
+                       sched_cids_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+// K1 runs on the context's second stream (results are independent of everything the main stream does
+// after witness creation); ipcfp_ctx_sync / profile reads wait for both.
+int launch_blake2b256_cid(ipcfp_ctx* ctx, const uint8_t* arena, const void* meta, const uint8_t* sched_cids40, uint32_t n,
+                          uint32_t* ok_bits, uint8_t* status, unsigned long long* counters) {
+    hipStream_t s = ctx->stream_k1;
+    IPCFP_HIP(ctx, hipMemsetAsync(ok_bits, 0, size_t(div_up(n, 32)) * 4, s));
+    IPCFP_HIP(ctx, hipMemsetAsync(counters, 0, sizeof(unsigned long long), s));
     if (n == 0) return IPCFP_OK;
     {
-        ProfileScope prof(ctx, IPCFP_K_BLAKE2B_CID);
+        ProfileScope prof(ctx, IPCFP_K_BLAKE2B_CID, s);
         const uint32_t wg = ctx->b2b_wg;
+        const K1Meta* m = static_cast<const K1Meta*>(meta);
         if (ctx->b2b_mode == 1)
-            hipLaunchKernelGGL(k_blake2b256_cid<1>, dim3(div_up(n, wg)), dim3(wg), 0, ctx->stream, arena, off, len,
-                               cids40, order, n, ok_bits, status, counters);
+            hipLaunchKernelGGL(k_blake2b256_cid<1>, dim3(div_up(n, wg)), dim3(wg), 0, s, arena, m, sched_cids40, n, ok_bits,
+                               status, counters);
         else
-            hipLaunchKernelGGL(k_blake2b256_cid<0>, dim3(div_up(n, wg)), dim3(wg), 0, ctx->stream, arena, off, len,
-                               cids40, order, n, ok_bits, status, counters);
+            hipLaunchKernelGGL(k_blake2b256_cid<0>, dim3(div_up(n, wg)), dim3(wg), 0, s, arena, m, sched_cids40, n, ok_bits,
+                               status, counters);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
 
-int launch_blake2b256_raw(ipcfp_ctx* ctx, const uint8_t* arena, const uint64_t* off, const uint32_t* len,
-                          const uint32_t* order, uint32_t n, uint8_t* out32) {
+int launch_blake2b256_raw(ipcfp_ctx* ctx, const uint8_t* arena, const void* meta, uint32_t n, uint8_t* out32) {
     if (n == 0) return IPCFP_OK;
     {
         ProfileScope prof(ctx, IPCFP_K_BLAKE2B_RAW);
         const uint32_t wg = ctx->b2b_wg;
+        const K1Meta* m = static_cast<const K1Meta*>(meta);
         if (ctx->b2b_mode == 1)
-            hipLaunchKernelGGL(k_blake2b256_raw<1>, dim3(div_up(n, wg)), dim3(wg), 0, ctx->stream, arena, off, len,
-                               order, n, reinterpret_cast<uint64_t*>(out32));
+            hipLaunchKernelGGL(k_blake2b256_raw<1>, dim3(div_up(n, wg)), dim3(wg), 0, ctx->stream, arena, m, n,
+                               reinterpret_cast<uint64_t*>(out32));
         else
-            hipLaunchKernelGGL(k_blake2b256_raw<0>, dim3(div_up(n, wg)), dim3(wg), 0, ctx->stream, arena, off, len,
-                               order, n, reinterpret_cast<uint64_t*>(out32));
+            hipLaunchKernelGGL(k_blake2b256_raw<0>, dim3(div_up(n, wg)), dim3(wg), 0, ctx->stream, arena, m, n,
+                               reinterpret_cast<uint64_t*>(out32));
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

@@ -10,11 +10,13 @@ namespace ipcfp {
 
 // --- blake2b_cid.hip (K1) ---
 int launch_chunk_order(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint32_t* bins_d, uint32_t* order_d);
-int launch_blake2b256_cid(ipcfp_ctx* ctx, const uint8_t* arena, const uint64_t* off, const uint32_t* len,
-                          const uint8_t* cids40, const uint32_t* order, uint32_t n, uint32_t* ok_bits,
-                          uint8_t* status, unsigned long long* counters);
-int launch_blake2b256_raw(ipcfp_ctx* ctx, const uint8_t* arena, const uint64_t* off, const uint32_t* len,
-                          const uint32_t* order, uint32_t n, uint8_t* out32);
+int launch_k1_layout(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint32_t* bins_d, uint32_t* order_d,
+                     uint32_t* sched_len_d, uint64_t* sched_off_d, uint64_t* total_d, uint64_t* scan_scratch_d,
+                     uint64_t* off_by_id_d, void* meta_d);
+int launch_gather_cids(ipcfp_ctx* ctx, const uint32_t* order_d, const uint8_t* cids_d, uint32_t n, uint8_t* sched_cids_d);
+int launch_blake2b256_cid(ipcfp_ctx* ctx, const uint8_t* arena, const void* meta, const uint8_t* sched_cids40, uint32_t n,
+                          uint32_t* ok_bits, uint8_t* status, unsigned long long* counters);
+int launch_blake2b256_raw(ipcfp_ctx* ctx, const uint8_t* arena, const void* meta, uint32_t n, uint8_t* out32);
 
 // --- repack.hip ---
 // new_off[i] = exclusive prefix sum of round_up(len[i], 16); *total_d receives the arena size.
