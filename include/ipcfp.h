@@ -99,6 +99,16 @@ enum {
     IPCFP_CID_UNCHECKED = 2   /* CID is not (v1, *, blake2b-256, 32): not hashed here   */
 };
 
+/* Host-side string forms (no GPU involved; usable without a context).
+ * ipcfp_cid_from_string: `Cid::try_from(&str)` (src/proofs/common/witness.rs:60-64): multibase b/B (base32),
+ *   f/F (base16), z (base58btc) or a bare CIDv0 "Qm…".  Returns the CID's byte length (written
+ *   zero-padded into the 40-byte slot), IPCFP_E_PARSE if the reference's parse would be Err, or
+ *   IPCFP_E_UNSUPPORTED for a valid CID longer than the slot.
+ * ipcfp_cid_to_string: `Cid::to_string()` — "b" + base32-lower for CIDv1, base58btc for CIDv0; returns
+ *   the string length (excluding NUL) or IPCFP_E_INVALID if cap is too small / the bytes are not a CID. */
+int ipcfp_cid_from_string(const char* s, uint8_t out40[IPCFP_CID_SLOT]);
+int ipcfp_cid_to_string(const uint8_t* cid, uint32_t len, char* out, uint32_t cap);
+
 /* ---- context ------------------------------------------------------------ */
 typedef struct ipcfp_ctx ipcfp_ctx_t;
 

@@ -23,6 +23,8 @@ __all__ = [
     "CID_UNCHECKED",
     "KERNEL_IDS",
     "pack_event_claims",
+    "cid_from_string",
+    "cid_to_string",
     "pack_cids",
     "CLAIM_DTYPE",
     "TIPSET_DTYPE",
@@ -169,6 +171,8 @@ def load_library() -> C.CDLL:
         "ipcfp_scan_events": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
         "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
+        "ipcfp_cid_from_string": (i32, [C.c_char_p, vp]),
+        "ipcfp_cid_to_string": (i32, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]),
         "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
         "ipcfp_verify_storage_proofs": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_verify_event_proofs": (i32, [vp, vp, vp, u64, vp, vp, vp]),
@@ -349,6 +353,19 @@ def pack_event_claims(parent_cids, child_cid, parent_epoch, child_epoch, exec_in
             break
         blob[starts[sel] + nt[sel] * 33 + j] = data[sel, j]
     return ts, cl, blob[: total + 64], total
+
+
+def cid_from_string(s: str):
+    """Host-side `Cid::try_from(&str)` of the engine: bytes, or None where the reference returns Err."""
+    out = np.zeros(CID_SLOT, dtype=np.uint8)
+    n = load_library().ipcfp_cid_from_string(s.encode(), _p(out))
+    return out.tobytes()[:n] if n > 0 else None
+
+
+def cid_to_string(cid: bytes):
+    buf = C.create_string_buffer(256)
+    n = load_library().ipcfp_cid_to_string(bytes(cid), len(cid), buf, 256)
+    return buf.value.decode() if n > 0 else None
 
 
 def pack_cids(cids) -> np.ndarray:

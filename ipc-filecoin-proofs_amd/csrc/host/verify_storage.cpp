@@ -93,6 +93,24 @@ int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcf
     return IPCFP_OK;
 }
 
+int ipcfp_cid_from_string(const char* s, uint8_t out40[IPCFP_CID_SLOT]) {
+    if (!s || !out40) return IPCFP_E_INVALID;
+    std::vector<uint8_t> bin;
+    if (!cid_from_string(s, bin)) return IPCFP_E_PARSE;
+    if (bin.size() > IPCFP_CID_SLOT) return IPCFP_E_UNSUPPORTED;
+    std::memset(out40, 0, IPCFP_CID_SLOT);
+    std::memcpy(out40, bin.data(), bin.size());
+    return int(bin.size());
+}
+
+int ipcfp_cid_to_string(const uint8_t* cid, uint32_t len, char* out, uint32_t cap) {
+    if (!cid || !out || !cid_binary_ok(cid, len)) return IPCFP_E_INVALID;
+    const std::string s = cid_to_string(cid, len);
+    if (s.size() + 1 > cap) return IPCFP_E_INVALID;
+    std::memcpy(out, s.c_str(), s.size() + 1);
+    return int(s.size());
+}
+
 int ipcfp_create_event_filter(ipcfp_ctx_t* ctx, const char* event_sig, const char* subnet_id,
                               ipcfp_event_filter_t* out) {
     if (!ctx || !event_sig || !subnet_id || !out) return IPCFP_E_INVALID;

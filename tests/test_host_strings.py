@@ -1,0 +1,61 @@
+"""CPU: the engine's host-side CID string handling (csrc/host/cidstr.cpp, exported through the C ABI)
+against the oracle's independent implementation and the well-known Filecoin CIDs.  No GPU involved."""
+import hashlib
+import os
+import random
+
+import pytest
+
+KNOWN = [
+    ("80", "bafy2bzacebc3bt6cedhoyw34drrmjvazhu4oj25er2ebk4u445pzycvq4ta4a"),
+    ("8300008341008080", "bafy2bzacedswlcz5ddgqnyo3sak3jmhmkxashisnlpq6ujgyhe4mlobzpnhs6"),
+    ("824080", "bafy2bzaceamp42wmmgr2g2ymg46euououzfyck7szknvfacqscohrvaikwfay"),
+]
+
+
+@pytest.mark.parametrize("blockhex,cid_str", KNOWN)
+def test_known_cids(blockhex, cid_str):
+    import ipc_filecoin_proofs_amd as ipcfp
+
+    cid = bytes.fromhex("0171a0e40220") + hashlib.blake2b(bytes.fromhex(blockhex), digest_size=32).digest()
+    assert ipcfp.cid_to_string(cid) == cid_str
+    assert ipcfp.cid_from_string(cid_str) == cid
+
+
+def test_engine_and_oracle_agree_on_random_and_malformed_strings(oracle):
+    import ipc_filecoin_proofs_amd as ipcfp
+
+    rng = random.Random(5)
+    cases = []
+    for _ in range(300):
+        kind = rng.randrange(5)
+        if kind == 0:  # blake2b dag-cbor
+            cid = bytes.fromhex("0171a0e40220") + os.urandom(32)
+        elif kind == 1:  # sha2-256 raw
+            cid = bytes.fromhex("01551220") + os.urandom(32)
+        elif kind == 2:  # identity multihash
+            n = rng.randrange(0, 30)
+            cid = bytes([0x01, 0x55, 0x00, n]) + os.urandom(n)
+        elif kind == 3:  # CIDv0
+            cid = bytes([0x12, 0x20]) + os.urandom(32)
+        else:  # multi-byte codec varint
+            cid = bytes([0x01, 0x81, 0x01, 0x12, 0x20]) + os.urandom(32)
+        s = oracle.cid_to_string(cid)
+        assert ipcfp.cid_to_string(cid) == s
+        cases.append(s)
+        cases.append(s.upper() if s[0] == "b" else s)
+        cases.append("f" + cid.hex() if cid[0] == 1 else s)
+        cases.append(s[:-1])
+        cases.append(s + "a")
+        cases.append(s[0] + s[2:])
+        t = list(s)
+        t[rng.randrange(len(t))] = rng.choice("!_09xyZ@")
+        cases.append("".join(t))
+    cases += ["", "b", "z", "f", "Qm", "bafy", "f0", "f01", "b" + "a" * 70, "z" + "1" * 40, "F0171A0E40220" + "00" * 32]
+    for s in cases:
+        got = ipcfp.cid_from_string(s)
+        want = oracle.cid_from_string(s)
+        if want is not None and len(want) > 40:
+            assert got is None  # valid but longer than the ABI slot
+        else:
+            assert got == want, s
