@@ -381,6 +381,29 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
                                      uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                                      const ipcfp_event_filter_t* filter, void* status_d);
 
+#define IPCFP_SCLAIM_CHILD_PARSED 1u        /* child_block_cid parses (storage/verifier.rs:85)              */
+#define IPCFP_SCLAIM_STATE_ROOT_CANON 2u    /* parent_state_root parses and equals its Cid::to_string()     */
+#define IPCFP_SCLAIM_ACTOR_STATE_CANON 4u
+#define IPCFP_SCLAIM_STORAGE_ROOT_CANON 8u
+#define IPCFP_SCLAIM_SLOT_PARSED 16u        /* slot hex decodes to exactly 32 bytes (:155-157)              */
+#define IPCFP_SCLAIM_VALUE_MATCHABLE 32u    /* value is "0x" + 64 hex digits                                */
+typedef struct ipcfp_storage_claim {
+    int64_t child_epoch;
+    uint64_t actor_id;
+    uint8_t child[IPCFP_CID_SLOT];
+    uint8_t state_root[IPCFP_CID_SLOT];
+    uint8_t actor_state[IPCFP_CID_SLOT];
+    uint8_t storage_root[IPCFP_CID_SLOT];
+    uint8_t slot[32];
+    uint8_t value[32];
+    uint32_t flags; /* IPCFP_SCLAIM_* */
+    uint32_t reserved;
+} ipcfp_storage_claim_t;
+
+/* verify_storage_proof over packed claims resident in HBM (claims_d: n structs, status_d: n bytes). */
+int ipcfp_verify_storage_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const void* claims_d, uint64_t n,
+                                       const ipcfp_trust_policy_t* trust, void* status_d);
+
 /* Rebuild the CID → block index of an existing witness in place (K4), e.g. once per verification
  * pass when the index build is to be charged to that pass.  No allocation.                    */
 int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);

@@ -21,6 +21,8 @@ from .binding import (  # noqa: F401
     CID_UNCHECKED,
     KERNEL_IDS,
     pack_event_claims,
+    pack_storage_claims,
+    SCLAIM_DTYPE,
     cid_from_string,
     cid_to_string,
     pack_cids,

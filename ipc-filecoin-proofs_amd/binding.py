@@ -23,6 +23,8 @@ __all__ = [
     "CID_UNCHECKED",
     "KERNEL_IDS",
     "pack_event_claims",
+    "pack_storage_claims",
+    "SCLAIM_DTYPE",
     "cid_from_string",
     "cid_to_string",
     "pack_cids",
@@ -106,6 +108,10 @@ CLAIM_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), (
                         ("event_index", np.uint64), ("emitter", np.uint64), ("message_cid", np.uint8, (CID_SLOT,)),
                         ("tipset", np.uint32), ("flags", np.uint32), ("n_topics", np.uint32),
                         ("topics_off", np.uint32), ("data_off", np.uint32), ("data_len", np.uint32)])
+SCLAIM_DTYPE = np.dtype([("child_epoch", np.int64), ("actor_id", np.uint64), ("child", np.uint8, (CID_SLOT,)),
+                         ("state_root", np.uint8, (CID_SLOT,)), ("actor_state", np.uint8, (CID_SLOT,)),
+                         ("storage_root", np.uint8, (CID_SLOT,)), ("slot", np.uint8, (32,)),
+                         ("value", np.uint8, (32,)), ("flags", np.uint32), ("reserved", np.uint32)])
 MATCH_DTYPE = np.dtype([("exec_index", np.uint64), ("event_index", np.uint64), ("emitter", np.uint64),
                         ("block", np.uint32), ("off", np.uint32), ("len", np.uint32), ("reserved", np.uint32)])
 
@@ -171,6 +177,7 @@ def load_library() -> C.CDLL:
         "ipcfp_scan_events": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
         "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
+        "ipcfp_verify_storage_claims_device": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_cid_from_string": (i32, [C.c_char_p, vp]),
         "ipcfp_cid_to_string": (i32, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]),
         "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
@@ -355,6 +362,22 @@ def pack_event_claims(parent_cids, child_cid, parent_epoch, child_epoch, exec_in
     return ts, cl, blob[: total + 64], total
 
 
+def pack_storage_claims(child_cid, state_root, child_epoch, actor_id, actor_state40, storage_root40, slot32, value32):
+    """Binary storage claims → ipcfp_storage_claim_t[n] with every flag set."""
+    n = len(actor_id)
+    cl = np.zeros(n, dtype=SCLAIM_DTYPE)
+    cl["child_epoch"] = child_epoch
+    cl["actor_id"] = actor_id
+    cl["child"][:, : len(child_cid)] = np.frombuffer(bytes(child_cid), dtype=np.uint8)
+    cl["state_root"][:, : len(state_root)] = np.frombuffer(bytes(state_root), dtype=np.uint8)
+    cl["actor_state"] = actor_state40
+    cl["storage_root"] = storage_root40
+    cl["slot"] = slot32
+    cl["value"] = value32
+    cl["flags"] = 63
+    return cl
+
+
 def cid_from_string(s: str):
     """Host-side `Cid::try_from(&str)` of the engine: bytes, or None where the reference returns Err."""
     out = np.zeros(CID_SLOT, dtype=np.uint8)
@@ -522,6 +545,12 @@ class Witness:
     def rebuild_index(self):
         """K4 again, in place (no allocation)."""
         self.eng._check(self.lib.ipcfp_witness_rebuild_index(self.eng.h, self.h), "rebuild_index")
+
+    def verify_storage_claims_device(self, claims_ptr: int, n: int, status_ptr: int, trust=None):
+        """Packed storage claims resident in HBM (ipcfp_storage_claim_t[n])."""
+        self.eng._check(self.lib.ipcfp_verify_storage_claims_device(
+            self.eng.h, self.h, claims_ptr, n, C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            status_ptr), "verify_storage_claims_device")
 
     def verify_event_claims_device(self, tipsets: np.ndarray, claims_ptr: int, n: int, blob_ptr: int, blob_len: int,
                                    status_ptr: int, trust=None, filt=None):

@@ -93,6 +93,19 @@ int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcf
     return IPCFP_OK;
 }
 
+int ipcfp_verify_storage_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const void* claims_d, uint64_t n,
+                                       const ipcfp_trust_policy_t* trust, void* status_d) {
+    if (!ctx || !w || w->ctx != ctx || (n && (!claims_d || !status_d))) return IPCFP_E_INVALID;
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    if (n == 0) return IPCFP_OK;
+    IPCFP_ENTER(ctx);
+    int rc = launch_verify_storage(ctx, witness_view(w), static_cast<const StorageClaimPacked*>(claims_d), uint32_t(n),
+                                   trust ? *trust : kAcceptAll, static_cast<uint8_t*>(status_d));
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IPCFP_OK;
+}
+
 int ipcfp_cid_from_string(const char* s, uint8_t out40[IPCFP_CID_SLOT]) {
     if (!s || !out40) return IPCFP_E_INVALID;
     std::vector<uint8_t> bin;

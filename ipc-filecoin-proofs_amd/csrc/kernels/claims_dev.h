@@ -33,6 +33,11 @@ struct StorageClaimPacked {
     uint32_t pad;
 };
 
+static_assert(sizeof(StorageClaimPacked) == sizeof(ipcfp_storage_claim_t), "packed storage claim layout");
+static_assert(SC_CHILD_PARSED == IPCFP_SCLAIM_CHILD_PARSED && SC_VALUE_MATCHABLE == IPCFP_SCLAIM_VALUE_MATCHABLE &&
+                  SC_SLOT_PARSED == IPCFP_SCLAIM_SLOT_PARSED && SC_STATE_ROOT_CANON == IPCFP_SCLAIM_STATE_ROOT_CANON,
+              "flags");
+
 // ---- events ----
 enum : uint32_t {
     EC_MSG_PARSED = 1u << 0,          // message_cid parses (else Err at events/verifier.rs:193)

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Measurements for BASELINE.json configs 2, 4 and 5 (the headline config 3 is bench.py).  One JSON
+line per config on stdout.  GPU box only; the oracle is used as the timed CPU baseline and as the
+checker of a sample."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+torch.cuda.init()
+import ipc_filecoin_proofs_amd as ipcfp  # noqa: E402
+from bench import make_cfg2  # noqa: E402
+from tools.synth import SEED_BASE, Tipset  # noqa: E402
+
+import claims  # noqa: E402
+import oracle_lib  # noqa: E402
+
+SCALE = float(os.environ.get("IPCFP_CFG_SCALE", "1.0"))
+
+
+def idaddr(i: int) -> bytes:
+    b = bytearray([0])
+    while True:
+        c = i & 0x7F
+        i >>= 7
+        if i:
+            b.append(c | 0x80)
+        else:
+            b.append(c)
+            return bytes(b)
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def cfg2(eng, orc):
+    out = {}
+    for n in (100_000, 4_000_000):
+        data, off, lens = make_cfg2(n, SEED_BASE + 2)
+        dig = eng.blake2b256(data, off, lens)
+        cids = np.zeros((n, 40), dtype=np.uint8)
+        cids[:, :6] = np.frombuffer(bytes.fromhex("0171a0e40220"), dtype=np.uint8)
+        cids[:, 6:38] = dig
+        bad = np.arange(7, n, 1024)
+        cids[bad, 6] ^= 1
+        w = eng.witness(data, off, lens, cids)
+        eng.profile_reset()
+        eng.profile_enable(True)
+        for _ in range(10):
+            w.verify_cids_async()
+        eng.profile_enable(False)
+        cnt, ms = eng.profile_read("blake2b_cid")
+        st, nbad = w.verify_cids()
+        assert nbad == len(bad) and (st[bad] == 0).all() and st.sum() == n - len(bad)
+        algo = float(lens.astype(np.float64).sum()) + n * 56
+        out[str(n)] = {"kernel_us": ms / cnt * 1e3, "cids_per_s": n / (ms / cnt * 1e-3), "algorithmic_GBps": algo / (ms / cnt * 1e-3) / 1e9}
+        if n == 100_000:
+            t0 = time.perf_counter()
+            ok, good = orc.blake2b256_verify(data, off, lens, np.ascontiguousarray(cids[:, 6:38]))
+            dt = time.perf_counter() - t0
+            assert np.array_equal(ok, st)
+            out["cpu_1thread_cids_per_s"] = n / dt
+        w.close()
+    return {"config": 2, "what": "Blake2b-256 CID verification of N x 1 KiB blocks (kernel-only, HBM resident)", **out}
+
+
+def cfg45(eng, orc):
+    n_actors = int(4_000_000 * SCALE)
+    n_contracts = int(10_000 * SCALE)
+    t0 = time.perf_counter()
+    T = Tipset(seed=SEED_BASE + 4, n_receipts=8, n_planted=0, n_actors=n_actors, n_contracts=n_contracts,
+               slots_per_contract=256, keep_full_state=0, n_actor_queries=int(65536 * 1.01 * min(1.0, SCALE * 4)))
+    t_gen = time.perf_counter() - t0
+    w = eng.witness(T.data, T.off, T.lens, T.cids)
+    st, nbad = w.verify_cids()
+    assert nbad == 0
+    ostore = orc.store(T.data, T.off, T.lens, T.cids)
+    res = []
+    # ---- config 4: actor gets ----
+    keys = [idaddr(int(i)) for i in T.query_ids]
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t_call = timed(lambda: w.hamt_get(T.actors_root, 5, "actor_state", keys), reps=3)
+    eng.profile_enable(False)
+    cnt, ms = eng.profile_read("hamt_get")
+    gs, gl = w.hamt_get(T.actors_root, 5, "actor_state", keys)
+    present = T.query_present.astype(bool)
+    assert (gs[present] == 1).all() and (gs[~present] == 32).all()
+    sample = 4000
+    t0 = time.perf_counter()
+    osx, ov = ostore.hamt_get(T.actors_root, 5, "actor_state", keys[:sample])
+    t_cpu = time.perf_counter() - t0
+    assert np.array_equal(osx, gs[:sample])
+    for k in range(0, sample, 97):
+        if gs[k] == 1:
+            o = int(T.off[gl[k]["block"]]) + int(gl[k]["off"])
+            assert T.data[o:o + int(gl[k]["len"])].tobytes() == ov[k]
+    res.append({"config": 4, "what": "HAMT state-tree actor lookup (SHA-256 key hash + walk), bit width 5",
+                "actors": n_actors, "gets": len(keys), "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"],
+                "kernel_us": ms / cnt * 1e3, "gets_per_s_kernel": len(keys) / (ms / cnt * 1e-3),
+                "gets_per_s_call_incl_h2d": len(keys) / t_call,
+                "cpu_gets_per_s_all_host_threads_sample%d" % sample: sample / t_cpu, "setup_s": t_gen})
+    # ---- config 5: storage proofs ----
+    n = len(T.sc_actor)
+    cl = ipcfp.pack_storage_claims(T.child_cid, T.state_root, T.child_epoch, T.sc_actor, T.sc_actor_state,
+                                   T.sc_storage_root, T.sc_slot, T.sc_value)
+    wrong = np.arange(500, n, 1000)
+    cl["value"][wrong, 31] ^= 1
+    d_cl = torch.from_numpy(cl.view(np.uint8).reshape(-1)).cuda()
+    d_st = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t_call = timed(lambda: w.verify_storage_claims_device(d_cl.data_ptr(), n, d_st.data_ptr()), reps=3)
+    eng.profile_enable(False)
+    cnt, ms = eng.profile_read("storage_verify")
+    got = d_st.cpu().numpy()
+    want = np.ones(n, dtype=np.uint8)
+    want[wrong] = 21
+    assert np.array_equal(got, want)
+    sample = 20000
+    sc = claims.StorageClaims(T, indices=np.arange(sample))
+    for k in wrong[wrong < sample]:
+        v = bytearray(T.sc_value[k].tobytes())
+        v[31] ^= 1
+        sc.set_str(int(k), "value", "0x" + bytes(v).hex())
+    t0 = time.perf_counter()
+    os1 = ostore.verify_storage_proofs(sc, mode=1, threads=1)
+    t_cpu1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    osa = ostore.verify_storage_proofs(sc, mode=1, threads=0)
+    t_cpua = time.perf_counter() - t0
+    assert np.array_equal(os1, got[:sample]) and np.array_equal(osa, os1)
+    res.append({"config": 5, "what": "EVM storage proofs: header -> state-tree HAMT -> EVM state -> storage HAMT -> value",
+                "contracts": n_contracts, "proofs": n, "kernel_us": ms / cnt * 1e3, "proofs_per_s_kernel": n / (ms / cnt * 1e-3),
+                "proofs_per_s_call": n / t_call, "cpu_proofs_per_s_1thread": sample / t_cpu1,
+                "cpu_proofs_per_s_all_threads": sample / t_cpua, "cpu_sample": sample})
+    w.close()
+    return res
+
+
+def main():
+    eng = ipcfp.Engine(0)
+    orc = oracle_lib.load()
+    print(json.dumps(cfg2(eng, orc)), flush=True)
+    for r in cfg45(eng, orc):
+        print(json.dumps(r), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
