@@ -31,7 +31,7 @@ struct EventMatch {  // == ipcfp_event_match_t
 // Returns TRUE or the first ERR_* in traversal order.
 template <typename F>
 __device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, const AmtRootInfo& root, int vkind, F&& f) {
-    constexpr int kMaxDepth = 14;  // height ≤ 64 / bit_width, bit_width ≥ 5 for FVM event AMTs; deeper trees are rejected
+    constexpr int kMaxDepth = 8;  // FVM event AMTs (bit width 5) are 1-2 levels deep; deeper than 8 levels is rejected
     if (root.height >= kMaxDepth) return IPCFP_ST_ERR_DECODE;
     uint32_t blk[kMaxDepth], noff[kMaxDepth], next_sub[kMaxDepth];
     uint64_t base[kMaxDepth];
@@ -116,7 +116,7 @@ struct ScanParams {
 };
 
 // PASS 1: counts[t] = number of matching events of receipt leaf t
-__global__ __launch_bounds__(256) void k_scan_pass1(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass1(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
                                                     ScanParams sp, uint32_t* __restrict__ counts,
                                                     unsigned long long* __restrict__ err) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_scan_pass1(WitnessView w, const LeafRef
 }
 
 // PASS 2: matching receipts write their matches in order; the recorded blocks are marked in w.touched
-__global__ __launch_bounds__(256) void k_scan_pass2(WitnessView w, CidKey receipts_root,
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass2(WitnessView w, CidKey receipts_root,
                                                     const LeafRef* __restrict__ receipts, uint32_t n, ScanParams sp,
                                                     const uint32_t* __restrict__ counts,
                                                     const uint32_t* __restrict__ offsets,

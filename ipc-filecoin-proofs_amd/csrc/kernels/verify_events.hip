@@ -314,7 +314,7 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     return IPCFP_ST_TRUE;
 }
 
-__global__ __launch_bounds__(256) void k_verify_events(WitnessView w, const EventClaimPacked* __restrict__ claims,
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(WitnessView w, const EventClaimPacked* __restrict__ claims,
                                                        uint32_t n, const TipsetCtxDev* __restrict__ ctxs,
                                                        const uint8_t* __restrict__ blob, ipcfp_trust_policy_t trust,
                                                        ipcfp_event_filter_t filter, int has_filter,

@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t verify_storage_one(const WitnessView& w, con
     return eq ? IPCFP_ST_TRUE : IPCFP_ST_FALSE_VALUE;                             // :169
 }
 
-__global__ __launch_bounds__(256) void k_verify_storage(WitnessView w, const StorageClaimPacked* __restrict__ claims,
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_storage(WitnessView w, const StorageClaimPacked* __restrict__ claims,
                                                         uint32_t n, ipcfp_trust_policy_t trust,
                                                         uint8_t* __restrict__ status) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

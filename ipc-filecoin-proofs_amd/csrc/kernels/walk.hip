@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_amt_get(WitnessView w, CidKey root, int
     if (loc) loc[t] = (st == IPCFP_ST_TRUE) ? l : ValueLoc{kNoBlock, 0, 0};
 }
 
-__global__ __launch_bounds__(256) void k_hamt_get(WitnessView w, CidKey root, uint32_t bit_width, int vkind,
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_get(WitnessView w, CidKey root, uint32_t bit_width, int vkind,
                                                   const uint8_t* __restrict__ keys,
                                                   const uint32_t* __restrict__ key_off,
                                                   const uint32_t* __restrict__ key_len, uint32_t n,

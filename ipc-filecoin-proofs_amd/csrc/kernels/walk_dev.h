@@ -16,6 +16,14 @@
 #include "cbor_dev.h"
 #include "sha256_dev.h"
 
+// The walk / scan / verify kernels are chains of dependent loads (one parser per lane): what hides
+// their latency is the number of wavefronts in flight, so they are compiled for this many waves per
+// SIMD (the register allocator spills the rest to scratch).  Measured on the 1M-receipt tipset —
+// DESIGN.md §4.
+#ifndef IPCFP_WALK_WAVES
+#define IPCFP_WALK_WAVES 4
+#endif
+
 namespace ipcfp {
 
 struct ValueLoc {
