@@ -68,8 +68,8 @@ struct Rd {
     // the last byte of an item never leaves the arena.
     const uint64_t* base8;  // p rounded down to 8 bytes
     uint32_t bias;          // p - base8
-    uint32_t cwi;           // index of the cached word (~0u: none)
-    uint64_t cw;            // the cached word
+    uint32_t cwi;           // index of the first cached word (0xfffffff0: none)
+    uint64_t cw0, cw1;      // the cached words cwi and cwi + 1 (a 16-byte window)
 
     __device__ __forceinline__ void init(const uint8_t* data, uint32_t len) {
         p = data;
@@ -79,39 +79,64 @@ struct Rd {
         const uintptr_t a = reinterpret_cast<uintptr_t>(data);
         base8 = reinterpret_cast<const uint64_t*>(a & ~uintptr_t(7));
         bias = uint32_t(a & 7);
-        cwi = ~0u;
-        cw = 0;
+        cwi = 0xfffffff0u;  // "nothing cached": neither cwi nor cwi + 1 is a reachable word index
+        cw0 = cw1 = 0;
+    }
+    // make words wi and wi + 1 the window (parsing moves forward: sliding by one word costs one load)
+    __device__ __forceinline__ void slide(uint32_t wi) {
+        if (wi == cwi) return;
+        if (wi == cwi + 1) {
+            cw0 = cw1;
+            cw1 = base8[wi + 1];
+        } else {
+            cw0 = base8[wi];
+            cw1 = base8[wi + 1];
+        }
+        cwi = wi;
     }
     // byte i of the item (i < n, or inside the block's padded tail)
     __device__ __forceinline__ uint32_t at(uint32_t i) {
         const uint32_t j = i + bias;
         const uint32_t wi = j >> 3;
-        if (wi != cwi) {
-            cw = base8[wi];
-            cwi = wi;
-        }
-        return uint32_t(cw >> ((j & 7u) * 8u)) & 0xffu;
+        if (wi != cwi && wi != cwi + 1) slide(wi);
+        const uint64_t w = wi == cwi ? cw0 : cw1;
+        return uint32_t(w >> ((j & 7u) * 8u)) & 0xffu;
     }
-    // the CID bytes [off, off+len) as a witness key (len ≤ 40)
+    // the 8 bytes at [i, i+8) as a little-endian u64 (unaligned).  The two aligned words that cover
+    // them are the window — still inside the arena (blocks are line-padded, the arena has tail slack).
+    __device__ __forceinline__ uint64_t peek64(uint32_t i) {
+        const uint32_t j = i + bias;
+        const uint32_t sh = (j & 7u) * 8u;
+        slide(j >> 3);
+        return sh ? (cw0 >> sh) | (cw1 << (64u - sh)) : cw0;
+    }
+    // the CID bytes [off, off+len) as a witness key (len ≤ 40): five unaligned words, tail masked
     __device__ __forceinline__ CidKey key_at(uint32_t off, uint32_t len) {
         CidKey k;
 #pragma unroll
         for (int w = 0; w < 5; ++w) {
+            const uint32_t lo = 8u * w;
             uint64_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const uint32_t idx = 8u * w + b;
-                if (idx < len) v |= uint64_t(at(off + idx)) << (8 * b);
+            if (lo < len) {
+                v = peek64(off + lo);
+                const uint32_t valid = len - lo;  // bytes of this word that belong to the CID
+                if (valid < 8) v &= (1ULL << (8u * valid)) - 1ULL;
             }
             k.w[w] = v;
         }
         return k;
     }
-    // 32 bytes at `off` equal to q[0..32)?
+    // 32 bytes at `off` equal to q[0..32)?  (q: any alignment)
     __device__ __forceinline__ bool equal32(uint32_t off, const uint8_t* q) {
-        bool eq = true;
-        for (int i = 0; i < 32; ++i) eq &= at(off + i) == q[i];
-        return eq;
+        uint64_t diff = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint64_t e = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) e |= uint64_t(q[8 * w + b]) << (8 * b);
+            diff |= peek64(off + 8u * w) ^ e;
+        }
+        return diff == 0;
     }
     __device__ __forceinline__ void fail() {
         if (!err) err = IPCFP_ST_ERR_DECODE;
@@ -134,22 +159,26 @@ struct Rd {
         arg = 0;
         if (err) return;
         if (pos >= n) return fail();
-        const uint32_t b = at(pos);
-        ++pos;
+        // one unaligned fetch covers the initial byte and up to 8 argument bytes minus one; the
+        // argument is big-endian.  Straight-line on purpose: lanes of a wavefront sit on different
+        // items, and a branchy decoder makes the wave execute every path.
+        const uint64_t raw = peek64(pos);
+        const uint32_t b = uint32_t(raw) & 0xffu;
         const uint32_t m = b >> 5, ai = b & 31u;
-        if (ai < 24) {
-            if (m == 7 && !(ai >= 20 && ai <= 22)) return fail();
-            major = m;
-            arg = ai;
-            return;
+        const bool imm = ai < 24;
+        const uint32_t nb = imm ? 0u : (1u << ((ai - 24u) & 3u));  // 1, 2, 4, 8 argument bytes
+        bool bad = ai > 27;                                          // indefinite length / reserved
+        bad |= m == 7 && (imm ? !(ai >= 20 && ai <= 22) : ai != 27);
+        bad |= nb > n - pos - 1;
+        if (bad) return fail();
+        uint64_t v = ai;
+        if (!imm) {
+            // argument bytes are raw bytes 1..nb (little-endian positions) → big-endian value
+            uint64_t be = __builtin_bswap64(raw >> 8);            // bytes 1..7 → top of the word
+            if (nb == 8) be |= uint64_t(at(pos + 8));             // the 8th argument byte lies beyond the fetch
+            v = nb == 8 ? be : (be >> (64u - 8u * nb));
         }
-        if (m == 7 && ai != 27) return fail();
-        if (ai > 27) return fail();  // indefinite length / reserved
-        const uint32_t nb = 1u << (ai - 24);
-        if (nb > n - pos) return fail();
-        uint64_t v = 0;
-        for (uint32_t k = 0; k < nb; ++k) v = (v << 8) | at(pos + k);
-        pos += nb;
+        pos += 1 + nb;
         major = m;
         arg = v;
     }
