@@ -68,45 +68,63 @@ __global__ __launch_bounds__(256) void k_enum_count(WitnessView w, const EnumNod
     counts[t] = c;
 }
 
+// One lane per OUTPUT entry (child): lane j finds its parent with a binary search over the exclusive
+// offsets, steps over the links before its own (the node was validated by k_enum_count) and resolves
+// one link.  A node's 8-32 children are thus resolved by as many lanes side by side instead of one lane
+// chasing 8-32 hash probes in sequence.
 __global__ __launch_bounds__(256) void k_enum_expand(WitnessView w, const EnumNode* __restrict__ frontier, uint32_t n,
-                                                     uint32_t level, int vkind, const uint32_t* __restrict__ counts,
-                                                     const uint32_t* __restrict__ offsets,
-                                                     EnumNode* __restrict__ next,
+                                                     uint32_t level, const uint32_t* __restrict__ offsets,
+                                                     uint32_t total, EnumNode* __restrict__ next,
                                                      unsigned long long* __restrict__ err) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    if (counts[t] == 0) return;
-    EnumNode e = frontier[t];
-    const uint32_t o = offsets[t];
-    if (e.leaf_ready || e.height < level) {
-        next[o] = e;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    // parent = last t with offsets[t] <= j  (entries that contribute nothing share their successor's offset)
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    EnumNode e = frontier[lo];
+    const uint32_t k = j - offsets[lo];
+    if (e.leaf_ready || e.height < level) {  // rides along (k == 0)
+        next[j] = e;
         return;
     }
-    // re-walk the (already validated) node to reach its links
     Rd r = open_block(w, e.block);
     r.pos = e.node_off;
     r.expect_array(3);
     uint32_t bo, bl;
     r.read_bytes(bo, bl);
     const uint64_t nl = r.read_array();
-    if (nl == 0) {
+    if (nl == 0) {  // a Leaf above height 0: carried down as-is
         e.leaf_ready = 1;
-        next[o] = e;
+        next[j] = e;
         return;
     }
-    const uint64_t span = amt_span(e.bit_width, e.height);
-    uint32_t sub = 0;
-    for (uint64_t j = 0; j < nl; ++j) {
-        while (!((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;  // j-th set bit (bitmap validated: popcount == nl)
-        CidKey key;
-        r.read_link_key(key);
-        EnumNode c{kNoBlock, 0, e.base + uint64_t(sub) * span, e.seq, uint16_t(e.height - 1), e.bit_width, 0};
-        const uint32_t b = witness_find(w, key);
-        if (b == kNoBlock) enum_error(err, e.seq, c.base, IPCFP_ST_ERR_MISSING_BLOCK);
-        else c.block = b;
-        next[o + uint32_t(j)] = c;
-        ++sub;
+    // the k-th set bit of the bitmap names the slot; step over the k links before ours
+    uint32_t sub = 0, seen = 0;
+    for (;; ++sub) {
+        if ((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u) {
+            if (seen == k) break;
+            ++seen;
+        }
     }
+    for (uint32_t q = 0; q < k; ++q) {
+        uint32_t m;
+        uint64_t a;
+        r.head(m, a);  // tag 42
+        r.head(m, a);  // byte-string header
+        r.pos += uint32_t(a);
+    }
+    CidKey key;
+    r.read_link_key(key);
+    const uint64_t span = amt_span(e.bit_width, e.height);
+    EnumNode c{kNoBlock, 0, e.base + uint64_t(sub) * span, e.seq, uint16_t(e.height - 1), e.bit_width, 0};
+    const uint32_t b = witness_find(w, key);
+    if (b == kNoBlock) enum_error(err, e.seq, c.base, IPCFP_ST_ERR_MISSING_BLOCK);
+    else c.block = b;
+    next[j] = c;
 }
 
 // leaf level: number of values per entry
@@ -196,8 +214,8 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
         if (level >= 1) {
             IPCFP_HIP(ctx, nxt.alloc(total));
             if (total)
-                hipLaunchKernelGGL(k_enum_expand, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
-                                   vkind, counts.p, offsets.p, nxt.p, err_d);
+                hipLaunchKernelGGL(k_enum_expand, dim3(div_up(total, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
+                                   offsets.p, uint32_t(total), nxt.p, err_d);
             cur.swap(nxt);  // the old frontier returns to the pool; reuse is stream-ordered
             n = uint32_t(total);
             if (n == 0) break;

@@ -58,11 +58,38 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     }
 }
 
+// n ≤ 4096: the whole scan in one workgroup, one launch (most tree levels are this small)
+__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict__ in, uint32_t n,
+                                                     uint32_t* __restrict__ out, uint64_t* __restrict__ total_out) {
+    __shared__ uint64_t smem[17];
+    const uint32_t base = threadIdx.x * 4u;
+    uint32_t r[4];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        r[k] = (base + k < n) ? in[base + k] : 0;
+        s += r[k];
+    }
+    uint64_t total;
+    uint64_t ex = block_exclusive_scan(s, smem, &total);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) out[base + k] = uint32_t(ex);
+        ex += r[k];
+    }
+    if (threadIdx.x == 0) *total_out = total;
+}
+
 // out[i] = sum of in[0..i); *total_d = sum of all.  scratch_d must hold div_up(n,1024)+1 u64.
 int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* out_d, uint64_t* total_d,
                     uint64_t* scratch_d) {
     if (n == 0) {
         IPCFP_HIP(ctx, hipMemsetAsync(total_d, 0, sizeof(uint64_t), ctx->stream));
+        return IPCFP_OK;
+    }
+    if (n <= 4096) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, in_d, n, out_d, total_d);
+        IPCFP_HIP(ctx, hipGetLastError());
         return IPCFP_OK;
     }
     const uint32_t ntiles = div_up(n, 1024);

@@ -40,6 +40,28 @@ __device__ __forceinline__ uint32_t decode_header(Rd& r, HeaderLite& h) {
     return r.ok() ? IPCFP_ST_TRUE : IPCFP_ST_ERR_DECODE;
 }
 
+// Wave-cooperative staging of one block into LDS: block headers are ≈1 KB and a single lane that
+// parses one from HBM pays a DRAM round trip per window word (≈190 µs for two headers on an otherwise
+// idle chip).  All 64 lanes copy the block with 16-byte loads, then ONE lane parses it out of LDS.
+// Every lane of the wavefront must call this.  Returns a reader over the LDS copy, or over HBM when
+// the block does not fit.
+__device__ __forceinline__ Rd open_block_staged(const WitnessView& w, uint32_t b, uint8_t* lds, uint32_t cap) {
+    const uint32_t len = w.len[b];
+    const uint8_t* src = w.arena + w.off[b];  // 128-byte aligned, padded to a line
+    Rd r;
+    if (len + 32u <= cap) {
+        const uint32_t words = (len + 15u + 16u) >> 4;  // whole 16-byte words, plus one for window over-reads
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(lds);
+        for (uint32_t i = threadIdx.x & 63u; i < words; i += 64u) d4[i] = s4[i];
+        __syncthreads();
+        r.init(lds, len);
+    } else {
+        r.init(src, len);
+    }
+    return r;
+}
+
 // `bs.get(cid)?.ok_or(..)?` + from_slice::<HeaderLite>
 __device__ __forceinline__ uint32_t load_header(const WitnessView& w, const CidKey& cid, HeaderLite& h, uint32_t& block) {
     block = witness_find(w, cid);

@@ -51,40 +51,66 @@ __device__ __forceinline__ void blake2b256_small(const uint8_t* buf, uint32_t le
 // ---------------------------------------------------------------------------
 // context headers: one thread per context
 // ---------------------------------------------------------------------------
-__global__ void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront (= one 64-thread workgroup) per context: the wave stages each header in LDS, lane 0 parses.
+constexpr uint32_t kHeaderLds = 8192;
+
+__global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
+    const uint32_t t = blockIdx.x;
     if (t >= n) return;
     TipsetCtxDev& c = ctxs[t];
-    c.child_status = IPCFP_ST_ERR_BAD_CLAIM;
-    c.parents_match = 0;
-    c.child_height = 0;
-    c.parent0_status = IPCFP_ST_ERR_BAD_CLAIM;
-    c.parent0_height = 0;
+    const bool lead = threadIdx.x == 0;
+    if (lead) {
+        c.child_status = IPCFP_ST_ERR_BAD_CLAIM;
+        c.parents_match = 0;
+        c.child_height = 0;
+        c.parent0_status = IPCFP_ST_ERR_BAD_CLAIM;
+        c.parent0_height = 0;
+    }
     if ((c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) != (TC_PARENTS_PARSED | TC_CHILD_PARSED)) return;
-    HeaderLite h;
-    uint32_t hb;
-    c.child_status = load_header(w, c.child, h, hb);  // events/verifier.rs:155-158
-    if (c.child_status == IPCFP_ST_TRUE) {
-        c.child_height = h.height;
-        c.receipts_root = h.parent_message_receipts;
-        // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
-        bool same = h.n_parents == c.n_parents;
-        if (same) {
-            Rd r = open_block(w, hb);
-            r.pos = h.parents_off;
-            for (uint32_t i = 0; i < c.n_parents && same; ++i) {
-                CidKey k;
-                r.read_link_key(k);
-                same = r.ok() && cid_equal(k, c.parents[i]);
+    // child header (events/verifier.rs:155-158)
+    const uint32_t hb = witness_find(w, c.child);  // uniform across the wave
+    if (hb == kNoBlock) {
+        if (lead) c.child_status = IPCFP_ST_ERR_MISSING_BLOCK;
+    } else {
+        Rd r = open_block_staged(w, hb, lds, kHeaderLds);
+        if (lead) {
+            HeaderLite h;
+            const uint32_t st = decode_header(r, h);
+            c.child_status = st;
+            if (st == IPCFP_ST_TRUE) {
+                c.child_height = h.height;
+                c.receipts_root = h.parent_message_receipts;
+                // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
+                bool same = h.n_parents == c.n_parents;
+                if (same) {
+                    Rd q = r;
+                    q.err = 0;
+                    q.pos = h.parents_off;
+                    for (uint32_t i = 0; i < c.n_parents && same; ++i) {
+                        CidKey k;
+                        q.read_link_key(k);
+                        same = q.ok() && cid_equal(k, c.parents[i]);
+                    }
+                }
+                c.parents_match = same ? 1u : 0u;
             }
         }
-        c.parents_match = same ? 1u : 0u;
+        __syncthreads();  // the LDS copy is reused below
     }
-    if (c.n_parents > 0) {
-        HeaderLite ph;
-        uint32_t pb;
-        c.parent0_status = load_header(w, c.parents[0], ph, pb);  // :171-174
-        if (c.parent0_status == IPCFP_ST_TRUE) c.parent0_height = ph.height;
+    if (c.n_parents > 0) {  // parent_cids[0] (:171-174)
+        const uint32_t pb = witness_find(w, c.parents[0]);
+        if (pb == kNoBlock) {
+            if (lead) c.parent0_status = IPCFP_ST_ERR_MISSING_BLOCK;
+        } else {
+            Rd r = open_block_staged(w, pb, lds, kHeaderLds);
+            if (lead) {
+                HeaderLite ph;
+                const uint32_t st = decode_header(r, ph);
+                c.parent0_status = st;
+                if (st == IPCFP_ST_TRUE) c.parent0_height = ph.height;
+            }
+        }
     }
 }
 
@@ -95,23 +121,35 @@ __global__ void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, ui
 // ---------------------------------------------------------------------------
 // One lane per parent block (the per-block work is independent; the error word orders the outcomes).
 // `err` must hold kNoEnumError on entry.
-__global__ void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx, AmtRootSpec* __restrict__ roots,
-                             unsigned long long* __restrict__ err) {
+__global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx,
+                                                   AmtRootSpec* __restrict__ roots,
+                                                   unsigned long long* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     const uint32_t P = ctx->n_parents;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.x;  // one wavefront per parent block; lane 0 parses what the wave staged
     if (b >= P) return;
+    const bool lead = threadIdx.x == 0;
     auto fail = [&](uint32_t seq, uint32_t code) { atomicMin(err, (unsigned long long)pack_enum_error(seq, 0, code)); };
     // reconstruct_execution_order (utils.rs:20-27): every parent header is decoded first
     CidKey tx[1];
     bool have_tx[1];
     {
-        HeaderLite h;
-        uint32_t hb;
-        const uint32_t st = load_header(w, ctx->parents[b], h, hb);
-        have_tx[0] = st == IPCFP_ST_TRUE;
-        if (have_tx[0]) tx[0] = h.messages;
-        else fail(b, st);
+        have_tx[0] = false;
+        const uint32_t hb = witness_find(w, ctx->parents[b]);
+        if (hb == kNoBlock) {
+            if (lead) fail(b, IPCFP_ST_ERR_MISSING_BLOCK);
+        } else {
+            Rd hr = open_block_staged(w, hb, lds, kHeaderLds);
+            if (lead) {
+                HeaderLite h;
+                const uint32_t st = decode_header(hr, h);
+                have_tx[0] = st == IPCFP_ST_TRUE;
+                if (have_tx[0]) tx[0] = h.messages;
+                else fail(b, st);
+            }
+        }
     }
+    if (!lead) return;  // the rest is a short chain on small blocks
     // collect_exec_list (utils.rs:56-91)
     {
         const uint32_t seq = P + 3 * b;
@@ -328,7 +366,7 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(Witness
 // ------------------------------ launchers -----------------------------------
 int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n) {
     if (n == 0) return IPCFP_OK;
-    hipLaunchKernelGGL(k_ctx_headers, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, w, ctxs_d, n);
+    hipLaunchKernelGGL(k_ctx_headers, dim3(n), dim3(64), 0, ctx->stream, w, ctxs_d, n);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
@@ -337,7 +375,7 @@ int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* 
                       unsigned long long* err_d) {
     const unsigned long long none = kNoEnumError;
     IPCFP_HIP(ctx, hipMemcpyAsync(err_d, &none, 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_exec_roots, dim3(1), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d);
+    hipLaunchKernelGGL(k_exec_roots, dim3(IPCFP_MAX_PARENTS), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
