@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass2(WitnessVie
                                                     EventMatch* __restrict__ matches,
                                                     uint8_t* __restrict__ has_match, uint64_t has_cap) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) {  // `Amtv0::load(&receipts_root, &rec_receipts)` records the root even without matches (:195-196)
+    const bool recording = w.touched != nullptr;
+    if (t == 0 && recording) {  // `Amtv0::load(&receipts_root, &rec_receipts)` records the root even without matches (:195-196)
         AmtRootInfo info;
         (void)amt_load(w, receipts_root, 0, VK_RECEIPT, info);
     }
@@ -159,11 +160,15 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass2(WitnessVie
     const uint32_t c = counts[t];
     if (leaf.index < has_cap) has_match[leaf.index] = c ? 1 : 0;
     if (c == 0) return;
-    // `r_amt.get(i)` on the recorder (:249): marks the receipt's path
-    AmtRootInfo rinfo;
-    if (amt_load(w, receipts_root, 0, VK_RECEIPT, rinfo) == IPCFP_ST_TRUE) {
-        ValueLoc rl;
-        (void)amt_get(w, rinfo, VK_RECEIPT, leaf.index, rl);
+    // `r_amt.get(i)` on the recorder (:249).  Its only observable effect is the recorded path: the index
+    // came out of this very AMT's enumeration, which validated every node, so the get cannot return None
+    // or Err — without a recorder there is nothing to do.
+    if (recording) {
+        AmtRootInfo rinfo;
+        if (amt_load(w, receipts_root, 0, VK_RECEIPT, rinfo) == IPCFP_ST_TRUE) {
+            ValueLoc rl;
+            (void)amt_get(w, rinfo, VK_RECEIPT, leaf.index, rl);
+        }
     }
     CidKey ev_root;
     if (!receipt_events_root(w, leaf, ev_root)) return;
