@@ -28,6 +28,12 @@
 #include "blake2b_dev.h"
 #include "launch.h"
 
+// Register budget: the default (130 VGPRs → 3 waves/SIMD).  Forcing 4 waves/SIMD (≤128 VGPRs) was measured
+// and is not faster (2.06 vs 2.10-2.15 TB/s at 4 M × 1 KiB): the VALU pipe is already ≈85-95 % busy.
+#ifndef IPCFP_K1_WAVES
+#define IPCFP_K1_WAVES 1
+#endif
+
 namespace ipcfp {
 
 // chunks a lane must compress for a block of `len` bytes (≥ 1: the empty message
@@ -66,7 +72,7 @@ struct K1Meta {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_blake2b256_cid(const uint8_t* __restrict__ arena,
+__global__ __launch_bounds__(256, IPCFP_K1_WAVES) void k_blake2b256_cid(const uint8_t* __restrict__ arena,
                                                        const K1Meta* __restrict__ meta,
                                                        const uint8_t* __restrict__ sched_cids40, uint32_t n,
                                                        uint32_t* __restrict__ ok_bits,
