@@ -318,6 +318,43 @@ typedef struct ipcfp_storage_proof {
 int ipcfp_create_event_filter(ipcfp_ctx_t* ctx, const char* event_sig, const char* subnet_id,
                               ipcfp_event_filter_t* out);
 
+/* ---- generator side -------------------------------------------------
+ * `generate_event_proof` (src/proofs/events/generator.rs:75-178) against the resident tipset: the
+ * witness `w` plays the RPC blockstore (every block the generator may load must be in it) and a
+ * bitmap over its blocks plays `RecordingBlockStore` (src/proofs/common/blockstore.rs:9-37).
+ *   parent_cids40/n_parents, child_cid40   the tipset pair (header CIDs, 40-byte slots)
+ *   filter, has_actor, actor               EventMatcher + optional emitter filter (generator.rs:26-40,187)
+ *   *status_out      IPCFP_ST_TRUE, or the ERR_* the reference's `?` surfaces first
+ *   matches[i]       (exec_index, event_index, emitter, event location) of proof i, receipt order
+ *   message_cids40   message CID of proof i = execution_order[exec_index] (generator.rs:152-169)
+ *   witness_block_ids / witness_cids40   the materialised witness: ids of the recorded blocks of
+ *                    `w` in `Cid: Ord` order (collect_witness_blocks, common/witness.rs:34-54)
+ * Outputs are truncated to cap_*; *n_proofs / *n_blocks always receive the full counts.      */
+int ipcfp_generate_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                                const uint8_t* child_cid40, const ipcfp_event_filter_t* filter, int has_actor,
+                                uint64_t actor, ipcfp_status_t* status_out, ipcfp_event_match_t* matches,
+                                uint8_t* message_cids40, uint64_t cap_proofs, uint64_t* n_proofs,
+                                uint32_t* witness_block_ids, uint8_t* witness_cids40, uint64_t cap_blocks,
+                                uint64_t* n_blocks);
+
+/* One generated StorageProof (the claim fields of src/proofs/storage/generator.rs:158-178). */
+typedef struct ipcfp_generated_storage {
+    uint8_t parent_state_root[IPCFP_CID_SLOT];
+    uint8_t actor_state_cid[IPCFP_CID_SLOT];
+    uint8_t storage_root[IPCFP_CID_SLOT];
+    uint8_t value[32];  /* left-padded slot value; all zero when the slot is absent */
+    uint32_t status;    /* IPCFP_ST_TRUE or the ERR_* generate_storage_proof returns */
+    uint32_t reserved;
+} ipcfp_generated_storage_t;
+
+/* `generate_storage_proof` (src/proofs/storage/generator.rs:29-69) for n (actor_id, slot) specs of one
+ * child block, one lane per spec; the witness ids are the union of the blocks all specs recorded
+ * (`generate_proof_bundle` dedupes the union, src/proofs/generator.rs:52-62), in `Cid: Ord` order. */
+int ipcfp_generate_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* child_cid40,
+                                  const uint64_t* actor_ids, const uint8_t* slots32, uint64_t n,
+                                  ipcfp_generated_storage_t* out, uint32_t* witness_block_ids, uint8_t* witness_cids40,
+                                  uint64_t cap_blocks, uint64_t* n_blocks);
+
 /* `TrustPolicy` (src/proofs/trust/mod.rs:8-16,53-78): the predicate is evaluated on the
  * host, before the device call, because it is a pure function of (epoch, cid).  */
 typedef struct ipcfp_trust_policy {

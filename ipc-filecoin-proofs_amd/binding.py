@@ -116,6 +116,11 @@ MATCH_DTYPE = np.dtype([("exec_index", np.uint64), ("event_index", np.uint64), (
                         ("block", np.uint32), ("off", np.uint32), ("len", np.uint32), ("reserved", np.uint32)])
 
 
+GEN_STORAGE_DTYPE = np.dtype([("parent_state_root", np.uint8, 40), ("actor_state_cid", np.uint8, 40),
+                              ("storage_root", np.uint8, 40), ("value", np.uint8, 32), ("status", np.uint32),
+                              ("reserved", np.uint32)])
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -183,6 +188,9 @@ def load_library() -> C.CDLL:
         "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
         "ipcfp_verify_storage_proofs": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_verify_event_proofs": (i32, [vp, vp, vp, u64, vp, vp, vp]),
+        "ipcfp_generate_event_proofs": (i32, [vp, vp, vp, C.c_uint32, vp, vp, i32, u64, vp, vp, vp, u64, C.POINTER(u64),
+                                              vp, vp, u64, C.POINTER(u64)]),
+        "ipcfp_generate_storage_proofs": (i32, [vp, vp, vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(u64)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -525,6 +533,42 @@ class Witness:
             bits = np.unpackbits(touched.view(np.uint8), bitorder="little")[: self.n]
             ids = np.nonzero(bits)[0]
         return int(st[0]), has, m, ids
+
+    # -- generator side -------------------------------------------------------------------------
+    def generate_event_proofs(self, parent_cids, child_cid: bytes, topic0: bytes, topic1: bytes, actor=None):
+        """generate_event_proof over this witness as the blockstore.  Returns
+        (status, matches structured[n], message_cids u8[n,40], witness block ids u32[m] in `Cid: Ord` order)."""
+        pc = pack_cids(parent_cids)
+        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        filt = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
+        st = np.zeros(1, dtype=np.uint8)
+        npf, nb = C.c_uint64(), C.c_uint64()
+        a = (0, 0) if actor is None else (1, int(actor))
+        args = (self.eng.h, self.h, _p(pc), len(parent_cids), _p(child), _p(filt), a[0], a[1], _p(st))
+        self.eng._check(self.lib.ipcfp_generate_event_proofs(*args, None, None, 0, C.byref(npf), None, None, 0,
+                                                             C.byref(nb)), "generate_event_proofs")
+        m = np.zeros(int(npf.value), dtype=MATCH_DTYPE)
+        msg = np.zeros((int(npf.value), CID_SLOT), dtype=np.uint8)
+        ids = np.zeros(int(nb.value), dtype=np.uint32)
+        if st[0] == 1 and (len(m) or len(ids)):
+            self.eng._check(self.lib.ipcfp_generate_event_proofs(*args, _p(m), _p(msg), len(m), C.byref(npf), _p(ids),
+                                                                 None, len(ids), C.byref(nb)), "generate_event_proofs")
+        return int(st[0]), m, msg, ids
+
+    def generate_storage_proofs(self, child_cid: bytes, actor_ids, slots32):
+        """generate_storage_proof for n (actor_id, slot) specs.  Returns (records GEN_STORAGE_DTYPE[n],
+        witness block ids of the union in `Cid: Ord` order)."""
+        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        ids_in = np.ascontiguousarray(actor_ids, dtype=np.uint64)
+        slots = np.ascontiguousarray(slots32, dtype=np.uint8).reshape(-1, 32)
+        n = len(ids_in)
+        out = np.zeros(n, dtype=GEN_STORAGE_DTYPE)
+        nb = C.c_uint64()
+        wid = np.zeros(max(self.n, 1), dtype=np.uint32)
+        self.eng._check(self.lib.ipcfp_generate_storage_proofs(self.eng.h, self.h, _p(child), _p(ids_in), _p(slots), n,
+                                                               _p(out), _p(wid), None, len(wid), C.byref(nb)),
+                        "generate_storage_proofs")
+        return out, wid[: int(nb.value)]
 
     # -- verifiers (claim arrays are ctypes arrays of the ipcfp.h structs) -------------------
     def verify_storage_proofs(self, claims_arr, n, trust=None):

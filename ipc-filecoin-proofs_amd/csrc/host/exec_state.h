@@ -1,0 +1,38 @@
+// csrc/host/exec_state.h — host-side handles shared by the verifier and the generator entry points.
+#pragma once
+#include "../common.h"
+#include "../kernels/exec_order.h"
+#include "../kernels/launch.h"
+
+namespace ipcfp {
+
+// device buffers of one context's execution order
+struct ExecState {
+    DevBuf<CidKey> keys;        // raw for_each sequence
+    DevBuf<uint32_t> slots;     // hash table → first raw position
+    DevBuf<uint32_t> first;     // 1 where the raw position is a first occurrence
+    DevBuf<uint32_t> pos;       // exclusive scan of `first` → execution index
+    uint32_t mask = 0;
+    uint64_t raw_len = 0, exec_len = 0;
+    uint32_t status = IPCFP_ST_ERR;
+};
+
+// reconstruct_execution_order (verify_txmeta = 1, events/utils.rs:16-30) or build_execution_order
+// (verify_txmeta = 0, events/utils.rs:32-46) of the context stored at ctx_d (device).  With a recording
+// view every block the traversal loads is marked.
+int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
+                     ExecState& ex, int verify_txmeta = 1);
+
+// device-resident result of one two-pass event scan (scan_events.cpp)
+struct ScanResult {
+    uint32_t status = IPCFP_ST_ERR;
+    uint64_t n_idx = 0, n_matches = 0;
+    DevBuf<uint8_t> has;
+    DevBuf<ipcfp_event_match_t> matches;
+};
+int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const ipcfp_event_filter_t& filter,
+                       int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out);
+
+CidKey key_from_slot(const uint8_t* slot40);
+
+}  // namespace ipcfp

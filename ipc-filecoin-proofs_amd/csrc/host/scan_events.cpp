@@ -6,6 +6,7 @@
 #include "../common.h"
 #include "../kernels/amt_enum.h"
 #include "../kernels/launch.h"
+#include "exec_state.h"
 
 using namespace ipcfp;
 
@@ -13,20 +14,13 @@ namespace ipcfp {
 CidKey key_from_slot(const uint8_t* slot40);
 }
 
-extern "C" {
+namespace ipcfp {
 
-int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* receipts_root40,
-                      const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
-                      uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
-                      ipcfp_event_match_t* matches, uint64_t cap_matches, uint64_t* n_matches, uint32_t* touched_bits) {
-    if (!ctx || !w || w->ctx != ctx || !receipts_root40 || !filter || !status_out || !n_receipts || !n_matches)
-        return IPCFP_E_INVALID;
-    IPCFP_ENTER(ctx);
-    *n_receipts = *n_matches = 0;
-    *status_out = IPCFP_ST_ERR;
+// PASS 1 + prefix sum + PASS 2 on the device.  `touched_d` (nullable, device, words = ceil(n/32)) is
+// OR-ed into, so a caller can accumulate one recorder across several steps (generate_event_proof).
+int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const ipcfp_event_filter_t& filter,
+                       int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out) {
     const WitnessView view = witness_view(w);
-    const CidKey root = key_from_slot(receipts_root40);
-
     DevBuf<unsigned long long> err;
     IPCFP_HIP(ctx, err.alloc(1));
     unsigned long long e0 = kNoEnumError;
@@ -35,7 +29,7 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
     int rc = amt_enumerate_cached(ctx, w, root, 0, VK_RECEIPT, &en);  // receipts in index order
     if (rc) return rc;
     if (en->error != kNoEnumError) {
-        *status_out = ipcfp_status_t(enum_error_code(en->error));
+        out.status = enum_error_code(en->error);
         return IPCFP_OK;
     }
     const LeafRef* leaves = reinterpret_cast<const LeafRef*>(en->leaves.p);
@@ -48,16 +42,15 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
         IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         n_idx = last.index + 1;
     }
-    DevBuf<uint32_t> counts, offsets, touched;
+    DevBuf<uint32_t> counts, offsets;
     DevBuf<uint64_t> scratch, total;
-    DevBuf<uint8_t> has;
     IPCFP_HIP(ctx, counts.alloc(n));
     IPCFP_HIP(ctx, offsets.alloc(n));
     IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
     IPCFP_HIP(ctx, total.alloc(1));
-    IPCFP_HIP(ctx, has.alloc(n_idx));
-    if (n_idx) IPCFP_HIP(ctx, hipMemsetAsync(has.p, 0, n_idx, ctx->stream));
-    rc = launch_scan_pass1(ctx, view, leaves, n, *filter, has_actor, actor, counts.p, err.p);
+    IPCFP_HIP(ctx, out.has.alloc(n_idx));
+    if (n_idx) IPCFP_HIP(ctx, hipMemsetAsync(out.has.p, 0, n_idx, ctx->stream));
+    rc = launch_scan_pass1(ctx, view, leaves, n, filter, has_actor, actor, counts.p, err.p);
     if (rc) return rc;
     rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total.p, scratch.p);
     if (rc) return rc;
@@ -67,32 +60,58 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
     IPCFP_HIP(ctx, hipMemcpyAsync(&e1, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (e1 != kNoEnumError) {
-        *status_out = ipcfp_status_t(enum_error_code(e1));
+        out.status = enum_error_code(e1);
         return IPCFP_OK;
     }
-    DevBuf<ipcfp_event_match_t> md;
-    IPCFP_HIP(ctx, md.alloc(nm));
-    const uint32_t words = div_up(w->n, 32);
+    IPCFP_HIP(ctx, out.matches.alloc(nm));
     WitnessView rec = view;
+    rec.touched = touched_d;
+    rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, counts.p, offsets.p, out.matches.p,
+                           out.has.p, n_idx);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // counts/offsets are released on return
+    out.n_idx = n_idx;
+    out.n_matches = nm;
+    out.status = IPCFP_ST_TRUE;
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp
+
+extern "C" {
+
+int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* receipts_root40,
+                      const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
+                      uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
+                      ipcfp_event_match_t* matches, uint64_t cap_matches, uint64_t* n_matches, uint32_t* touched_bits) {
+    if (!ctx || !w || w->ctx != ctx || !receipts_root40 || !filter || !status_out || !n_receipts || !n_matches)
+        return IPCFP_E_INVALID;
+    IPCFP_ENTER(ctx);
+    *n_receipts = *n_matches = 0;
+    *status_out = IPCFP_ST_ERR;
+    const uint32_t words = div_up(w->n, 32);
+    DevBuf<uint32_t> touched;
     if (touched_bits) {
         IPCFP_HIP(ctx, touched.alloc(words));
         IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, size_t(words) * 4, ctx->stream));
-        rec.touched = touched.p;
     }
-    rc = launch_scan_pass2(ctx, rec, root, leaves, n, *filter, has_actor, actor, counts.p, offsets.p, md.p, has.p,
-                           n_idx);
+    ScanResult res;
+    int rc = scan_events_device(ctx, w, key_from_slot(receipts_root40), *filter, has_actor, actor,
+                                touched_bits ? touched.p : nullptr, res);
     if (rc) return rc;
-    *n_receipts = n_idx;
-    *n_matches = nm;
-    if (receipt_has_match && n_idx)
-        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match, has.p, n_idx < cap_receipts ? n_idx : cap_receipts,
+    *status_out = ipcfp_status_t(res.status);
+    if (res.status != IPCFP_ST_TRUE) return IPCFP_OK;
+    *n_receipts = res.n_idx;
+    *n_matches = res.n_matches;
+    if (receipt_has_match && res.n_idx)
+        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match, res.has.p, res.n_idx < cap_receipts ? res.n_idx : cap_receipts,
                                       hipMemcpyDeviceToHost, ctx->stream));
-    if (matches && nm)
-        IPCFP_HIP(ctx, hipMemcpyAsync(matches, md.p, (nm < cap_matches ? nm : cap_matches) * sizeof(ipcfp_event_match_t),
+    if (matches && res.n_matches)
+        IPCFP_HIP(ctx, hipMemcpyAsync(matches, res.matches.p,
+                                      (res.n_matches < cap_matches ? res.n_matches : cap_matches) * sizeof(ipcfp_event_match_t),
                                       hipMemcpyDeviceToHost, ctx->stream));
     if (touched_bits) IPCFP_HIP(ctx, hipMemcpyAsync(touched_bits, touched.p, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *status_out = IPCFP_ST_TRUE;
     return IPCFP_OK;
 }
 

@@ -15,6 +15,7 @@
 #include "../kernels/exec_order.h"
 #include "../kernels/launch.h"
 #include "cidstr.h"
+#include "exec_state.h"
 
 using namespace ipcfp;
 
@@ -23,25 +24,14 @@ namespace ipcfp {
 void parse_cid_claim(const char* s, CidKey& key, bool& parsed, bool& canonical);
 CidKey key_from_slot(const uint8_t* slot40);
 
-// device buffers of one context's execution order
-struct ExecState {
-    DevBuf<CidKey> keys;        // raw for_each sequence
-    DevBuf<uint32_t> slots;     // hash table → first raw position
-    DevBuf<uint32_t> first;     // 1 where the raw position is a first occurrence
-    DevBuf<uint32_t> pos;       // exclusive scan of `first` → execution index
-    uint32_t mask = 0;
-    uint64_t raw_len = 0, exec_len = 0;
-    uint32_t status = IPCFP_ST_ERR;
-};
-
 // Reconstruct the execution order of the context stored at ctx_d (device) on the device.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex) {
+                     ExecState& ex, int verify_txmeta) {
     DevBuf<AmtRootSpec> roots;
     DevBuf<unsigned long long> err;
     IPCFP_HIP(ctx, roots.alloc(2 * size_t(n_parents) + 1));
     IPCFP_HIP(ctx, err.alloc(1));
-    int rc = launch_exec_roots(ctx, view, ctx_d, roots.p, err.p);
+    int rc = launch_exec_roots(ctx, view, ctx_d, roots.p, err.p, verify_txmeta);
     if (rc) return rc;
     AmtEnumResult en;
     rc = amt_enumerate(ctx, view, roots.p, 2 * n_parents, VK_CID, err.p, en);

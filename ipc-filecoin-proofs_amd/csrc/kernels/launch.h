@@ -57,7 +57,7 @@ struct LeafRef;
 struct EventClaimPacked;
 int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n);
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
-                      unsigned long long* err_d);
+                      unsigned long long* err_d, int verify_txmeta = 1);
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,
                       uint32_t* slots_d, uint32_t mask, uint32_t* first_d);
 int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const uint32_t* first_d,
@@ -74,6 +74,14 @@ int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receip
                       uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
                       const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint8_t* has_match_d,
                       uint64_t has_cap);
+
+// --- generate.hip ---
+int launch_generate_storage(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& child, const void* specs_d, uint32_t n,
+                            void* out_d);
+int launch_mark_cids(ipcfp_ctx* ctx, const WitnessView& w, const CidKey* keys_d, uint32_t n, uint32_t* missing_d);
+int launch_gather_keys(ipcfp_ctx* ctx, const CidKey* table_d, uint64_t table_len, const uint64_t* index_d, uint32_t n,
+                       CidKey* out_d, uint32_t* oor_d);
+int launch_gather_block_cids(ipcfp_ctx* ctx, const uint8_t* cids_d, const uint32_t* ids_d, uint32_t n, CidKey* out_d);
 
 // device view of a witness (host helper, witness.cpp)
 WitnessView witness_view(const ipcfp_witness* w, uint32_t* touched_bits = nullptr);

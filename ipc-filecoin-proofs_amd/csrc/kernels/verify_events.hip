@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev*
 // `err` must hold kNoEnumError on entry.
 __global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx,
                                                    AmtRootSpec* __restrict__ roots,
-                                                   unsigned long long* __restrict__ err) {
+                                                   unsigned long long* __restrict__ err, int verify_txmeta) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     const uint32_t P = ctx->n_parents;
     const uint32_t b = blockIdx.x;  // one wavefront per parent block; lane 0 parses what the wave staged
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCt
                     re.w[2] = (d[1] >> 16) | (d[2] << 48);
                     re.w[3] = (d[2] >> 16) | (d[3] << 48);
                     re.w[4] = d[3] >> 16;
-                    if (!cid_equal(re, tx[0])) {
+                    // verify_txmeta = false on the generation path (build_execution_order, utils.rs:44)
+                    if (verify_txmeta && !cid_equal(re, tx[0])) {
                         fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
                     } else {
                         bls.root = lens[0] <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
@@ -372,10 +373,11 @@ int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_
 }
 
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
-                      unsigned long long* err_d) {
+                      unsigned long long* err_d, int verify_txmeta) {
     const unsigned long long none = kNoEnumError;
     IPCFP_HIP(ctx, hipMemcpyAsync(err_d, &none, 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_exec_roots, dim3(IPCFP_MAX_PARENTS), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d);
+    hipLaunchKernelGGL(k_exec_roots, dim3(IPCFP_MAX_PARENTS), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d,
+                       verify_txmeta);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -227,6 +227,62 @@ uint8_t orc_scan_events(void* store, const uint8_t* receipts_root40, const ipcfp
     });
 }
 
+// generate_event_proof: proofs as (exec, event, emitter) triples + message CIDs + topic/data blobs are
+// re-derivable from the triples, so only the triples, the message CIDs and the witness order are returned.
+uint8_t orc_generate_event_proof(void* store, const uint8_t* parent_cids40, uint32_t n_parents, const uint8_t* child40,
+                                 const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor,
+                                 uint64_t* triples, uint8_t* msg_cids40, uint64_t cap_proofs, uint64_t* n_proofs,
+                                 uint8_t* witness40, uint64_t cap_witness, uint64_t* n_witness) {
+    Store* s = static_cast<Store*>(store);
+    *n_proofs = *n_witness = 0;
+    return guarded([&]() -> uint8_t {
+        std::vector<Cid> parents;
+        for (uint32_t i = 0; i < n_parents; ++i) {
+            const uint8_t* slot = parent_cids40 + IPCFP_CID_SLOT * i;
+            parents.push_back(Cid{Bytes(slot, slot + cid_slot_len(slot))});
+        }
+        Cid child{Bytes(child40, child40 + cid_slot_len(child40))};
+        GeneratedEventBundle b = generate_event_proof(s->bs, parents, child, *filter, has_actor != 0, actor);
+        *n_proofs = b.proofs.size();
+        for (size_t i = 0; i < b.proofs.size() && i < cap_proofs; ++i) {
+            triples[3 * i] = b.proofs[i].exec_index;
+            triples[3 * i + 1] = b.proofs[i].event_index;
+            triples[3 * i + 2] = b.proofs[i].emitter;
+            std::memset(msg_cids40 + IPCFP_CID_SLOT * i, 0, IPCFP_CID_SLOT);
+            std::memcpy(msg_cids40 + IPCFP_CID_SLOT * i, b.proofs[i].message_cid.b.data(), b.proofs[i].message_cid.b.size());
+        }
+        *n_witness = b.witness.size();
+        for (size_t i = 0; i < b.witness.size() && i < cap_witness; ++i) {
+            std::memset(witness40 + IPCFP_CID_SLOT * i, 0, IPCFP_CID_SLOT);
+            std::memcpy(witness40 + IPCFP_CID_SLOT * i, b.witness[i].b.data(), b.witness[i].b.size());
+        }
+        return IPCFP_ST_TRUE;
+    });
+}
+
+// generate_storage_proof: out3 = parent_state_root, actor_state, storage_root (3 × 40); value32; witness.
+uint8_t orc_generate_storage_proof(void* store, const uint8_t* child40, uint64_t actor_id, const uint8_t* slot32,
+                                   uint8_t* out3x40, uint8_t* value32, uint8_t* witness40, uint64_t cap_witness,
+                                   uint64_t* n_witness) {
+    Store* s = static_cast<Store*>(store);
+    *n_witness = 0;
+    return guarded([&]() -> uint8_t {
+        Cid child{Bytes(child40, child40 + cid_slot_len(child40))};
+        GeneratedStorageProof p = generate_storage_proof(s->bs, child, actor_id, slot32);
+        std::memset(out3x40, 0, 3 * IPCFP_CID_SLOT);
+        std::memcpy(out3x40, p.parent_state_root.b.data(), p.parent_state_root.b.size());
+        std::memcpy(out3x40 + IPCFP_CID_SLOT, p.actor_state_cid.b.data(), p.actor_state_cid.b.size());
+        std::memcpy(out3x40 + 2 * IPCFP_CID_SLOT, p.storage_root.b.data(), p.storage_root.b.size());
+        std::memcpy(value32, p.value, 32);
+        *n_witness = p.witness.size();
+        for (size_t i = 0; i < p.witness.size() && i < cap_witness; ++i) {
+            std::memset(witness40 + IPCFP_CID_SLOT * i, 0, IPCFP_CID_SLOT);
+            std::memcpy(witness40 + IPCFP_CID_SLOT * i, p.witness[i].b.data(), p.witness[i].b.size());
+        }
+        return IPCFP_ST_TRUE;
+    });
+}
+
 // string helpers for tests / fixtures
 int orc_cid_to_string(const uint8_t* cid, uint32_t len, char* out, uint32_t cap) {
     std::string s = cid_to_string(Cid{Bytes(cid, cid + len)});

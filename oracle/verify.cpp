@@ -439,4 +439,109 @@ void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_eve
     if (touched) touched->assign(needed.begin(), needed.end());
 }
 
+// ---- generator side --------------------------------------------------------------------------
+GeneratedEventBundle generate_event_proof(const Blockstore& bs, const std::vector<Cid>& parent_cids, const Cid& child_cid,
+                                          const ipcfp_event_filter_t& filter, bool has_actor, uint64_t actor) {
+    GeneratedEventBundle out;
+    std::set<Cid> needed;
+    // Step 1: extract_child_info (generator.rs:112-119) — receipts root of the child header
+    HeaderLite child_hdr = decode_header(must_get(bs, child_cid, "child header"));
+    const Cid receipts_root = child_hdr.parent_message_receipts;
+    // Step 2: collect_base_witness (:122-145)
+    std::vector<Cid> txmeta;
+    for (const Cid& p : parent_cids) {
+        needed.insert(p);
+        txmeta.push_back(decode_header(must_get(bs, p, "parent header")).messages);
+    }
+    needed.insert(child_cid);
+    needed.insert(receipts_root);
+    for (const Cid& t : txmeta) needed.insert(t);
+    // Step 3: record_transaction_amts (:148-177)
+    for (const Cid& t : txmeta) {
+        RecordingBlockStore rec(bs);
+        const Bytes& raw = must_get(rec, t, "TxMeta");
+        Reader r(raw);
+        r.expect_array(2);
+        Cid bls = read_cid(r), secp = read_cid(r);
+        r.finish();
+        for (const Cid* root : {&bls, &secp}) {
+            AmtRoot a = amt_load(rec, *root, 0, check_cid_value);
+            amt_for_each(rec, a, check_cid_value, [](uint64_t, const ValueLoc&) {});
+        }
+        for (const Cid& c : rec.take_seen()) needed.insert(c);
+    }
+    // Step 4: build_execution_order → collect_exec_list(verify_txmeta = false) (utils.rs:33-45)
+    std::vector<Cid> exec;
+    {
+        std::set<Bytes> seen;
+        for (const Cid& t : txmeta) {
+            const Bytes& raw = must_get(bs, t, "TxMeta");
+            Reader r(raw);
+            r.expect_array(2);
+            Cid bls = read_cid(r), secp = read_cid(r);
+            r.finish();
+            for (const Cid* root : {&bls, &secp}) {
+                AmtRoot a = amt_load(bs, *root, 0, check_cid_value);
+                amt_for_each(bs, a, check_cid_value, [&](uint64_t, const ValueLoc& v) {
+                    Reader vr(v.block->data() + v.off, v.len);
+                    Cid c = read_cid(vr);
+                    if (seen.insert(c.b).second) exec.push_back(c);
+                });
+            }
+        }
+    }
+    // Step 5: find_matching_events (:180-307)
+    std::vector<uint8_t> has;
+    std::vector<ScanMatch> ms;
+    std::vector<Cid> touched;
+    scan_events(bs, receipts_root, filter, has_actor, actor, has, ms, &touched);
+    for (const auto& m : ms) {
+        if (m.exec_index >= exec.size()) throw Err(IPCFP_ST_ERR, "Missing message at index");  // :244-246
+        out.proofs.push_back({m.exec_index, m.event_index, m.emitter, exec[m.exec_index], m.topics, m.data});
+    }
+    for (const Cid& c : touched) needed.insert(c);  // :98-101
+    // Step 6: materialize (witness.rs:43-56)
+    for (const Cid& c : needed) {
+        (void)must_get(bs, c, "block");
+        out.witness.push_back(c);
+    }
+    return out;
+}
+
+GeneratedStorageProof generate_storage_proof(const Blockstore& bs, const Cid& child_cid, uint64_t actor_id,
+                                             const uint8_t slot[32]) {
+    GeneratedStorageProof out;
+    std::set<Cid> needed;
+    // Step 1: extract_and_verify_parent_state (storage/generator.rs:72-103)
+    HeaderLite hdr = decode_header(must_get(bs, child_cid, "child header"));
+    out.parent_state_root = hdr.parent_state_root;
+    needed.insert(child_cid);             // :41
+    needed.insert(out.parent_state_root); // :42
+    // Step 3: load_actor_and_storage_root (:106-134)
+    {
+        RecordingBlockStore rec(bs);
+        ActorState actor = get_actor_state(rec, out.parent_state_root, actor_id);
+        out.actor_state_cid = actor.state;
+        out.storage_root = parse_evm_state_contract(must_get(rec, out.actor_state_cid, "EVM state"));
+        needed.insert(out.actor_state_cid);
+        needed.insert(out.storage_root);
+        for (const Cid& c : rec.take_seen()) needed.insert(c);
+    }
+    // Step 4: read_storage_value (:137-155)
+    {
+        RecordingBlockStore rec(bs);
+        Bytes raw;
+        if (!read_storage_slot(rec, out.storage_root, slot, raw)) raw.clear();
+        std::memset(out.value, 0, 32);
+        if (raw.size() >= 32) std::memcpy(out.value, raw.data() + raw.size() - 32, 32);
+        else std::memcpy(out.value + 32 - raw.size(), raw.data(), raw.size());
+        for (const Cid& c : rec.take_seen()) needed.insert(c);
+    }
+    for (const Cid& c : needed) {
+        (void)must_get(bs, c, "block");
+        out.witness.push_back(c);
+    }
+    return out;
+}
+
 }  // namespace orc

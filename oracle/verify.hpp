@@ -53,4 +53,30 @@ void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_eve
                  uint64_t actor, std::vector<uint8_t>& receipt_has_match, std::vector<ScanMatch>& matches,
                  std::vector<Cid>* touched);
 
+// ---- generator side (offline: the RPC-backed store of the reference is any Blockstore) ----
+struct GeneratedEventProof {
+    uint64_t exec_index, event_index, emitter;
+    Cid message_cid;
+    std::vector<std::array<uint8_t, 32>> topics;
+    Bytes data;
+};
+struct GeneratedEventBundle {
+    std::vector<GeneratedEventProof> proofs;
+    std::vector<Cid> witness;  // `WitnessCollector::materialize()` order: BTreeSet<Cid>
+};
+// generate_event_proof (src/proofs/events/generator.rs:60-107).  What the reference reads from the RPC
+// tipset JSON (child.blocks[0].parent_message_receipts, parent.blocks[i].messages) is read from the
+// headers in the store.
+GeneratedEventBundle generate_event_proof(const Blockstore& bs, const std::vector<Cid>& parent_cids, const Cid& child_cid,
+                                          const ipcfp_event_filter_t& filter, bool has_actor, uint64_t actor);
+
+struct GeneratedStorageProof {
+    Cid parent_state_root, actor_state_cid, storage_root;
+    uint8_t value[32];
+    std::vector<Cid> witness;  // materialize() order
+};
+// generate_storage_proof (src/proofs/storage/generator.rs:29-67)
+GeneratedStorageProof generate_storage_proof(const Blockstore& bs, const Cid& child_cid, uint64_t actor_id,
+                                             const uint8_t slot[32]);
+
 }  // namespace orc

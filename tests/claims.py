@@ -67,36 +67,103 @@ def make_filter(topic0: bytes, topic1: bytes) -> EventFilter:
     return f
 
 
+def _cbor_item(b: bytes, pos: int):
+    """Minimal DAG-CBOR reader for test fixtures: returns (value, next_pos); uints, bytes, text, arrays only."""
+    ib = b[pos]
+    major, info = ib >> 5, ib & 31
+    pos += 1
+    if info < 24:
+        arg = info
+    else:
+        nb = {24: 1, 25: 2, 26: 4, 27: 8}[info]
+        arg = int.from_bytes(b[pos:pos + nb], "big")
+        pos += nb
+    if major == 0:
+        return arg, pos
+    if major == 2:
+        return bytes(b[pos:pos + arg]), pos + arg
+    if major == 3:
+        return bytes(b[pos:pos + arg]).decode(), pos + arg
+    if major == 4:
+        out = []
+        for _ in range(arg):
+            v, pos = _cbor_item(b, pos)
+            out.append(v)
+        return out, pos
+    raise ValueError(f"unexpected CBOR major type {major}")
+
+
+def extract_evm_log(stamped_event: bytes):
+    """`extract_evm_log` (src/proofs/common/evm.rs:13-59) on a StampedEvent's bytes → (emitter, topics, data) or None."""
+    (emitter, entries), _ = _cbor_item(stamped_event, 0)
+    kv = {}
+    for _flags, key, _codec, value in entries:
+        kv[key] = value  # a repeated key keeps the last value
+    if "topics" in kv:
+        t = kv["topics"]
+        if len(t) % 32:
+            return None
+        return emitter, [t[i:i + 32] for i in range(0, len(t), 32)], kv.get("data", b"")
+    topics = []
+    for k in ("t1", "t2", "t3", "t4"):
+        if k not in kv:
+            break
+        if len(kv[k]) != 32:
+            return None
+        topics.append(kv[k])
+    if not topics:
+        return None
+    return emitter, topics, kv.get("d", b"")
+
+
 class EventClaims:
     """Owns the Python strings behind an array of EventProof structs."""
 
-    def __init__(self, T, indices=None):
-        idx = np.arange(len(T.claim_exec)) if indices is None else np.asarray(indices)
-        self.n = len(idx)
-        self.arr = (EventProof * self.n)()
+    def __init__(self, T, indices=None, generated=None):
+        """From the synthetic tipset's own claim table (default), or — `generated=(matches, message_cids)` —
+        from what ipcfp_generate_event_proofs returned, the way generate_event_proof fills EventProof
+        (src/proofs/events/generator.rs:274-293): topics/data are read back from the located event."""
+        if generated is not None:
+            matches, msg_cids = generated
+            rows = []
+            for m, mc in zip(matches, msg_cids):
+                o = int(T.off[m["block"]]) + int(m["off"])
+                log = extract_evm_log(T.data[o:o + int(m["len"])].tobytes())
+                assert log is not None and log[0] == int(m["emitter"])
+                rows.append((int(m["exec_index"]), int(m["event_index"]), int(m["emitter"]), cid40_str(mc), log[1], log[2]))
+        else:
+            idx = np.arange(len(T.claim_exec)) if indices is None else np.asarray(indices)
+            rows = []
+            for i in idx:
+                e = int(T.claim_exec[i])
+                nt = int(T.claim_ntopics[i])
+                rows.append((e, int(T.claim_event[i]), int(T.claim_emitter[i]), cid40_str(T.exec_order[e]),
+                             [T.claim_topics[i, t].tobytes() for t in range(nt)],
+                             T.claim_data[i, : int(T.claim_datalen[i])].tobytes()))
+        self.n = len(rows)
+        self.arr = (EventProof * max(self.n, 1))()
         self._keep = []
         parents = [cid_str(c).encode() for c in T.parent_cids]
         self.parent_arr = (C.c_char_p * len(parents))(*parents)
         child = cid_str(T.child_cid).encode()
         self._keep += [parents, child]
-        for k, i in enumerate(idx):
+        for k, (e, ev, emitter, msg_s, topic_list, data_b) in enumerate(rows):
             p = self.arr[k]
             p.parent_epoch = T.parent_epoch
             p.child_epoch = T.child_epoch
             p.parent_tipset_cids = self.parent_arr
             p.n_parent_tipset_cids = len(parents)
             p.child_block_cid = child
-            e = int(T.claim_exec[i])
-            msg = cid40_str(T.exec_order[e]).encode()
-            nt = int(T.claim_ntopics[i])
-            topics = [hex0x(T.claim_topics[i, t].tobytes()).encode() for t in range(nt)]
+            msg = msg_s.encode()
+            nt = len(topic_list)
+            topics = [hex0x(t).encode() for t in topic_list]
             tarr = (C.c_char_p * max(nt, 1))(*topics)
-            data = hex0x(T.claim_data[i, : int(T.claim_datalen[i])].tobytes()).encode()
+            data = hex0x(data_b).encode()
             self._keep += [msg, topics, tarr, data]
             p.message_cid = msg
             p.exec_index = e
-            p.event_index = int(T.claim_event[i])
-            p.emitter = int(T.claim_emitter[i])
+            p.event_index = ev
+            p.emitter = emitter
             p.topics = tarr
             p.n_topics = nt
             p.data = data

@@ -48,6 +48,11 @@ class Oracle:
         lib.orc_scan_events.restype = C.c_uint8
         lib.orc_scan_events.argtypes = [vp, vp, vp, C.c_int, u64, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64),
                                         vp, u64, C.POINTER(u64)]
+        lib.orc_generate_event_proof.restype = C.c_uint8
+        lib.orc_generate_event_proof.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_int, u64, vp, vp, u64, C.POINTER(u64),
+                                                 vp, u64, C.POINTER(u64)]
+        lib.orc_generate_storage_proof.restype = C.c_uint8
+        lib.orc_generate_storage_proof.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, C.POINTER(u64)]
         lib.orc_verify_event_proofs.restype = None
         lib.orc_verify_event_proofs.argtypes = [vp, vp, u64, vp, vp, vp, C.c_int, C.c_int]
         lib.orc_verify_storage_proofs.restype = None
@@ -193,6 +198,35 @@ class OracleStore:
                                       _p(has), cap_receipts, C.byref(nr), _p(trip), cap_matches, C.byref(nm),
                                       _p(touched), cap_touched, C.byref(nt))
         return int(st), has[: nr.value], trip[: nm.value], (touched[: nt.value] if want_touched else None)
+
+    def generate_event_proof(self, parent_cids, child_cid: bytes, topic0: bytes, topic1: bytes, actor=None,
+                             cap_proofs=1 << 20, cap_witness=1 << 21):
+        """(status, triples u64[n,3], message cids u8[n,40], witness cids u8[m,40] in BTreeSet order)"""
+        pc = np.zeros((len(parent_cids), 40), dtype=np.uint8)
+        for i, c in enumerate(parent_cids):
+            pc[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
+        child = np.frombuffer(child_cid.ljust(40, b"\0"), dtype=np.uint8).copy()
+        filt = np.frombuffer(topic0 + topic1, dtype=np.uint8).copy()
+        trip = np.zeros((cap_proofs, 3), dtype=np.uint64)
+        msg = np.zeros((cap_proofs, 40), dtype=np.uint8)
+        wit = np.zeros((cap_witness, 40), dtype=np.uint8)
+        n_p, n_w = C.c_uint64(), C.c_uint64()
+        st = self.lib.orc_generate_event_proof(self.h, _p(pc), len(parent_cids), _p(child), _p(filt),
+                                               0 if actor is None else 1, 0 if actor is None else actor, _p(trip),
+                                               _p(msg), cap_proofs, C.byref(n_p), _p(wit), cap_witness, C.byref(n_w))
+        return int(st), trip[: n_p.value], msg[: n_p.value], wit[: n_w.value]
+
+    def generate_storage_proof(self, child_cid: bytes, actor_id: int, slot32: bytes, cap_witness=1 << 16):
+        """(status, [parent_state_root, actor_state_cid, storage_root] u8[3,40], value u8[32], witness cids)"""
+        child = np.frombuffer(child_cid.ljust(40, b"\0"), dtype=np.uint8).copy()
+        slot = np.frombuffer(slot32, dtype=np.uint8).copy()
+        out3 = np.zeros((3, 40), dtype=np.uint8)
+        val = np.zeros(32, dtype=np.uint8)
+        wit = np.zeros((cap_witness, 40), dtype=np.uint8)
+        n_w = C.c_uint64()
+        st = self.lib.orc_generate_storage_proof(self.h, _p(child), int(actor_id), _p(slot), _p(out3), _p(val), _p(wit),
+                                                 cap_witness, C.byref(n_w))
+        return int(st), out3, val, wit[: n_w.value]
 
 
 _cached = None
