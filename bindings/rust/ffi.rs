@@ -43,6 +43,12 @@ pub struct ipcfp_storage_proof_t {
 }
 
 #[repr(C)] pub struct ipcfp_event_filter_t { pub topic0: [u8; 32], pub topic1: [u8; 32] }
+#[repr(C)] pub struct ipcfp_value_loc_t { pub block: u32, pub off: u32, pub len: u32 }
+#[repr(C)] pub struct ipcfp_event_match_t { pub exec_index: u64, pub event_index: u64, pub emitter: u64,
+                                            pub event: ipcfp_value_loc_t, pub reserved: u32 }
+#[repr(C)] pub struct ipcfp_generated_storage_t { pub parent_state_root: [u8; 40], pub actor_state_cid: [u8; 40],
+                                                  pub storage_root: [u8; 40], pub value: [u8; 32], pub status: u32,
+                                                  pub reserved: u32 }
 #[repr(C)] pub struct ipcfp_trust_policy_t { pub kind: c_int, pub ec_chain_empty: c_int, pub min_epoch: i64, pub max_epoch: i64 }
 
 extern "C" {
@@ -60,6 +66,15 @@ extern "C" {
                                      status: *mut u8) -> c_int;
     pub fn ipcfp_verify_storage_proofs(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, proofs: *const ipcfp_storage_proof_t,
                                        n: u64, trust: *const ipcfp_trust_policy_t, status: *mut u8) -> c_int;
+    pub fn ipcfp_generate_event_proofs(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, parent_cids40: *const u8, n_parents: u32,
+                                       child_cid40: *const u8, filter: *const ipcfp_event_filter_t, has_actor: c_int, actor: u64,
+                                       status_out: *mut u8, matches: *mut ipcfp_event_match_t, message_cids40: *mut u8,
+                                       cap_proofs: u64, n_proofs: *mut u64, witness_block_ids: *mut u32, witness_cids40: *mut u8,
+                                       cap_blocks: u64, n_blocks: *mut u64) -> c_int;
+    pub fn ipcfp_generate_storage_proofs(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, child_cid40: *const u8,
+                                         actor_ids: *const u64, slots32: *const u8, n: u64, out: *mut ipcfp_generated_storage_t,
+                                         witness_block_ids: *mut u32, witness_cids40: *mut u8, cap_blocks: u64,
+                                         n_blocks: *mut u64) -> c_int;
     // … the remaining primitives (ipcfp_amt_get, ipcfp_hamt_get, ipcfp_scan_events, ipcfp_exec_order,
     //   ipcfp_*_batch, ipcfp_verify_event_claims_device, profiling) bind the same way.
 }
