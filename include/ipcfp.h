@@ -144,6 +144,7 @@ enum {
     IPCFP_K_STORAGE_VERIFY = 9,
     IPCFP_K_EXEC_ORDER = 10,
     IPCFP_K_BLAKE2B_RAW = 11,
+    IPCFP_K_BASE64 = 12,
     IPCFP_K_COUNT = 16
 };
 int ipcfp_profile_enable(ipcfp_ctx_t* ctx, int on);
@@ -444,6 +445,30 @@ int ipcfp_verify_storage_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, con
 /* Rebuild the CID → block index of an existing witness in place (K4), e.g. once per verification
  * pass when the index build is to be charged to that pass.  No allocation.                    */
 int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);
+
+/* ---- bundle wire format ----------------------------------------------
+ * `UnifiedProofBundle` (src/proofs/common/bundle.rs:39-45) as the JSON serde_json writes for the
+ * derived structs: {"storage_proofs":[StorageProof…],"event_proofs":[EventProof…],"blocks":[{"cid":
+ * [bytes…],"data":"<base64>"}…]}.  Parsing follows `#[derive(Deserialize)]`: unknown fields are
+ * skipped, a missing or duplicate field, a wrong type or invalid base64 is IPCFP_E_PARSE (the
+ * reference's `Err` before any proof is looked at).  The host locates the strings; every block's
+ * base64 (`deserialize_base64`, bundle.rs:30-37) is decoded on the device into the witness arena.  */
+typedef struct ipcfp_bundle ipcfp_bundle_t;
+#define IPCFP_BUNDLE_CID_STRINGS 1u /* also accept "cid":"bafy…" (extension; serde_json writes a byte array) */
+int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, uint32_t flags, ipcfp_bundle_t** out);
+void ipcfp_bundle_destroy(ipcfp_bundle_t* b);
+ipcfp_witness_t* ipcfp_bundle_witness(ipcfp_bundle_t* b); /* owned by the bundle */
+uint64_t ipcfp_bundle_block_count(const ipcfp_bundle_t* b);
+uint64_t ipcfp_bundle_event_count(const ipcfp_bundle_t* b);
+uint64_t ipcfp_bundle_storage_count(const ipcfp_bundle_t* b);
+const ipcfp_event_proof_t* ipcfp_bundle_event_proofs(const ipcfp_bundle_t* b);     /* strings owned by the bundle */
+const ipcfp_storage_proof_t* ipcfp_bundle_storage_proofs(const ipcfp_bundle_t* b);
+/* `verify_proof_bundle` (src/proofs/verifier.rs:12-62): every storage proof, then every event proof,
+ * against the bundle's own blocks.  One status per proof; the reference returns Err at the first
+ * status >= 64 in that order (storage first) and otherwise the two Vec<bool> (status == 1). */
+int ipcfp_verify_proof_bundle(ipcfp_ctx_t* ctx, ipcfp_bundle_t* b, const ipcfp_trust_policy_t* trust,
+                              const ipcfp_event_filter_t* filter, ipcfp_status_t* storage_status,
+                              ipcfp_status_t* event_status);
 
 #ifdef __cplusplus
 } /* extern "C" */

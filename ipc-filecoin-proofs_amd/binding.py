@@ -15,6 +15,8 @@ __all__ = [
     "Engine",
     "EngineError",
     "Witness",
+    "Bundle",
+    "GEN_STORAGE_DTYPE",
     "lib_path",
     "load_library",
     "ST",
@@ -52,6 +54,7 @@ KERNEL_IDS = {
     "storage_verify": 9,
     "exec_order": 10,
     "blake2b_raw": 11,
+    "base64": 12,
 }
 
 
@@ -191,6 +194,15 @@ def load_library() -> C.CDLL:
         "ipcfp_generate_event_proofs": (i32, [vp, vp, vp, C.c_uint32, vp, vp, i32, u64, vp, vp, vp, u64, C.POINTER(u64),
                                               vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_generate_storage_proofs": (i32, [vp, vp, vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(u64)]),
+        "ipcfp_bundle_parse_json": (i32, [vp, C.c_char_p, u64, C.c_uint32, C.POINTER(vp)]),
+        "ipcfp_bundle_destroy": (None, [vp]),
+        "ipcfp_bundle_witness": (vp, [vp]),
+        "ipcfp_bundle_block_count": (u64, [vp]),
+        "ipcfp_bundle_event_count": (u64, [vp]),
+        "ipcfp_bundle_storage_count": (u64, [vp]),
+        "ipcfp_bundle_event_proofs": (vp, [vp]),
+        "ipcfp_bundle_storage_proofs": (vp, [vp]),
+        "ipcfp_verify_proof_bundle": (i32, [vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -311,6 +323,10 @@ class Engine:
     def witness(self, data, off, lens, cids40) -> "Witness":
         return Witness(self, data, off, lens, cids40)
 
+    def bundle(self, text: bytes, flags: int = 0) -> "Bundle":
+        """Parse a `UnifiedProofBundle` JSON; the blocks are base64-decoded on the device."""
+        return Bundle(self, text, flags)
+
     def witness_from_blocks(self, blocks, cids) -> "Witness":
         """blocks: list[bytes]; cids: list[bytes] binary CIDs (≤ 40 B each)."""
         data, off, lens = _table(blocks)
@@ -408,6 +424,47 @@ def pack_cids(cids) -> np.ndarray:
     return out
 
 
+class Bundle:
+    """A parsed `UnifiedProofBundle` JSON (``ipcfp_bundle_t``): witness in HBM + the claim structs."""
+
+    CID_STRINGS = 1
+
+    def __init__(self, eng: "Engine", text: bytes, flags: int = 0):
+        self.eng = eng
+        self.lib = eng.lib
+        h = C.c_void_p()
+        text = bytes(text)
+        eng._check(self.lib.ipcfp_bundle_parse_json(eng.h, text, len(text), flags, C.byref(h)), "bundle_parse_json")
+        self.h = h
+        self.n_blocks = int(self.lib.ipcfp_bundle_block_count(h))
+        self.n_events = int(self.lib.ipcfp_bundle_event_count(h))
+        self.n_storage = int(self.lib.ipcfp_bundle_storage_count(h))
+        w = Witness.__new__(Witness)  # a view: the bundle owns the witness
+        w.eng, w.lib, w.h, w.n, w._borrowed = eng, eng.lib, C.c_void_p(self.lib.ipcfp_bundle_witness(h)), self.n_blocks, True
+        self.witness = w
+
+    def verify(self, trust=None, filt=None):
+        """verify_proof_bundle → (storage_status u8[], event_status u8[])."""
+        ss = np.zeros(max(self.n_storage, 1), dtype=np.uint8)
+        es = np.zeros(max(self.n_events, 1), dtype=np.uint8)
+        self.eng._check(self.lib.ipcfp_verify_proof_bundle(
+            self.eng.h, self.h, C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(ss), _p(es)), "verify_proof_bundle")
+        return ss[: self.n_storage], es[: self.n_events]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.witness.h = None
+            self.lib.ipcfp_bundle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Witness:
     """HBM-resident witness store (``ipcfp_witness_t``)."""
 
@@ -433,7 +490,8 @@ class Witness:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.ipcfp_witness_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.ipcfp_witness_destroy(self.h)
             self.h = None
 
     def __del__(self):
