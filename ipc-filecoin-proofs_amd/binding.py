@@ -455,7 +455,8 @@ class Bundle:
     def close(self):
         if getattr(self, "h", None):
             self.witness.h = None
-            self.lib.ipcfp_bundle_destroy(self.h)
+            if self.eng.h:  # a context that is already gone took its device memory with it
+                self.lib.ipcfp_bundle_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -490,7 +491,7 @@ class Witness:
 
     def close(self):
         if getattr(self, "h", None):
-            if not getattr(self, "_borrowed", False):
+            if not getattr(self, "_borrowed", False) and self.eng.h:
                 self.lib.ipcfp_witness_destroy(self.h)
             self.h = None
 

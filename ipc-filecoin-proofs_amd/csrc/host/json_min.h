@@ -228,7 +228,6 @@ struct JsonCursor {
 
     // serde's IgnoredAny: any well-formed value
     bool skip_value(int depth = 0) {
-        if (depth > 127) return fail("recursion limit exceeded");
         ws();
         if (p >= end) return fail("expected a value");
         const char c = *p;
@@ -236,6 +235,8 @@ struct JsonCursor {
             std::string tmp;
             return string(tmp);
         }
+        // serde_json: 128 levels; entering the 128th container is the error
+        if ((c == '{' || c == '[') && depth + 1 >= 128) return fail("recursion limit exceeded");
         if (c == '{') {
             ++p;
             if (consume('}')) return true;
