@@ -13,6 +13,7 @@ use anyhow::{anyhow, Result};
 
 #[repr(C)] pub struct ipcfp_ctx_t { _p: [u8; 0] }
 #[repr(C)] pub struct ipcfp_witness_t { _p: [u8; 0] }
+#[repr(C)] pub struct ipcfp_bundle_t { _p: [u8; 0] }
 
 #[repr(C)]
 pub struct ipcfp_event_proof_t {
@@ -75,6 +76,14 @@ extern "C" {
                                          actor_ids: *const u64, slots32: *const u8, n: u64, out: *mut ipcfp_generated_storage_t,
                                          witness_block_ids: *mut u32, witness_cids40: *mut u8, cap_blocks: u64,
                                          n_blocks: *mut u64) -> c_int;
+    pub fn ipcfp_bundle_parse_json(ctx: *mut ipcfp_ctx_t, json: *const c_char, len: u64, flags: u32,
+                                   out: *mut *mut ipcfp_bundle_t) -> c_int;
+    pub fn ipcfp_bundle_destroy(b: *mut ipcfp_bundle_t);
+    pub fn ipcfp_bundle_event_count(b: *const ipcfp_bundle_t) -> u64;
+    pub fn ipcfp_bundle_storage_count(b: *const ipcfp_bundle_t) -> u64;
+    pub fn ipcfp_verify_proof_bundle(ctx: *mut ipcfp_ctx_t, b: *mut ipcfp_bundle_t, trust: *const ipcfp_trust_policy_t,
+                                     filter: *const ipcfp_event_filter_t, storage_status: *mut u8,
+                                     event_status: *mut u8) -> c_int;
     // … the remaining primitives (ipcfp_amt_get, ipcfp_hamt_get, ipcfp_scan_events, ipcfp_exec_order,
     //   ipcfp_*_batch, ipcfp_verify_event_claims_device, profiling) bind the same way.
 }
@@ -110,6 +119,25 @@ impl Engine {
                                                cids.as_ptr(), blocks.len() as u64, &mut w) };
         if rc != 0 { return Err(anyhow!("ipcfp_witness_create: {rc}")); }
         Ok(Witness { eng: self, w })
+    }
+}
+impl Engine {
+    /// `serde_json::from_str::<UnifiedProofBundle>(text)` + `verify_proof_bundle(&bundle, policy, filter)`
+    /// (src/proofs/verifier.rs:12-62) without materialising the blocks on the host: the base64 of every
+    /// `ProofBlock.data` is decoded on the device straight into the witness arena.
+    pub fn verify_proof_bundle_json(&self, text: &str, trust: &ipcfp_trust_policy_t,
+                                    filter: Option<&ipcfp_event_filter_t>) -> Result<(Vec<bool>, Vec<bool>)> {
+        let mut b = std::ptr::null_mut();
+        let rc = unsafe { ipcfp_bundle_parse_json(self.ctx, text.as_ptr() as *const c_char, text.len() as u64, 0, &mut b) };
+        if rc != 0 { return Err(anyhow!("bundle JSON: {rc}")); }
+        let (ns, ne) = unsafe { (ipcfp_bundle_storage_count(b) as usize, ipcfp_bundle_event_count(b) as usize) };
+        let (mut ss, mut es) = (vec![0u8; ns.max(1)], vec![0u8; ne.max(1)]);
+        let rc = unsafe { ipcfp_verify_proof_bundle(self.ctx, b, trust, filter.map_or(std::ptr::null(), |f| f as *const _),
+                                                    ss.as_mut_ptr(), es.as_mut_ptr()) };
+        unsafe { ipcfp_bundle_destroy(b) };
+        if rc != 0 { return Err(anyhow!("ipcfp_verify_proof_bundle: {rc}")); }
+        // storage proofs are checked first and the first Err aborts (verifier.rs:19-28)
+        Ok((statuses_to_result(&ss[..ns])?, statuses_to_result(&es[..ne])?))
     }
 }
 impl Drop for Engine { fn drop(&mut self) { unsafe { ipcfp_ctx_destroy(self.ctx) } } }

@@ -153,47 +153,57 @@ bool parse_storage(JsonCursor& js, RawStorage& s) {
     return ok && f.complete(0xff, "StorageProof");
 }
 
+struct CidSpan {  // CidSpan of kernels/base64.hip: the body of the `[…]` byte array
+    uint64_t src;
+    uint32_t len;
+    uint32_t pad;
+};
+
 struct RawBlocks {
-    std::vector<uint8_t> cids;  // 40-byte slots
+    std::vector<CidSpan> cid_spans;
     std::vector<Span> spans;
     std::vector<uint64_t> dst_off;
     std::vector<uint32_t> len;
     uint64_t arena_bytes = 0, units = 0, payload = 0;
-    bool too_long_cid = false;
     std::string extra;  // unescaped data strings, addressed as if appended to the JSON text
 };
 
-// Cid as serde_json sees it: [b0, b1, …] (u8 each); optionally a multibase string
-bool parse_cid(JsonCursor& js, uint32_t flags, std::vector<uint8_t>& out) {
-    out.clear();
+// Cid as serde_json sees it: [b0, b1, …] (u8 each).  The host only LOCATES the array body — it cannot
+// contain a ']' unless it is malformed — and the device parses and validates the numbers
+// (k_parse_cid_arrays).  Optionally a multibase string, rewritten to the array form behind the text.
+bool locate_cid(JsonCursor& js, uint32_t flags, RawBlocks& b, CidSpan& sp) {
     if (js.peek('"')) {
         std::string s;
         if (!js.string(s)) return false;
         if (!(flags & IPCFP_BUNDLE_CID_STRINGS)) return js.fail("invalid type: string, expected a CID as bytes");
-        if (!cid_from_string(s.c_str(), out)) return js.fail("invalid CID string");
+        std::vector<uint8_t> bin;
+        if (!cid_from_string(s.c_str(), bin)) return js.fail("invalid CID string");
+        std::string body;
+        for (size_t i = 0; i < bin.size(); ++i) body += (i ? "," : "") + std::to_string(unsigned(bin[i]));
+        sp.src = uint64_t(js.end - js.begin) + b.extra.size();
+        sp.len = uint32_t(body.size());
+        b.extra += body;
         return true;
     }
-    const bool ok = parse_array(js, [&] {
-        uint64_t v;
-        if (!js.u64(v)) return false;
-        if (v > 255) return js.fail("invalid value: CID byte out of range");
-        out.push_back(uint8_t(v));
-        return true;
-    });
-    if (!ok) return false;
-    if (!cid_binary_ok(out.data(), out.size())) return js.fail("invalid CID bytes");
+    if (!js.expect('[', "invalid type: expected a CID as a byte sequence")) return false;
+    const char* close = static_cast<const char*>(std::memchr(js.p, ']', size_t(js.end - js.p)));
+    if (!close) return js.fail("unterminated array");
+    if (size_t(close - js.p) > 4096) return js.fail("invalid CID bytes");  // 104 bytes need < 1 KiB of text
+    sp.src = uint64_t(js.p - js.begin);
+    sp.len = uint32_t(close - js.p);
+    js.p = close + 1;
     return true;
 }
 
 bool parse_block(JsonCursor& js, uint32_t flags, RawBlocks& b) {
     Fields f(js);
-    std::vector<uint8_t> cid;
+    CidSpan cs{0, 0, 0};
     const char* ds = nullptr;
     size_t dn = 0;
     bool plain = true;
     std::string unescaped;
     const bool ok = parse_object(js, 3, [&](const std::string& k) -> int {
-        if (k == "cid") return f.first(0, "cid") && parse_cid(js, flags, cid) ? 1 : -1;
+        if (k == "cid") return f.first(0, "cid") && locate_cid(js, flags, b, cs) ? 1 : -1;
         if (k == "data") {
             if (!f.first(1, "data")) return -1;
             if (!js.string_span(ds, dn, plain)) return -1;
@@ -209,19 +219,13 @@ bool parse_block(JsonCursor& js, uint32_t flags, RawBlocks& b) {
         return 0;
     });
     if (!ok || !f.complete(3, "ProofBlock")) return false;
-    if (cid.size() > IPCFP_CID_SLOT) {
-        b.too_long_cid = true;
-        return js.fail("CID longer than 40 bytes");
-    }
     // base64 0.21 STANDARD: canonical padding ⇒ a multiple of 4 characters
     if (dn & 3u) return js.fail("base64: invalid length / padding");
     if (dn >= 0xfffffff0ull) return js.fail("block too large");
     uint32_t pads = 0;
     if (dn && ds[dn - 1] == '=') pads = (ds[dn - 2] == '=') ? 2 : 1;
     const uint32_t dec = uint32_t(dn / 4 * 3) - pads;
-    const size_t at = b.cids.size();
-    b.cids.resize(at + IPCFP_CID_SLOT, 0);
-    std::memcpy(b.cids.data() + at, cid.data(), cid.size());
+    b.cid_spans.push_back(cs);
     Span sp;
     if (plain) sp.src = uint64_t(ds - js.begin);
     else {
@@ -276,7 +280,7 @@ int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, ui
     ok = ok && f.complete(7, "UnifiedProofBundle");
     if (ok && !js.at_end()) ok = js.fail("trailing characters");
     if (!ok)
-        return set_error(ctx, blocks.too_long_cid ? IPCFP_E_UNSUPPORTED : IPCFP_E_PARSE, "bundle JSON: %s", js.err.c_str());
+        return set_error(ctx, IPCFP_E_PARSE, "bundle JSON: %s", js.err.c_str());
     const uint64_t n = blocks.spans.size();
     if (n >= 0xffffffffull) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
 
@@ -290,37 +294,49 @@ int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, ui
     {
         DevBuf<uint8_t> text_d, arena_d, cids_d;
         DevBuf<Span> spans_d;
+        DevBuf<CidSpan> cspans_d;
         DevBuf<uint64_t> off_d;
         DevBuf<uint32_t> len_d;
         DevBuf<unsigned long long> bad_d;
         const uint64_t xlen = blocks.extra.size();
         IPCFP_HIP(ctx, text_d.alloc(len + xlen + 32));
         IPCFP_HIP(ctx, arena_d.alloc(blocks.arena_bytes + 256));
-        IPCFP_HIP(ctx, cids_d.alloc(blocks.cids.size()));
+        IPCFP_HIP(ctx, cids_d.alloc(n * IPCFP_CID_SLOT));
+        IPCFP_HIP(ctx, cspans_d.alloc(n));
         IPCFP_HIP(ctx, spans_d.alloc(n));
         IPCFP_HIP(ctx, off_d.alloc(n));
         IPCFP_HIP(ctx, len_d.alloc(n));
-        IPCFP_HIP(ctx, bad_d.alloc(1));
-        const unsigned long long none = ~0ULL;
-        IPCFP_HIP(ctx, hipMemcpyAsync(bad_d.p, &none, 8, hipMemcpyHostToDevice, ctx->stream));
+        IPCFP_HIP(ctx, bad_d.alloc(2));
+        const unsigned long long none = ~0ULL, none2[2] = {none, none};
+        IPCFP_HIP(ctx, hipMemcpyAsync(bad_d.p, none2, 16, hipMemcpyHostToDevice, ctx->stream));
         if (n) {
             IPCFP_HIP(ctx, hipMemcpyAsync(text_d.p, json, len, hipMemcpyHostToDevice, ctx->stream));
             if (xlen)
                 IPCFP_HIP(ctx, hipMemcpyAsync(text_d.p + len, blocks.extra.data(), xlen, hipMemcpyHostToDevice, ctx->stream));
             IPCFP_HIP(ctx, hipMemsetAsync(text_d.p + len + xlen, 0, 32, ctx->stream));
             IPCFP_HIP(ctx, hipMemsetAsync(arena_d.p, 0, blocks.arena_bytes + 256, ctx->stream));
-            IPCFP_HIP(ctx, hipMemcpyAsync(cids_d.p, blocks.cids.data(), blocks.cids.size(), hipMemcpyHostToDevice, ctx->stream));
+            IPCFP_HIP(ctx, hipMemcpyAsync(cspans_d.p, blocks.cid_spans.data(), n * sizeof(CidSpan), hipMemcpyHostToDevice, ctx->stream));
             IPCFP_HIP(ctx, hipMemcpyAsync(spans_d.p, blocks.spans.data(), n * sizeof(Span), hipMemcpyHostToDevice, ctx->stream));
             IPCFP_HIP(ctx, hipMemcpyAsync(off_d.p, blocks.dst_off.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
             IPCFP_HIP(ctx, hipMemcpyAsync(len_d.p, blocks.len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
             int rc = launch_base64_decode(ctx, text_d.p, spans_d.p, uint32_t(n), uint32_t(blocks.units), off_d.p, arena_d.p,
                                           bad_d.p);
             if (rc) return rc;
+            rc = launch_parse_cid_arrays(ctx, text_d.p, cspans_d.p, uint32_t(n), cids_d.p, bad_d.p + 1);
+            if (rc) return rc;
         }
-        unsigned long long bad = none;
-        IPCFP_HIP(ctx, hipMemcpyAsync(&bad, bad_d.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long bad[2] = {none, none};
+        IPCFP_HIP(ctx, hipMemcpyAsync(bad, bad_d.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (bad != none) return set_error(ctx, IPCFP_E_PARSE, "bundle JSON: blocks[%llu].data is not valid base64", bad);
+        // serde reads `cid` and `data` in text order, block by block: report the earlier block
+        const unsigned long long b64_blk = bad[0], cid_blk = bad[1] == none ? none : bad[1] >> 2;
+        if (cid_blk != none && cid_blk <= b64_blk) {
+            if ((bad[1] & 3) == 2)
+                return set_error(ctx, IPCFP_E_UNSUPPORTED, "bundle JSON: blocks[%llu].cid is longer than 40 bytes", cid_blk);
+            return set_error(ctx, IPCFP_E_PARSE, "bundle JSON: blocks[%llu].cid is not a CID byte array", cid_blk);
+        }
+        if (b64_blk != none)
+            return set_error(ctx, IPCFP_E_PARSE, "bundle JSON: blocks[%llu].data is not valid base64", b64_blk);
         int rc = ipcfp_witness_create_device(ctx, arena_d.p, blocks.arena_bytes, off_d.p, len_d.p, cids_d.p, n, &b->witness);
         if (rc) return rc;
         IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -79,6 +79,9 @@ int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receip
 int launch_base64_decode(ipcfp_ctx* ctx, const uint8_t* text_d, const void* spans_d, uint32_t n_blocks, uint32_t n_units,
                          const uint64_t* dst_off_d, uint8_t* arena_d, unsigned long long* first_bad_d);
 
+int launch_parse_cid_arrays(ipcfp_ctx* ctx, const uint8_t* text_d, const void* spans_d, uint32_t n, uint8_t* cids_d,
+                            unsigned long long* first_bad_d);
+
 // --- generate.hip ---
 int launch_generate_storage(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& child, const void* specs_d, uint32_t n,
                             void* out_d);
