@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../common.h"
 
@@ -141,10 +142,34 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
     // K1 may run on a second stream (IPCFP_K1_STREAM=1).  Measured on the 1M-receipt tipset it does NOT
     // pay: the VALU-bound hash kernel takes CUs from the latency-bound walk kernels, whose host-visible
     // chain of levels then runs slower (step 4.95 → 5.59 ms), so the default is one stream.
+    // IPCFP_K1_STREAM=2: the second stream is confined to a share of the CUs (IPCFP_K1_CU_PERCENT, default 75;
+    // the mask sets bits in an even pattern so every shader engine / XCD keeps free CUs), so the walk
+    // kernels' chain of small launches always finds idle CUs while K1 grinds beside it.
     ctx->stream_k1 = ctx->stream;
-    if (const char* e = std::getenv("IPCFP_K1_STREAM"))
-        if (std::atoi(e) == 1 && hipStreamCreateWithFlags(&ctx->stream_k1, hipStreamNonBlocking) != hipSuccess)
+    if (const char* e = std::getenv("IPCFP_K1_STREAM")) {
+        const int mode = std::atoi(e);
+        if (mode == 1 && hipStreamCreateWithFlags(&ctx->stream_k1, hipStreamNonBlocking) != hipSuccess)
             ctx->stream_k1 = ctx->stream;
+        if (mode == 2) {
+            int pct = 75;
+            if (const char* f = std::getenv("IPCFP_K1_CU_PERCENT")) pct = std::atoi(f);
+            if (pct < 10) pct = 10;
+            if (pct > 100) pct = 100;
+            const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+            std::vector<uint32_t> mask(size_t((cus + 31) / 32), 0u);
+            // Bresenham spread of pct% ones over the CU bits
+            int acc = 0;
+            for (int i = 0; i < cus; ++i) {
+                acc += pct;
+                if (acc >= 100) {
+                    acc -= 100;
+                    mask[size_t(i) >> 5] |= 1u << (i & 31);
+                }
+            }
+            if (hipExtStreamCreateWithCUMask(&ctx->stream_k1, uint32_t(mask.size()), mask.data()) != hipSuccess)
+                ctx->stream_k1 = ctx->stream;
+        }
+    }
     if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = std::atoi(e) == 1 ? 1 : 0;
     if (const char* e = std::getenv("IPCFP_B2B_WG")) {
         const int wg = std::atoi(e);
@@ -184,7 +209,8 @@ int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
 int ipcfp_ctx_device_info(ipcfp_ctx_t* ctx, char name[64], int* cu_count, uint64_t* hbm_bytes) {
     if (!ctx) return IPCFP_E_INVALID;
     if (name) {
-        std::strncpy(name, ctx->props.name, 63);
+        // the marketing name comes from libdrm's amdgpu.ids, which a minimal image may lack
+        std::strncpy(name, ctx->props.name[0] ? ctx->props.name : ctx->props.gcnArchName, 63);
         name[63] = 0;
     }
     if (cu_count) *cu_count = ctx->props.multiProcessorCount;

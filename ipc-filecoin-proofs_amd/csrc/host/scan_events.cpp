@@ -36,7 +36,9 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     const uint32_t n = uint32_t(en->n);
     // receipt indices are ascending: the last leaf gives the size of the per-index byte map
     uint64_t n_idx = 0;
-    if (n) {
+    if (n && en->dense) {
+        n_idx = n;  // leaf i has index i
+    } else if (n) {
         LeafRef last;
         IPCFP_HIP(ctx, hipMemcpyAsync(&last, leaves + (n - 1), sizeof last, hipMemcpyDeviceToHost, ctx->stream));
         IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -65,6 +65,7 @@ struct AmtEnumResult {
     DevBuf<LeafRef> leaves;
     uint64_t n_leaves = 0;
     uint64_t error = kNoEnumError;  // packed first error (after the final sync)
+    bool dense = false;             // every AMT held exactly the indices 0..count-1 (the fast path succeeded)
 };
 
 // Enumerate `n_roots` AMTs (device array `roots_d`) whose values have type `vkind`.

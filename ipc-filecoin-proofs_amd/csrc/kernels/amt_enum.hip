@@ -191,6 +191,156 @@ __global__ __launch_bounds__(256) void k_enum_emit(WitnessView w, const EnumNode
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense fast path.  fvm_ipld_amt writes message lists, receipts and events with indices 0..count-1, so
+// the whole shape of the tree follows from the root's (height, bit width, count): node p of a level has
+// min(W, remaining) entries with the low bits of its bitmap set, and child q of a level hangs off parent
+// q / W at slot q % W.  With the shape known there is nothing to count or prefix-sum: ONE kernel per
+// level (the first child's lane validates the parent completely, every lane resolves its own link) and
+// ONE leaf kernel that validates and emits.  Anything that is not exactly that shape — a sparse node, a
+// lying count, a missing block, a decode error — raises `anomaly` and the caller redoes the walk with
+// the general level-synchronous path, which also knows how to order errors.
+// ---------------------------------------------------------------------------------------------
+struct DenseRoot {
+    uint32_t height, bit_width;
+    uint64_t count;
+};
+
+__host__ __device__ inline uint64_t dense_nodes(const DenseRoot& r, uint32_t level) {
+    if (r.height < level) return 1;  // rides along until its own level
+    const uint64_t shift = uint64_t(r.bit_width) * (level + 1);
+    if (shift >= 64) return 1;
+    const uint64_t n = (r.count + (1ULL << shift) - 1) >> shift;
+    return n ? n : 1;
+}
+
+__device__ __forceinline__ bool bmap_is_low(const AmtNode& nd, uint32_t m) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t lo = uint32_t(k) * 32u;
+        const uint32_t want = m >= lo + 32 ? 0xffffffffu : (m > lo ? (1u << (m - lo)) - 1u : 0u);
+        ok = ok && nd.bmap[k] == want;
+    }
+    return ok;
+}
+
+// frontier entering `level` (≥ 1) → frontier entering level-1; one lane per child
+__global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNode* __restrict__ cur,
+                                                     const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t level,
+                                                     uint32_t n_next, int vkind, EnumNode* __restrict__ next,
+                                                     uint32_t* __restrict__ anomaly) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_next) return;
+    // which root, and where its entries start on both levels
+    uint32_t r = 0, cur_off = 0, next_off = 0;
+    DenseRoot dr = roots[0];
+    uint64_t n_here = dense_nodes(dr, level - 1);
+    while (j >= next_off + n_here) {
+        next_off += uint32_t(n_here);
+        cur_off += uint32_t(dense_nodes(dr, level));
+        dr = roots[++r];
+        n_here = dense_nodes(dr, level - 1);
+    }
+    const uint32_t q = j - next_off;
+    if (dr.height < level) {  // rides along
+        next[j] = cur[cur_off];
+        return;
+    }
+    const uint32_t W = 1u << dr.bit_width;
+    const uint32_t p = q >> dr.bit_width, k = q & (W - 1u);
+    const EnumNode e = cur[cur_off + p];
+    EnumNode c{kNoBlock, 0, 0, e.seq, uint16_t(level - 1), e.bit_width, 0};
+    if (e.block == kNoBlock) {
+        next[j] = c;
+        return;
+    }
+    const uint64_t remaining = n_here - uint64_t(p) * W;
+    const uint32_t m = remaining < W ? uint32_t(remaining) : W;  // links this parent must hold
+    if (k == 0) {
+        AmtNode nd;
+        if (!enum_read_node(w, e, vkind, nd) || nd.nlinks != m || !bmap_is_low(nd, m)) atomicOr(anomaly, 1u);
+    }
+    Rd r2 = open_block(w, e.block);
+    r2.pos = e.node_off;
+    r2.expect_array(3);
+    uint32_t bo, bl;
+    r2.read_bytes(bo, bl);
+    const uint64_t nl = r2.read_array();
+    if (!r2.ok() || nl <= k) {  // the validating lane reports it
+        next[j] = c;
+        return;
+    }
+    for (uint32_t i = 0; i < k; ++i) {
+        uint32_t mt;
+        uint64_t a;
+        r2.head(mt, a);  // tag 42
+        r2.head(mt, a);  // byte-string header
+        r2.pos += uint32_t(a);
+    }
+    CidKey key;
+    r2.read_link_key(key);
+    c.base = e.base + uint64_t(k) * amt_span(e.bit_width, level);
+    const uint32_t b = r2.ok() ? witness_find(w, key) : kNoBlock;
+    if (b == kNoBlock) atomicOr(anomaly, 1u);
+    c.block = b;
+    next[j] = c;
+}
+
+// leaf level: one lane per leaf node validates it in one pass and writes its values' locations
+__global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumNode* __restrict__ cur,
+                                                      const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t n_nodes,
+                                                      int vkind, LeafRef* __restrict__ leaves, uint32_t* __restrict__ anomaly) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_nodes) return;
+    uint32_t r = 0, node_off0 = 0;
+    uint64_t leaf_off = 0;
+    DenseRoot dr = roots[0];
+    uint64_t n_here = dense_nodes(dr, 0);
+    while (t >= node_off0 + n_here) {
+        node_off0 += uint32_t(n_here);
+        leaf_off += dr.count;
+        dr = roots[++r];
+        n_here = dense_nodes(dr, 0);
+    }
+    const uint32_t p = t - node_off0;
+    const EnumNode e = cur[t];
+    if (e.block == kNoBlock) return;  // reported where the link failed to resolve
+    const uint32_t W = 1u << dr.bit_width;
+    const uint64_t remaining = dr.count - uint64_t(p) * W;
+    const uint32_t m = remaining < W ? uint32_t(remaining) : W;
+    Rd rd = open_block(w, e.block);
+    rd.pos = e.node_off;
+    rd.expect_array(3);
+    uint32_t bo, bl;
+    rd.read_bytes(bo, bl);
+    bool ok = rd.ok() && bl == (W + 7) / 8;
+    if (ok) {  // bitmap = the low m bits (bits at or above the width do not count when W < 8)
+        for (uint32_t i = 0; i < bl; ++i) {
+            const uint32_t lo = i * 8u;
+            uint32_t want = m >= lo + 8 ? 0xffu : (m > lo ? (1u << (m - lo)) - 1u : 0u);
+            uint32_t have = rd.at(bo + i);
+            if (W < 8) have &= (1u << W) - 1u;
+            ok = ok && have == want;
+        }
+    }
+    ok = ok && rd.read_array() == 0;  // a leaf holds no links
+    const uint64_t nv = rd.read_array();
+    ok = ok && rd.ok() && nv == m;
+    LeafRef* out = leaves + leaf_off + uint64_t(p) * W;
+    for (uint32_t i = 0; ok && i < m; ++i) {
+        const uint32_t start = rd.pos;
+        check_value(rd, vkind);
+        ok = rd.ok();
+        out[i] = LeafRef{e.block, start, rd.pos - start, e.seq, e.base + i};
+    }
+    if (ok && e.node_off == 0) {
+        rd.finish();
+        ok = rd.ok();
+    }
+    if (!ok) atomicOr(anomaly, 1u);
+}
+
 __global__ void k_enum_check(const uint64_t* __restrict__ actual, uint64_t expected, uint32_t* __restrict__ mismatch) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && *actual != expected) atomicOr(mismatch, 1u);
 }
@@ -219,6 +369,11 @@ static uint64_t predicted_frontier(const std::vector<uint64_t>& info, uint32_t l
     return total;
 }
 
+static uint64_t amt_span_host(uint32_t bw, uint64_t height) {
+    const uint64_t shift = uint64_t(bw) * height;
+    return shift >= 64 ? ~0ULL : (1ULL << shift);
+}
+
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
                   unsigned long long* err_d, AmtEnumResult& out) {
     out.n_leaves = 0;
@@ -242,6 +397,66 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     IPCFP_HIP(ctx, hipMemcpyAsync(&max_height, small.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, hipMemcpyAsync(root_info.data(), root_info_d.p, root_info.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    // ---- dense fast path: the tree's shape follows from the roots; one kernel per level ----
+    out.dense = false;
+    {
+        std::vector<DenseRoot> dr(n_roots);
+        bool try_dense = true;
+        uint64_t n_leaves = 0;
+        for (uint32_t i = 0; i < n_roots && try_dense; ++i) {
+            if (root_info[2 * size_t(i)] == ~0ULL) try_dense = false;  // a dead root: let the general path sort it out
+            dr[i].height = uint32_t(root_info[2 * size_t(i)]);
+            dr[i].bit_width = uint32_t(root_info[2 * size_t(i)] >> 32);
+            dr[i].count = root_info[2 * size_t(i) + 1];
+            if (dr[i].count == 0 && dr[i].height > 0) try_dense = false;  // empty tree with a tall root
+            if (dr[i].count > amt_span_host(dr[i].bit_width, dr[i].height + 1)) try_dense = false;
+            n_leaves += dr[i].count;
+        }
+        std::vector<uint64_t> n_level(max_height + 1, 0);
+        for (uint32_t level = 0; level <= max_height && try_dense; ++level) {
+            for (uint32_t i = 0; i < n_roots; ++i) n_level[level] += dense_nodes(dr[i], level);
+            try_dense = n_level[level] < 0x7fffffffULL;
+        }
+        try_dense = try_dense && n_leaves < 0x7fffffffULL && n_level[max_height] == n_roots;
+        if (try_dense) {
+            DevBuf<EnumNode> a, b;
+            DevBuf<DenseRoot> dr_d;
+            DevBuf<uint32_t> anomaly;
+            uint64_t biggest = n_roots;
+            for (auto v : n_level) biggest = v > biggest ? v : biggest;
+            IPCFP_HIP(ctx, a.alloc(biggest));
+            IPCFP_HIP(ctx, b.alloc(biggest));
+            IPCFP_HIP(ctx, dr_d.alloc(n_roots));
+            IPCFP_HIP(ctx, anomaly.alloc(1));
+            IPCFP_HIP(ctx, out.leaves.alloc(n_leaves));
+            IPCFP_HIP(ctx, hipMemsetAsync(anomaly.p, 0, 4, ctx->stream));
+            IPCFP_HIP(ctx, hipMemcpyAsync(dr_d.p, dr.data(), size_t(n_roots) * sizeof(DenseRoot), hipMemcpyHostToDevice, ctx->stream));
+            const EnumNode* src = cur.p;
+            for (uint32_t level = max_height; level >= 1; --level) {
+                const uint32_t nn = uint32_t(n_level[level - 1]);
+                hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p, n_roots,
+                                   level, nn, vkind, a.p, anomaly.p);
+                src = a.p;
+                a.swap(b);  // `src` now lives in b; the next level writes a
+            }
+            hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_level[0], 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p,
+                               n_roots, uint32_t(n_level[0]), vkind, out.leaves.p, anomaly.p);
+            uint32_t bad = 0;
+            unsigned long long e = kNoEnumError;  // err_d is untouched here: report what earlier stages left in it
+            IPCFP_HIP(ctx, hipMemcpyAsync(&bad, anomaly.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            IPCFP_HIP(ctx, hipMemcpyAsync(&e, err_d, 8, hipMemcpyDeviceToHost, ctx->stream));
+            IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            IPCFP_HIP(ctx, hipGetLastError());
+            if (!bad) {
+                out.n_leaves = n_leaves;
+                out.error = e;
+                out.dense = true;
+                return IPCFP_OK;
+            }
+            out.leaves.release();
+        }
+    }
 
     // ---- speculative pass: every level launched back to back with PREDICTED sizes, one sync at the end ----
     {
@@ -413,7 +628,7 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     e->n = en.n_leaves;
     e->error = en.error;
     uint32_t not_dense = 0;
-    if (en.n_leaves) {
+    if (en.n_leaves && !en.dense) {
         const uint32_t n = uint32_t(en.n_leaves);
         hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, flag.p);
         IPCFP_HIP(ctx, hipMemcpyAsync(&not_dense, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
