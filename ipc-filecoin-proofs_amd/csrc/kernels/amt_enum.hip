@@ -214,17 +214,6 @@ __host__ __device__ inline uint64_t dense_nodes(const DenseRoot& r, uint32_t lev
     return n ? n : 1;
 }
 
-__device__ __forceinline__ bool bmap_is_low(const AmtNode& nd, uint32_t m) {
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t lo = uint32_t(k) * 32u;
-        const uint32_t want = m >= lo + 32 ? 0xffffffffu : (m > lo ? (1u << (m - lo)) - 1u : 0u);
-        ok = ok && nd.bmap[k] == want;
-    }
-    return ok;
-}
-
 // frontier entering `level` (≥ 1) → frontier entering level-1; one lane per child
 __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNode* __restrict__ cur,
                                                      const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t level,
@@ -259,7 +248,7 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
     const uint32_t m = remaining < W ? uint32_t(remaining) : W;  // links this parent must hold
     if (k == 0) {
         AmtNode nd;
-        if (!enum_read_node(w, e, vkind, nd) || nd.nlinks != m || !bmap_is_low(nd, m)) atomicOr(anomaly, 1u);
+        if (!enum_read_node(w, e, vkind, nd) || nd.nlinks != m || !nd.is_low(m)) atomicOr(anomaly, 1u);
     }
     Rd r2 = open_block(w, e.block);
     r2.pos = e.node_off;

@@ -131,10 +131,24 @@ struct Rd {
         uint64_t diff = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            uint64_t e = 0;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) e |= uint64_t(q[8 * w + b]) << (8 * b);
+            uint64_t e;
+            __builtin_memcpy(&e, q + 8 * w, 8);  // one unaligned 8-byte load (gfx950 runs in unaligned-access mode)
             diff |= peek64(off + 8u * w) ^ e;
+        }
+        return diff == 0;
+    }
+    // n bytes at `off` equal to q[0..n)?  (q: any alignment)
+    __device__ __forceinline__ bool equal_bytes(uint32_t off, const uint8_t* q, uint32_t n) {
+        uint64_t diff = 0;
+        for (uint32_t i = 0; i < n; i += 8) {
+            const uint32_t valid = n - i;
+            uint64_t e = 0;
+            if (valid >= 8) __builtin_memcpy(&e, q + i, 8);  // one unaligned 8-byte load
+            else
+                for (uint32_t k = 0; k < valid; ++k) e |= uint64_t(q[i + k]) << (8u * k);  // never read past q + n
+            uint64_t d = peek64(off + i) ^ e;
+            if (valid < 8) d &= (1ull << (8u * valid)) - 1ull;
+            diff |= d;
         }
         return diff == 0;
     }

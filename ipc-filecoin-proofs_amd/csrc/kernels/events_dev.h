@@ -23,7 +23,12 @@ struct EvmLogLoc {
     uint32_t n_topics;
     uint32_t topic_off[4];  // Case B: offsets of t1..t4 values; Case A: topic_off[0] = start of the concatenation
     ByteRange data;
-    __device__ __forceinline__ uint32_t topic_at(uint32_t i) const { return case_a ? topic_off[0] + 32u * i : topic_off[i]; }
+    __device__ __forceinline__ uint32_t topic_at(uint32_t i) const {
+        // masks, not topic_off[i]: a dynamically indexed member would push the struct to scratch
+        const uint32_t o = (topic_off[0] & (i == 0 ? ~0u : 0u)) | (topic_off[1] & (i == 1 ? ~0u : 0u)) |
+                           (topic_off[2] & (i == 2 ? ~0u : 0u)) | (topic_off[3] & (i == 3 ? ~0u : 0u));
+        return case_a ? topic_off[0] + 32u * i : o;
+    }
 };
 
 // Decode one StampedEvent `[emitter, [[flags, key, codec, value]…]]` located at r (already

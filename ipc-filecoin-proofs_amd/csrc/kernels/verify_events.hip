@@ -284,7 +284,8 @@ __device__ __forceinline__ bool ev_trusted(const ipcfp_trust_policy_t& t, long l
 
 __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const EventClaimPacked& c,
                                                      const TipsetCtxDev& tc, const uint8_t* __restrict__ blob,
-                                                     const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter) {
+                                                     const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t& filter,
+                                                     bool has_filter) {
     // Step 1: verify_trust_anchors (events/verifier.rs:124-144)
     if (!(tc.flags & TC_PARENTS_PARSED) || !(tc.flags & TC_CHILD_PARSED)) return IPCFP_ST_ERR_BAD_CLAIM;  // :130-131
     if (!ev_trusted(trust, c.parent_epoch)) return IPCFP_ST_FALSE_UNTRUSTED_PARENT;                          // :134
@@ -347,9 +348,8 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
         if (!er.equal32(log.topic_at(i), claimed + 1)) return IPCFP_ST_FALSE_TOPIC;
     }
     if (!(c.flags & EC_DATA_MATCHABLE) || c.data_len != log.data.len) return IPCFP_ST_FALSE_DATA;             // :284-287
-    for (uint32_t i = 0; i < c.data_len; ++i)
-        if (blob[c.data_off + i] != er.at(log.data.off + i)) return IPCFP_ST_FALSE_DATA;
-    if (filter && !log_matches(er, log, *filter)) return IPCFP_ST_FALSE_FILTER;                               // :247-251
+    if (!er.equal_bytes(log.data.off, blob + c.data_off, c.data_len)) return IPCFP_ST_FALSE_DATA;
+    if (has_filter && !log_matches(er, log, filter)) return IPCFP_ST_FALSE_FILTER;                             // :247-251
     return IPCFP_ST_TRUE;
 }
 
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(Witness
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const EventClaimPacked& c = claims[t];
-    status[t] = uint8_t(verify_event_one(w, c, ctxs[c.context], blob, trust, has_filter ? &filter : nullptr));
+    status[t] = uint8_t(verify_event_one(w, c, ctxs[c.context], blob, trust, filter, has_filter != 0));
 }
 
 // ------------------------------ launchers -----------------------------------

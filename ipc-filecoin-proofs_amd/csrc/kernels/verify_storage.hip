@@ -8,6 +8,8 @@
 // which line decided.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../common.h"
 #include "claims_dev.h"
 #include "launch.h"
@@ -58,9 +60,13 @@ __device__ __forceinline__ uint32_t verify_storage_one(const WitnessView& w, con
     return eq ? IPCFP_ST_TRUE : IPCFP_ST_FALSE_VALUE;                             // :169
 }
 
-__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_storage(WitnessView w, const StorageClaimPacked* __restrict__ claims,
-                                                        uint32_t n, ipcfp_trust_policy_t trust,
-                                                        uint8_t* __restrict__ status) {
+// WAVES = wavefronts per SIMD the register allocator must leave room for.  verify_storage_one inlines six
+// layout attempts, each a Keccak + SHA-256 + HAMT walk: at 4 waves (128 VGPRs) it spills 384 bytes per
+// lane to scratch, at 3 waves (168 VGPRs) it does not.  IPCFP_STORAGE_WAVES selects (default: see launch).
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_verify_storage(WitnessView w, const StorageClaimPacked* __restrict__ claims,
+                                                               uint32_t n, ipcfp_trust_policy_t trust,
+                                                               uint8_t* __restrict__ status) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     status[t] = uint8_t(verify_storage_one(w, claims[t], trust));
@@ -71,8 +77,15 @@ int launch_verify_storage(ipcfp_ctx* ctx, const WitnessView& w, const StorageCla
     if (n == 0) return IPCFP_OK;
     {
         ProfileScope prof(ctx, IPCFP_K_STORAGE_VERIFY);
-        hipLaunchKernelGGL(k_verify_storage, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, claims_d, n, trust,
-                           status_d);
+        static const int waves = [] {
+            const char* e = std::getenv("IPCFP_STORAGE_WAVES");
+            const int v = e ? std::atoi(e) : 4;
+            return v >= 2 && v <= 4 ? v : 4;
+        }();
+        const dim3 g(div_up(n, 256)), blk(256);
+        if (waves == 2) hipLaunchKernelGGL(k_verify_storage<2>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d);
+        else if (waves == 3) hipLaunchKernelGGL(k_verify_storage<3>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d);
+        else hipLaunchKernelGGL(k_verify_storage<4>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

@@ -45,27 +45,44 @@ constexpr uint32_t kAmtMaxBitWidth = 8;
 
 struct AmtNode {
     uint32_t width;       // 1 << bit_width
-    uint32_t bmap[8];     // up to 256 bits, bit i ⇔ bmap[i/32] >> (i%32)  (LSB-first bytes ⇒ same bit order)
+    // up to 256 bits as four words, bit i ⇔ b[i/64] >> (i%64) (LSB-first bytes ⇒ same bit order).  Always
+    // accessed with compile-time word indices (select chains): a dynamically indexed array would live
+    // in scratch memory, and every walk kernel carries one of these per lane.
+    uint64_t b[4];
     uint32_t nlinks, nvalues;
     // position bookkeeping for the entry the caller asked for
     uint32_t want;        // ordinal (rank) of the wanted link/value, or ~0u
     uint32_t want_off, want_len;  // value: item offset/len; link: CID bytes offset/len
-    __device__ __forceinline__ bool bit(uint32_t i) const { return (bmap[i >> 5] >> (i & 31)) & 1u; }
+    __device__ __forceinline__ uint64_t word(uint32_t k) const {
+        // masks, not selects: LLVM folds a select of loads into a load from a selected ADDRESS, which is
+        // exactly the dynamic index this is here to avoid
+        return (b[0] & (k == 0 ? ~0ull : 0ull)) | (b[1] & (k == 1 ? ~0ull : 0ull)) | (b[2] & (k == 2 ? ~0ull : 0ull)) |
+               (b[3] & (k == 3 ? ~0ull : 0ull));
+    }
+    __device__ __forceinline__ bool bit(uint32_t i) const { return (word(i >> 6) >> (i & 63)) & 1ull; }
     __device__ __forceinline__ uint32_t rank(uint32_t i) const {
         uint32_t r = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t lo = uint32_t(k) * 32u;
-            if (i >= lo + 32) r += __popc(bmap[k]);
-            else if (i > lo) r += __popc(bmap[k] & ((1u << (i - lo)) - 1u));
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = uint32_t(k) * 64u;
+            if (i >= lo + 64) r += __popcll(b[k]);
+            else if (i > lo) r += __popcll(b[k] & ((1ull << (i - lo)) - 1ull));
         }
         return r;
     }
     __device__ __forceinline__ uint32_t popcount() const {
-        uint32_t r = 0;
+        return __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
+    }
+    // the low m bits set and nothing else (m ≤ 256)
+    __device__ __forceinline__ bool is_low(uint32_t m) const {
+        bool ok = true;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r += __popc(bmap[k]);
-        return r;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = uint32_t(k) * 64u;
+            const uint64_t want = m >= lo + 64 ? ~0ull : (m > lo ? (1ull << (m - lo)) - 1ull : 0ull);
+            ok = ok && b[k] == want;
+        }
+        return ok;
     }
 };
 
@@ -77,8 +94,6 @@ __device__ __forceinline__ void amt_read_node(Rd& r, uint32_t bw, int vkind, uin
     nd.nlinks = nd.nvalues = 0;
     nd.want = ~0u;
     nd.want_off = nd.want_len = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) nd.bmap[k] = 0;
     r.expect_array(3);
     uint32_t bo, bl;
     r.read_bytes(bo, bl);
@@ -87,8 +102,18 @@ __device__ __forceinline__ void amt_read_node(Rd& r, uint32_t bw, int vkind, uin
     const bool bmap_len_ok = bl == need;
     // keep the bits we can hold; a wrong length is an error AFTER links/values decode (order is
     // irrelevant: every failure here is ERR_DECODE)
-    for (uint32_t k = 0; k < bl && k < 32; ++k) nd.bmap[k >> 2] |= r.at(bo + k) << (8 * (k & 3));
-    if (nd.width < 32) nd.bmap[0] &= (1u << nd.width) - 1u;  // bits ≥ width are ignored (bw < 3)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = 8u * uint32_t(k);
+        uint64_t v = 0;
+        if (bl > lo) {  // unaligned 8-byte fetch, bytes past the string masked off
+            v = r.peek64(bo + lo);
+            const uint32_t valid = bl - lo;
+            if (valid < 8) v &= (1ull << (8u * valid)) - 1ull;
+        }
+        nd.b[k] = v;
+    }
+    if (nd.width < 64) nd.b[0] &= (1ull << nd.width) - 1ull;  // bits ≥ width are ignored (bw < 3)
     if (bmap_len_ok && sub != ~0u && sub < nd.width && nd.bit(sub)) nd.want = nd.rank(sub);
     const uint64_t nl = r.read_array();
     if (!r.ok()) return;

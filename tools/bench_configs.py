@@ -157,7 +157,11 @@ def cfg45(eng, orc):
 def main():
     eng = ipcfp.Engine(0)
     orc = oracle_lib.load()
-    print(json.dumps(cfg2(eng, orc)), flush=True)
+    only = os.environ.get("IPCFP_CFG_ONLY", "")
+    if only in ("", "2"):
+        print(json.dumps(cfg2(eng, orc)), flush=True)
+    if only == "2":
+        return
     for r in cfg45(eng, orc):
         print(json.dumps(r), flush=True)
     eng.close()
