@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <memory>
+#include <cstring>
 #include <string>
 #include <utility>
 #include <vector>
@@ -52,6 +53,18 @@ struct ipcfp_ctx {
     std::vector<hipEvent_t> free_events;           // recycled events
     uint64_t prof_count[IPCFP_K_COUNT] = {};
     double prof_ms[IPCFP_K_COUNT] = {};
+    // --- small device→host read-backs go through pinned memory (ipcfp::d2h_small / sync_stream): a
+    // hipMemcpyAsync into pageable memory is staged and waited for by the runtime, 20-80 µs apiece, and a
+    // verification step reads back a dozen scalars (level sizes, error words, counts) ---
+    uint8_t* pinned = nullptr;
+    size_t pinned_cap = 0, pinned_used = 0;
+    struct PendingRead {
+        void* dst;
+        size_t off, n;
+        hipStream_t stream;
+    };
+    std::vector<PendingRead> pending;
+    int call_depth = 0;
 };
 
 namespace ipcfp {
@@ -65,6 +78,35 @@ int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...);
             return ::ipcfp::set_error((ctx), IPCFP_E_HIP, "%s failed: %s (%s:%d)", #call,       \
                                       hipGetErrorString(_e), __FILE__, __LINE__);               \
     } while (0)
+
+// Queue an asynchronous read-back of n bytes; `dst` is valid after the next sync_stream on `s`.
+inline hipError_t d2h_small(ipcfp_ctx* ctx, void* dst, const void* src_d, size_t n, hipStream_t s) {
+    const size_t need = (n + 15) & ~size_t(15);
+    if (!ctx->pinned || ctx->pinned_used + need > ctx->pinned_cap) return hipMemcpyAsync(dst, src_d, n, hipMemcpyDeviceToHost, s);
+    const size_t off = ctx->pinned_used;
+    ctx->pinned_used += need;
+    ctx->pending.push_back({dst, off, n, s});
+    return hipMemcpyAsync(ctx->pinned + off, src_d, n, hipMemcpyDeviceToHost, s);
+}
+// hipStreamSynchronize + delivery of the read-backs queued on that stream.  Every synchronisation of an
+// engine stream goes through here.
+inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
+    const hipError_t e = hipStreamSynchronize(s);
+    bool others = false;
+    for (auto& r : ctx->pending) {
+        if (r.stream == s) {
+            if (e == hipSuccess) std::memcpy(r.dst, ctx->pinned + r.off, r.n);
+            r.dst = nullptr;
+        } else if (r.dst) {
+            others = true;
+        }
+    }
+    if (!others) {
+        ctx->pending.clear();
+        ctx->pinned_used = 0;
+    }
+    return e;
+}
 
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfileScope {
@@ -121,8 +163,18 @@ struct DevBuf {
 // the allocation pool DevBufs draw from.
 struct CallScope {
     DevPool* prev;
-    explicit CallScope(ipcfp_ctx* c) : prev(g_tls_pool) { g_tls_pool = &c->pool; }
-    ~CallScope() { g_tls_pool = prev; }
+    ipcfp_ctx* ctx;
+    explicit CallScope(ipcfp_ctx* c) : prev(g_tls_pool), ctx(c) {
+        g_tls_pool = &c->pool;
+        if (c->call_depth++ == 0) {  // read-backs a failed call left behind point at dead stack frames
+            c->pending.clear();
+            c->pinned_used = 0;
+        }
+    }
+    ~CallScope() {
+        g_tls_pool = prev;
+        --ctx->call_depth;
+    }
 };
 #define IPCFP_ENTER(ctx)                                 \
     IPCFP_HIP((ctx), hipSetDevice((ctx)->device));       \

@@ -326,8 +326,8 @@ int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, ui
             if (rc) return rc;
         }
         unsigned long long bad[2] = {none, none};
-        IPCFP_HIP(ctx, hipMemcpyAsync(bad, bad_d.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, d2h_small(ctx, bad, bad_d.p, 16, ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
         // serde reads `cid` and `data` in text order, block by block: report the earlier block
         const unsigned long long b64_blk = bad[0], cid_blk = bad[1] == none ? none : bad[1] >> 2;
         if (cid_blk != none && cid_blk <= b64_blk) {
@@ -339,7 +339,7 @@ int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, ui
             return set_error(ctx, IPCFP_E_PARSE, "bundle JSON: blocks[%llu].data is not valid base64", b64_blk);
         int rc = ipcfp_witness_create_device(ctx, arena_d.p, blocks.arena_bytes, off_d.p, len_d.p, cids_d.p, n, &b->witness);
         if (rc) return rc;
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     }
 
     // ---- claims: the reference's structs, strings owned by the bundle ----

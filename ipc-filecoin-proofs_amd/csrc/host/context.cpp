@@ -175,6 +175,10 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
         const int wg = std::atoi(e);
         if (wg == 64 || wg == 128 || wg == 192 || wg == 256) ctx->b2b_wg = uint32_t(wg);
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 64 * 1024, hipHostMallocDefault) == hipSuccess)
+        ctx->pinned_cap = 64 * 1024;
+    else
+        ctx->pinned = nullptr;  // read-backs fall back to pageable copies
     *out = ctx;
     return IPCFP_OK;
 }
@@ -190,6 +194,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     ctx->pool.drain();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

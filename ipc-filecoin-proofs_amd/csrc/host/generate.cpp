@@ -72,7 +72,7 @@ int materialize(ipcfp_ctx* ctx, ipcfp_witness* w, const uint32_t* touched_d, uin
     const uint32_t words = div_up(uint32_t(w->n), 32);
     std::vector<uint32_t> bits(words);
     IPCFP_HIP(ctx, hipMemcpyAsync(bits.data(), touched_d, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     std::vector<uint32_t> ids;
     for (uint32_t wd = 0; wd < words; ++wd) {
         uint32_t m = bits[wd];
@@ -94,7 +94,7 @@ int materialize(ipcfp_ctx* ctx, ipcfp_witness* w, const uint32_t* touched_d, uin
     if (rc) return rc;
     std::vector<uint8_t> cids(size_t(n) * IPCFP_CID_SLOT);
     IPCFP_HIP(ctx, hipMemcpyAsync(cids.data(), keys_d.p, cids.size(), hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     std::vector<uint32_t> perm(n);
     for (uint32_t i = 0; i < n; ++i) perm[i] = i;
     // a witness may hold the same CID twice (last one wins in the index): only the indexed copy can be
@@ -159,8 +159,8 @@ int ipcfp_generate_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
     IPCFP_HIP(ctx, hipMemcpyAsync(tc_d.p, &tc, sizeof tc, hipMemcpyHostToDevice, ctx->stream));
     int rc = launch_ctx_headers(ctx, rec, tc_d.p, 1);
     if (rc) return rc;
-    IPCFP_HIP(ctx, hipMemcpyAsync(&tc, tc_d.p, sizeof tc, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, &tc, tc_d.p, sizeof tc, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     if (tc.child_status != IPCFP_ST_TRUE) {
         *status_out = ipcfp_status_t(tc.child_status);
         return IPCFP_OK;
@@ -196,7 +196,7 @@ int ipcfp_generate_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
         std::vector<ipcfp_event_match_t> mh(nm);
         IPCFP_HIP(ctx, hipMemcpyAsync(mh.data(), scan.matches.p, nm * sizeof(ipcfp_event_match_t), hipMemcpyDeviceToHost,
                                       ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
         std::vector<uint64_t> idx(nm);
         for (uint64_t i = 0; i < nm; ++i) idx[i] = mh[i].exec_index;
         IPCFP_HIP(ctx, exec_idx.alloc(nm));
@@ -219,8 +219,8 @@ int ipcfp_generate_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
     rc = launch_mark_cids(ctx, rec, base_d.p, uint32_t(base.size()), missing_d);
     if (rc) return rc;
     uint32_t flag[2] = {0, 0};
-    IPCFP_HIP(ctx, hipMemcpyAsync(flag, oor_d, 8, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, flag, oor_d, 8, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     if (flag[0]) {  // "Missing message at index" (generator.rs:158-160) precedes materialisation
         *status_out = IPCFP_ST_ERR;
         return IPCFP_OK;
@@ -265,7 +265,7 @@ int ipcfp_generate_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ui
     int rc = launch_generate_storage(ctx, rec, key_from_slot(child_cid40), specs_d.p, uint32_t(n), out_d.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(out, out_d.p, n * sizeof(StorageGenHost), hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     // the bundle's witness is the union over the proofs that succeeded; a failing spec aborts
     // generate_proof_bundle (src/proofs/generator.rs:42-49), which the caller sees in out[i].status
     return materialize(ctx, w, touched.p, witness_block_ids, witness_cids40, cap_blocks, n_blocks);

@@ -50,7 +50,7 @@ int ipcfp_amt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid4
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, st.p, n, hipMemcpyDeviceToHost, ctx->stream));
     if (loc) IPCFP_HIP(ctx, hipMemcpyAsync(loc, lc.p, n * sizeof(ipcfp_value_loc_t), hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 
@@ -83,7 +83,7 @@ int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, st.p, n, hipMemcpyDeviceToHost, ctx->stream));
     if (loc) IPCFP_HIP(ctx, hipMemcpyAsync(loc, lc.p, n * sizeof(ipcfp_value_loc_t), hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 

@@ -24,7 +24,8 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     DevBuf<unsigned long long> err;
     IPCFP_HIP(ctx, err.alloc(1));
     unsigned long long e0 = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemcpyAsync(err.p, &e0, 8, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(err.p, 0xff, 8, ctx->stream));  // kNoEnumError
+    (void)e0;
     const EnumCached* en = nullptr;
     int rc = amt_enumerate_cached(ctx, w, root, 0, VK_RECEIPT, &en);  // receipts in index order
     if (rc) return rc;
@@ -40,8 +41,8 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         n_idx = n;  // leaf i has index i
     } else if (n) {
         LeafRef last;
-        IPCFP_HIP(ctx, hipMemcpyAsync(&last, leaves + (n - 1), sizeof last, hipMemcpyDeviceToHost, ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, d2h_small(ctx, &last, leaves + (n - 1), sizeof last, ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
         n_idx = last.index + 1;
     }
     DevBuf<uint32_t> counts, offsets;
@@ -58,9 +59,9 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     if (rc) return rc;
     uint64_t nm = 0;
     unsigned long long e1 = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemcpyAsync(&nm, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipMemcpyAsync(&e1, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, &nm, total.p, 8, ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, &e1, err.p, 8, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     if (e1 != kNoEnumError) {
         out.status = enum_error_code(e1);
         return IPCFP_OK;
@@ -71,7 +72,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, counts.p, offsets.p, out.matches.p,
                            out.has.p, n_idx);
     if (rc) return rc;
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // counts/offsets are released on return
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // counts/offsets are released on return
     out.n_idx = n_idx;
     out.n_matches = nm;
     out.status = IPCFP_ST_TRUE;
@@ -113,7 +114,7 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
                                       (res.n_matches < cap_matches ? res.n_matches : cap_matches) * sizeof(ipcfp_event_match_t),
                                       hipMemcpyDeviceToHost, ctx->stream));
     if (touched_bits) IPCFP_HIP(ctx, hipMemcpyAsync(touched_bits, touched.p, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 

@@ -36,9 +36,7 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     AmtEnumResult en;
     rc = amt_enumerate(ctx, view, roots.p, 2 * n_parents, VK_CID, err.p, en);
     if (rc) return rc;
-    unsigned long long e = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemcpyAsync(&e, err.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned long long e = en.error;  // read back by the enumerator: stage-1 errors and its own, merged
     ex.status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
     ex.raw_len = ex.exec_len = 0;
     if (ex.status != IPCFP_ST_TRUE) return IPCFP_OK;
@@ -60,8 +58,8 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     rc = launch_scan_u32(ctx, ex.first.p, n, ex.pos.p, total.p, scratch.p);
     if (rc) return rc;
     uint64_t distinct = 0;
-    IPCFP_HIP(ctx, hipMemcpyAsync(&distinct, total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `en.leaves` alive until the kernels are done
+    IPCFP_HIP(ctx, d2h_small(ctx, &distinct, total.p, 8, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // also keeps `en.leaves` alive until the kernels are done
     ex.exec_len = distinct;
     return IPCFP_OK;
 }
@@ -80,9 +78,8 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
                                   ctx->stream));
     int rc = launch_ctx_headers(ctx, view, tcs_d.p, uint32_t(tcs.size()));
     if (rc) return rc;
-    IPCFP_HIP(ctx, hipMemcpyAsync(tcs.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), hipMemcpyDeviceToHost,
-                                  ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, tcs.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
     for (size_t k = 0; k < tcs.size(); ++k) {
         TipsetCtxDev& tc = tcs[k];
@@ -117,7 +114,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
                                   ctx->stream));
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, blob_d, trust ? *trust : accept_all, filter, status_d);
     if (rc) return rc;
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // contexts / exec tables are released on return
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // contexts / exec tables are released on return
     return IPCFP_OK;
 }
 
@@ -242,7 +239,7 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     int rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, trust, filter, sd.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 
@@ -267,7 +264,7 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
     int rc = verify_packed(ctx, w, tcs, static_cast<const EventClaimPacked*>(claims_d), uint32_t(n),
                            static_cast<const uint8_t*>(blob_d), trust, filter, static_cast<uint8_t*>(status_d));
     if (rc) return rc;
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 
@@ -300,7 +297,7 @@ int ipcfp_exec_order(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent
         if (rc) return rc;
         const uint64_t take = ex.exec_len < cap ? ex.exec_len : cap;
         IPCFP_HIP(ctx, hipMemcpyAsync(out_cids40, out.p, take * IPCFP_CID_SLOT, hipMemcpyDeviceToHost, ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     }
     return IPCFP_OK;
 }

@@ -89,7 +89,7 @@ int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcf
     int rc = launch_verify_storage(ctx, witness_view(w), cd.p, uint32_t(n), trust ? *trust : kAcceptAll, sd.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 
@@ -102,7 +102,7 @@ int ipcfp_verify_storage_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, con
     int rc = launch_verify_storage(ctx, witness_view(w), static_cast<const StorageClaimPacked*>(claims_d), uint32_t(n),
                                    trust ? *trust : kAcceptAll, static_cast<uint8_t*>(status_d));
     if (rc) return rc;
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 

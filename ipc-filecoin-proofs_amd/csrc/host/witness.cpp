@@ -58,8 +58,8 @@ int finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, 
     rc = launch_gather_cids(ctx, w->order.p, w->cids.p, n, w->k1_cids.p);
     if (rc) return rc;
     uint64_t total = 0;
-    IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, &total, total_d, sizeof total, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     w->arena_bytes = total + kTailSlack;
     IPCFP_HIP(ctx, w->arena.alloc(w->arena_bytes));
     IPCFP_HIP(ctx, hipMemsetAsync(w->arena.p + total, 0, kTailSlack, ctx->stream));
@@ -68,7 +68,7 @@ int finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, 
 
     rc = witness_build_index(ctx, w);
     if (rc) return rc;
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 
@@ -156,13 +156,15 @@ int ipcfp_witness_verify_cids_async(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
 }
 
 int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* status, uint64_t* n_bad) {
+    if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
+    IPCFP_ENTER(ctx);
     int rc = ipcfp_witness_verify_cids_async(ctx, w);
     if (rc) return rc;
     unsigned long long bad = 0;
     if (status && w->n)
         IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream_k1));
-    IPCFP_HIP(ctx, hipMemcpyAsync(&bad, w->counters.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream_k1));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
+    IPCFP_HIP(ctx, d2h_small(ctx, &bad, w->counters.p, sizeof bad, ctx->stream_k1));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream_k1));
     if (n_bad) *n_bad = bad;
     return IPCFP_OK;
 }
@@ -170,7 +172,7 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
 int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
     IPCFP_ENTER(ctx);
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     w->enum_cache.clear();  // enumerations are derived from the index
     return witness_build_index(ctx, w);
 }
@@ -220,22 +222,22 @@ int hash_batch(ipcfp_ctx_t* ctx, HashKind kind, const uint8_t* bytes, uint64_t n
                               new_off.p, meta.p);
         if (rc) return rc;
         uint64_t total = 0;
-        IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d, 8, hipMemcpyDeviceToHost, ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, d2h_small(ctx, &total, total_d, 8, ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
         IPCFP_HIP(ctx, arena.alloc(total + kTailSlack));
         rc = launch_repack(ctx, b.p, off_d.p, len_d.p, new_off.p, uint32_t(n), arena.p);
         if (rc) return rc;
         rc = launch_blake2b256_raw(ctx, arena.p, meta.p, uint32_t(n), o.p);
         if (rc) return rc;
         IPCFP_HIP(ctx, hipMemcpyAsync(out32, o.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
         return IPCFP_OK;
     }
     rc = (kind == H_KECCAK) ? launch_keccak256(ctx, b.p, off_d.p, len_d.p, uint32_t(n), o.p)
                             : launch_sha256(ctx, b.p, off_d.p, len_d.p, uint32_t(n), o.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(out32, o.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 }  // namespace

@@ -383,9 +383,9 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                        cur.p, small.p, err_d, root_info_d.p);
     uint32_t max_height = 0;
     std::vector<uint64_t> root_info(2 * size_t(n_roots));
-    IPCFP_HIP(ctx, hipMemcpyAsync(&max_height, small.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipMemcpyAsync(root_info.data(), root_info_d.p, root_info.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, &max_height, small.p, 4, ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, root_info.data(), root_info_d.p, root_info.size() * 8, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
 
     // ---- dense fast path: the tree's shape follows from the roots; one kernel per level ----
     out.dense = false;
@@ -433,9 +433,9 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                                n_roots, uint32_t(n_level[0]), vkind, out.leaves.p, anomaly.p);
             uint32_t bad = 0;
             unsigned long long e = kNoEnumError;  // err_d is untouched here: report what earlier stages left in it
-            IPCFP_HIP(ctx, hipMemcpyAsync(&bad, anomaly.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            IPCFP_HIP(ctx, hipMemcpyAsync(&e, err_d, 8, hipMemcpyDeviceToHost, ctx->stream));
-            IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            IPCFP_HIP(ctx, d2h_small(ctx, &bad, anomaly.p, 4, ctx->stream));
+            IPCFP_HIP(ctx, d2h_small(ctx, &e, err_d, 8, ctx->stream));
+            IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
             IPCFP_HIP(ctx, hipGetLastError());
             if (!bad) {
                 out.n_leaves = n_leaves;
@@ -514,9 +514,9 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             }
             uint32_t bad = 0;
             unsigned long long e = kNoEnumError;
-            IPCFP_HIP(ctx, hipMemcpyAsync(&bad, mismatch.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            IPCFP_HIP(ctx, hipMemcpyAsync(&e, err_spec.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-            IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            IPCFP_HIP(ctx, d2h_small(ctx, &bad, mismatch.p, 4, ctx->stream));
+            IPCFP_HIP(ctx, d2h_small(ctx, &e, err_spec.p, 8, ctx->stream));
+            IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
             IPCFP_HIP(ctx, hipGetLastError());
             if (!bad) {
                 IPCFP_HIP(ctx, hipMemcpyAsync(err_d, err_spec.p, 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -541,8 +541,8 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
         int rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total_d.p, scratch.p);
         if (rc) return rc;
         uint64_t total = 0;
-        IPCFP_HIP(ctx, hipMemcpyAsync(&total, total_d.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, d2h_small(ctx, &total, total_d.p, 8, ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
         if (total >= 0x7fffffffULL)
             return set_error(ctx, IPCFP_E_UNSUPPORTED, "AMT enumeration expands to %llu entries",
                              (unsigned long long)total);
@@ -564,8 +564,8 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
         }
     }
     unsigned long long e = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemcpyAsync(&e, err_d, 8, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IPCFP_HIP(ctx, d2h_small(ctx, &e, err_d, 8, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     IPCFP_HIP(ctx, hipGetLastError());
     out.error = e;
     return IPCFP_OK;
@@ -609,7 +609,8 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     spec.version = uint32_t(version);
     unsigned long long e0 = kNoEnumError;
     IPCFP_HIP(ctx, hipMemcpyAsync(roots.p, &spec, sizeof spec, hipMemcpyHostToDevice, ctx->stream));
-    IPCFP_HIP(ctx, hipMemcpyAsync(err.p, &e0, 8, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(err.p, 0xff, 8, ctx->stream));  // kNoEnumError
+    (void)e0;
     IPCFP_HIP(ctx, hipMemsetAsync(flag.p, 0, 4, ctx->stream));
     AmtEnumResult en;
     int rc = amt_enumerate(ctx, view, roots.p, 1, vkind, err.p, en);
@@ -620,8 +621,8 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     if (en.n_leaves && !en.dense) {
         const uint32_t n = uint32_t(en.n_leaves);
         hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, flag.p);
-        IPCFP_HIP(ctx, hipMemcpyAsync(&not_dense, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        IPCFP_HIP(ctx, d2h_small(ctx, &not_dense, flag.p, 4, ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     }
     e->dense = !not_dense;
     // move the leaves into the cache entry (byte-typed buffer)

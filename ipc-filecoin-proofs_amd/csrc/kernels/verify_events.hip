@@ -375,7 +375,8 @@ int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
                       unsigned long long* err_d, int verify_txmeta) {
     const unsigned long long none = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemcpyAsync(err_d, &none, 8, hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(err_d, 0xff, 8, ctx->stream));  // kNoEnumError
+    (void)none;
     hipLaunchKernelGGL(k_exec_roots, dim3(IPCFP_MAX_PARENTS), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d,
                        verify_txmeta);
     IPCFP_HIP(ctx, hipGetLastError());
