@@ -12,6 +12,7 @@ struct ExecState {
     DevBuf<uint32_t> slots;     // hash table → first raw position
     DevBuf<uint32_t> first;     // 1 where the raw position is a first occurrence
     DevBuf<uint32_t> pos;       // exclusive scan of `first` → execution index
+    DevBuf<uint64_t> total;     // device: number of distinct messages (= exec_len)
     uint32_t mask = 0;
     uint64_t raw_len = 0, exec_len = 0;
     uint32_t status = IPCFP_ST_ERR;
@@ -20,8 +21,9 @@ struct ExecState {
 // reconstruct_execution_order (verify_txmeta = 1, events/utils.rs:16-30) or build_execution_order
 // (verify_txmeta = 0, events/utils.rs:32-46) of the context stored at ctx_d (device).  With a recording
 // view every block the traversal loads is marked.
+// `host_len` = false leaves exec_len on the device only (ExecState::total) and saves a synchronisation.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex, int verify_txmeta = 1);
+                     ExecState& ex, int verify_txmeta = 1, bool host_len = true);
 
 // device-resident result of one two-pass event scan (scan_events.cpp)
 struct ScanResult {

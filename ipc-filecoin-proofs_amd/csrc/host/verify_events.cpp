@@ -26,7 +26,7 @@ CidKey key_from_slot(const uint8_t* slot40);
 
 // Reconstruct the execution order of the context stored at ctx_d (device) on the device.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex, int verify_txmeta) {
+                     ExecState& ex, int verify_txmeta, bool host_len) {
     DevBuf<AmtRootSpec> roots;
     DevBuf<unsigned long long> err;
     IPCFP_HIP(ctx, roots.alloc(2 * size_t(n_parents) + 1));
@@ -52,14 +52,16 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 4, ctx->stream));
     rc = launch_exec_dedup(ctx, view, en.leaves.p, n, ex.keys.p, ex.slots.p, ex.mask, ex.first.p);
     if (rc) return rc;
-    DevBuf<uint64_t> scratch, total;
+    DevBuf<uint64_t> scratch;
     IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
-    IPCFP_HIP(ctx, total.alloc(1));
-    rc = launch_scan_u32(ctx, ex.first.p, n, ex.pos.p, total.p, scratch.p);
+    IPCFP_HIP(ctx, ex.total.alloc(1));
+    rc = launch_scan_u32(ctx, ex.first.p, n, ex.pos.p, ex.total.p, scratch.p);
     if (rc) return rc;
+    // `en.leaves` and `scratch` go back to the pool here; reuse is ordered on the one stream
+    if (!host_len) return IPCFP_OK;
     uint64_t distinct = 0;
-    IPCFP_HIP(ctx, d2h_small(ctx, &distinct, total.p, 8, ctx->stream));
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // also keeps `en.leaves` alive until the kernels are done
+    IPCFP_HIP(ctx, d2h_small(ctx, &distinct, ex.total.p, 8, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     ex.exec_len = distinct;
     return IPCFP_OK;
 }
@@ -78,11 +80,25 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
                                   ctx->stream));
     int rc = launch_ctx_headers(ctx, view, tcs_d.p, uint32_t(tcs.size()));
     if (rc) return rc;
-    IPCFP_HIP(ctx, d2h_small(ctx, tcs.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    // the header facts come back with the first synchronisation below (the enumerator's), not one of their own
+    std::vector<TipsetCtxDev> facts(tcs.size());
+    IPCFP_HIP(ctx, d2h_small(ctx, facts.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
     std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
+    bool synced = false;
+    for (size_t k = 0; k < tcs.size(); ++k) {
+        // The execution order is built for every context whose claim strings parsed, before the header
+        // facts are known on the host; a context that fails steps 1-2 simply never looks at it.
+        const TipsetCtxDev& in = tcs[k];
+        if (!(in.flags & TC_PARENTS_PARSED) || !(in.flags & TC_CHILD_PARSED) || in.n_parents == 0) continue;
+        execs[k].reset(new ExecState());
+        rc = build_exec_order(ctx, view, tcs_d.p + k, in.n_parents, *execs[k], 1, /*host_len=*/false);
+        if (rc) return rc;
+        synced = true;
+    }
+    if (!synced) IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     for (size_t k = 0; k < tcs.size(); ++k) {
         TipsetCtxDev& tc = tcs[k];
+        tc = facts[k];
         tc.exec_status = IPCFP_ST_ERR_BAD_CLAIM;
         tc.exec_slots = nullptr;
         tc.receipt_leaves = nullptr;
@@ -91,16 +107,13 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         const bool reachable = (tc.flags & TC_PARENTS_PARSED) && (tc.flags & TC_CHILD_PARSED) &&
                                tc.child_status == IPCFP_ST_TRUE && tc.parents_match && tc.n_parents > 0 &&
                                tc.parent0_status == IPCFP_ST_TRUE;
-        if (!reachable) continue;
-        execs[k].reset(new ExecState());
-        rc = build_exec_order(ctx, view, tcs_d.p + k, tc.n_parents, *execs[k]);
-        if (rc) return rc;
+        if (!reachable || !execs[k]) continue;
         tc.exec_status = execs[k]->status;
         tc.exec_mask = execs[k]->mask;
         tc.exec_slots = execs[k]->slots.p;
         tc.exec_keys = execs[k]->keys.p;
         tc.exec_pos = execs[k]->pos.p;
-        tc.exec_len = execs[k]->exec_len;
+        tc.exec_len = 0;  // patched on the device below
         // receipts AMT of this context: enumerate once (shared with ipcfp_scan_events through the witness cache)
         const EnumCached* rc_enum = nullptr;
         rc = amt_enumerate_cached(ctx, w, tc.receipts_root, 0, VK_RECEIPT, &rc_enum);
@@ -112,6 +125,11 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     }
     IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
                                   ctx->stream));
+    for (size_t k = 0; k < tcs.size(); ++k)
+        if (tcs[k].exec_slots && execs[k]->status == IPCFP_ST_TRUE && execs[k]->total.p) {
+            rc = launch_set_exec_len(ctx, tcs_d.p + k, execs[k]->total.p);
+            if (rc) return rc;
+        }
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, blob_d, trust ? *trust : accept_all, filter, status_d);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // contexts / exec tables are released on return

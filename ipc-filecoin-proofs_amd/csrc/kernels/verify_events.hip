@@ -54,62 +54,74 @@ __device__ __forceinline__ void blake2b256_small(const uint8_t* buf, uint32_t le
 // One wavefront (= one 64-thread workgroup) per context: the wave stages each header in LDS, lane 0 parses.
 constexpr uint32_t kHeaderLds = 8192;
 
+// Two wavefronts per context, side by side: block 2t decodes the child header, block 2t+1 the first
+// parent header (a header decode is ~100 CBOR items parsed by ONE lane — tens of microseconds of pure
+// latency — so the two are not done one after the other).
 __global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = blockIdx.x >> 1;
+    const bool child_part = (blockIdx.x & 1u) == 0;
     if (t >= n) return;
     TipsetCtxDev& c = ctxs[t];
     const bool lead = threadIdx.x == 0;
-    if (lead) {
-        c.child_status = IPCFP_ST_ERR_BAD_CLAIM;
-        c.parents_match = 0;
-        c.child_height = 0;
-        c.parent0_status = IPCFP_ST_ERR_BAD_CLAIM;
-        c.parent0_height = 0;
-    }
-    if ((c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) != (TC_PARENTS_PARSED | TC_CHILD_PARSED)) return;
-    // child header (events/verifier.rs:155-158)
-    const uint32_t hb = witness_find(w, c.child);  // uniform across the wave
-    if (hb == kNoBlock) {
-        if (lead) c.child_status = IPCFP_ST_ERR_MISSING_BLOCK;
-    } else {
-        Rd r = open_block_staged(w, hb, lds, kHeaderLds);
-        if (lead) {
-            HeaderLite h;
-            const uint32_t st = decode_header(r, h);
-            c.child_status = st;
-            if (st == IPCFP_ST_TRUE) {
-                c.child_height = h.height;
-                c.receipts_root = h.parent_message_receipts;
-                // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
-                bool same = h.n_parents == c.n_parents;
-                if (same) {
-                    Rd q = r;
-                    q.err = 0;
-                    q.pos = h.parents_off;
-                    for (uint32_t i = 0; i < c.n_parents && same; ++i) {
-                        CidKey k;
-                        q.read_link_key(k);
-                        same = q.ok() && cid_equal(k, c.parents[i]);
+    const bool parsed = (c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
+    if (child_part) {
+        uint32_t status = IPCFP_ST_ERR_BAD_CLAIM, match = 0;
+        long long height = 0;
+        if (parsed) {
+            // child header (events/verifier.rs:155-158)
+            const uint32_t hb = witness_find(w, c.child);  // uniform across the wave
+            if (hb == kNoBlock) {
+                status = IPCFP_ST_ERR_MISSING_BLOCK;
+            } else {
+                Rd r = open_block_staged(w, hb, lds, kHeaderLds);
+                if (lead) {
+                    HeaderLite h;
+                    status = decode_header(r, h);
+                    if (status == IPCFP_ST_TRUE) {
+                        height = h.height;
+                        c.receipts_root = h.parent_message_receipts;
+                        // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
+                        bool same = h.n_parents == c.n_parents;
+                        if (same) {
+                            Rd q = r;
+                            q.err = 0;
+                            q.pos = h.parents_off;
+                            for (uint32_t i = 0; i < c.n_parents && same; ++i) {
+                                CidKey k;
+                                q.read_link_key(k);
+                                same = q.ok() && cid_equal(k, c.parents[i]);
+                            }
+                        }
+                        match = same ? 1u : 0u;
                     }
                 }
-                c.parents_match = same ? 1u : 0u;
             }
         }
-        __syncthreads();  // the LDS copy is reused below
-    }
-    if (c.n_parents > 0) {  // parent_cids[0] (:171-174)
-        const uint32_t pb = witness_find(w, c.parents[0]);
-        if (pb == kNoBlock) {
-            if (lead) c.parent0_status = IPCFP_ST_ERR_MISSING_BLOCK;
-        } else {
-            Rd r = open_block_staged(w, pb, lds, kHeaderLds);
-            if (lead) {
-                HeaderLite ph;
-                const uint32_t st = decode_header(r, ph);
-                c.parent0_status = st;
-                if (st == IPCFP_ST_TRUE) c.parent0_height = ph.height;
+        if (lead) {
+            c.child_status = status;
+            c.parents_match = match;
+            c.child_height = height;
+        }
+    } else {
+        uint32_t status = IPCFP_ST_ERR_BAD_CLAIM;
+        long long height = 0;
+        if (parsed && c.n_parents > 0) {  // parent_cids[0] (:171-174)
+            const uint32_t pb = witness_find(w, c.parents[0]);
+            if (pb == kNoBlock) {
+                status = IPCFP_ST_ERR_MISSING_BLOCK;
+            } else {
+                Rd r = open_block_staged(w, pb, lds, kHeaderLds);
+                if (lead) {
+                    HeaderLite ph;
+                    status = decode_header(r, ph);
+                    if (status == IPCFP_ST_TRUE) height = ph.height;
+                }
             }
+        }
+        if (lead) {
+            c.parent0_status = status;
+            c.parent0_height = height;
         }
     }
 }
@@ -364,10 +376,22 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(Witness
     status[t] = uint8_t(verify_event_one(w, c, ctxs[c.context], blob, trust, filter, has_filter != 0));
 }
 
+// exec_len of a context = the total of the first-occurrence scan, copied on the device so the host
+// never waits for it
+__global__ void k_set_exec_len(TipsetCtxDev* __restrict__ c, const uint64_t* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) c->exec_len = *total;
+}
+
 // ------------------------------ launchers -----------------------------------
+int launch_set_exec_len(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d) {
+    hipLaunchKernelGGL(k_set_exec_len, dim3(1), dim3(64), 0, ctx->stream, ctx_d, total_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n) {
     if (n == 0) return IPCFP_OK;
-    hipLaunchKernelGGL(k_ctx_headers, dim3(n), dim3(64), 0, ctx->stream, w, ctxs_d, n);
+    hipLaunchKernelGGL(k_ctx_headers, dim3(2 * n), dim3(64), 0, ctx->stream, w, ctxs_d, n);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
