@@ -62,14 +62,20 @@ struct Rd {
     uint32_t n;
     uint32_t pos;
     uint32_t err;
-    // Byte access goes through a one-word window: parsing is a chain of dependent loads, and a lane
-    // that fetches 8 aligned bytes at a time issues ≈6× fewer of them than one that fetches single
-    // bytes.  Blocks sit 16-byte aligned in the arena with tail slack, so the aligned word that holds
-    // the last byte of an item never leaves the arena.
-    const uint64_t* base8;  // p rounded down to 8 bytes
-    uint32_t bias;          // p - base8
-    uint32_t cwi;           // index of the first cached word (0xfffffff0: none)
-    uint64_t cw0, cw1;      // the cached words cwi and cwi + 1 (a 16-byte window)
+    // Byte access goes through a window that is filled 16 aligned bytes at a time.  Parsing is a chain of
+    // dependent loads in which every lane of a wavefront reads a DIFFERENT block, so each load instruction
+    // is 64 separate line requests to the texture-address unit: what the walk kernels pay for is the NUMBER
+    // of load instructions, not the bytes.  One 16-byte load per chunk is half the instructions of a window
+    // fed 8 bytes at a time (and ≈12× fewer than single bytes).  The window is the current chunk (lo, hi)
+    // plus the high word of the chunk before it (ph): a parser only moves forward, so when an 8-byte peek
+    // straddles into the next chunk the low word of the old chunk is never needed again.  Blocks sit
+    // line-aligned in the arena with tail slack, so the chunk after the one that holds an item's last
+    // byte never leaves the arena.
+    const ulonglong2* base16;  // p rounded down to 16 bytes
+    uint32_t bias;             // p - base16
+    uint32_t cwi;              // index of the current chunk (0xfffffff0: none)
+    uint32_t phi;              // index of the chunk whose high word is in `ph` (0xffffffff: none)
+    uint64_t lo, hi, ph;
 
     __device__ __forceinline__ void init(const uint8_t* data, uint32_t len) {
         p = data;
@@ -77,38 +83,78 @@ struct Rd {
         pos = 0;
         err = 0;
         const uintptr_t a = reinterpret_cast<uintptr_t>(data);
-        base8 = reinterpret_cast<const uint64_t*>(a & ~uintptr_t(7));
-        bias = uint32_t(a & 7);
-        cwi = 0xfffffff0u;  // "nothing cached": neither cwi nor cwi + 1 is a reachable word index
-        cw0 = cw1 = 0;
+        base16 = reinterpret_cast<const ulonglong2*>(a & ~uintptr_t(15));
+        bias = uint32_t(a & 15);
+        cwi = 0xfffffff0u;
+        phi = 0xffffffffu;
+        lo = hi = ph = 0;
     }
-    // make words wi and wi + 1 the window (parsing moves forward: sliding by one word costs one load)
-    __device__ __forceinline__ void slide(uint32_t wi) {
-        if (wi == cwi) return;
-        if (wi == cwi + 1) {
-            cw0 = cw1;
-            cw1 = base8[wi + 1];
-        } else {
-            cw0 = base8[wi];
-            cw1 = base8[wi + 1];
-        }
-        cwi = wi;
+    // The window state as plain values.  at()/peek64() copy the members into one of these on entry and
+    // store them back on exit, so that every member is read and written UNCONDITIONALLY: always_inline
+    // functions are optimised on their own before they are inlined, and there LLVM merges `hi` loaded on
+    // one path with `lo` loaded on another into a single load from a phi of two addresses — after
+    // inlining that variable offset keeps the whole reader (and everything behind it) in scratch memory.
+    struct Win {
+        uint32_t cwi, phi;
+        uint64_t lo, hi, ph;
+    };
+    // make chunk ci the current one (moving forward by one chunk keeps the old high word)
+    __device__ __forceinline__ static void slide(Win& w, const ulonglong2* base16, uint32_t ci) {
+        if (ci == w.cwi) return;
+        const bool next = ci == w.cwi + 1;
+        w.ph = next ? w.hi : w.ph;
+        w.phi = next ? w.cwi : 0xffffffffu;
+        const ulonglong2 v = base16[ci];
+        w.lo = v.x;
+        w.hi = v.y;
+        w.cwi = ci;
+    }
+    __device__ __forceinline__ Win win() const { return Win{cwi, phi, lo, hi, ph}; }
+    __device__ __forceinline__ void keep(const Win& w) {
+        cwi = w.cwi;
+        phi = w.phi;
+        lo = w.lo;
+        hi = w.hi;
+        ph = w.ph;
     }
     // byte i of the item (i < n, or inside the block's padded tail)
     __device__ __forceinline__ uint32_t at(uint32_t i) {
         const uint32_t j = i + bias;
-        const uint32_t wi = j >> 3;
-        if (wi != cwi && wi != cwi + 1) slide(wi);
-        const uint64_t w = wi == cwi ? cw0 : cw1;
-        return uint32_t(w >> ((j & 7u) * 8u)) & 0xffu;
+        const uint32_t ci = j >> 4;
+        const bool high = (j & 8u) != 0;
+        Win w = win();
+        const bool from_prev = ci == w.phi && high;
+        if (!from_prev) slide(w, base16, ci);
+        const uint64_t m = high ? ~0ull : 0ull;
+        const uint64_t cur = (w.hi & m) | (w.lo & ~m);
+        const uint64_t word = from_prev ? w.ph : cur;
+        keep(w);
+        return uint32_t(word >> ((j & 7u) * 8u)) & 0xffu;
     }
-    // the 8 bytes at [i, i+8) as a little-endian u64 (unaligned).  The two aligned words that cover
-    // them are the window — still inside the arena (blocks are line-padded, the arena has tail slack).
+    // the 8 bytes at [i, i+8) as a little-endian u64 (unaligned)
     __device__ __forceinline__ uint64_t peek64(uint32_t i) {
         const uint32_t j = i + bias;
+        const uint32_t ci = j >> 4;
         const uint32_t sh = (j & 7u) * 8u;
-        slide(j >> 3);
-        return sh ? (cw0 >> sh) | (cw1 << (64u - sh)) : cw0;
+        Win w = win();
+        uint64_t first, second;
+        if ((j & 8u) == 0) {  // both words inside chunk ci
+            slide(w, base16, ci);
+            first = w.lo;
+            second = w.hi;
+        } else {              // high word of chunk ci, low word of chunk ci + 1
+            if (ci == w.phi) {
+                first = w.ph;  // the current chunk is ci + 1
+            } else {
+                slide(w, base16, ci);
+                first = w.hi;
+                slide(w, base16, ci + 1);
+            }
+            second = w.lo;
+        }
+        keep(w);
+        // (second << 1) << (63 - sh) is second << (64 - sh), and 0 for sh == 0: no branch on sh
+        return (first >> sh) | ((second << 1) << (63u - sh));
     }
     // the CID bytes [off, off+len) as a witness key (len ≤ 40): five unaligned words, tail masked
     __device__ __forceinline__ CidKey key_at(uint32_t off, uint32_t len) {

@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass1(WitnessVie
 }
 
 // PASS 2: matching receipts write their matches in order; the recorded blocks are marked in w.touched
-__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass2(WitnessView w, CidKey receipts_root,
+// (only the few matching receipts do any work here, so occupancy is irrelevant and the register allocator
+// gets the whole file: at 4 waves/SIMD this kernel spilled ≈1 KB per lane)
+__global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey receipts_root,
                                                     const LeafRef* __restrict__ receipts, uint32_t n, ScanParams sp,
                                                     const uint32_t* __restrict__ counts,
                                                     const uint32_t* __restrict__ offsets,

@@ -49,8 +49,8 @@ __device__ __forceinline__ Rd open_block_staged(const WitnessView& w, uint32_t b
     const uint32_t len = w.len[b];
     const uint8_t* src = w.arena + w.off[b];  // 128-byte aligned, padded to a line
     Rd r;
-    if (len + 32u <= cap) {
-        const uint32_t words = (len + 15u + 16u) >> 4;  // whole 16-byte words, plus one for window over-reads
+    if (len + 48u <= cap) {
+        const uint32_t words = ((len + 15u) >> 4) + 2u;  // whole 16-byte chunks, plus two for window over-reads
         const uint4* s4 = reinterpret_cast<const uint4*>(src);
         uint4* d4 = reinterpret_cast<uint4*>(lds);
         for (uint32_t i = threadIdx.x & 63u; i < words; i += 64u) d4[i] = s4[i];
