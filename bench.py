@@ -137,6 +137,7 @@ def main():
         w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len,
                                      t_status.data_ptr())                               # exec order + verify
         if world > 1:
+            eng.sync()  # K1 runs on the engine's second stream: its bitmap is complete after ctx_sync
             payload[:bitmap_bytes].copy_(t_bitmap)
             payload[bitmap_bytes:].copy_(t_status)
             dist.all_gather_into_tensor(gathered, payload)                               # the one collective

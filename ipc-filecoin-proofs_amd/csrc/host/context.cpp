@@ -139,17 +139,37 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
         delete ctx;
         return IPCFP_E_NO_DEVICE;
     }
-    // K1 may run on a second stream (IPCFP_K1_STREAM=1).  Measured on the 1M-receipt tipset it does NOT
-    // pay: the VALU-bound hash kernel takes CUs from the latency-bound walk kernels, whose host-visible
-    // chain of levels then runs slower (step 4.95 → 5.59 ms), so the default is one stream.
+    // K1 runs on a second stream beside the walk kernels (IPCFP_K1_STREAM: 0 = one stream, 1 = second stream
+    // [default], 2 = second stream with a CU mask, 3 = low-priority second stream).  The VALU-bound hash kernel
+    // and the latency-bound chain of walk kernels share the chip: measured on the 1M-receipt tipset the step
+    // drops 2.61 → 2.50 ms (the walk kernels lose ≈0.1 ms to K1, K1's 0.27 ms disappears from the critical
+    // path); CU masks and stream priorities add nothing over the plain second stream.  K1's results are
+    // complete after ipcfp_ctx_sync / ipcfp_witness_verify_cids, which wait for both streams.
     // IPCFP_K1_STREAM=2: the second stream is confined to a share of the CUs (IPCFP_K1_CU_PERCENT, default 75;
     // the mask sets bits in an even pattern so every shader engine / XCD keeps free CUs), so the walk
     // kernels' chain of small launches always finds idle CUs while K1 grinds beside it.
     ctx->stream_k1 = ctx->stream;
-    if (const char* e = std::getenv("IPCFP_K1_STREAM")) {
-        const int mode = std::atoi(e);
+    {
+        const char* e = std::getenv("IPCFP_K1_STREAM");
+        const int mode = e ? std::atoi(e) : 1;
         if (mode == 1 && hipStreamCreateWithFlags(&ctx->stream_k1, hipStreamNonBlocking) != hipSuccess)
             ctx->stream_k1 = ctx->stream;
+        if (mode == 3) {
+            // K1 on the LOWEST-priority stream, the walk kernels on the highest: the dispatcher serves the chain
+            // of small latency-bound launches first and K1's wavefronts fill whatever is idle
+            int least = 0, greatest = 0;
+            hipStream_t hi = nullptr, lo = nullptr;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+                hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, greatest) == hipSuccess &&
+                hipStreamCreateWithPriority(&lo, hipStreamNonBlocking, least) == hipSuccess) {
+                (void)hipStreamDestroy(ctx->stream);
+                ctx->stream = hi;
+                ctx->stream_k1 = lo;
+            } else {
+                if (hi) (void)hipStreamDestroy(hi);
+                ctx->stream_k1 = ctx->stream;
+            }
+        }
         if (mode == 2) {
             int pct = 75;
             if (const char* f = std::getenv("IPCFP_K1_CU_PERCENT")) pct = std::atoi(f);
