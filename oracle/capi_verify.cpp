@@ -81,6 +81,12 @@ void orc_verify_event_proofs(void* store, const ipcfp_event_proof_t* proofs, uin
     std::unordered_map<std::string, ExecCache> caches;
     std::vector<const ExecCache*> which(n, nullptr);
     for (uint64_t i = 0; i < n; ++i) {
+        // proofs of one bundle usually share the very same string array: skip the key building for them
+        if (i > 0 && proofs[i].parent_tipset_cids == proofs[i - 1].parent_tipset_cids &&
+            proofs[i].n_parent_tipset_cids == proofs[i - 1].n_parent_tipset_cids) {
+            which[i] = which[i - 1];
+            continue;
+        }
         std::string key;
         for (uint32_t k = 0; k < proofs[i].n_parent_tipset_cids; ++k) {
             key += proofs[i].parent_tipset_cids[k] ? proofs[i].parent_tipset_cids[k] : "";
