@@ -42,3 +42,31 @@ def pack_bits(flags: np.ndarray) -> np.ndarray:
     """bool/0-1 bytes → little-endian bitmap bytes (bit i of byte i//8), the form the engine's
     CID bitmap has."""
     return np.packbits(np.asarray(flags, dtype=np.uint8), bitorder="little")
+
+
+class PaddedGather:
+    """The per-step collective of bench.py: every rank contributes one message of ITS OWN length (shards are
+    generated independently, so block counts differ slightly); messages are padded to the longest one,
+    agreed once at setup, and all-gathered into a [world, width] tensor."""
+
+    def __init__(self, local_len: int, dist, device="cpu"):
+        import torch
+
+        self.dist = dist
+        self.world = dist.get_world_size()
+        t = torch.tensor([int(local_len)], dtype=torch.int64, device=device)
+        lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world)]
+        dist.all_gather(lens, t)
+        self.lens = [int(x.item()) for x in lens]
+        self.width = max(self.lens)
+        self.payload = torch.zeros(self.width, dtype=torch.uint8, device=device)
+        self.gathered = torch.empty(self.world * self.width, dtype=torch.uint8, device=device)
+
+    def run(self):
+        """One all-gather of `payload` (the caller fills payload[:local_len] beforehand)."""
+        self.dist.all_gather_into_tensor(self.gathered, self.payload)
+
+    def message(self, rank: int):
+        """Rank `rank`'s unpadded message out of the last gather."""
+        lo = rank * self.width
+        return self.gathered[lo: lo + self.lens[rank]]

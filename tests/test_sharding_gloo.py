@@ -82,3 +82,38 @@ def test_shard_bounds():
     b = shard.shard_bounds(1_000_003, 8)
     assert b[0][0] == 0 and b[-1][1] == 1_000_003 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     assert shard.pack_bits(np.array([1, 0, 0, 0, 0, 0, 0, 0, 1])).tolist() == [1, 1]
+
+
+def _padded_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    from ipc_filecoin_proofs_amd.shard import PaddedGather
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # ranks own independently generated shards: message lengths differ (bench.py's per-step collective)
+    local_len = 1000 + 37 * rank
+    g = PaddedGather(local_len, dist)
+    ok = g.lens == [1000 + 37 * r for r in range(world)] and g.width == 1000 + 37 * (world - 1)
+    for step in range(3):
+        g.payload[:local_len] = torch.full((local_len,), (rank * 16 + step) & 0xFF, dtype=torch.uint8)
+        g.run()
+        for r in range(world):
+            m = g.message(r)
+            ok = ok and len(m) == 1000 + 37 * r and bool((m == ((r * 16 + step) & 0xFF)).all())
+    np.save(os.path.join(out_dir, f"p{rank}.npy"), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_padded_gather(tmp_path):
+    """bench.py --gpus N closes every step with this collective; uneven message lengths must work."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_padded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / f"p{r}.npy")[0]
