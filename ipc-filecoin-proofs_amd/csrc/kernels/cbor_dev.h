@@ -57,6 +57,13 @@ __device__ __noinline__ bool utf8_ok_bytes(const uint8_t* s, uint32_t len) {
     return true;
 }
 
+// Per-lane line staging through LDS (see Rd::staged_chunk) is a per-translation-unit choice: it pays where
+// lanes parse whole blocks front to back (k_verify_events: 0.58 → 0.46 ms) and costs where access is sparse or
+// occupancy matters more (the enumeration levels, scan pass 1: +8 %), so only verify_events.hip turns it on.
+#ifndef IPCFP_LINE_STAGE
+#define IPCFP_LINE_STAGE 0
+#endif
+
 struct Rd {
     const uint8_t* p;
     uint32_t n;
@@ -76,6 +83,7 @@ struct Rd {
     uint32_t cwi;              // index of the current chunk (0xfffffff0: none)
     uint32_t phi;              // index of the chunk whose high word is in `ph` (0xffffffff: none)
     uint64_t lo, hi, ph;
+    bool stage;                // chunk loads go through the lane's LDS line slot (IPCFP_LINE_STAGE builds only)
 
     __device__ __forceinline__ void init(const uint8_t* data, uint32_t len) {
         p = data;
@@ -88,6 +96,8 @@ struct Rd {
         cwi = 0xfffffff0u;
         phi = 0xffffffffu;
         lo = hi = ph = 0;
+        stage = IPCFP_LINE_STAGE != 0;
+        if (IPCFP_LINE_STAGE) stage_invalidate();  // LDS holds garbage (or another workgroup's lines) until written
     }
     // The window state as plain values.  at()/peek64() copy the members into one of these on entry and
     // store them back on exit, so that every member is read and written UNCONDITIONALLY: always_inline
@@ -97,6 +107,7 @@ struct Rd {
     struct Win {
         uint32_t cwi, phi;
         uint64_t lo, hi, ph;
+        bool stage;
     };
     // make chunk ci the current one (moving forward by one chunk keeps the old high word)
     __device__ __forceinline__ static void slide(Win& w, const ulonglong2* base16, uint32_t ci) {
@@ -104,12 +115,64 @@ struct Rd {
         const bool next = ci == w.cwi + 1;
         w.ph = next ? w.hi : w.ph;
         w.phi = next ? w.cwi : 0xffffffffu;
-        const ulonglong2 v = base16[ci];
+        const ulonglong2 v = (IPCFP_LINE_STAGE && w.stage) ? staged_chunk(base16 + ci) : base16[ci];
         w.lo = v.x;
         w.hi = v.y;
         w.cwi = ci;
     }
-    __device__ __forceinline__ Win win() const { return Win{cwi, phi, lo, hi, ph}; }
+    // ---- per-lane line staging (IPCFP_LINE_STAGE) -------------------------------------------------------
+    // A lane walks its block 16 bytes at a time, and with ~1300 lanes per CU sharing a 16 KB L1 the line is
+    // gone again before the lane asks for its next chunk: every chunk is an L2 (or HBM) round trip and the
+    // same 128-byte line crosses L2→L1 up to eight times (k_verify_events: FETCH_SIZE 1.94 GB for a 0.44 GB
+    // witness).  With staging, the first touch of a line fetches the REST of the line (chunks k..7, issued
+    // back to back: one latency, one L2→L1 transfer) into the lane's LDS slot, and the following chunks are
+    // LDS reads.  Layout [chunk][lane] — a wavefront reading the same chunk index is conflict-free.  The
+    // slot's tag (line address | first valid chunk) lives in LDS as well, so any number of readers on one lane
+    // (a node reader, an item reader, a copy rewound to an earlier offset) share the slot safely: a reader that
+    // finds another line there simply refills.
+    struct StageLds {
+        ulonglong2 chunk[8][256];
+        unsigned long long tag[256];
+    };
+    __device__ __forceinline__ static StageLds& stage_lds() {
+        __shared__ StageLds s;
+        return s;
+    }
+    __device__ __forceinline__ static void stage_invalidate() { stage_lds().tag[threadIdx.x & 255u] = ~0ull; }
+    // slow path, deliberately NOT inlined: it is reached once per half line, and inlined at every peek it costs
+    // each walk kernel ≈30 VGPRs (an occupancy step)
+    __device__ __attribute__((noinline)) static void stage_refill(unsigned long long line, uint32_t k, uint32_t lane) {
+        StageLds& s = stage_lds();
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(line);
+        // the rest of the line in half-line bursts (four 16-byte loads in flight): the upper half always, the
+        // lower half only when the reader starts inside it
+        if (k < 4) {
+            const ulonglong2 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+            s.chunk[0][lane] = t0;
+            s.chunk[1][lane] = t1;
+            s.chunk[2][lane] = t2;
+            s.chunk[3][lane] = t3;
+        }
+        {
+            const ulonglong2 t4 = src[4], t5 = src[5], t6 = src[6], t7 = src[7];
+            s.chunk[4][lane] = t4;
+            s.chunk[5][lane] = t5;
+            s.chunk[6][lane] = t6;
+            s.chunk[7][lane] = t7;
+        }
+        s.tag[lane] = line | (k < 4 ? 0ull : 4ull);
+    }
+    __device__ __forceinline__ static ulonglong2 staged_chunk(const ulonglong2* addr) {
+        StageLds& s = stage_lds();
+        const uint32_t lane = threadIdx.x & 255u;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(addr);
+        const unsigned long long line = a & ~127ull;
+        const uint32_t k = uint32_t(a >> 4) & 7u;
+        const unsigned long long tag = s.tag[lane];
+        if ((tag & ~127ull) != line || k < uint32_t(tag & 7ull)) stage_refill(line, k, lane);
+        return s.chunk[k][lane];
+    }
+    __device__ __forceinline__ Win win() const { return Win{cwi, phi, lo, hi, ph, stage}; }
     __device__ __forceinline__ void keep(const Win& w) {
         cwi = w.cwi;
         phi = w.phi;

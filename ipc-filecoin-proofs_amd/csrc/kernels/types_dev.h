@@ -56,6 +56,7 @@ __device__ __forceinline__ Rd open_block_staged(const WitnessView& w, uint32_t b
         for (uint32_t i = threadIdx.x & 63u; i < words; i += 64u) d4[i] = s4[i];
         __syncthreads();
         r.init(lds, len);
+        r.stage = false;  // already in LDS
     } else {
         r.init(src, len);
     }

@@ -4,6 +4,7 @@
 // Replaces src/proofs/events/verifier.rs:51-290 and src/proofs/events/utils.rs:16-30,48-94.
 // Check order and every Ok(false)/Err outcome follow SURVEY.md A.10; the status byte names the
 // reference line that decided.
+#define IPCFP_LINE_STAGE 1  // k_verify_events parses whole blocks front to back: see cbor_dev.h
 #include <hip/hip_runtime.h>
 
 #include "../common.h"
