@@ -139,25 +139,27 @@ struct Rd {
         return s;
     }
     __device__ __forceinline__ static void stage_invalidate() { stage_lds().tag[threadIdx.x & 255u] = ~0ull; }
-    // Refill: the rest of the line straight from global memory into LDS (`global_load_lds_dwordx4`: the data
-    // never passes through VGPRs; lane L's 16 bytes land at M0 + 16·L, which is exactly the [chunk][lane]
-    // layout).  The upper half always, the lower half only when the reader starts inside it.  hipcc does not
-    // order LDS reads after these loads by itself, hence the explicit vmcnt wait.
-    __device__ __forceinline__ static void stage_refill(unsigned long long line, uint32_t k, uint32_t lane) {
+    // slow path, deliberately NOT inlined: it is reached once per half line, and inlined at every peek it costs
+    // each walk kernel ≈30 VGPRs (an occupancy step)
+    __device__ __attribute__((noinline)) static void stage_refill(unsigned long long line, uint32_t k, uint32_t lane) {
         StageLds& s = stage_lds();
-        typedef const __attribute__((address_space(1))) void* gptr;
-        typedef __attribute__((address_space(3))) void* lptr;
-        const uint32_t wave_first = lane & ~63u;
-        const uint8_t* src = reinterpret_cast<const uint8_t*>(line);
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(line);
+        // the rest of the line in half-line bursts (four 16-byte loads in flight): the upper half always, the
+        // lower half only when the reader starts inside it
         if (k < 4) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_global_load_lds((gptr)(src + 16 * q), (lptr)&s.chunk[q][wave_first], 16, 0, 0);
+            const ulonglong2 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3];
+            s.chunk[0][lane] = t0;
+            s.chunk[1][lane] = t1;
+            s.chunk[2][lane] = t2;
+            s.chunk[3][lane] = t3;
         }
-#pragma unroll
-        for (int q = 4; q < 8; ++q)
-            __builtin_amdgcn_global_load_lds((gptr)(src + 16 * q), (lptr)&s.chunk[q][wave_first], 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const ulonglong2 t4 = src[4], t5 = src[5], t6 = src[6], t7 = src[7];
+            s.chunk[4][lane] = t4;
+            s.chunk[5][lane] = t5;
+            s.chunk[6][lane] = t6;
+            s.chunk[7][lane] = t7;
+        }
         s.tag[lane] = line | (k < 4 ? 0ull : 4ull);
     }
     __device__ __forceinline__ static ulonglong2 staged_chunk(const ulonglong2* addr) {
