@@ -94,6 +94,64 @@ __device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, cons
     return IPCFP_ST_TRUE;
 }
 
+// Amt::<V>::load + for_each fused for the overwhelmingly common shape — a v3 AMT whose root is a leaf (height 0:
+// up to 2^bit_width values, e.g. ≤ 32 events of one receipt) — in ONE pass over the root block: the callback is
+// the per-value type check, so decoding the node first (amt_load) and visiting it afterwards (for_each) would
+// parse every value twice.  *handled = false (nothing consumed, f never called) when the root is taller or holds
+// links: the caller then takes amt_load + amt_for_each_lane.  Every decode failure is ERR_DECODE on both routes.
+template <typename F>
+__device__ __forceinline__ uint32_t amt3_for_each_leaf_root(const WitnessView& w, const CidKey& root, bool& handled, F&& f) {
+    handled = true;
+    const uint32_t b = witness_find(w, root);
+    if (b == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+    Rd r = open_block(w, b);
+    r.expect_array(4);
+    const uint64_t bw = r.read_uint();
+    if (r.ok() && (bw < 1 || bw > kAmtMaxBitWidth)) r.fail();
+    const uint64_t height = r.read_uint();
+    (void)r.read_uint();  // count: not checked by load or for_each
+    if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+    if (height != 0) {
+        handled = false;
+        return IPCFP_ST_TRUE;
+    }
+    AmtNode nd;  // only the bitmap words are used here
+    nd.width = 1u << uint32_t(bw);
+    r.expect_array(3);
+    uint32_t bo, bl;
+    r.read_bytes(bo, bl);
+    if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+    const bool bmap_len_ok = bl == (nd.width + 7) / 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = 8u * uint32_t(k);
+        uint64_t v = 0;
+        if (bl > lo) {
+            v = r.peek64(bo + lo);
+            const uint32_t valid = bl - lo;
+            if (valid < 8) v &= (1ull << (8u * valid)) - 1ull;
+        }
+        nd.b[k] = v;
+    }
+    if (nd.width < 64) nd.b[0] &= (1ull << nd.width) - 1ull;
+    const uint64_t nl = r.read_array();
+    if (!r.ok()) return IPCFP_ST_ERR_DECODE;
+    if (nl != 0) {  // links in a height-0 root: an error on the general route as well, let it say which
+        handled = false;
+        return IPCFP_ST_TRUE;
+    }
+    const uint64_t nv = r.read_array();
+    if (!r.ok() || !bmap_len_ok || nv != nd.popcount()) return IPCFP_ST_ERR_DECODE;
+    uint32_t sub = 0;
+    for (uint64_t j = 0; j < nv && r.ok(); ++j) {
+        while (!nd.bit(sub)) ++sub;  // nv == popcount: a set bit exists
+        f(uint64_t(sub), b, r);
+        ++sub;
+    }
+    r.finish();
+    return r.ok() ? uint32_t(IPCFP_ST_TRUE) : uint32_t(IPCFP_ST_ERR_DECODE);
+}
+
 // decode a receipt value; returns false when events_root is null
 __device__ __forceinline__ bool receipt_events_root(const WitnessView& w, const LeafRef& l, CidKey& root) {
     Rd r;
@@ -124,16 +182,21 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass1(WitnessVie
     uint32_t c = 0;
     CidKey ev_root;
     if (receipt_events_root(w, receipts[t], ev_root)) {
-        AmtRootInfo info;
-        uint32_t st = amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info);  // generator.rs:215
-        if (st == IPCFP_ST_TRUE)
-            st = amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t, uint32_t, Rd& er) {
-                uint64_t emitter;
-                EvmLogLoc log;
-                decode_event_log(er, emitter, log);                // parses (and type-checks) the StampedEvent
-                if (sp.has_actor && emitter != sp.actor) return;  // :220-224
-                if (log_matches(er, log, sp.filter)) ++c;         // :227-231
-            });
+        auto visit = [&](uint64_t, uint32_t, Rd& er) {
+            uint64_t emitter;
+            EvmLogLoc log;
+            decode_event_log(er, emitter, log);                // parses (and type-checks) the StampedEvent
+            if (sp.has_actor && emitter != sp.actor) return;  // :220-224
+            if (log_matches(er, log, sp.filter)) ++c;         // :227-231
+        };
+        bool handled;
+        uint32_t st = amt3_for_each_leaf_root(w, ev_root, handled, visit);  // generator.rs:215 + :218
+        if (!handled) {
+            c = 0;
+            AmtRootInfo info;
+            st = amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info);
+            if (st == IPCFP_ST_TRUE) st = amt_for_each_lane(w, info, VK_STAMPED_EVENT, visit);
+        }
         if (st != IPCFP_ST_TRUE) {
             atomicMin(err, (unsigned long long)pack_enum_error(1, t, st));
             c = 0;
