@@ -246,31 +246,53 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
     }
     const uint64_t remaining = n_here - uint64_t(p) * W;
     const uint32_t m = remaining < W ? uint32_t(remaining) : W;  // links this parent must hold
-    if (k == 0) {
-        AmtNode nd;
-        if (!enum_read_node(w, e, vkind, nd) || nd.nlinks != m || !nd.is_low(m)) atomicOr(anomaly, 1u);
-    }
+    // The parent is validated BY ITS CHILDREN, each lane a share, instead of by one lane parsing all of it (a
+    // node of eight links is 350 bytes = 22 dependent chunk loads for that one lane — the latency of a level):
+    //   every lane   the node header: array(3), bitmap = exactly the low m bits, links array of m entries;
+    //   lane k       link k, assumed to start 43·k bytes after the first one — true iff links 0..k-1 are the
+    //                standard 43-byte form (tag 42, 39-byte string, identity multibase byte, 38-byte CID), which
+    //                lanes 0..k-1 check on theirs: by induction every start is right or some lane objects;
+    //   lane m-1     what follows the last link: an empty values array and, in a child block, the end of the block.
+    // Together that is everything CollapsedNode::expand checks; any other shape is an anomaly (general path).
     Rd r2 = open_block(w, e.block);
     r2.pos = e.node_off;
     r2.expect_array(3);
     uint32_t bo, bl;
     r2.read_bytes(bo, bl);
+    bool ok = r2.ok() && bl == (W + 7) / 8;
+    if (ok) {
+        for (uint32_t i = 0; i < bl; ++i) {
+            const uint32_t lo = i * 8u;
+            const uint32_t want = m >= lo + 8 ? 0xffu : (m > lo ? (1u << (m - lo)) - 1u : 0u);
+            uint32_t have = r2.at(bo + i);
+            if (W < 8) have &= (1u << W) - 1u;
+            ok = ok && have == want;
+        }
+    }
     const uint64_t nl = r2.read_array();
-    if (!r2.ok() || nl <= k) {  // the validating lane reports it
+    ok = ok && r2.ok() && nl == m;
+    if (!ok) {
+        atomicOr(anomaly, 1u);
         next[j] = c;
         return;
     }
-    for (uint32_t i = 0; i < k; ++i) {
-        uint32_t mt;
-        uint64_t a;
-        r2.head(mt, a);  // tag 42
-        r2.head(mt, a);  // byte-string header
-        r2.pos += uint32_t(a);
-    }
+    const uint32_t mine = r2.pos + 43u * k;
     CidKey key;
-    r2.read_link_key(key);
+    ok = mine + 43u <= r2.n;  // never read outside the block on the strength of an unverified assumption
+    if (ok) {
+        r2.pos = mine;
+        r2.read_link_key(key);
+        ok = r2.ok() && r2.pos - mine == 43u;
+    }
+    if (ok && k == m - 1) {
+        ok = r2.read_array() == 0 && r2.ok();
+        if (ok && e.node_off == 0) {  // a child block holds exactly this node (the root's tail was checked by amt_load)
+            r2.finish();
+            ok = r2.ok();
+        }
+    }
     c.base = e.base + uint64_t(k) * amt_span(e.bit_width, level);
-    const uint32_t b = r2.ok() ? witness_find(w, key) : kNoBlock;
+    const uint32_t b = ok ? witness_find(w, key) : kNoBlock;
     if (b == kNoBlock) atomicOr(anomaly, 1u);
     c.block = b;
     next[j] = c;
