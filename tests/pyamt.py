@@ -45,8 +45,10 @@ class Store:
     def __init__(self):
         self.blocks = {}  # cid -> bytes, insertion ordered
 
-    def put(self, block: bytes) -> bytes:
-        c = cid_of(block)
+    def put(self, block: bytes, sha256_cid: bool = False) -> bytes:
+        """Store under the usual blake2b-256 CID, or under a CIDv1 dag-cbor sha2-256 CID (36 bytes: a legal
+        link of a different length — the witness store never re-hashes)."""
+        c = (bytes.fromhex("01711220") + hashlib.sha256(block).digest()) if sha256_cid else cid_of(block)
         self.blocks[c] = block
         return c
 
@@ -60,12 +62,13 @@ class Store:
             off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
         c40 = np.zeros((len(cids), 40), dtype=np.uint8)
         for i, c in enumerate(cids):
-            c40[i, :38] = np.frombuffer(c, dtype=np.uint8)
+            c40[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
         return np.frombuffer(data, dtype=np.uint8).copy(), off, lens, c40
 
 
-def _node(store, bw, height, items, base):
-    """items: sorted [(index, encoded value)] inside [base, base + W^(height+1)) → encoded node bytes."""
+def _node(store, bw, height, items, base, odd_links=()):
+    """items: sorted [(index, encoded value)] inside [base, base + W^(height+1)) → encoded node bytes.
+    odd_links: bases of child nodes that are linked through a sha2-256 CID instead of the standard one."""
     W = 1 << bw
     bmap = bytearray((W + 7) // 8)
     links, values = [], []
@@ -80,12 +83,15 @@ def _node(store, bw, height, items, base):
             sub = [(i, v) for i, v in items if base + s * span <= i < base + (s + 1) * span]
             if sub:
                 bmap[s >> 3] |= 1 << (s & 7)
-                links.append(link(store.put(_node(store, bw, height - 1, sub, base + s * span))))
+                child_base = base + s * span
+                child = _node(store, bw, height - 1, sub, child_base, odd_links)
+                links.append(link(store.put(child, sha256_cid=(height - 1, child_base) in odd_links)))
     return array([bstr(bmap), array(links), array(values)])
 
 
-def build_amt(store, items, version=0, bit_width=3, height=None, count=None):
-    """items: {index: encoded value}.  Returns the root CID.  `height` / `count` may lie."""
+def build_amt(store, items, version=0, bit_width=3, height=None, count=None, odd_links=()):
+    """items: {index: encoded value}.  Returns the root CID.  `height` / `count` may lie.
+    odd_links: {(child height, child base index)} linked through a 36-byte sha2-256 CID."""
     bw = 3 if version == 0 else bit_width
     W = 1 << bw
     srt = sorted(items.items())
@@ -95,7 +101,7 @@ def build_amt(store, items, version=0, bit_width=3, height=None, count=None):
         h += 1
     if height is not None:
         h = height
-    node = _node(store, bw, h, srt, 0)
+    node = _node(store, bw, h, srt, 0, set(odd_links))
     cnt = len(srt) if count is None else count
     root = array(([uint(bw)] if version != 0 else []) + [uint(h), uint(cnt), node])
     return store.put(root)

@@ -41,6 +41,10 @@ CASES = {
     "count too small": dict(idx=range(50), count=40),
     "count zero but values": dict(idx=range(5), count=0),
     "tall root": dict(idx=range(20), height=3),
+    # dense, but one interior link is a 36-byte sha2-256 CID: the 43-byte link stride of the fast path is wrong
+    "odd link first child": dict(idx=range(600), odd_links={(1, 0)}),
+    "odd link middle": dict(idx=range(600), odd_links={(0, 264), (1, 128)}),
+    "odd link last": dict(idx=range(600), odd_links={(0, 592)}),
     "empty": dict(idx=[]),
     "empty tall": dict(idx=[], height=2),
 }
@@ -51,7 +55,8 @@ def test_scan_over_receipt_amt_shapes(engine, oracle, name):
     c = CASES[name]
     store = pyamt.Store()
     items = {i: pyamt.receipt(gas=1000 + i) for i in c["idx"]}
-    root = pyamt.build_amt(store, items, version=0, height=c.get("height"), count=c.get("count"))
+    root = pyamt.build_amt(store, items, version=0, height=c.get("height"), count=c.get("count"),
+                           odd_links=c.get("odd_links", ()))
     gs, has = run_scan(engine, oracle, store, root)
     assert gs == 1
     idx = list(c["idx"])
