@@ -237,11 +237,9 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
     }
     CidKey ev_root;
     if (!receipt_events_root(w, leaf, ev_root)) return;
-    AmtRootInfo info;
-    if (amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info) != IPCFP_ST_TRUE) return;  // :259
     uint32_t k = 0;
     const uint32_t o = offsets[t];
-    (void)amt_for_each_lane(w, info, VK_STAMPED_EVENT, [&](uint64_t j, uint32_t b, Rd& er) {
+    auto visit = [&](uint64_t j, uint32_t b, Rd& er) {
         const uint32_t start = er.pos;
         uint64_t emitter;
         EvmLogLoc log;
@@ -250,7 +248,16 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
         if (!log_matches(er, log, sp.filter)) return;
         if (matches && k < c) matches[o + k] = EventMatch{leaf.index, j, emitter, ValueLoc{b, start, er.pos - start}, 0};
         ++k;
-    });
+    };
+    // the same blocks in the same order as PASS 1, which found them sound: nothing here can fail (:259-:262)
+    bool handled;
+    (void)amt3_for_each_leaf_root(w, ev_root, handled, visit);
+    if (!handled) {
+        k = 0;
+        AmtRootInfo info;
+        if (amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info) != IPCFP_ST_TRUE) return;
+        (void)amt_for_each_lane(w, info, VK_STAMPED_EVENT, visit);
+    }
 }
 
 int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
