@@ -13,6 +13,8 @@ struct ExecState {
     DevBuf<uint32_t> first;     // 1 where the raw position is a first occurrence
     DevBuf<uint32_t> pos;       // exclusive scan of `first` → execution index
     DevBuf<uint64_t> total;     // device: number of distinct messages (= exec_len)
+    DevBuf<AmtRootSpec> roots;  // stage 1 output: the BLS / secp message AMT roots of every parent block
+    DevBuf<unsigned long long> err;  // packed first error of the whole reconstruction
     uint32_t mask = 0;
     uint64_t raw_len = 0, exec_len = 0;
     uint32_t status = IPCFP_ST_ERR;
@@ -22,8 +24,11 @@ struct ExecState {
 // (verify_txmeta = 0, events/utils.rs:32-46) of the context stored at ctx_d (device).  With a recording
 // view every block the traversal loads is marked.
 // `host_len` = false leaves exec_len on the device only (ExecState::total) and saves a synchronisation.
+// `prepared` = true: stage 1 (ex.roots / ex.err) was already run by launch_tipset_prepare.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex, int verify_txmeta = 1, bool host_len = true);
+                     ExecState& ex, int verify_txmeta = 1, bool host_len = true, bool prepared = false);
+// allocate ex.roots / ex.err for a context with n_parents parent blocks and reset the error word
+int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents);
 
 // device-resident result of one two-pass event scan (scan_events.cpp)
 struct ScanResult {

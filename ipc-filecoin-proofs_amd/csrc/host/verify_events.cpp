@@ -24,17 +24,25 @@ namespace ipcfp {
 void parse_cid_claim(const char* s, CidKey& key, bool& parsed, bool& canonical);
 CidKey key_from_slot(const uint8_t* slot40);
 
+int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents) {
+    IPCFP_HIP(ctx, ex.roots.alloc(2 * size_t(n_parents) + 1));
+    IPCFP_HIP(ctx, ex.err.alloc(1));
+    IPCFP_HIP(ctx, hipMemsetAsync(ex.err.p, 0xff, 8, ctx->stream));  // kNoEnumError
+    return IPCFP_OK;
+}
+
 // Reconstruct the execution order of the context stored at ctx_d (device) on the device.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex, int verify_txmeta, bool host_len) {
-    DevBuf<AmtRootSpec> roots;
-    DevBuf<unsigned long long> err;
-    IPCFP_HIP(ctx, roots.alloc(2 * size_t(n_parents) + 1));
-    IPCFP_HIP(ctx, err.alloc(1));
-    int rc = launch_exec_roots(ctx, view, ctx_d, roots.p, err.p, verify_txmeta);
-    if (rc) return rc;
+                     ExecState& ex, int verify_txmeta, bool host_len, bool prepared) {
+    int rc;
+    if (!prepared) {
+        rc = exec_state_prepare(ctx, ex, n_parents);
+        if (rc) return rc;
+        rc = launch_exec_roots(ctx, view, ctx_d, ex.roots.p, ex.err.p, verify_txmeta);
+        if (rc) return rc;
+    }
     AmtEnumResult en;
-    rc = amt_enumerate(ctx, view, roots.p, 2 * n_parents, VK_CID, err.p, en);
+    rc = amt_enumerate(ctx, view, ex.roots.p, 2 * n_parents, VK_CID, ex.err.p, en);
     if (rc) return rc;
     const unsigned long long e = en.error;  // read back by the enumerator: stage-1 errors and its own, merged
     ex.status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
@@ -78,20 +86,40 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     IPCFP_HIP(ctx, tcs_d.alloc(tcs.size()));
     IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
                                   ctx->stream));
-    int rc = launch_ctx_headers(ctx, view, tcs_d.p, uint32_t(tcs.size()));
+    // The tipset prologue — header facts of every context and stage 1 of every execution order (parent
+    // headers, TxMeta re-hash, message AMT roots) — is one launch.  The execution order is prepared for every
+    // context whose claim strings parsed, before the header facts are known on the host; a context that fails
+    // steps 1-2 simply never looks at it.
+    struct PrepareJob {
+        TipsetCtxDev* ctx;
+        AmtRootSpec* roots;
+        unsigned long long* err;
+    };
+    std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
+    std::vector<PrepareJob> jobs(tcs.size());
+    int rc;
+    for (size_t k = 0; k < tcs.size(); ++k) {
+        const TipsetCtxDev& in = tcs[k];
+        jobs[k] = PrepareJob{tcs_d.p + k, nullptr, nullptr};
+        if (!(in.flags & TC_PARENTS_PARSED) || !(in.flags & TC_CHILD_PARSED) || in.n_parents == 0) continue;
+        execs[k].reset(new ExecState());
+        rc = exec_state_prepare(ctx, *execs[k], in.n_parents);
+        if (rc) return rc;
+        jobs[k].roots = execs[k]->roots.p;
+        jobs[k].err = execs[k]->err.p;
+    }
+    DevBuf<PrepareJob> jobs_d;
+    IPCFP_HIP(ctx, jobs_d.alloc(jobs.size()));
+    IPCFP_HIP(ctx, hipMemcpyAsync(jobs_d.p, jobs.data(), jobs.size() * sizeof(PrepareJob), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_tipset_prepare(ctx, view, jobs_d.p, uint32_t(jobs.size()));
     if (rc) return rc;
     // the header facts come back with the first synchronisation below (the enumerator's), not one of their own
     std::vector<TipsetCtxDev> facts(tcs.size());
     IPCFP_HIP(ctx, d2h_small(ctx, facts.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
-    std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
     bool synced = false;
     for (size_t k = 0; k < tcs.size(); ++k) {
-        // The execution order is built for every context whose claim strings parsed, before the header
-        // facts are known on the host; a context that fails steps 1-2 simply never looks at it.
-        const TipsetCtxDev& in = tcs[k];
-        if (!(in.flags & TC_PARENTS_PARSED) || !(in.flags & TC_CHILD_PARSED) || in.n_parents == 0) continue;
-        execs[k].reset(new ExecState());
-        rc = build_exec_order(ctx, view, tcs_d.p + k, in.n_parents, *execs[k], 1, /*host_len=*/false);
+        if (!execs[k]) continue;
+        rc = build_exec_order(ctx, view, tcs_d.p + k, tcs[k].n_parents, *execs[k], 1, /*host_len=*/false, /*prepared=*/true);
         if (rc) return rc;
         synced = true;
     }

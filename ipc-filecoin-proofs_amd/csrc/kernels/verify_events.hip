@@ -58,12 +58,7 @@ constexpr uint32_t kHeaderLds = 8192;
 // Two wavefronts per context, side by side: block 2t decodes the child header, block 2t+1 the first
 // parent header (a header decode is ~100 CBOR items parsed by ONE lane — tens of microseconds of pure
 // latency — so the two are not done one after the other).
-__global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
-    const uint32_t t = blockIdx.x >> 1;
-    const bool child_part = (blockIdx.x & 1u) == 0;
-    if (t >= n) return;
-    TipsetCtxDev& c = ctxs[t];
+__device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtxDev& c, bool child_part, uint8_t* lds) {
     const bool lead = threadIdx.x == 0;
     const bool parsed = (c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
     if (child_part) {
@@ -127,6 +122,13 @@ __global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev*
     }
 }
 
+__global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
+    const uint32_t t = blockIdx.x >> 1;
+    if (t >= n) return;
+    ctx_headers_body(w, ctxs[t], (blockIdx.x & 1u) == 0, lds);
+}
+
 // ---------------------------------------------------------------------------
 // execution order, stage 1 (one thread): parent headers → TxMeta → AMT roots
 //   error sequence numbers: parent header b → b;  TxMeta of block b → P + 3b;
@@ -134,12 +136,10 @@ __global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev*
 // ---------------------------------------------------------------------------
 // One lane per parent block (the per-block work is independent; the error word orders the outcomes).
 // `err` must hold kNoEnumError on entry.
-__global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx,
-                                                   AmtRootSpec* __restrict__ roots,
-                                                   unsigned long long* __restrict__ err, int verify_txmeta) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
-    const uint32_t P = ctx->n_parents;
-    const uint32_t b = blockIdx.x;  // one wavefront per parent block; lane 0 parses what the wave staged
+__device__ __forceinline__ void exec_roots_body(const WitnessView& w, const TipsetCtxDev* __restrict__ ctx,
+                                                AmtRootSpec* __restrict__ roots, unsigned long long* __restrict__ err,
+                                                int verify_txmeta, uint32_t b, uint8_t* lds) {
+    const uint32_t P = ctx->n_parents;  // one wavefront per parent block b; lane 0 parses what the wave staged
     if (b >= P) return;
     const bool lead = threadIdx.x == 0;
     auto fail = [&](uint32_t seq, uint32_t code) { atomicMin(err, (unsigned long long)pack_enum_error(seq, 0, code)); };
@@ -221,6 +221,33 @@ __global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCt
         roots[2 * b] = bls;
         roots[2 * b + 1] = secp;
     }
+}
+
+__global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx,
+                                                   AmtRootSpec* __restrict__ roots,
+                                                   unsigned long long* __restrict__ err, int verify_txmeta) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
+    exec_roots_body(w, ctx, roots, err, verify_txmeta, blockIdx.x, lds);
+}
+
+// The whole tipset prologue of the verify path in ONE launch: per context, two wavefronts decode the child and
+// the first parent header (ctx_headers_body) and one wavefront per parent block decodes its header, its TxMeta
+// and re-hashes it (exec_roots_body).  They are independent single-lane parses of tens of microseconds each;
+// launched one after the other they were the longest idle stretch of a step.
+struct PrepareJob {
+    TipsetCtxDev* ctx;
+    AmtRootSpec* roots;          // nullptr: no execution order for this context
+    unsigned long long* err;
+};
+constexpr uint32_t kPrepareSlots = 2 + kMaxParents;
+
+__global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, const PrepareJob* __restrict__ jobs, uint32_t n_jobs) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
+    const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
+    if (job >= n_jobs) return;
+    const PrepareJob jb = jobs[job];
+    if (slot < 2) ctx_headers_body(w, *jb.ctx, slot == 0, lds);
+    else if (jb.roots) exec_roots_body(w, jb.ctx, jb.roots, jb.err, 1, slot - 2, lds);
 }
 
 // stage 2: leaf values (tag-42 links, already validated) → message CID keys
@@ -384,6 +411,14 @@ __global__ void k_set_exec_len(TipsetCtxDev* __restrict__ c, const uint64_t* __r
 }
 
 // ------------------------------ launchers -----------------------------------
+int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs_d, uint32_t n_jobs) {
+    if (n_jobs == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, ctx->stream, w,
+                       static_cast<const PrepareJob*>(jobs_d), n_jobs);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 int launch_set_exec_len(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d) {
     hipLaunchKernelGGL(k_set_exec_len, dim3(1), dim3(64), 0, ctx->stream, ctx_d, total_d);
     IPCFP_HIP(ctx, hipGetLastError());
