@@ -37,8 +37,13 @@ struct ScanResult {
     DevBuf<uint8_t> has;
     DevBuf<ipcfp_event_match_t> matches;
 };
+// `cap_matches`: how many matches the caller can take.  With a known capacity PASS 2 is launched right behind
+// PASS 1 (the kernel clips its writes) and the scan has ONE synchronisation; with kAllMatches the match count is
+// read back first and out.matches is sized to it.
+constexpr uint64_t kAllMatches = ~0ull;
 int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const ipcfp_event_filter_t& filter,
-                       int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out);
+                       int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out,
+                       uint64_t cap_matches = kAllMatches);
 
 CidKey key_from_slot(const uint8_t* slot40);
 

@@ -19,7 +19,7 @@ namespace ipcfp {
 // PASS 1 + prefix sum + PASS 2 on the device.  `touched_d` (nullable, device, words = ceil(n/32)) is
 // OR-ed into, so a caller can accumulate one recorder across several steps (generate_event_proof).
 int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const ipcfp_event_filter_t& filter,
-                       int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out) {
+                       int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out, uint64_t cap_matches) {
     const WitnessView view = witness_view(w);
     DevBuf<unsigned long long> err;
     IPCFP_HIP(ctx, err.alloc(1));
@@ -61,18 +61,27 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     unsigned long long e1 = kNoEnumError;
     IPCFP_HIP(ctx, d2h_small(ctx, &nm, total.p, 8, ctx->stream));
     IPCFP_HIP(ctx, d2h_small(ctx, &e1, err.p, 8, ctx->stream));
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    if (e1 != kNoEnumError) {
+    uint64_t cap = cap_matches;
+    if (cap_matches > (1ull << 26)) {  // unknown (kAllMatches) or too big to reserve blindly:
+        // size the match list to the count — one more synchronisation
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+        if (e1 != kNoEnumError) {
+            out.status = enum_error_code(e1);
+            return IPCFP_OK;
+        }
+        cap = nm;
+    }
+    IPCFP_HIP(ctx, out.matches.alloc(cap));
+    WitnessView rec = view;
+    rec.touched = touched_d;
+    rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, counts.p, offsets.p,
+                           cap ? out.matches.p : nullptr, cap, out.has.p, n_idx);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // delivers nm / e1 when they were not waited for above
+    if (e1 != kNoEnumError) {  // PASS 2 ran on a tipset PASS 1 rejected: its output is discarded
         out.status = enum_error_code(e1);
         return IPCFP_OK;
     }
-    IPCFP_HIP(ctx, out.matches.alloc(nm));
-    WitnessView rec = view;
-    rec.touched = touched_d;
-    rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, counts.p, offsets.p, out.matches.p,
-                           out.has.p, n_idx);
-    if (rc) return rc;
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // counts/offsets are released on return
     out.n_idx = n_idx;
     out.n_matches = nm;
     out.status = IPCFP_ST_TRUE;
@@ -100,7 +109,7 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
     }
     ScanResult res;
     int rc = scan_events_device(ctx, w, key_from_slot(receipts_root40), *filter, has_actor, actor,
-                                touched_bits ? touched.p : nullptr, res);
+                                touched_bits ? touched.p : nullptr, res, matches ? cap_matches : 0);
     if (rc) return rc;
     *status_out = ipcfp_status_t(res.status);
     if (res.status != IPCFP_ST_TRUE) return IPCFP_OK;

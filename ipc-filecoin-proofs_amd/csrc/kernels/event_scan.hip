@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
                                                     const LeafRef* __restrict__ receipts, uint32_t n, ScanParams sp,
                                                     const uint32_t* __restrict__ counts,
                                                     const uint32_t* __restrict__ offsets,
-                                                    EventMatch* __restrict__ matches,
+                                                    EventMatch* __restrict__ matches, uint64_t matches_cap,
                                                     uint8_t* __restrict__ has_match, uint64_t has_cap) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool recording = w.touched != nullptr;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
         decode_event_log(er, emitter, log);
         if (sp.has_actor && emitter != sp.actor) return;
         if (!log_matches(er, log, sp.filter)) return;
-        if (matches && k < c) matches[o + k] = EventMatch{leaf.index, j, emitter, ValueLoc{b, start, er.pos - start}, 0};
+        if (matches && k < c && uint64_t(o) + k < matches_cap) matches[o + k] = EventMatch{leaf.index, j, emitter, ValueLoc{b, start, er.pos - start}, 0};
         ++k;
     };
     // the same blocks in the same order as PASS 1, which found them sound: nothing here can fail (:259-:262)
@@ -276,15 +276,15 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
 
 int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
                       uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
-                      const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint8_t* has_match_d,
-                      uint64_t has_cap) {
+                      const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint64_t matches_cap,
+                      uint8_t* has_match_d, uint64_t has_cap) {
     ScanParams sp{filter, actor, has_actor ? 1u : 0u, 0};
     const uint32_t threads = n ? n : 1;
     {
         ProfileScope prof(ctx, IPCFP_K_REPLAY);
         hipLaunchKernelGGL(k_scan_pass2, dim3(div_up(threads, 256)), dim3(256), 0, ctx->stream, w, receipts_root,
-                           receipts_d, n, sp, counts_d, offsets_d, static_cast<EventMatch*>(matches_d), has_match_d,
-                           has_cap);
+                           receipts_d, n, sp, counts_d, offsets_d, static_cast<EventMatch*>(matches_d), matches_cap,
+                           has_match_d, has_cap);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

@@ -75,8 +75,8 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
                       unsigned long long* err_d);
 int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
                       uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
-                      const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint8_t* has_match_d,
-                      uint64_t has_cap);
+                      const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint64_t matches_cap,
+                      uint8_t* has_match_d, uint64_t has_cap);
 
 // --- base64.hip ---
 int launch_base64_decode(ipcfp_ctx* ctx, const uint8_t* text_d, const void* spans_d, uint32_t n_blocks, uint32_t n_units,
