@@ -95,8 +95,8 @@ inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
     bool others = false;
     for (auto& r : ctx->pending) {
         if (r.stream == s) {
-            if (e == hipSuccess) std::memcpy(r.dst, ctx->pinned + r.off, r.n);
-            r.dst = nullptr;
+            if (r.dst && e == hipSuccess) std::memcpy(r.dst, ctx->pinned + r.off, r.n);
+            r.dst = nullptr;  // delivered (or lost with the failed synchronisation): never written twice
         } else if (r.dst) {
             others = true;
         }
