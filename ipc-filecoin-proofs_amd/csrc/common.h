@@ -203,7 +203,7 @@ struct ipcfp_witness {
     uint64_t n = 0;        // blocks
     uint64_t nbytes = 0;   // payload bytes (sum of len)
     uint64_t arena_bytes = 0;
-    ipcfp::DevBuf<uint8_t> arena;     // 16-byte aligned blocks + 256 B tail slack
+    ipcfp::DevBuf<uint8_t> arena;     // blocks on 128-byte lines, in K1 schedule order, + 256 B tail slack
     ipcfp::DevBuf<uint64_t> off;      // n
     ipcfp::DevBuf<uint32_t> len;      // n
     ipcfp::DevBuf<uint8_t> cids;      // n × 40

@@ -70,7 +70,8 @@ struct AmtEnumResult {
 
 // Enumerate `n_roots` AMTs (device array `roots_d`) whose values have type `vkind`.
 // `err_d` is a device u64 initialised by the caller (kNoEnumError or earlier-stage errors); the
-// enumerator atomicMin's into it.  Synchronises the stream twice (tree height, value count).
+// enumerator atomicMin's into it.  Synchronises the stream twice on the dense path (root shapes; anomaly flag
+// + error word), once more per level on the general path.
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
                   unsigned long long* err_d, AmtEnumResult& out);
 

@@ -3,8 +3,8 @@
 // The reference keeps the witness as `HashMap<Cid, Vec<u8>>`
 // (`load_witness_store`, src/proofs/events/verifier.rs:79-89,
 // src/proofs/storage/verifier.rs:68-78).  The engine keeps ONE byte arena with
-// every block starting on a 16-byte boundary, so the hash and walk kernels can
-// use 16-byte loads, plus the (offset, length) table.  When the caller's blocks
+// every block starting on a 128-byte line, so the hash and walk kernels can
+// use 16-byte loads and no line is shared by two blocks, plus the (offset, length) table.  When the caller's blocks
 // are packed at arbitrary offsets this kernel re-lays them out; it runs at copy
 // speed and only at witness creation.
 #include <hip/hip_runtime.h>

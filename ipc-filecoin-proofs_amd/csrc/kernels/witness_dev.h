@@ -12,7 +12,7 @@ namespace ipcfp {
 constexpr uint32_t kNoBlock = 0xffffffffu;
 
 struct WitnessView {
-    const uint8_t* arena;    // 16-byte aligned blocks
+    const uint8_t* arena;    // every block on its own 128-byte line(s), + 256 B tail slack
     const uint64_t* off;     // n
     const uint32_t* len;     // n
     const uint8_t* cids;     // n × 40, zero padded
