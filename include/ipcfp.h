@@ -456,6 +456,11 @@ int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);
 typedef struct ipcfp_bundle ipcfp_bundle_t;
 #define IPCFP_BUNDLE_CID_STRINGS 1u /* also accept "cid":"bafy…" (extension; serde_json writes a byte array) */
 int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, uint32_t flags, ipcfp_bundle_t** out);
+/* Host half of the parse only (no context, no device): structure, field types, string escapes and base64
+ * lengths; the CONTENT of `cid` arrays and `data` strings is checked on the device by the call above.
+ * err_out (nullable) receives the first problem as text. */
+int ipcfp_bundle_check_json(const char* json, uint64_t len, uint32_t flags, uint64_t* n_storage, uint64_t* n_events,
+                            uint64_t* n_blocks, char* err_out, uint32_t err_cap);
 void ipcfp_bundle_destroy(ipcfp_bundle_t* b);
 ipcfp_witness_t* ipcfp_bundle_witness(ipcfp_bundle_t* b); /* owned by the bundle */
 uint64_t ipcfp_bundle_block_count(const ipcfp_bundle_t* b);

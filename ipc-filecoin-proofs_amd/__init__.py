@@ -13,6 +13,9 @@ from .binding import (  # noqa: F401
     Engine,
     EngineError,
     Witness,
+    Bundle,
+    bundle_check_json,
+    GEN_STORAGE_DTYPE,
     lib_path,
     load_library,
     ST,

@@ -16,6 +16,7 @@ __all__ = [
     "EngineError",
     "Witness",
     "Bundle",
+    "bundle_check_json",
     "GEN_STORAGE_DTYPE",
     "lib_path",
     "load_library",
@@ -196,6 +197,8 @@ def load_library() -> C.CDLL:
         "ipcfp_generate_storage_proofs": (i32, [vp, vp, vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_bundle_parse_json": (i32, [vp, C.c_char_p, u64, C.c_uint32, C.POINTER(vp)]),
         "ipcfp_bundle_destroy": (None, [vp]),
+        "ipcfp_bundle_check_json": (i32, [C.c_char_p, u64, C.c_uint32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
+                                          C.c_char_p, C.c_uint32]),
         "ipcfp_bundle_witness": (vp, [vp]),
         "ipcfp_bundle_block_count": (u64, [vp]),
         "ipcfp_bundle_event_count": (u64, [vp]),
@@ -422,6 +425,16 @@ def pack_cids(cids) -> np.ndarray:
             raise EngineError(f"CID {i} is {len(c)} bytes; the ABI slot is {CID_SLOT}")
         out[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
     return out
+
+
+def bundle_check_json(text: bytes, flags: int = 0):
+    """Host half of the bundle parse (no GPU): → (ok, n_storage, n_events, n_blocks, error text)."""
+    lib = load_library()
+    text = bytes(text)
+    ns, ne, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    err = C.create_string_buffer(256)
+    rc = lib.ipcfp_bundle_check_json(text, len(text), flags, C.byref(ns), C.byref(ne), C.byref(nb), err, 256)
+    return rc == 0, int(ns.value), int(ne.value), int(nb.value), err.value.decode(errors="replace")
 
 
 class Bundle:

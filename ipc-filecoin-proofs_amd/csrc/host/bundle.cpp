@@ -253,14 +253,13 @@ const char* keep(ipcfp_bundle& b, std::string&& s) {
 
 extern "C" {
 
-int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, uint32_t flags, ipcfp_bundle_t** out) {
-    if (!ctx || !out || (len && !json)) return IPCFP_E_INVALID;
-    *out = nullptr;
-    IPCFP_ENTER(ctx);
-    JsonCursor js(json, size_t(len));
-    std::vector<RawEvent> ev;
-    std::vector<RawStorage> stg;
-    RawBlocks blocks;
+}  // extern "C"
+
+namespace {
+// The host half of the parse: tokenise, copy the claim fields out, locate every block's `cid` array and `data`
+// string.  What is left to the device is the CONTENT of those two (base64 alphabet / padding, CID bytes).
+bool tokenise_bundle(JsonCursor& js, uint32_t flags, std::vector<RawEvent>& ev, std::vector<RawStorage>& stg,
+                     RawBlocks& blocks) {
     Fields f(js);
     bool ok = parse_object(js, 1, [&](const std::string& k) -> int {
         if (k == "storage_proofs")
@@ -279,6 +278,42 @@ int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, ui
     });
     ok = ok && f.complete(7, "UnifiedProofBundle");
     if (ok && !js.at_end()) ok = js.fail("trailing characters");
+    return ok;
+}
+}  // namespace
+
+extern "C" {
+
+// Host half only — no context, no device: IPCFP_OK iff the text tokenises as a UnifiedProofBundle (structure,
+// field types, string escapes, base64 LENGTHS); the contents of `cid` arrays and `data` strings are what the
+// device checks in ipcfp_bundle_parse_json.  Exists so that the tokeniser can be tested without a GPU.
+int ipcfp_bundle_check_json(const char* json, uint64_t len, uint32_t flags, uint64_t* n_storage, uint64_t* n_events,
+                            uint64_t* n_blocks, char* err_out, uint32_t err_cap) {
+    if (len && !json) return IPCFP_E_INVALID;
+    JsonCursor js(json, size_t(len));
+    std::vector<RawEvent> ev;
+    std::vector<RawStorage> stg;
+    RawBlocks blocks;
+    const bool ok = tokenise_bundle(js, flags, ev, stg, blocks);
+    if (n_storage) *n_storage = stg.size();
+    if (n_events) *n_events = ev.size();
+    if (n_blocks) *n_blocks = blocks.spans.size();
+    if (err_out && err_cap) {
+        std::strncpy(err_out, ok ? "" : js.err.c_str(), err_cap - 1);
+        err_out[err_cap - 1] = 0;
+    }
+    return ok ? IPCFP_OK : IPCFP_E_PARSE;
+}
+
+int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, uint32_t flags, ipcfp_bundle_t** out) {
+    if (!ctx || !out || (len && !json)) return IPCFP_E_INVALID;
+    *out = nullptr;
+    IPCFP_ENTER(ctx);
+    JsonCursor js(json, size_t(len));
+    std::vector<RawEvent> ev;
+    std::vector<RawStorage> stg;
+    RawBlocks blocks;
+    bool ok = tokenise_bundle(js, flags, ev, stg, blocks);
     if (!ok)
         return set_error(ctx, IPCFP_E_PARSE, "bundle JSON: %s", js.err.c_str());
     const uint64_t n = blocks.spans.size();
