@@ -419,6 +419,16 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
                                      uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                                      const ipcfp_event_filter_t* filter, void* status_d);
 
+/* Host-only lowering of the reference's structs to the packed form (no context, no device; parallel over
+ * claims): what ipcfp_verify_event_proofs does before its upload, for callers that keep claims packed or
+ * resident in HBM and call ipcfp_verify_event_claims_device.  The handle owns the three arrays. */
+typedef struct ipcfp_packed_events ipcfp_packed_events_t;
+int ipcfp_pack_event_proofs(const ipcfp_event_proof_t* proofs, uint64_t n, ipcfp_packed_events_t** out);
+void ipcfp_packed_events_destroy(ipcfp_packed_events_t* p);
+const ipcfp_tipset_ref_t* ipcfp_packed_events_tipsets(const ipcfp_packed_events_t* p, uint32_t* n);
+const ipcfp_event_claim_t* ipcfp_packed_events_claims(const ipcfp_packed_events_t* p, uint64_t* n);
+const uint8_t* ipcfp_packed_events_blob(const ipcfp_packed_events_t* p, uint64_t* len);
+
 #define IPCFP_SCLAIM_CHILD_PARSED 1u        /* child_block_cid parses (storage/verifier.rs:85)              */
 #define IPCFP_SCLAIM_STATE_ROOT_CANON 2u    /* parent_state_root parses and equals its Cid::to_string()     */
 #define IPCFP_SCLAIM_ACTOR_STATE_CANON 4u

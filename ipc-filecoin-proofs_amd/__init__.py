@@ -15,6 +15,7 @@ from .binding import (  # noqa: F401
     Witness,
     Bundle,
     bundle_check_json,
+    pack_event_proofs,
     GEN_STORAGE_DTYPE,
     lib_path,
     load_library,

@@ -17,6 +17,7 @@ __all__ = [
     "Witness",
     "Bundle",
     "bundle_check_json",
+    "pack_event_proofs",
     "GEN_STORAGE_DTYPE",
     "lib_path",
     "load_library",
@@ -195,6 +196,11 @@ def load_library() -> C.CDLL:
         "ipcfp_generate_event_proofs": (i32, [vp, vp, vp, C.c_uint32, vp, vp, i32, u64, vp, vp, vp, u64, C.POINTER(u64),
                                               vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_generate_storage_proofs": (i32, [vp, vp, vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(u64)]),
+        "ipcfp_pack_event_proofs": (i32, [vp, u64, C.POINTER(vp)]),
+        "ipcfp_packed_events_destroy": (None, [vp]),
+        "ipcfp_packed_events_tipsets": (vp, [vp, C.POINTER(C.c_uint32)]),
+        "ipcfp_packed_events_claims": (vp, [vp, C.POINTER(u64)]),
+        "ipcfp_packed_events_blob": (vp, [vp, C.POINTER(u64)]),
         "ipcfp_bundle_parse_json": (i32, [vp, C.c_char_p, u64, C.c_uint32, C.POINTER(vp)]),
         "ipcfp_bundle_destroy": (None, [vp]),
         "ipcfp_bundle_check_json": (i32, [C.c_char_p, u64, C.c_uint32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
@@ -425,6 +431,31 @@ def pack_cids(cids) -> np.ndarray:
             raise EngineError(f"CID {i} is {len(c)} bytes; the ABI slot is {CID_SLOT}")
         out[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
     return out
+
+
+def pack_event_proofs(claims_arr, n: int):
+    """Host-only lowering of an array of ipcfp_event_proof_t (strings) to the packed ABI form (no GPU):
+    → (tipsets TIPSET_DTYPE[], claims CLAIM_DTYPE[n], blob u8[])."""
+    lib = load_library()
+    h = C.c_void_p()
+    rc = lib.ipcfp_pack_event_proofs(C.cast(claims_arr, C.c_void_p), n, C.byref(h))
+    if rc != 0:
+        raise EngineError(f"pack_event_proofs: {lib.ipcfp_strerror(rc).decode()} ({rc})")
+    try:
+        nt, nc, nb = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        pt = lib.ipcfp_packed_events_tipsets(h, C.byref(nt))
+        pc = lib.ipcfp_packed_events_claims(h, C.byref(nc))
+        pb = lib.ipcfp_packed_events_blob(h, C.byref(nb))
+
+        def view(ptr, count, dtype):
+            if not count:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype).copy()
+
+        return view(pt, nt.value, TIPSET_DTYPE), view(pc, nc.value, CLAIM_DTYPE), view(pb, nb.value, np.uint8)
+    finally:
+        lib.ipcfp_packed_events_destroy(h)
 
 
 def bundle_check_json(text: bytes, flags: int = 0):

@@ -16,6 +16,7 @@
 #include "../kernels/launch.h"
 #include "cidstr.h"
 #include "exec_state.h"
+#include "pack_claims.h"
 
 using namespace ipcfp;
 
@@ -166,16 +167,6 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
 
 }  // namespace ipcfp
 
-namespace {
-
-bool parse_hex0x(const char* s, bool allow_upper_x, std::vector<uint8_t>& out) {
-    // the reference formats "0x" + lowercase hex and compares ignoring ASCII case, so a claimed
-    // string matches iff it is '0' 'x'|'X' followed by hex digits of the same bytes
-    if (!s || s[0] != '0' || !(s[1] == 'x' || (allow_upper_x && s[1] == 'X'))) return false;
-    return hex_decode(s + 2, std::strlen(s + 2), out);
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -187,90 +178,22 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     if (n == 0) return IPCFP_OK;
     IPCFP_ENTER(ctx);
 
-    // ---- parse claims, group by tipset context ----
-    std::vector<EventClaimPacked> packed(n);
-    std::vector<uint8_t> blob;
-    std::vector<TipsetCtxDev> tcs;
-    std::unordered_map<std::string, uint32_t> ctx_index;
-    const char* const* last_parents = nullptr;
-    const char* last_child = nullptr;
-    uint32_t last_np = 0, last_ctx = 0;
-    bool have_last = false;
-    for (uint64_t i = 0; i < n; ++i) {
-        const ipcfp_event_proof_t& p = proofs[i];
-        EventClaimPacked& c = packed[i];
-        std::memset(&c, 0, sizeof c);
-        c.parent_epoch = p.parent_epoch;
-        c.child_epoch = p.child_epoch;
-        c.exec_index = p.exec_index;
-        c.event_index = p.event_index;
-        c.emitter = p.emitter;
-        // context
-        uint32_t ci;
-        if (have_last && p.parent_tipset_cids == last_parents && p.child_block_cid == last_child &&
-            p.n_parent_tipset_cids == last_np) {
-            ci = last_ctx;  // same string arrays as the previous proof
-        } else {
-            std::string key;
-            for (uint32_t k = 0; k < p.n_parent_tipset_cids; ++k) {
-                key += p.parent_tipset_cids[k] ? p.parent_tipset_cids[k] : "";
-                key.push_back('\n');
-            }
-            key.push_back('|');
-            key += p.child_block_cid ? p.child_block_cid : "";
-            auto it = ctx_index.find(key);
-            if (it == ctx_index.end()) {
-                if (p.n_parent_tipset_cids > kMaxParents)
-                    return set_error(ctx, IPCFP_E_UNSUPPORTED, "proof %llu names %u parent blocks (engine limit %u)",
-                                     (unsigned long long)i, p.n_parent_tipset_cids, kMaxParents);
-                TipsetCtxDev tc;
-                std::memset(&tc, 0, sizeof tc);
-                tc.n_parents = p.n_parent_tipset_cids;
-                bool all = true;
-                for (uint32_t k = 0; k < tc.n_parents; ++k) {
-                    bool parsed, canon;
-                    parse_cid_claim(p.parent_tipset_cids[k], tc.parents[k], parsed, canon);
-                    all = all && parsed;
-                }
-                if (all) tc.flags |= TC_PARENTS_PARSED;
-                bool parsed, canon;
-                parse_cid_claim(p.child_block_cid, tc.child, parsed, canon);
-                if (parsed) tc.flags |= TC_CHILD_PARSED;
-                ci = uint32_t(tcs.size());
-                tcs.push_back(tc);
-                ctx_index.emplace(std::move(key), ci);
-            } else {
-                ci = it->second;
-            }
-            last_parents = p.parent_tipset_cids;
-            last_child = p.child_block_cid;
-            last_np = p.n_parent_tipset_cids;
-            last_ctx = ci;
-            have_last = true;
-        }
-        c.context = ci;
-        bool parsed, canon;
-        parse_cid_claim(p.message_cid, c.message, parsed, canon);
-        if (parsed) c.flags |= EC_MSG_PARSED;
-        // topics: n × [matchable, 32 bytes]
-        c.n_topics = p.n_topics;
-        c.topics_off = uint32_t(blob.size());
-        for (uint32_t k = 0; k < p.n_topics; ++k) {
-            std::vector<uint8_t> t;
-            const bool ok = parse_hex0x(p.topics ? p.topics[k] : nullptr, true, t) && t.size() == 32;
-            blob.push_back(ok ? 1 : 0);
-            const size_t at = blob.size();
-            blob.resize(at + 32, 0);
-            if (ok) std::memcpy(blob.data() + at, t.data(), 32);
-        }
-        std::vector<uint8_t> d;
-        if (parse_hex0x(p.data, true, d)) {
-            c.flags |= EC_DATA_MATCHABLE;
-            c.data_off = uint32_t(blob.size());
-            c.data_len = uint32_t(d.size());
-            blob.insert(blob.end(), d.begin(), d.end());
-        }
-        if (blob.size() >= 0xf0000000ULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "claim blob too large");
+    // ---- parse claims, group by tipset context (host/pack_claims.cpp: parallel over claim ranges) ----
+    PackedEvents pk;
+    {
+        std::string perr;
+        const int prc = pack_event_claims_host(proofs, n, pk, perr);
+        if (prc) return set_error(ctx, prc, "%s", perr.c_str());
+    }
+    std::vector<EventClaimPacked>& packed = pk.claims;
+    std::vector<uint8_t>& blob = pk.blob;
+    std::vector<TipsetCtxDev> tcs(pk.tipsets.size());
+    for (size_t k = 0; k < tcs.size(); ++k) {
+        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
+        tcs[k].flags = pk.tipsets[k].flags;
+        tcs[k].n_parents = pk.tipsets[k].n_parents;
+        tcs[k].child = key_from_slot(pk.tipsets[k].child);
+        for (uint32_t j = 0; j < pk.tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(pk.tipsets[k].parents[j]);
     }
 
     // ---- upload, then the shared device path ----
