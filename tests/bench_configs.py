@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Measurements for BASELINE.json configs 2, 4 and 5 (the headline config 3 is bench.py).  One JSON
 line per config on stdout.  GPU box only; the oracle is used as the timed CPU baseline and as the
-checker of a sample."""
+checker of a sample — which is why this script lives under tests/ (only tests/, smoke() and bench.py's
+cpu_baseline leg touch oracle/).  `python tests/bench_configs.py`"""
 import json
 import os
 import sys
