@@ -220,7 +220,7 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "config3 tipset: %d receipts per GPU (Amtv0<Receipt> + one Amt<StampedEvent> each, 5 parent "
+                "workload": "BASELINE.json configs[2] (the 1M-receipt tipset the metric is quoted on): %d receipts per GPU (Amtv0<Receipt> + one Amt<StampedEvent> each, 5 parent "
                             "headers with TxMeta and message AMTs), %d witness blocks, %.3f GB; one EventProof claim per "
                             "receipt; step = CID index + Blake2b-256 CID check of every block + event-filter scan + "
                             "exec-order reconstruction + verify_event_proof of every claim" %
