@@ -448,6 +448,10 @@ typedef struct ipcfp_storage_claim {
     uint32_t reserved;
 } ipcfp_storage_claim_t;
 
+/* Host-only, parallel lowering of n StorageProof structs to packed claims (what ipcfp_verify_storage_proofs does
+ * before its upload), written to the caller's array of n ipcfp_storage_claim_t. */
+int ipcfp_pack_storage_proofs(const ipcfp_storage_proof_t* proofs, uint64_t n, ipcfp_storage_claim_t* claims);
+
 /* verify_storage_proof over packed claims resident in HBM (claims_d: n structs, status_d: n bytes). */
 int ipcfp_verify_storage_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const void* claims_d, uint64_t n,
                                        const ipcfp_trust_policy_t* trust, void* status_d);

@@ -16,6 +16,7 @@ from .binding import (  # noqa: F401
     Bundle,
     bundle_check_json,
     pack_event_proofs,
+    pack_storage_proofs,
     GEN_STORAGE_DTYPE,
     lib_path,
     load_library,

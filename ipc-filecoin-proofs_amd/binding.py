@@ -18,6 +18,7 @@ __all__ = [
     "Bundle",
     "bundle_check_json",
     "pack_event_proofs",
+    "pack_storage_proofs",
     "GEN_STORAGE_DTYPE",
     "lib_path",
     "load_library",
@@ -197,6 +198,7 @@ def load_library() -> C.CDLL:
                                               vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_generate_storage_proofs": (i32, [vp, vp, vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_pack_event_proofs": (i32, [vp, u64, C.POINTER(vp)]),
+        "ipcfp_pack_storage_proofs": (i32, [vp, u64, vp]),
         "ipcfp_packed_events_destroy": (None, [vp]),
         "ipcfp_packed_events_tipsets": (vp, [vp, C.POINTER(C.c_uint32)]),
         "ipcfp_packed_events_claims": (vp, [vp, C.POINTER(u64)]),
@@ -456,6 +458,16 @@ def pack_event_proofs(claims_arr, n: int):
         return view(pt, nt.value, TIPSET_DTYPE), view(pc, nc.value, CLAIM_DTYPE), view(pb, nb.value, np.uint8)
     finally:
         lib.ipcfp_packed_events_destroy(h)
+
+
+def pack_storage_proofs(claims_arr, n: int) -> np.ndarray:
+    """Host-only lowering of an array of ipcfp_storage_proof_t (strings) → SCLAIM_DTYPE[n] (no GPU)."""
+    lib = load_library()
+    out = np.zeros(n, dtype=SCLAIM_DTYPE)
+    rc = lib.ipcfp_pack_storage_proofs(C.cast(claims_arr, C.c_void_p), n, _p(out))
+    if rc != 0:
+        raise EngineError(f"pack_storage_proofs: {lib.ipcfp_strerror(rc).decode()} ({rc})")
+    return out
 
 
 def bundle_check_json(text: bytes, flags: int = 0):

@@ -173,6 +173,48 @@ int pack_event_claims_host(const ipcfp_event_proof_t* proofs, uint64_t n, Packed
 
 }  // namespace ipcfp
 
+namespace ipcfp {
+
+// One StorageProof → ipcfp_storage_claim_t: the same lowering ipcfp_verify_storage_proofs performs
+// (host/verify_storage.cpp), kept here as its own copy so that the exported, parallel packer could be added
+// without touching that path; the two are unified once this one has run on a GPU-side test.
+//   child_block_cid           must parse                                    (storage/verifier.rs:85)
+//   parent_state_root, actor_state_cid, storage_root   compared as STRINGS with `Cid::to_string()` of the
+//                             decoded value, so only a canonical spelling can match (:110,126,144)
+//   slot   hex::decode_to_slice(slot.trim_start_matches("0x"), &mut [u8; 32])  (:155-157)
+//   value  compared with "0x" + hex(padded) ignoring ASCII case               (:160-169)
+static void lower_storage_one(const ipcfp_storage_proof_t& p, StorageClaimPacked& c) {
+    std::memset(&c, 0, sizeof c);
+    c.child_epoch = p.child_epoch;
+    c.actor_id = p.actor_id;
+    bool parsed, canon;
+    parse_cid_claim(p.child_block_cid, c.child, parsed, canon);
+    if (parsed) c.flags |= SC_CHILD_PARSED;
+    parse_cid_claim(p.parent_state_root, c.state_root, parsed, canon);
+    if (parsed && canon) c.flags |= SC_STATE_ROOT_CANON;
+    parse_cid_claim(p.actor_state_cid, c.actor_state, parsed, canon);
+    if (parsed && canon) c.flags |= SC_ACTOR_STATE_CANON;
+    parse_cid_claim(p.storage_root, c.storage_root, parsed, canon);
+    if (parsed && canon) c.flags |= SC_STORAGE_ROOT_CANON;
+    std::vector<uint8_t> b;
+    if (p.slot) {
+        const char* s = p.slot;
+        while (s[0] == '0' && s[1] == 'x') s += 2;
+        if (std::strlen(s) == 64 && hex_decode(s, 64, b)) {
+            std::memcpy(c.slot, b.data(), 32);
+            c.flags |= SC_SLOT_PARSED;
+        }
+    }
+    if (p.value && std::strlen(p.value) == 66 && p.value[0] == '0' && (p.value[1] == 'x' || p.value[1] == 'X')) {
+        if (hex_decode(p.value + 2, 64, b)) {
+            std::memcpy(c.value, b.data(), 32);
+            c.flags |= SC_VALUE_MATCHABLE;
+        }
+    }
+}
+
+}  // namespace ipcfp
+
 struct ipcfp_packed_events {
     ipcfp::PackedEvents p;
 };
@@ -206,6 +248,28 @@ const ipcfp_event_claim_t* ipcfp_packed_events_claims(const ipcfp_packed_events_
 const uint8_t* ipcfp_packed_events_blob(const ipcfp_packed_events_t* p, uint64_t* len) {
     if (len) *len = p ? p->p.blob.size() : 0;
     return p ? p->p.blob.data() : nullptr;
+}
+
+// Host-only, parallel: n StorageProof structs → n ipcfp_storage_claim_t written to `claims` (caller's array).
+int ipcfp_pack_storage_proofs(const ipcfp_storage_proof_t* proofs, uint64_t n, ipcfp_storage_claim_t* claims) {
+    if (n && (!proofs || !claims)) return IPCFP_E_INVALID;
+    auto* out = reinterpret_cast<ipcfp::StorageClaimPacked*>(claims);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    const unsigned n_threads = unsigned(std::max<uint64_t>(1, std::min<uint64_t>({uint64_t(hw), 32, n / 4096})));
+    auto work = [&](unsigned t) {
+        const uint64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
+        for (uint64_t i = lo; i < hi; ++i) ipcfp::lower_storage_one(proofs[i], out[i]);
+    };
+    if (n_threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    return IPCFP_OK;
 }
 
 }  // extern "C"

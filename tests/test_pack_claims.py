@@ -72,3 +72,42 @@ def test_unparsable_strings_and_several_tipsets():
     o = int(cl["topics_off"][5])
     assert cl["n_topics"][5] == 3 and [int(blob[o + 33 * t]) for t in range(3)] == [0, 1, 0]
     assert blob[o + 34: o + 66].tobytes() == b"\xcd" * 32
+
+
+def storage_tip():
+    return Tipset(n_receipts=50, n_planted=1, n_actors=30000, n_contracts=100, slots_per_contract=200,
+                  storage_layout_mix=1, n_actor_queries=4, keep_full_state=0)
+
+
+def test_storage_claims_equal_numpy_packer():
+    """Strings → ipcfp_storage_claim_t, ≥ 8192 claims (several threads), byte for byte the numpy packer's output."""
+    tip = storage_tip()
+    n = len(tip.sc_actor)
+    assert n >= 2 * 8192
+    sc = claims.StorageClaims(tip)
+    got = ipcfp.pack_storage_proofs(sc.arr, sc.n)
+    want = ipcfp.pack_storage_claims(tip.child_cid, tip.state_root, tip.child_epoch, tip.sc_actor, tip.sc_actor_state,
+                                     tip.sc_storage_root, tip.sc_slot, tip.sc_value)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_storage_claims_with_unparsable_strings():
+    tip = Tipset(n_receipts=50, n_planted=1, n_actors=500, n_contracts=3, slots_per_contract=6, storage_layout_mix=1)
+    sc = claims.StorageClaims(tip, indices=np.arange(10))
+    good = claims.cid_str(tip.state_root)
+    sc.set_str(1, "child_block_cid", "nope")
+    sc.set_str(2, "parent_state_root", good.upper())          # parses, but is not the canonical spelling
+    sc.set_str(3, "actor_state_cid", "f" + tip.sc_actor_state[3, :38].tobytes().hex())  # base16 multibase: same
+    sc.set_str(4, "storage_root", "")
+    sc.set_str(5, "slot", "0x0x" + "11" * 32)                 # trim_start_matches strips every leading "0x"
+    sc.set_str(6, "slot", "0x" + "11" * 31)
+    sc.set_str(7, "value", "0X" + "AB" * 32)
+    sc.set_str(8, "value", "0x" + "ab" * 31)
+    sc.set_str(9, "value", "ab" * 33)
+    f = ipcfp.pack_storage_proofs(sc.arr, sc.n)["flags"]
+    assert f[0] == 63
+    assert f[1] == 63 & ~1 and f[2] == 63 & ~2 and f[3] == 63 & ~4 and f[4] == 63 & ~8
+    assert f[5] == 63 and f[6] == 63 & ~16
+    assert f[7] == 63 and f[8] == 63 & ~32 and f[9] == 63 & ~32
+    out = ipcfp.pack_storage_proofs(sc.arr, sc.n)
+    assert out["slot"][5].tobytes() == b"\x11" * 32 and out["value"][7].tobytes() == b"\xab" * 32
