@@ -14,6 +14,7 @@ use anyhow::{anyhow, Result};
 #[repr(C)] pub struct ipcfp_ctx_t { _p: [u8; 0] }
 #[repr(C)] pub struct ipcfp_witness_t { _p: [u8; 0] }
 #[repr(C)] pub struct ipcfp_bundle_t { _p: [u8; 0] }
+#[repr(C)] pub struct ipcfp_packed_events_t { _p: [u8; 0] }
 
 #[repr(C)]
 pub struct ipcfp_event_proof_t {
@@ -84,6 +85,10 @@ extern "C" {
     pub fn ipcfp_verify_proof_bundle(ctx: *mut ipcfp_ctx_t, b: *mut ipcfp_bundle_t, trust: *const ipcfp_trust_policy_t,
                                      filter: *const ipcfp_event_filter_t, storage_status: *mut u8,
                                      event_status: *mut u8) -> c_int;
+    // host-only, parallel lowering of the reference's structs to the packed claim form (no device involved)
+    pub fn ipcfp_pack_event_proofs(proofs: *const ipcfp_event_proof_t, n: u64, out: *mut *mut ipcfp_packed_events_t) -> c_int;
+    pub fn ipcfp_packed_events_destroy(p: *mut ipcfp_packed_events_t);
+    pub fn ipcfp_pack_storage_proofs(proofs: *const ipcfp_storage_proof_t, n: u64, claims: *mut u8 /* n × ipcfp_storage_claim_t */) -> c_int;
     // … the remaining primitives (ipcfp_amt_get, ipcfp_hamt_get, ipcfp_scan_events, ipcfp_exec_order,
     //   ipcfp_*_batch, ipcfp_verify_event_claims_device, profiling) bind the same way.
 }
