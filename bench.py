@@ -74,8 +74,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--receipts", type=int, default=1_000_000, help="receipts per GPU shard")
-    ap.add_argument("--cpu-sample", type=int, default=50_000, help="claims verified by the cpu_baseline leg")
+    ap.add_argument("--cpu-sample", type=int, default=50_000, help="claims the 1-thread cpu_baseline leg verifies")
+    ap.add_argument("--cpu-sample-mt", type=int, default=200_000, help="claims the all-cores cpu_baseline leg verifies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--t2-reps", type=int, default=3, help="repetitions of the PCIe-inclusive window (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -184,6 +186,46 @@ def main():
     if scan_result["status"] != 1 or scan_result["matches"] < len(tip.planted):
         raise SystemExit("bench self-check failed: the scan missed planted matches")
 
+    # ---- window T2: the same pass end to end from HOST memory — witness upload over PCIe, repack,
+    # CID index, K1, scan, claim upload, verify, status bytes and CID verdicts back.  `value` above is window T3
+    # (inputs resident in HBM); T2 is what the ≥10x-over-CPU claim is judged on.
+    t2 = None
+    if world == 1 and args.t2_reps > 0:
+        reps = []
+        for _ in range(args.t2_reps + 1):  # the first repetition warms the pinned ring and the allocator
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            w2 = eng.witness(tip.data, tip.off, tip.lens, tip.cids)
+            tb = time.perf_counter()
+            w2.verify_cids_async()
+            st2, _, nm2, _ = w2.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                            want_touched=False, counts_only=True)
+            tc_ = time.perf_counter()
+            status2 = w2.verify_event_claims(ts, cl, blob, blob_len)
+            td = time.perf_counter()
+            cs2, nbad2 = w2.cid_results()
+            te = time.perf_counter()
+            w2.close()
+            if st2 != 1 or nbad2 or not np.array_equal(status2, status) or nm2 != scan_result["matches"]:
+                raise SystemExit("bench self-check failed: the from-host pass differs from the resident one")
+            reps.append({"total": te - ta, "witness_create_h2d_repack_index": tb - ta, "k1_launch_scan": tc_ - tb,
+                         "claims_h2d_verify_status_d2h": td - tc_, "cid_verdicts_d2h": te - td})
+        reps = reps[1:]
+        best = min(reps, key=lambda r: r["total"])
+        h2d_bytes = int(tip.data.size + tip.off.nbytes + tip.lens.nbytes + tip.cids.nbytes + cl.nbytes + blob_len)
+        t2 = {"value": n_claims / best["total"], "unit": "proofs/s", "ms_per_tipset": best["total"] * 1e3,
+              "ms_phases": {k: round(v * 1e3, 3) for k, v in best.items() if k != "total"},
+              "h2d_bytes": h2d_bytes, "h2d_GBps_if_all_transfer": h2d_bytes / best["total"] / 1e9, "reps": len(reps),
+              "ms_all_reps": [round(r["total"] * 1e3, 3) for r in reps],
+              "note": "pageable host numpy buffers in, host status bytes out; claims in packed binary form"}
+
+    # ---- the full scan result, untimed, for the oracle cross-check of the cpu_baseline leg ----
+    gpu_scan = None
+    if world == 1 and not args.no_cpu_baseline:
+        gs, ghas, gm, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                        want_touched=False)
+        gpu_scan = (gs, ghas, gm)
+
     kern = {}
     for k in ("blake2b_cid", "cid_index", "event_scan", "replay", "event_verify", "exec_order"):
         cnt, ms = eng.profile_read(k)
@@ -250,8 +292,15 @@ def main():
             },
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kern.items()},
         }
+        if t2 is not None:
+            out["value_T2"] = t2["value"]
+            out["window_T2"] = t2
+        out["window"] = "T3 (inputs resident in HBM; index rebuilt and every cached enumeration dropped each step)"
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(tip, status, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(tip, status, args.cpu_sample, args.cpu_sample_mt, cid_status, gpu_scan)
+            cb = out["cpu_baseline"]
+            out["speedup_vs_cpu_all_cores"] = {"T3": out["value"] / cb["value"],
+                                               "T2": (t2["value"] / cb["value"]) if t2 else None}
         print(json.dumps(out))
     w.close()
     eng.close()
@@ -259,59 +308,118 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(tip, gpu_status, sample):
-    """The scalar C++ oracle — a restatement of the reference path; the Rust reference cannot be built in
-    this image — timed on this box's host cores.  Variant B2 of BASELINE.md §2: witness store and
-    execution order built once (the as-written reference rebuilds the execution order per proof, which
-    is quadratic and cannot finish at this size).  The fixed parts of the step run on the FULL tipset;
-    the per-claim verifier runs on a bounded sample and is scaled linearly to all claims.  The sample's
-    verdicts double as a check of the GPU's."""
+def cpu_baseline(tip, gpu_status, sample, sample_mt=None, gpu_cid_status=None, gpu_scan=None):
+    """The C++ oracle — a restatement of the reference path; the Rust reference cannot be built in this image —
+    compiled on THIS box with -O3 -march=native and timed on its host cores.  Variant B2 of BASELINE.md §2
+    (witness store and execution order built once per tipset), single thread AND all cores; `value` is the
+    all-cores number, the strongest CPU figure.  Variant B1 (as written: execution order rebuilt per proof,
+    quadratic) is timed on a reduced tipset and labelled as such.  The fixed parts of the step run on the FULL
+    tipset; the per-claim verifier runs on a bounded sample and is scaled linearly.  Everything the oracle
+    computes on the way doubles as a check of what the GPU reported."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import claims as claims_mod
     import oracle_lib
+    from tools.synth import Tipset
 
-    orc = oracle_lib.load()
+    orc, march = oracle_lib.load_native()
+    cores = orc.num_procs()
     n = len(tip.claim_exec)
     sample = min(sample, n)
-    t0 = time.perf_counter()
-    st = orc.store(tip.data, tip.off, tip.lens, tip.cids)
-    t_store = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ok, good = orc.blake2b256_verify(tip.data, tip.off, tip.lens, np.ascontiguousarray(tip.cids[:, 6:38]))
-    t_cid = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    s, has, trip, _ = st.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
-                                     want_touched=False)
-    t_scan = time.perf_counter() - t0
+    sample_mt = min(sample_mt or sample, n)
+    expect32 = np.ascontiguousarray(tip.cids[:, 6:38])
+    ecs = {1: claims_mod.EventClaims(tip, indices=np.arange(sample))}
+    ecs[0] = ecs[1] if sample_mt == sample else claims_mod.EventClaims(tip, indices=np.arange(sample_mt))
     ec1 = claims_mod.EventClaims(tip, indices=np.arange(1))
-    ecs = claims_mod.EventClaims(tip, indices=np.arange(sample))
+    legs = {}
+    for threads in (1, 0):
+        sec = {}
+        st = None
+        for _ in range(2):  # the second build finds the allocator's arenas grown; keep the better of the two
+            if st is not None:
+                st.close()
+            t0 = time.perf_counter()
+            st = orc.store(tip.data, tip.off, tip.lens, tip.cids, threads=threads)
+            dt = time.perf_counter() - t0
+            sec["store_build"] = min(sec.get("store_build", dt), dt)
+        t0 = time.perf_counter()
+        ok, good = orc.blake2b256_verify(tip.data, tip.off, tip.lens, expect32, threads=threads)
+        sec["cid_check"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        s, has, trip, _ = st.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                         want_touched=False, threads=threads)
+        sec["event_scan"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        st.verify_event_proofs(ec1, mode=2, threads=threads)  # builds the execution order kept in the store
+        sec["exec_order"] = time.perf_counter() - t0
+        e = ecs[threads]
+        t0 = time.perf_counter()
+        got = st.verify_event_proofs(e, mode=2, threads=threads)
+        sec["verify_sample"] = time.perf_counter() - t0
+        st.close()
+        # ---- the oracle's results against the GPU's ----
+        if good != int((gpu_cid_status == 1).sum() if gpu_cid_status is not None else tip.n_blocks) or s != 1:
+            raise SystemExit("cpu_baseline: the oracle's CID check / scan status differs from the GPU's")
+        if gpu_cid_status is not None and not np.array_equal(ok, (gpu_cid_status == 1).astype(np.uint8)):
+            raise SystemExit("cpu_baseline: per-block CID verdicts differ from the GPU's")
+        if not np.array_equal(got, gpu_status[:e.n]):
+            raise SystemExit("cpu_baseline: the oracle's verdicts differ from the GPU's on the sample")
+        if gpu_scan is not None:
+            gs, ghas, gm = gpu_scan
+            same = (gs == s and np.array_equal(ghas, has) and len(gm) == len(trip) and
+                    np.array_equal(gm["exec_index"], trip[:, 0]) and np.array_equal(gm["event_index"], trip[:, 1]) and
+                    np.array_equal(gm["emitter"], trip[:, 2]))
+            if not same:
+                raise SystemExit("cpu_baseline: the oracle's scan (has-match map / match list) differs from the GPU's")
+        fixed = sec["store_build"] + sec["cid_check"] + sec["event_scan"] + sec["exec_order"]
+        sec["step"] = fixed + sec["verify_sample"] * (n / e.n)
+        sec["verify_sample_claims"] = e.n
+        legs[threads] = sec
+    # ---- variant B1, as written, on a reduced tipset (never extrapolated) ----
+    nb1 = 1500
+    tb = Tipset(n_receipts=nb1, n_parents=5, dup_permille=20, n_planted=3, max_events=4, no_events_permille=0, variety=0)
+    eb = claims_mod.EventClaims(tb)
+    sb = orc.store(tb.data, tb.off, tb.lens, tb.cids)
     t0 = time.perf_counter()
-    st.verify_event_proofs(ec1, mode=1, threads=1)  # builds the execution-order cache: the fixed part
-    t_exec = time.perf_counter() - t0
+    r0 = sb.verify_event_proofs(eb, mode=0)
+    t_b1 = time.perf_counter() - t0
     t0 = time.perf_counter()
-    s1 = st.verify_event_proofs(ecs, mode=1, threads=1)
-    t_sample = max(time.perf_counter() - t0 - t_exec, 1e-9)
-    t0 = time.perf_counter()
-    sall = st.verify_event_proofs(ecs, mode=1, threads=0)
-    t_sample_mt = max(time.perf_counter() - t0 - t_exec, 1e-9)
-    if good != tip.n_blocks or s != 1 or not np.array_equal(s1, gpu_status[:sample]) or not np.array_equal(s1, sall):
-        raise SystemExit("cpu_baseline: the oracle's verdicts differ from the GPU's on the sample")
-    fixed = t_store + t_cid + t_scan + t_exec
-    t_step_1 = fixed + t_sample * (n / sample)
-    t_step_mt = fixed + t_sample_mt * (n / sample)
+    r1 = sb.verify_event_proofs(eb, mode=1, threads=1)
+    t_b2_small = time.perf_counter() - t0
+    sb.close()
+    if not np.array_equal(r0, r1) or not (r0 == 1).all():
+        raise SystemExit("cpu_baseline: B1 and B2 disagree on the reduced tipset")
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
-        "value": n / t_step_1,
+        "value": n / legs[0]["step"],
         "unit": "proofs/s",
-        "cores": 1,
+        "cores": cores,
         "kind": "port",
-        "sample": "scalar C++ oracle (restatement of the reference; the Rust crate cannot be built here), -O3, 1 thread: "
-                  "store build + Blake2b CID check + event scan + exec-order on the FULL %d-receipt tipset, "
-                  "verify_event_proof on the first %d of %d claims scaled linearly; exec order cached per tipset "
-                  "(BASELINE.md variant B2)" % (tip.params["n_receipts"], sample, n),
-        "seconds": {"store_build": t_store, "cid_check": t_cid, "event_scan": t_scan, "exec_order": t_exec,
-                    "verify_sample": t_sample, "verify_sample_all_threads": t_sample_mt, "step_1_thread": t_step_1},
-        "value_verify_all_host_threads": n / t_step_mt,
+        "sample": "C++ oracle (restatement of the reference; the Rust crate cannot be built here), g++ -O3 -march=%s, "
+                  "OpenMP on all %d host processors: sharded store build + Blake2b CID check + two-pass event scan + "
+                  "exec-order on the FULL %d-receipt tipset, verify_event_proof on the first %d of %d claims scaled "
+                  "linearly; store and exec order built once per tipset (BASELINE.md variant B2 all-cores)"
+                  % (march, cores, tip.params["n_receipts"], legs[0]["verify_sample_claims"], n),
+        "seconds": {k: v for k, v in legs[0].items()},
+        "value_1_thread": n / legs[1]["step"],
+        "seconds_1_thread": {k: v for k, v in legs[1].items()},
+        "scaling_1_to_all": legs[1]["step"] / legs[0]["step"],
+        "b1_as_written": {"receipts": nb1, "proofs_per_s": eb.n / t_b1, "seconds": t_b1,
+                          "b2_1_thread_same_tipset_proofs_per_s": eb.n / t_b2_small,
+                          "note": "reference semantics incl. per-proof execution-order rebuild "
+                                  "(events/verifier.rs:190): quadratic, measured at %d receipts, NOT extrapolated" % nb1},
         "host_cpus": os.cpu_count(),
+        "cpu_model": cpu_model,
+        "march": march,
+        "checked_against_gpu": "every block's CID verdict, scan status + has-match map + (exec, event, emitter) match "
+                               "list, and the status byte of every sampled claim",
     }
 
 

@@ -185,6 +185,9 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
 /* Launch-only form: results stay in HBM; read them with the accessors below
  * after ipcfp_ctx_sync().                                                      */
 int ipcfp_witness_verify_cids_async(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);
+/* Results of the last ipcfp_witness_verify_cids_async on this witness (waits for it): same outputs as
+ * ipcfp_witness_verify_cids, without launching K1 again.                          */
+int ipcfp_witness_cid_results(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* status, uint64_t* n_bad);
 /* Device pointers owned by the witness: the ⌈n/32⌉-word OK bitmap (bit i of
  * word i/32 set ⇔ block i is IPCFP_CID_OK) — the buffer a multi-GPU host
  * all-gathers — and the n status bytes.                                        */
@@ -413,11 +416,20 @@ typedef struct ipcfp_event_claim {
 
 /* verify_event_proof over packed claims resident in HBM.  `tipsets` is a small HOST table;
  * claims_d / blob_d / status_d are DEVICE pointers (n claims, blob_len bytes, n status bytes).
- * Synchronous: returns after the status bytes are written.                                   */
+ * Synchronous: returns after the status bytes are written.  A claim whose `tipset` index or blob offsets
+ * fall outside n_tipsets / blob_len gets IPCFP_ST_ERR_BAD_CLAIM (never followed).                */
 int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets,
                                      uint32_t n_tipsets, const void* claims_d, uint64_t n, const void* blob_d,
                                      uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                                      const ipcfp_event_filter_t* filter, void* status_d);
+
+/* The same over packed claims in HOST memory (tipsets, claims, blob, status: host): upload, verify, status bytes
+ * back — the PCIe-inclusive form of verify_event_proof for callers that hold binary claims
+ * (src/proofs/events/verifier.rs:51-74).                                                           */
+int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets,
+                              uint32_t n_tipsets, const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob,
+                              uint64_t blob_len, const ipcfp_trust_policy_t* trust,
+                              const ipcfp_event_filter_t* filter, ipcfp_status_t* status);
 
 /* Host-only lowering of the reference's structs to the packed form (no context, no device; parallel over
  * claims): what ipcfp_verify_event_proofs does before its upload, for callers that keep claims packed or

@@ -177,6 +177,7 @@ def load_library() -> C.CDLL:
         "ipcfp_witness_byte_count": (u64, [vp]),
         "ipcfp_witness_verify_cids": (i32, [vp, vp, vp, C.POINTER(u64)]),
         "ipcfp_witness_verify_cids_async": (i32, [vp, vp]),
+        "ipcfp_witness_cid_results": (i32, [vp, vp, vp, C.POINTER(u64)]),
         "ipcfp_witness_cid_bitmap_device": (vp, [vp]),
         "ipcfp_witness_cid_status_device": (vp, [vp]),
         "ipcfp_blake2b256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
@@ -187,6 +188,7 @@ def load_library() -> C.CDLL:
         "ipcfp_exec_order": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_scan_events": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
         "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
+        "ipcfp_verify_event_claims": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
         "ipcfp_verify_storage_claims_device": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_cid_from_string": (i32, [C.c_char_p, vp]),
@@ -574,6 +576,13 @@ class Witness:
         self.eng._check(self.lib.ipcfp_witness_verify_cids(self.eng.h, self.h, _p(st), C.byref(bad)), "verify_cids")
         return st, int(bad.value)
 
+    def cid_results(self, want_status=True):
+        """(status u8[n] | None, n_bad) of the last verify_cids_async — waits for it, launches nothing."""
+        st = np.zeros(self.n, dtype=np.uint8) if want_status else None
+        bad = C.c_uint64()
+        self.eng._check(self.lib.ipcfp_witness_cid_results(self.eng.h, self.h, _p(st), C.byref(bad)), "cid_results")
+        return st, int(bad.value)
+
     def verify_cids_async(self):
         self.eng._check(self.lib.ipcfp_witness_verify_cids_async(self.eng.h, self.h), "verify_cids_async")
 
@@ -719,6 +728,19 @@ class Witness:
             self.eng.h, self.h, _p(tipsets), len(tipsets), claims_ptr, n, blob_ptr, blob_len,
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, status_ptr), "verify_event_claims_device")
+
+    def verify_event_claims(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray, blob_len: int,
+                            trust=None, filt=None) -> np.ndarray:
+        """Packed claims in HOST memory: upload + verify + status bytes back (PCIe-inclusive)."""
+        tipsets = np.ascontiguousarray(tipsets, dtype=TIPSET_DTYPE)
+        claims = np.ascontiguousarray(claims, dtype=CLAIM_DTYPE)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        st = np.zeros(len(claims), dtype=np.uint8)
+        self.eng._check(self.lib.ipcfp_verify_event_claims(
+            self.eng.h, self.h, _p(tipsets), len(tipsets), _p(claims), len(claims), _p(blob), blob_len,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st)), "verify_event_claims")
+        return st
 
     @property
     def cid_bitmap_ptr(self) -> int:

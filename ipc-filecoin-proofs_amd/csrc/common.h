@@ -29,6 +29,9 @@ struct DevPool {
 };
 extern thread_local DevPool* g_tls_pool;
 
+struct UploadRing;  // host/upload.cpp
+void upload_ring_destroy(UploadRing* r);
+
 struct ProfiledLaunch {
     int kernel_id;
     hipEvent_t start, stop;
@@ -65,6 +68,7 @@ struct ipcfp_ctx {
     };
     std::vector<PendingRead> pending;
     int call_depth = 0;
+    ipcfp::UploadRing* upload_ring = nullptr;  // pinned staging ring of ipcfp::upload (created on first use)
 };
 
 namespace ipcfp {
@@ -107,6 +111,10 @@ inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
     }
     return e;
 }
+
+// Pageable (or pinned) host memory → HBM, stream-ordered on `s`; large transfers are staged by several threads
+// through the context's pinned ring (host/upload.cpp).
+int upload(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t bytes, hipStream_t s);
 
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfileScope {

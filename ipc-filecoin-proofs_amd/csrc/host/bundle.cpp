@@ -244,7 +244,14 @@ bool parse_block(JsonCursor& js, uint32_t flags, RawBlocks& b) {
     return true;
 }
 
+// Claim strings cross the C ABI NUL-terminated, but a JSON string may hold "\u0000".  Cutting the string there
+// would let `"bafy…\u0000junk"` verify as if the suffix were absent, where the reference sees a string that
+// neither parses (`Cid::try_from`, hex::decode) nor compares equal (`==`, eq_ignore_ascii_case).  Every NUL is
+// replaced by 0x01: a byte that, like NUL, is in no multibase / hex alphabet and equals no character of a
+// canonical form — so each field keeps the reference's outcome (Err for a parsed field, Ok(false) for a compared one).
 const char* keep(ipcfp_bundle& b, std::string&& s) {
+    for (char& c : s)
+        if (c == '\0') c = '\x01';
     b.strings.push_back(std::move(s));
     return b.strings.back().c_str();
 }

@@ -80,13 +80,20 @@ int pack_event_claims_host(const ipcfp_event_proof_t* proofs, uint64_t n, Packed
             p.n_parent_tipset_cids == last_np) {
             ci = last_ctx;  // same string arrays as the previous proof
         } else {
+            // length-prefixed, so that no two distinct (parents…, child) tuples share a key: count, then
+            // (length, bytes) per string — a null pointer is length 0xffffffff
             std::string key;
-            for (uint32_t k = 0; k < p.n_parent_tipset_cids; ++k) {
-                key += p.parent_tipset_cids && p.parent_tipset_cids[k] ? p.parent_tipset_cids[k] : "";
-                key.push_back('\n');
-            }
-            key.push_back('|');
-            key += p.child_block_cid ? p.child_block_cid : "";
+            auto put_u32 = [&key](uint32_t v) { key.append(reinterpret_cast<const char*>(&v), 4); };
+            auto put_str = [&](const char* str) {
+                if (!str) return put_u32(0xffffffffu);
+                const size_t l = std::strlen(str);
+                put_u32(uint32_t(l));
+                key.append(str, l);
+            };
+            put_u32(p.n_parent_tipset_cids);
+            for (uint32_t k = 0; k < p.n_parent_tipset_cids; ++k)
+                put_str(p.parent_tipset_cids ? p.parent_tipset_cids[k] : nullptr);
+            put_str(p.child_block_cid);
             auto it = ctx_index.find(key);
             if (it == ctx_index.end()) {
                 if (p.n_parent_tipset_cids > uint32_t(IPCFP_MAX_PARENTS)) {

@@ -79,7 +79,7 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
 // Shared device path of the string and the packed entry points: prepare every tipset context
 // (header facts, execution order) and verify the batch.  `claims_d`, `blob_d`, `status_d` are device.
 int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
-                  uint32_t n, const uint8_t* blob_d, const ipcfp_trust_policy_t* trust,
+                  uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                   const ipcfp_event_filter_t* filter, uint8_t* status_d) {
     static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
     const WitnessView view = witness_view(w);
@@ -159,7 +159,8 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
             rc = launch_set_exec_len(ctx, tcs_d.p + k, execs[k]->total.p);
             if (rc) return rc;
         }
-    rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, blob_d, trust ? *trust : accept_all, filter, status_d);
+    rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, uint32_t(tcs.size()), blob_d, blob_len,
+                              trust ? *trust : accept_all, filter, status_d);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // contexts / exec tables are released on return
     return IPCFP_OK;
@@ -205,7 +206,7 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     IPCFP_HIP(ctx, hipMemcpyAsync(cd.p, packed.data(), n * sizeof(EventClaimPacked), hipMemcpyHostToDevice, ctx->stream));
     if (!blob.empty())
         IPCFP_HIP(ctx, hipMemcpyAsync(bd.p, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
-    int rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, trust, filter, sd.p);
+    int rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, blob.size(), trust, filter, sd.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
@@ -216,7 +217,6 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
                                      uint32_t n_tipsets, const void* claims_d, uint64_t n, const void* blob_d,
                                      uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                                      const ipcfp_event_filter_t* filter, void* status_d) {
-    (void)blob_len;
     if (!ctx || !w || w->ctx != ctx || (n && (!claims_d || !status_d || !tipsets))) return IPCFP_E_INVALID;
     if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
     if (n == 0) return IPCFP_OK;
@@ -231,8 +231,44 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
         for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
     }
     int rc = verify_packed(ctx, w, tcs, static_cast<const EventClaimPacked*>(claims_d), uint32_t(n),
-                           static_cast<const uint8_t*>(blob_d), trust, filter, static_cast<uint8_t*>(status_d));
+                           static_cast<const uint8_t*>(blob_d), blob_len, trust, filter, static_cast<uint8_t*>(status_d));
     if (rc) return rc;
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    return IPCFP_OK;
+}
+
+// Packed claims in HOST memory: upload, verify, status bytes back (the T2 window of the benchmarks: PCIe inclusive).
+int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets, uint32_t n_tipsets,
+                              const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob, uint64_t blob_len,
+                              const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                              ipcfp_status_t* status) {
+    if (!ctx || !w || w->ctx != ctx || (n && (!claims || !status || !tipsets)) || (blob_len && !blob)) return IPCFP_E_INVALID;
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    if (n == 0) return IPCFP_OK;
+    IPCFP_ENTER(ctx);
+    std::vector<TipsetCtxDev> tcs(n_tipsets);
+    for (uint32_t k = 0; k < n_tipsets; ++k) {
+        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
+        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
+        tcs[k].flags = tipsets[k].flags;
+        tcs[k].n_parents = tipsets[k].n_parents;
+        tcs[k].child = key_from_slot(tipsets[k].child);
+        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
+    }
+    DevBuf<EventClaimPacked> cd;
+    DevBuf<uint8_t> bd, sd;
+    IPCFP_HIP(ctx, cd.alloc(n));
+    IPCFP_HIP(ctx, bd.alloc(blob_len + 64));
+    IPCFP_HIP(ctx, sd.alloc(n));
+    int rc = upload(ctx, cd.p, claims, n * sizeof(EventClaimPacked), ctx->stream);
+    if (rc) return rc;
+    if (blob_len) {
+        rc = upload(ctx, bd.p, blob, blob_len, ctx->stream);
+        if (rc) return rc;
+    }
+    rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, blob_len, trust, filter, sd.p);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }

@@ -104,13 +104,15 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
     IPCFP_HIP(ctx, raw_off.alloc(n));
     IPCFP_HIP(ctx, raw_len.alloc(n));
     IPCFP_HIP(ctx, raw_cids.alloc(n * IPCFP_CID_SLOT));
-    if (nbytes) IPCFP_HIP(ctx, hipMemcpyAsync(raw_bytes.p, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = IPCFP_OK;
+    // tables first: the layout kernels only need len[] and can run while the payload is still crossing PCIe
     if (n) {
-        IPCFP_HIP(ctx, hipMemcpyAsync(raw_off.p, off, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        IPCFP_HIP(ctx, hipMemcpyAsync(raw_len.p, len, n * 4, hipMemcpyHostToDevice, ctx->stream));
-        IPCFP_HIP(ctx, hipMemcpyAsync(raw_cids.p, cids40, n * IPCFP_CID_SLOT, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload(ctx, raw_len.p, len, n * 4, ctx->stream))) return rc;
+        if ((rc = upload(ctx, raw_off.p, off, n * 8, ctx->stream))) return rc;
+        if ((rc = upload(ctx, raw_cids.p, cids40, n * IPCFP_CID_SLOT, ctx->stream))) return rc;
     }
-    int rc = finish_create(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p, true);
+    if (nbytes && (rc = upload(ctx, raw_bytes.p, bytes, nbytes, ctx->stream))) return rc;
+    rc = finish_create(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p, true);
     if (rc) return rc;
     *out = w.release();
     return IPCFP_OK;
@@ -160,6 +162,19 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
     IPCFP_ENTER(ctx);
     int rc = ipcfp_witness_verify_cids_async(ctx, w);
     if (rc) return rc;
+    unsigned long long bad = 0;
+    if (status && w->n)
+        IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream_k1));
+    IPCFP_HIP(ctx, d2h_small(ctx, &bad, w->counters.p, sizeof bad, ctx->stream_k1));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream_k1));
+    if (n_bad) *n_bad = bad;
+    return IPCFP_OK;
+}
+
+// Results of the last ipcfp_witness_verify_cids_async: waits for K1's stream, copies back.
+int ipcfp_witness_cid_results(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* status, uint64_t* n_bad) {
+    if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
+    IPCFP_ENTER(ctx);
     unsigned long long bad = 0;
     if (status && w->n)
         IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream_k1));

@@ -144,11 +144,13 @@ struct CidSpan {
 };
 
 __device__ __forceinline__ bool uvarint_dev(const uint8_t* p, uint32_t n, uint32_t& pos, uint64_t& v) {
+    // unsigned-varint as `Cid::read_bytes` reads it: at most 9 bytes, and a non-minimal form (a zero final byte
+    // after the first) is rejected — the same rule as Rd::cid_ok and the host's cidstr.cpp
     v = 0;
     for (int i = 0; i < 9 && pos < n; ++i) {
         const uint8_t b = p[pos++];
         v |= uint64_t(b & 0x7f) << (7 * i);
-        if (!(b & 0x80)) return true;
+        if (!(b & 0x80)) return !(b == 0 && i > 0);
     }
     return false;
 }

@@ -66,8 +66,8 @@ int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leave
 int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const uint32_t* first_d,
                         const uint32_t* pos_d, CidKey* out_d);
 int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
-                         const TipsetCtxDev* ctxs_d, const uint8_t* blob_d, const ipcfp_trust_policy_t& trust,
-                         const ipcfp_event_filter_t* filter, uint8_t* status_d);
+                         const TipsetCtxDev* ctxs_d, uint32_t n_ctxs, const uint8_t* blob_d, uint64_t blob_len,
+                         const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d);
 
 // --- event_scan.hip (K6 scan, K8 replay bitmap) ---
 int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,

@@ -393,14 +393,26 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     return IPCFP_ST_TRUE;
 }
 
+// A packed claim that points outside the tipset table or the blob (only a caller of the packed entry points can
+// build one; the string lowering cannot) is answered with ERR_BAD_CLAIM instead of being followed.
+__device__ __forceinline__ bool claim_in_bounds(const EventClaimPacked& c, uint32_t n_ctxs, uint64_t blob_len) {
+    return c.context < n_ctxs && c.n_topics <= (1u << 20) && uint64_t(c.topics_off) + 33ull * c.n_topics <= blob_len &&
+           uint64_t(c.data_off) + c.data_len <= blob_len;
+}
+
 __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(WitnessView w, const EventClaimPacked* __restrict__ claims,
-                                                       uint32_t n, const TipsetCtxDev* __restrict__ ctxs,
-                                                       const uint8_t* __restrict__ blob, ipcfp_trust_policy_t trust,
+                                                       uint32_t n, const TipsetCtxDev* __restrict__ ctxs, uint32_t n_ctxs,
+                                                       const uint8_t* __restrict__ blob, uint64_t blob_len,
+                                                       ipcfp_trust_policy_t trust,
                                                        ipcfp_event_filter_t filter, int has_filter,
                                                        uint8_t* __restrict__ status) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const EventClaimPacked& c = claims[t];
+    if (!claim_in_bounds(c, n_ctxs, blob_len)) {
+        status[t] = IPCFP_ST_ERR_BAD_CLAIM;
+        return;
+    }
     status[t] = uint8_t(verify_event_one(w, c, ctxs[c.context], blob, trust, filter, has_filter != 0));
 }
 
@@ -464,15 +476,15 @@ int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const 
 }
 
 int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
-                         const TipsetCtxDev* ctxs_d, const uint8_t* blob_d, const ipcfp_trust_policy_t& trust,
-                         const ipcfp_event_filter_t* filter, uint8_t* status_d) {
+                         const TipsetCtxDev* ctxs_d, uint32_t n_ctxs, const uint8_t* blob_d, uint64_t blob_len,
+                         const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d) {
     if (n == 0) return IPCFP_OK;
     ipcfp_event_filter_t f{};
     if (filter) f = *filter;
     {
         ProfileScope prof(ctx, IPCFP_K_EVENT_VERIFY);
         hipLaunchKernelGGL(k_verify_events, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, claims_d, n, ctxs_d,
-                           blob_d, trust, f, filter ? 1 : 0, status_d);
+                           n_ctxs, blob_d, blob_len, trust, f, filter ? 1 : 0, status_d);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

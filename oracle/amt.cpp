@@ -1,6 +1,10 @@
 // oracle/amt.cpp — TEST INFRASTRUCTURE (see amt.hpp for provenance).
 #include "amt.hpp"
 
+#include <omp.h>
+
+#include <memory>
+
 namespace orc {
 
 namespace {
@@ -138,6 +142,95 @@ void amt_for_each(const Blockstore& bs, const AmtRoot& root, const ValueChecker&
                   const std::function<void(uint64_t, const ValueLoc&)>& f) {
     Node nd = root_node(root, check);
     node_for_each(bs, nd, root.height, root.bit_width, 0, check, f);
+}
+
+
+int use_threads(int threads) {
+    const int n = threads > 0 ? threads : omp_get_num_procs();
+    omp_set_num_threads(n);  // sticky: every parallel entry point sets it explicitly
+    return n;
+}
+
+namespace {
+// one subtree of the frontier, or the failure met where it would have been loaded
+struct Sub {
+    std::unique_ptr<Node> node;
+    uint64_t height = 0, base = 0;
+    bool failed = false;
+    uint8_t status = 0;
+    std::string what;
+    std::vector<AmtItem> items;
+};
+}  // namespace
+
+void amt_collect(const Blockstore& bs, const AmtRoot& root, const ValueChecker& check, std::vector<AmtItem>& out,
+                 int threads) {
+    out.clear();
+    const int nthreads = use_threads(threads);
+    std::vector<Sub> frontier(1);
+    frontier[0].node.reset(new Node(root_node(root, check)));
+    frontier[0].height = root.height;
+    frontier[0].base = 0;
+    // expand level by level until there is enough independent work; a child that fails to load stays in the
+    // frontier as a failure AT ITS POSITION, so the first failure in depth-first order can be told at the end
+    while (frontier.size() < size_t(nthreads) * 8) {
+        bool any_link = false;
+        for (const Sub& s : frontier) any_link = any_link || (!s.failed && s.node->is_link);
+        if (!any_link) break;
+        std::vector<Sub> next;
+        for (Sub& s : frontier) {
+            if (s.failed || !s.node->is_link) {
+                next.push_back(std::move(s));
+                continue;
+            }
+            if (s.height == 0) {
+                Sub f;
+                f.failed = true;
+                f.status = IPCFP_ST_ERR_DECODE;
+                f.what = "AMT link node at height 0";
+                next.push_back(std::move(f));
+                continue;
+            }
+            const uint64_t span = nodes_for_height(root.bit_width, s.height);
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < s.node->width; ++i) {
+                if (!s.node->bit(i)) continue;
+                Sub c;
+                c.height = s.height - 1;
+                c.base = s.base + uint64_t(i) * span;
+                try {
+                    c.node.reset(new Node(load_child(bs, s.node->links[k], root.bit_width, check)));
+                } catch (const Err& e) {
+                    c.failed = true;
+                    c.status = e.status;
+                    c.what = e.what();
+                }
+                ++k;
+                next.push_back(std::move(c));
+            }
+        }
+        frontier.swap(next);
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t q = 0; q < int64_t(frontier.size()); ++q) {
+        Sub& s = frontier[size_t(q)];
+        if (s.failed) continue;
+        try {
+            node_for_each(bs, *s.node, s.height, root.bit_width, s.base, check,
+                          [&](uint64_t i, const ValueLoc& v) { s.items.push_back(AmtItem{i, v}); });
+        } catch (const Err& e) {
+            s.failed = true;
+            s.status = e.status;
+            s.what = e.what();
+        }
+    }
+    size_t total = 0;
+    for (const Sub& s : frontier) {
+        if (s.failed) throw Err(s.status, s.what);
+        total += s.items.size();
+    }
+    out.reserve(total);
+    for (const Sub& s : frontier) out.insert(out.end(), s.items.begin(), s.items.end());
 }
 
 }  // namespace orc

@@ -47,4 +47,19 @@ bool amt_get(const Blockstore& bs, const AmtRoot& root, uint64_t index, const Va
 void amt_for_each(const Blockstore& bs, const AmtRoot& root, const ValueChecker& check,
                   const std::function<void(uint64_t, const ValueLoc&)>& f);
 
+
+// Amt::for_each collected into a vector, in ascending index order: (index, value).  Baseline variant B2
+// "all cores" (BASELINE.md §2): the subtrees below the top levels are walked by `threads` OpenMP threads
+// (0 = every processor).  The outcome is the sequential for_each's: on failure the Err thrown is the one
+// the depth-first traversal meets first.
+struct AmtItem {
+    uint64_t index;
+    ValueLoc value;
+};
+void amt_collect(const Blockstore& bs, const AmtRoot& root, const ValueChecker& check, std::vector<AmtItem>& out,
+                 int threads);
+
+// omp_set_num_threads(threads), 0 = omp_get_num_procs(); returns the count in effect
+int use_threads(int threads);
+
 }  // namespace orc

@@ -2,6 +2,8 @@
 // scalar hash restatements (see hashes.hpp).  Batch forms take the same
 // (bytes, off[], len[]) table the product's C ABI takes, so a parity test feeds
 // identical buffers to both sides.
+#include <omp.h>
+
 #include <cstdint>
 #include <cstring>
 
@@ -32,6 +34,21 @@ uint64_t orc_blake2b256_verify(const uint8_t* bytes, const uint64_t* off, const 
                                const uint8_t* expect32, uint64_t n, uint8_t* ok) {
     uint64_t good = 0;
     for (uint64_t i = 0; i < n; ++i) {
+        uint8_t d[32];
+        orc::blake2b256(bytes + off[i], len[i], d);
+        ok[i] = std::memcmp(d, expect32 + 32 * i, 32) == 0;
+        good += ok[i];
+    }
+    return good;
+}
+
+// the same check on `threads` OpenMP threads (0 = every processor): baseline variant B2 all-cores
+uint64_t orc_blake2b256_verify_mt(const uint8_t* bytes, const uint64_t* off, const uint32_t* len,
+                                  const uint8_t* expect32, uint64_t n, uint8_t* ok, int threads) {
+    omp_set_num_threads(threads > 0 ? threads : omp_get_num_procs());
+    uint64_t good = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : good)
+    for (int64_t i = 0; i < int64_t(n); ++i) {
         uint8_t d[32];
         orc::blake2b256(bytes + off[i], len[i], d);
         ok[i] = std::memcmp(d, expect32 + 32 * i, 32) == 0;

@@ -21,6 +21,8 @@ struct Store {
     const uint32_t* len;
     const uint8_t* cids40;
     uint64_t n;
+    // mode 2 of orc_verify_event_proofs: execution orders kept across calls, keyed by the tipset key strings
+    std::unordered_map<std::string, ExecCache> exec_caches;
 };
 
 size_t cid_slot_len(const uint8_t* slot) {
@@ -32,14 +34,52 @@ size_t cid_slot_len(const uint8_t* slot) {
     return 0;
 }
 
+// threads == 1: the reference's loop (events/verifier.rs:79-89).  Otherwise the store is 2^k sub-maps filled by
+// separate threads, each visiting its blocks in input order (duplicate CID: the last block still wins).
 void load_store(MemoryBlockstore& bs, const uint8_t* bytes, const uint64_t* off, const uint32_t* len,
-                const uint8_t* cids40, uint64_t n) {
-    bs.map.reserve(size_t(n) * 2);
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint8_t* slot = cids40 + IPCFP_CID_SLOT * i;
+                const uint8_t* cids40, uint64_t n, int threads = 1) {
+    if (threads == 1) {
+        bs.reshard(1);
+        bs.shards[0].reserve(size_t(n) * 2);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint8_t* slot = cids40 + IPCFP_CID_SLOT * i;
+            const size_t l = cid_slot_len(slot);
+            Cid c{Bytes(slot, slot + (l ? l : IPCFP_CID_SLOT))};
+            bs.put_keyed(c, bytes + off[i], len[i]);
+        }
+        return;
+    }
+    const int nt = use_threads(threads);
+    size_t ns = 1;
+    while (ns < size_t(nt) * 4) ns <<= 1;
+    bs.reshard(ns);
+    std::vector<uint32_t> shard_of(n);
+    std::vector<uint8_t> klen(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < int64_t(n); ++i) {
+        const uint8_t* slot = cids40 + IPCFP_CID_SLOT * uint64_t(i);
         const size_t l = cid_slot_len(slot);
-        Cid c{Bytes(slot, slot + (l ? l : IPCFP_CID_SLOT))};
-        bs.put_keyed(c, bytes + off[i], len[i]);
+        klen[size_t(i)] = uint8_t(l ? l : IPCFP_CID_SLOT);
+        shard_of[size_t(i)] = uint32_t(MemoryBlockstore::shard_bits(Bytes(slot, slot + klen[size_t(i)])) & bs.mask);
+    }
+    // block ids grouped by sub-map, ascending inside a group (counting sort)
+    std::vector<uint64_t> start(ns + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) ++start[shard_of[i] + 1];
+    for (size_t s = 0; s < ns; ++s) start[s + 1] += start[s];
+    std::vector<uint32_t> ids(n);
+    {
+        std::vector<uint64_t> cur(start.begin(), start.end() - 1);
+        for (uint64_t i = 0; i < n; ++i) ids[cur[shard_of[i]]++] = uint32_t(i);
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t s = 0; s < int64_t(ns); ++s) {
+        MemoryBlockstore::Map& m = bs.shards[size_t(s)];
+        m.reserve((start[size_t(s) + 1] - start[size_t(s)]) * 2);
+        for (uint64_t q = start[size_t(s)]; q < start[size_t(s) + 1]; ++q) {
+            const uint64_t i = ids[q];
+            const uint8_t* slot = cids40 + IPCFP_CID_SLOT * i;
+            m[Bytes(slot, slot + klen[i])] = Bytes(bytes + off[i], bytes + off[i] + len[i]);
+        }
     }
 }
 
@@ -63,11 +103,23 @@ void* orc_store_create(const uint8_t* bytes, const uint64_t* off, const uint32_t
     load_store(s->bs, bytes, off, len, cids40, n);
     return s;
 }
+// the same store built on `threads` OpenMP threads (0 = every processor): baseline variant B2 all-cores
+void* orc_store_create_mt(const uint8_t* bytes, const uint64_t* off, const uint32_t* len, const uint8_t* cids40,
+                          uint64_t n, int threads) {
+    auto* s = new Store();
+    s->bytes = bytes; s->off = off; s->len = len; s->cids40 = cids40; s->n = n;
+    load_store(s->bs, bytes, off, len, cids40, n, threads);
+    return s;
+}
 void orc_store_destroy(void* s) { delete static_cast<Store*>(s); }
+uint64_t orc_store_size(void* s) { return static_cast<Store*>(s)->bs.size(); }
+int orc_num_procs(void) { return omp_get_num_procs(); }
 
 // mode 0: exactly as written — sequential, exec order rebuilt per proof (events/verifier.rs:190).
 // mode 1: "fair" baseline — exec order computed once per distinct parent tipset key and looked
 //         up through a hash map; OpenMP over proofs with `threads` threads (0 = all).
+// mode 2: mode 1 with the execution orders kept in the store across calls (a timing harness builds them with a
+//         one-claim call and then times the per-claim verifier alone).
 void orc_verify_event_proofs(void* store, const ipcfp_event_proof_t* proofs, uint64_t n,
                              const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter, uint8_t* status,
                              int mode, int threads) {
@@ -78,7 +130,8 @@ void orc_verify_event_proofs(void* store, const ipcfp_event_proof_t* proofs, uin
         return;
     }
     // one ExecCache per distinct tipset key (the strings of parent_tipset_cids)
-    std::unordered_map<std::string, ExecCache> caches;
+    std::unordered_map<std::string, ExecCache> local_caches;
+    std::unordered_map<std::string, ExecCache>& caches = mode == 2 ? s->exec_caches : local_caches;
     std::vector<const ExecCache*> which(n, nullptr);
     for (uint64_t i = 0; i < n; ++i) {
         // proofs of one bundle usually share the very same string array: skip the key building for them
@@ -102,11 +155,11 @@ void orc_verify_event_proofs(void* store, const ipcfp_event_proof_t* proofs, uin
                 parents.push_back(c);
             }
             // an unparsable key never reaches the execution order (Err at step 1): any cache will do
-            it = caches.emplace(key, parsed ? build_exec_cache(s->bs, parents) : ExecCache()).first;
+            it = caches.emplace(key, parsed ? build_exec_cache(s->bs, parents, threads) : ExecCache()).first;
         }
         which[i] = &it->second;
     }
-    if (threads > 0) omp_set_num_threads(threads);
+    use_threads(threads);
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < int64_t(n); ++i)
         status[i] = guarded([&] { return verify_event_proof_one(s->bs, proofs[i], trust, filter, which[i]); });
@@ -125,10 +178,118 @@ void orc_verify_storage_proofs(void* store, const ipcfp_storage_proof_t* proofs,
         }
         return;
     }
-    if (threads > 0) omp_set_num_threads(threads);
+    use_threads(threads);
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < int64_t(n); ++i)
         status[i] = guarded([&] { return verify_storage_proof_one(s->bs, proofs[i], trust); });
+}
+
+// ---- packed claims → the reference's string structs (full-size parity runs) ---------------------------
+// Building millions of ctypes string structs in Python takes minutes; these two rebuild the strings in C++ from
+// the packed claims of include/ipcfp.h (binary CIDs → Cid::to_string, bytes → "0x" + hex) and hand them to the
+// very same verify_*_proof_one.  Only claims whose every flag is set can be expressed (the flags record facts
+// about strings that no longer exist); anything else gets status 255.
+static std::string hex0x_of(const uint8_t* p, size_t n) {
+    static const char* d = "0123456789abcdef";
+    std::string s = "0x";
+    for (size_t i = 0; i < n; ++i) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); }
+    return s;
+}
+static std::string slot_to_string(const uint8_t* slot40) {
+    return cid_to_string(Cid{Bytes(slot40, slot40 + cid_slot_len(slot40))});
+}
+
+void orc_verify_storage_claims_packed(void* store, const ipcfp_storage_claim_t* claims, uint64_t n,
+                                      const ipcfp_trust_policy_t* trust, uint8_t* status, int threads) {
+    Store* s = static_cast<Store*>(store);
+    use_threads(threads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < int64_t(n); ++i) {
+        const ipcfp_storage_claim_t& c = claims[i];
+        if (c.flags != 63u) {
+            status[i] = 255;
+            continue;
+        }
+        const std::string child = slot_to_string(c.child), sr = slot_to_string(c.state_root),
+                          as = slot_to_string(c.actor_state), st = slot_to_string(c.storage_root),
+                          slot = hex0x_of(c.slot, 32), value = hex0x_of(c.value, 32);
+        ipcfp_storage_proof_t p{};
+        p.child_epoch = c.child_epoch;
+        p.child_block_cid = child.c_str();
+        p.parent_state_root = sr.c_str();
+        p.actor_id = c.actor_id;
+        p.actor_state_cid = as.c_str();
+        p.storage_root = st.c_str();
+        p.slot = slot.c_str();
+        p.value = value.c_str();
+        status[i] = guarded([&] { return verify_storage_proof_one(s->bs, p, trust); });
+    }
+}
+
+void orc_verify_event_claims_packed(void* store, const ipcfp_tipset_ref_t* tipsets, uint32_t n_tipsets,
+                                    const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob,
+                                    const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                                    uint8_t* status, int threads) {
+    Store* s = static_cast<Store*>(store);
+    struct Ts {
+        std::vector<std::string> parents;
+        std::vector<const char*> parent_ptrs;
+        std::string child;
+        ExecCache cache;
+        bool ok;
+    };
+    std::vector<Ts> ts(n_tipsets);
+    for (uint32_t k = 0; k < n_tipsets; ++k) {
+        ts[k].ok = tipsets[k].flags == 3u && tipsets[k].n_parents <= IPCFP_MAX_PARENTS;
+        if (!ts[k].ok) continue;
+        std::vector<Cid> parents;
+        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) {
+            const uint8_t* slot = tipsets[k].parents[j];
+            parents.push_back(Cid{Bytes(slot, slot + cid_slot_len(slot))});
+            ts[k].parents.push_back(cid_to_string(parents.back()));
+        }
+        for (auto& str : ts[k].parents) ts[k].parent_ptrs.push_back(str.c_str());
+        ts[k].child = slot_to_string(tipsets[k].child);
+        ts[k].cache = build_exec_cache(s->bs, parents, threads);
+    }
+    use_threads(threads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < int64_t(n); ++i) {
+        const ipcfp_event_claim_t& c = claims[i];
+        if (c.tipset >= n_tipsets || !ts[c.tipset].ok || c.flags != 3u || c.n_topics > 8) {
+            status[i] = 255;
+            continue;
+        }
+        const Ts& t = ts[c.tipset];
+        std::string topic_s[8];
+        const char* topic_p[8];
+        bool expressible = true;
+        for (uint32_t k = 0; k < c.n_topics; ++k) {
+            const uint8_t* e = blob + c.topics_off + 33u * k;
+            expressible = expressible && e[0] == 1;
+            topic_s[k] = hex0x_of(e + 1, 32);
+            topic_p[k] = topic_s[k].c_str();
+        }
+        if (!expressible) {
+            status[i] = 255;
+            continue;
+        }
+        const std::string msg = slot_to_string(c.message_cid), data = hex0x_of(blob + c.data_off, c.data_len);
+        ipcfp_event_proof_t p{};
+        p.parent_epoch = c.parent_epoch;
+        p.child_epoch = c.child_epoch;
+        p.parent_tipset_cids = t.parent_ptrs.data();
+        p.n_parent_tipset_cids = uint32_t(t.parent_ptrs.size());
+        p.child_block_cid = t.child.c_str();
+        p.message_cid = msg.c_str();
+        p.exec_index = c.exec_index;
+        p.event_index = c.event_index;
+        p.emitter = c.emitter;
+        p.topics = topic_p;
+        p.n_topics = c.n_topics;
+        p.data = data.c_str();
+        status[i] = guarded([&] { return verify_event_proof_one(s->bs, p, trust, filter, &t.cache); });
+    }
 }
 
 // ---- primitives (parity targets of the device primitives) ------------------
@@ -168,6 +329,7 @@ void orc_hamt_get(void* store, const uint8_t* root_cid40, uint32_t bit_width, in
     Store* s = static_cast<Store*>(store);
     Cid root{Bytes(root_cid40, root_cid40 + cid_slot_len(root_cid40))};
     ValueChecker chk = checker_for(value_kind);
+    use_threads(0);
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t i = 0; i < int64_t(n); ++i) {
         out_len[i] = 0;
@@ -204,10 +366,22 @@ uint8_t orc_exec_order(void* store, const uint8_t* parent_cids40, uint32_t n_par
 
 // find_matching_events.  receipt_has_match: one byte per receipt index (cap_receipts); matches as
 // (exec_index, event_index, emitter) triples (cap_matches); touched CIDs in Cid order (cap_touched).
+uint8_t orc_scan_events_mt(void* store, const uint8_t* receipts_root40, const ipcfp_event_filter_t* filter, int has_actor,
+                           uint64_t actor, uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
+                           uint64_t* match_triples, uint64_t cap_matches, uint64_t* n_matches, uint8_t* touched40,
+                           uint64_t cap_touched, uint64_t* n_touched, int threads);
 uint8_t orc_scan_events(void* store, const uint8_t* receipts_root40, const ipcfp_event_filter_t* filter, int has_actor,
                         uint64_t actor, uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
                         uint64_t* match_triples, uint64_t cap_matches, uint64_t* n_matches, uint8_t* touched40,
                         uint64_t cap_touched, uint64_t* n_touched) {
+    return orc_scan_events_mt(store, receipts_root40, filter, has_actor, actor, receipt_has_match, cap_receipts,
+                              n_receipts, match_triples, cap_matches, n_matches, touched40, cap_touched, n_touched, 1);
+}
+// threads: 1 = the sequential loops as written; 0 = every processor (baseline variant B2 all-cores)
+uint8_t orc_scan_events_mt(void* store, const uint8_t* receipts_root40, const ipcfp_event_filter_t* filter, int has_actor,
+                           uint64_t actor, uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
+                           uint64_t* match_triples, uint64_t cap_matches, uint64_t* n_matches, uint8_t* touched40,
+                           uint64_t cap_touched, uint64_t* n_touched, int threads) {
     Store* s = static_cast<Store*>(store);
     *n_receipts = *n_matches = *n_touched = 0;
     return guarded([&]() -> uint8_t {
@@ -215,7 +389,7 @@ uint8_t orc_scan_events(void* store, const uint8_t* receipts_root40, const ipcfp
         std::vector<uint8_t> has;
         std::vector<ScanMatch> ms;
         std::vector<Cid> touched;
-        scan_events(s->bs, root, *filter, has_actor != 0, actor, has, ms, touched40 ? &touched : nullptr);
+        scan_events(s->bs, root, *filter, has_actor != 0, actor, has, ms, touched40 ? &touched : nullptr, threads);
         *n_receipts = has.size();
         for (size_t i = 0; i < has.size() && i < cap_receipts; ++i) receipt_has_match[i] = has[i];
         *n_matches = ms.size();

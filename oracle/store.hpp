@@ -32,11 +32,28 @@ struct Blockstore {
 };
 
 struct MemoryBlockstore : Blockstore {
-    std::unordered_map<Bytes, Bytes, BytesHash> map;
-    void put_keyed(const Cid& c, const uint8_t* data, size_t len) { map[c.b] = Bytes(data, data + len); }
+    // One `HashMap<Cid, Vec<u8>>`, kept as 2^k independent sub-maps selected by hash bits: the reference's map is
+    // the k = 0 case; the all-cores baseline (BASELINE.md variant B2) builds the sub-maps on separate threads.
+    using Map = std::unordered_map<Bytes, Bytes, BytesHash>;
+    std::vector<Map> shards;
+    size_t mask = 0;
+    explicit MemoryBlockstore(size_t n_shards = 1) { reshard(n_shards); }
+    void reshard(size_t n_shards) {  // n_shards: a power of two; drops the content
+        shards.assign(n_shards, Map());
+        mask = n_shards - 1;
+    }
+    static size_t shard_bits(const Bytes& key) { return BytesHash()(key) >> 40; }
+    Map& shard_of(const Bytes& key) { return shards[shard_bits(key) & mask]; }
+    void put_keyed(const Cid& c, const uint8_t* data, size_t len) { shard_of(c.b)[c.b] = Bytes(data, data + len); }
     const Bytes* get(const Cid& c) const override {
-        auto it = map.find(c.b);
-        return it == map.end() ? nullptr : &it->second;
+        const Map& m = shards[shard_bits(c.b) & mask];
+        auto it = m.find(c.b);
+        return it == m.end() ? nullptr : &it->second;
+    }
+    size_t size() const {
+        size_t n = 0;
+        for (const Map& m : shards) n += m.size();
+        return n;
     }
 };
 

@@ -5,8 +5,11 @@
 // `Ok(false)` → a FALSE_* status; `Err` → throw orc::Err (status ERR_*).
 #include "verify.hpp"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <set>
+#include <unordered_set>
 
 #include "hashes.hpp"
 
@@ -34,7 +37,7 @@ static std::vector<Cid> parse_claim_cids(const char* const* v, uint32_t n) {
 // collect_exec_list (events/utils.rs:48-94), verify_txmeta = true
 static std::vector<Cid> collect_exec_list(const Blockstore& bs, const std::vector<Cid>& txmeta_cids) {
     std::vector<Cid> out;
-    std::set<Bytes> seen;
+    std::unordered_set<Bytes, BytesHash> seen;  // HashSet<Cid> (events/utils.rs:54,57)
     for (const Cid& tx : txmeta_cids) {
         const Bytes& raw = must_get(bs, tx, "TxMeta");  // :58-60
         Reader r(raw);
@@ -95,12 +98,86 @@ static bool eq_ignore_ascii_case(const std::string& a, const char* b) {
 }
 
 // ---- event proof ---------------------------------------------------------------
-ExecCache build_exec_cache(const Blockstore& bs, const std::vector<Cid>& parents) {
+// TxMeta of one parent block → its (bls, secp) AMT roots, with the re-hash check (events/utils.rs:58-72)
+static void txmeta_roots(const Blockstore& bs, const Cid& tx, Cid& bls, Cid& secp) {
+    const Bytes& raw = must_get(bs, tx, "TxMeta");
+    Reader r(raw);
+    r.expect_array(2);
+    bls = read_cid(r);
+    secp = read_cid(r);
+    r.finish();
+    Bytes enc;
+    enc.push_back(0x82);
+    for (const Cid* c : {&bls, &secp}) {
+        enc.push_back(0xd8); enc.push_back(0x2a);
+        const size_t l = c->b.size() + 1;
+        if (l < 24) enc.push_back(uint8_t(0x40 | l));
+        else { enc.push_back(0x58); enc.push_back(uint8_t(l)); }
+        enc.push_back(0x00);
+        enc.insert(enc.end(), c->b.begin(), c->b.end());
+    }
+    if (cid_for_block(enc.data(), enc.size()) != tx) throw Err(IPCFP_ST_ERR_TXMETA_MISMATCH, "TxMeta mismatch");
+}
+
+ExecCache build_exec_cache(const Blockstore& bs, const std::vector<Cid>& parents, int threads) {
     ExecCache c;
     try {
-        std::vector<Cid> exec = reconstruct_execution_order(bs, parents);
-        c.index.reserve(exec.size() * 2);
-        for (size_t i = 0; i < exec.size(); ++i) c.index.emplace(exec[i].b, i);  // exec is already de-duplicated
+        if (threads == 1) {
+            std::vector<Cid> exec = reconstruct_execution_order(bs, parents);
+            c.shards[0].reserve(exec.size() * 2);
+            for (size_t i = 0; i < exec.size(); ++i) c.shards[0].emplace(exec[i].b, i);  // exec is already de-duplicated
+            c.len = exec.size();
+            c.ok = true;
+            return c;
+        }
+        const int nt = use_threads(threads);
+        // reconstruct_execution_order (utils.rs:20-27) + collect_exec_list (:56-91), the for_each walks in parallel
+        std::vector<Cid> tx;
+        for (const Cid& p : parents) tx.push_back(decode_header(must_get(bs, p, "parent header")).messages);
+        std::vector<Bytes> raw;  // the concatenated for_each sequences, duplicates included
+        for (const Cid& t : tx) {
+            Cid roots[2];
+            txmeta_roots(bs, t, roots[0], roots[1]);
+            for (const Cid& root : roots) {
+                AmtRoot a = amt_load(bs, root, 0, check_cid_value);
+                std::vector<AmtItem> items;
+                amt_collect(bs, a, check_cid_value, items, threads);
+                const size_t at = raw.size();
+                raw.resize(at + items.size());
+#pragma omp parallel for schedule(static)
+                for (int64_t k = 0; k < int64_t(items.size()); ++k) {
+                    Reader vr(items[size_t(k)].value.block->data() + items[size_t(k)].value.off, items[size_t(k)].value.len);
+                    raw[at + size_t(k)] = read_cid(vr).b;  // validated by the walk: cannot throw
+                }
+            }
+        }
+        // `if seen.insert(c) { out.push(c) }`: sub-map s owns the keys whose hash selects it, visited in raw order
+        size_t ns = 1;
+        while (ns < size_t(nt) * 4) ns <<= 1;
+        c.shards.assign(ns, ExecCache::Map());
+        c.mask = ns - 1;
+        const size_t n = raw.size();
+        std::vector<uint32_t> shard_of(n);
+        std::vector<uint8_t> first(n, 0);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < int64_t(n); ++i) shard_of[size_t(i)] = uint32_t((BytesHash()(raw[size_t(i)]) >> 40) & c.mask);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t sidx = 0; sidx < int64_t(ns); ++sidx) {
+            ExecCache::Map& m = c.shards[size_t(sidx)];
+            m.reserve(n / ns * 2 + 16);
+            for (size_t i = 0; i < n; ++i)
+                if (shard_of[i] == uint32_t(sidx) && m.emplace(raw[i], i).second) first[i] = 1;
+        }
+        std::vector<uint64_t> exec_index(n);
+        uint64_t run = 0;
+        for (size_t i = 0; i < n; ++i) {
+            exec_index[i] = run;
+            run += first[i];
+        }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int64_t sidx = 0; sidx < int64_t(ns); ++sidx)
+            for (auto& kv : c.shards[size_t(sidx)]) kv.second = exec_index[kv.second];
+        c.len = run;
         c.ok = true;
     } catch (const Err& e) {
         c.err_status = e.status;
@@ -126,9 +203,9 @@ uint8_t verify_event_proof_one(const Blockstore& bs, const ipcfp_event_proof_t& 
     if (exec_cache) {
         if (!exec_cache->ok) throw Err(exec_cache->err_status, "reconstruct_execution_order failed");   // :190
         Cid msg = parse_claim_cid(p.message_cid);                                                       // :193
-        auto hit = exec_cache->index.find(msg.b);
-        if (hit == exec_cache->index.end()) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                      // :194
-        if (hit->second != p.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;                              // :199
+        const uint64_t* hit = exec_cache->find(msg.b);
+        if (!hit) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                                                // :194
+        if (*hit != p.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;                                     // :199
     } else {
         std::vector<Cid> exec = reconstruct_execution_order(bs, parent_cids);                           // :190
         Cid msg = parse_claim_cid(p.message_cid);                                                       // :193
@@ -377,7 +454,7 @@ uint8_t verify_storage_proof_one(const Blockstore& bs, const ipcfp_storage_proof
 // ---- event scan ------------------------------------------------------------------------
 void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_event_filter_t& filter, bool has_actor,
                  uint64_t actor, std::vector<uint8_t>& receipt_has_match, std::vector<ScanMatch>& matches,
-                 std::vector<Cid>* touched) {
+                 std::vector<Cid>* touched, int threads) {
     receipt_has_match.clear();
     matches.clear();
     std::set<Cid> needed;
@@ -390,8 +467,17 @@ void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_eve
     std::vector<Item> receipts;
     {
         AmtRoot plain = amt_load(bs, receipts_root, 0, check_receipt);
-        amt_for_each(bs, plain, check_receipt,
-                     [&](uint64_t i, const ValueLoc& v) { receipts.push_back({i, decode_receipt(v)}); });
+        if (threads == 1) {
+            amt_for_each(bs, plain, check_receipt,
+                         [&](uint64_t i, const ValueLoc& v) { receipts.push_back({i, decode_receipt(v)}); });
+        } else {
+            std::vector<AmtItem> items;
+            amt_collect(bs, plain, check_receipt, items, threads);
+            receipts.resize(items.size());
+#pragma omp parallel for schedule(static)
+            for (int64_t k = 0; k < int64_t(items.size()); ++k)
+                receipts[size_t(k)] = Item{items[size_t(k)].index, decode_receipt(items[size_t(k)].value)};
+        }
     }
     auto matches_log = [&](const EvmLog& log) {  // EventMatcher::matches_log (:38-40)
         return log.topics.size() >= 2 && std::memcmp(log.topics[0].data(), filter.topic0, 32) == 0 &&
@@ -401,10 +487,9 @@ void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_eve
     for (const auto& it : receipts) max_index = std::max(max_index, it.index + 1);
     receipt_has_match.assign(max_index, 0);
     // PASS 1 (:209-239)
-    std::vector<size_t> matching;
-    for (size_t k = 0; k < receipts.size(); ++k) {
+    auto pass1_one = [&](size_t k) -> bool {
         const auto& it = receipts[k];
-        if (!it.rc.has_events_root) continue;
+        if (!it.rc.has_events_root) return false;
         RecordingBlockStore temp(bs);
         AmtRoot e_amt = amt_load(temp, it.rc.events_root, 3, check_stamped_event);
         bool has = false;
@@ -414,10 +499,41 @@ void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_eve
             EvmLog log;
             if (extract_evm_log(se, log) && matches_log(log)) has = true;
         });
-        if (has) {
-            matching.push_back(k);
-            receipt_has_match[it.index] = 1;
+        return has;
+    };
+    std::vector<size_t> matching;
+    if (threads == 1) {
+        for (size_t k = 0; k < receipts.size(); ++k)
+            if (pass1_one(k)) {
+                matching.push_back(k);
+                receipt_has_match[receipts[k].index] = 1;
+            }
+    } else {
+        use_threads(threads);
+        std::vector<uint8_t> has(receipts.size(), 0);
+        // the sequential loop stops at the first failing receipt: keep the failure with the smallest k
+        size_t err_k = SIZE_MAX;
+        uint8_t err_status = 0;
+        std::string err_what;
+#pragma omp parallel for schedule(dynamic, 512)
+        for (int64_t k = 0; k < int64_t(receipts.size()); ++k) {
+            try {
+                has[size_t(k)] = pass1_one(size_t(k)) ? 1 : 0;
+            } catch (const Err& e) {
+#pragma omp critical(orc_scan_err)
+                if (size_t(k) < err_k) {
+                    err_k = size_t(k);
+                    err_status = e.status;
+                    err_what = e.what();
+                }
+            }
         }
+        if (err_k != SIZE_MAX) throw Err(err_status, err_what);
+        for (size_t k = 0; k < receipts.size(); ++k)
+            if (has[k]) {
+                matching.push_back(k);
+                receipt_has_match[receipts[k].index] = 1;
+            }
     }
     // PASS 2 (:242-301)
     for (size_t k : matching) {
@@ -473,7 +589,7 @@ GeneratedEventBundle generate_event_proof(const Blockstore& bs, const std::vecto
     // Step 4: build_execution_order → collect_exec_list(verify_txmeta = false) (utils.rs:33-45)
     std::vector<Cid> exec;
     {
-        std::set<Bytes> seen;
+        std::unordered_set<Bytes, BytesHash> seen;  // HashSet<Cid> (events/utils.rs:54)
         for (const Cid& t : txmeta) {
             const Bytes& raw = must_get(bs, t, "TxMeta");
             Reader r(raw);

@@ -17,14 +17,25 @@ std::vector<Cid> reconstruct_execution_order(const Blockstore& bs, const std::ve
 struct ExecCache {
     bool ok = false;
     uint8_t err_status = 0;                                // Err of reconstruct_execution_order, if any
-    std::unordered_map<Bytes, uint64_t, BytesHash> index;  // message CID → execution index
+    // message CID → execution index; sub-maps selected by hash bits so the all-cores build fills them in parallel
+    using Map = std::unordered_map<Bytes, uint64_t, BytesHash>;
+    std::vector<Map> shards = std::vector<Map>(1);
+    size_t mask = 0;
+    uint64_t len = 0;                                      // number of distinct messages
+    const uint64_t* find(const Bytes& key) const {
+        const Map& m = shards[(BytesHash()(key) >> 40) & mask];
+        auto it = m.find(key);
+        return it == m.end() ? nullptr : &it->second;
+    }
 };
 
 // verify_single_proof (src/proofs/events/verifier.rs:92-121) → status byte; Err is thrown.
 // exec_cache == nullptr: exactly as written (execution order rebuilt for this proof, :190).
 uint8_t verify_event_proof_one(const Blockstore& bs, const ipcfp_event_proof_t& p, const ipcfp_trust_policy_t* trust,
                                const ipcfp_event_filter_t* filter, const ExecCache* exec_cache = nullptr);
-ExecCache build_exec_cache(const Blockstore& bs, const std::vector<Cid>& parents);
+// threads == 1: reconstruct_execution_order as written, then indexed.  Otherwise (0 = every processor) the ten
+// message AMTs are enumerated and de-duplicated on `threads` OpenMP threads — same order, same Err.
+ExecCache build_exec_cache(const Blockstore& bs, const std::vector<Cid>& parents, int threads = 1);
 
 // verify_storage_proof steps 2-6 (src/proofs/storage/verifier.rs:24-63) over an already loaded store.
 uint8_t verify_storage_proof_one(const Blockstore& bs, const ipcfp_storage_proof_t& p,
@@ -49,9 +60,11 @@ struct ScanMatch {
 // `matches` = pass-2 (exec_index, event_index, EventData) in emission order; `touched` (nullable) = the
 // union of every RecordingBlockStore's take_seen() that generate_event_proof feeds to the collector
 // for this step (rec_events per matching receipt + rec_receipts), sorted in `Cid: Ord`.
+// `threads` != 1 (0 = every processor): the receipt list and PASS 1 run on OpenMP threads (baseline variant B2
+// all-cores); outcomes — including which Err surfaces first — are those of the sequential loops.
 void scan_events(const Blockstore& bs, const Cid& receipts_root, const ipcfp_event_filter_t& filter, bool has_actor,
                  uint64_t actor, std::vector<uint8_t>& receipt_has_match, std::vector<ScanMatch>& matches,
-                 std::vector<Cid>* touched);
+                 std::vector<Cid>* touched, int threads = 1);
 
 // ---- generator side (offline: the RPC-backed store of the reference is any Blockstore) ----
 struct GeneratedEventProof {

@@ -116,6 +116,7 @@ def cases():
             ("block cid string", blk(cid='"bafy2bzaceaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa"')),
             ("block cid empty", blk(cid="[]")), ("block cid 256", blk(cid=cid_arr.replace("[1,", "[256,"))),
             ("block cid negative", blk(cid=cid_arr.replace("[1,", "[-1,"))), ("block cid float", blk(cid=cid_arr.replace("[1,", "[1.0,"))),
+            ("block cid non-minimal varint", blk(cid=cid_arr.replace("[1,113,", "[1,241,0,"))),
             ("block cid short", blk(cid=cid_arr[:-4] + "]")), ("block cid long", blk(cid=cid_arr[:-1] + ",7]")),
             ("block cid v0", blk(cid="[18,32," + ",".join(["9"] * 32) + "]")), ("block cid v2", blk(cid=cid_arr.replace("[1,", "[2,"))),
             ("block cid sha256", blk(cid="[1,113,18,32," + ",".join(["9"] * 32) + "]")),

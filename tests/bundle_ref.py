@@ -142,6 +142,8 @@ def _uvarint(b, pos):
         pos += 1
         v |= (c & 0x7F) << (7 * i)
         if not c & 0x80:
+            if c == 0 and i > 0:
+                raise BundleError("non-minimal varint")  # unsigned-varint rejects it (as the oracle's read_varint)
             return v, pos
     raise BundleError("varint")
 
@@ -268,10 +270,21 @@ def bundle_json(storage, events, blocks) -> str:
 
 
 def claims_from_parsed(parsed):
-    """parsed bundle → (EventClaims-like, StorageClaims-like) ctypes arrays for the oracle / engine."""
+    """parsed bundle → (EventClaims-like, StorageClaims-like) ctypes arrays for the oracle / engine.
+    A C string cannot carry the NUL a JSON string may hold ("\\u0000"): it is replaced by 0x01, which — like NUL —
+    is in no multibase / hex alphabet and equals no character of a canonical form, so every parse and every
+    compare of the reference keeps its outcome (the engine's bundle lowering does the same)."""
     import ctypes as C
 
     import claims
+
+    parsed = {
+        "event_proofs": [{k: ([t.replace("\0", "\x01") for t in v] if isinstance(v, list) else
+                              v.replace("\0", "\x01") if isinstance(v, str) else v) for k, v in p.items()}
+                         for p in parsed["event_proofs"]],
+        "storage_proofs": [{k: v.replace("\0", "\x01") if isinstance(v, str) else v for k, v in p.items()}
+                           for p in parsed["storage_proofs"]],
+    }
 
     class Holder:
         pass

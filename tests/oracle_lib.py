@@ -37,6 +37,17 @@ class Oracle:
         lib.orc_cid_for_block.argtypes = [C.c_char_p, u64, vp]
         lib.orc_store_create.restype = vp
         lib.orc_store_create.argtypes = [vp, vp, vp, vp, u64]
+        lib.orc_store_create_mt.restype = vp
+        lib.orc_store_create_mt.argtypes = [vp, vp, vp, vp, u64, C.c_int]
+        lib.orc_store_size.restype = u64
+        lib.orc_store_size.argtypes = [vp]
+        lib.orc_num_procs.restype = C.c_int
+        lib.orc_num_procs.argtypes = []
+        lib.orc_blake2b256_verify_mt.restype = u64
+        lib.orc_blake2b256_verify_mt.argtypes = [vp, vp, vp, vp, u64, vp, C.c_int]
+        lib.orc_scan_events_mt.restype = C.c_uint8
+        lib.orc_scan_events_mt.argtypes = [vp, vp, vp, C.c_int, u64, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64),
+                                           vp, u64, C.POINTER(u64), C.c_int]
         lib.orc_store_destroy.restype = None
         lib.orc_store_destroy.argtypes = [vp]
         lib.orc_amt_get.restype = None
@@ -55,6 +66,10 @@ class Oracle:
         lib.orc_generate_storage_proof.argtypes = [vp, vp, u64, vp, vp, vp, vp, u64, C.POINTER(u64)]
         lib.orc_verify_event_proofs.restype = None
         lib.orc_verify_event_proofs.argtypes = [vp, vp, u64, vp, vp, vp, C.c_int, C.c_int]
+        lib.orc_verify_storage_claims_packed.restype = None
+        lib.orc_verify_storage_claims_packed.argtypes = [vp, vp, u64, vp, vp, C.c_int]
+        lib.orc_verify_event_claims_packed.restype = None
+        lib.orc_verify_event_claims_packed.argtypes = [vp, vp, C.c_uint32, vp, u64, vp, vp, vp, vp, C.c_int]
         lib.orc_verify_storage_proofs.restype = None
         lib.orc_verify_storage_proofs.argtypes = [vp, vp, u64, vp, vp, C.c_int, C.c_int]
 
@@ -89,8 +104,12 @@ class Oracle:
         self.lib.orc_cid_for_block(data, len(data), _p(out))
         return out.tobytes()[:38]
 
-    def store(self, data, off, lens, cids40):
-        return OracleStore(self, data, off, lens, cids40)
+    def store(self, data, off, lens, cids40, threads=1):
+        """threads=1: the reference's sequential load_witness_store; 0 = every processor (baseline B2 all-cores)"""
+        return OracleStore(self, data, off, lens, cids40, threads)
+
+    def num_procs(self) -> int:
+        return int(self.lib.orc_num_procs())
 
     def hash_batch(self, kind: str, data, off, lens):
         k = {"blake2b256": 0, "keccak256": 1, "sha256": 2}[kind]
@@ -101,13 +120,16 @@ class Oracle:
         self.lib.orc_hash_batch(k, _p(data), _p(off), _p(lens), len(off), _p(out))
         return out
 
-    def blake2b256_verify(self, data, off, lens, expect32):
+    def blake2b256_verify(self, data, off, lens, expect32, threads=1):
         data = np.ascontiguousarray(data, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         expect32 = np.ascontiguousarray(expect32, dtype=np.uint8)
         ok = np.zeros(len(off), dtype=np.uint8)
-        good = self.lib.orc_blake2b256_verify(_p(data), _p(off), _p(lens), _p(expect32), len(off), _p(ok))
+        if threads == 1:
+            good = self.lib.orc_blake2b256_verify(_p(data), _p(off), _p(lens), _p(expect32), len(off), _p(ok))
+        else:
+            good = self.lib.orc_blake2b256_verify_mt(_p(data), _p(off), _p(lens), _p(expect32), len(off), _p(ok), threads)
         return ok, int(good)
 
 
@@ -117,14 +139,21 @@ VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "ve
 class OracleStore:
     """MemoryBlockstore over a witness table (keeps the arrays alive)."""
 
-    def __init__(self, orc: Oracle, data, off, lens, cids40):
+    def __init__(self, orc: Oracle, data, off, lens, cids40, threads=1):
         self.orc = orc
         self.lib = orc.lib
         self.data = np.ascontiguousarray(data, dtype=np.uint8)
         self.off = np.ascontiguousarray(off, dtype=np.uint64)
         self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
         self.cids = np.ascontiguousarray(cids40, dtype=np.uint8).reshape(-1, 40)
-        self.h = self.lib.orc_store_create(_p(self.data), _p(self.off), _p(self.lens), _p(self.cids), len(self.off))
+        if threads == 1:
+            self.h = self.lib.orc_store_create(_p(self.data), _p(self.off), _p(self.lens), _p(self.cids), len(self.off))
+        else:
+            self.h = self.lib.orc_store_create_mt(_p(self.data), _p(self.off), _p(self.lens), _p(self.cids),
+                                                  len(self.off), threads)
+
+    def size(self) -> int:
+        return int(self.lib.orc_store_size(self.h))
 
     def close(self):
         if self.h:
@@ -177,6 +206,28 @@ class OracleStore:
                                            _p(st), mode, threads)
         return st
 
+    def verify_storage_claims_packed(self, claims: np.ndarray, trust=None, threads=0):
+        """Packed ipcfp_storage_claim_t[n] (all flags set) → status bytes, through the string verifier."""
+        claims = np.ascontiguousarray(claims)
+        st = np.zeros(len(claims), dtype=np.uint8)
+        self.lib.orc_verify_storage_claims_packed(self.h, _p(claims), len(claims),
+                                                  C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+                                                  _p(st), threads)
+        return st
+
+    def verify_event_claims_packed(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray, trust=None,
+                                   filt=None, threads=0):
+        """Packed ipcfp_event_claim_t[n] (all flags set) → status bytes, through the string verifier (B2)."""
+        tipsets = np.ascontiguousarray(tipsets)
+        claims = np.ascontiguousarray(claims)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        st = np.zeros(len(claims), dtype=np.uint8)
+        self.lib.orc_verify_event_claims_packed(self.h, _p(tipsets), len(tipsets), _p(claims), len(claims), _p(blob),
+                                                C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+                                                C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None,
+                                                _p(st), threads)
+        return st
+
     def exec_order(self, parent_cids, cap=1 << 21):
         pc = np.zeros((len(parent_cids), 40), dtype=np.uint8)
         for i, c in enumerate(parent_cids):
@@ -187,16 +238,16 @@ class OracleStore:
         return int(st), out[: min(cnt.value, cap)]
 
     def scan_events(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor=None, cap_receipts=1 << 21,
-                    cap_matches=1 << 20, cap_touched=1 << 21, want_touched=True):
+                    cap_matches=1 << 20, cap_touched=1 << 21, want_touched=True, threads=1):
         filt = np.frombuffer(topic0 + topic1, dtype=np.uint8).copy()
         root = np.frombuffer(receipts_root.ljust(40, b"\0"), dtype=np.uint8).copy()
         has = np.zeros(cap_receipts, dtype=np.uint8)
         trip = np.zeros((cap_matches, 3), dtype=np.uint64)
         touched = np.zeros((cap_touched, 40), dtype=np.uint8) if want_touched else None
         nr, nm, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        st = self.lib.orc_scan_events(self.h, _p(root), _p(filt), 0 if actor is None else 1, 0 if actor is None else actor,
-                                      _p(has), cap_receipts, C.byref(nr), _p(trip), cap_matches, C.byref(nm),
-                                      _p(touched), cap_touched, C.byref(nt))
+        st = self.lib.orc_scan_events_mt(self.h, _p(root), _p(filt), 0 if actor is None else 1,
+                                         0 if actor is None else actor, _p(has), cap_receipts, C.byref(nr), _p(trip),
+                                         cap_matches, C.byref(nm), _p(touched), cap_touched, C.byref(nt), threads)
         return int(st), has[: nr.value], trip[: nm.value], (touched[: nt.value] if want_touched else None)
 
     def generate_event_proof(self, parent_cids, child_cid: bytes, topic0: bytes, topic1: bytes, actor=None,
@@ -230,10 +281,11 @@ class OracleStore:
 
 
 _cached = None
+_cached_native = None
 
 
 def build():
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    subprocess.run(["make", "-s", "-j8", "-C", ORACLE_DIR], check=True)
 
 
 def load() -> Oracle:
@@ -243,3 +295,19 @@ def load() -> Oracle:
             build()
         _cached = Oracle(C.CDLL(LIB))
     return _cached
+
+
+def load_native():
+    """The oracle compiled ON THIS MACHINE with -march=native (oracle/_native/, `make native`) — what bench.py's
+    cpu_baseline leg times.  Returns (oracle, "native"), or (portable oracle, "x86-64-v3") when
+    the build is not possible here."""
+    global _cached_native
+    if _cached_native is None:
+        lib = os.path.join(ORACLE_DIR, "_native", "libipcfp_oracle.so")
+        try:
+            subprocess.run(["make", "-s", "-j16", "-C", ORACLE_DIR, "native"], check=True, timeout=600,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            _cached_native = (Oracle(C.CDLL(lib)), "native")
+        except (OSError, subprocess.SubprocessError):
+            _cached_native = (load(), "x86-64-v3")
+    return _cached_native

@@ -98,7 +98,18 @@ def test_generate_serialise_parse_verify(tip, engine, oracle):
     storage += [dict(storage[0], value="0x" + "ff" * 32), dict(storage[1], storage_root="not-a-cid")]
     events += [dict(events[0], message_cid=events[-1]["message_cid"] if len(events) > 1 else events[0]["child_block_cid"]),
                dict(events[0], exec_index=10 ** 9), dict(events[0], data="0x00")]
+    # "\u0000" inside a claim string: the suffix must not be cut off — a compared field is Ok(false),
+    # a parsed field is Err, exactly what the reference does with the full Rust string
+    n_plain_s, n_plain_e = len(storage), len(events)
+    storage += [dict(storage[0], parent_state_root=storage[0]["parent_state_root"] + "\0junk"),   # 18 FALSE_STATE_ROOT
+                dict(storage[0], child_block_cid=storage[0]["child_block_cid"] + "\0x"),          # 69 ERR_BAD_CLAIM
+                dict(storage[0], value=storage[0]["value"] + "\0ff"),                             # 21 FALSE_VALUE
+                dict(storage[0], slot=storage[0]["slot"] + "\0")]                                 # 69 ERR_BAD_CLAIM
+    events += [dict(events[0], message_cid=events[0]["message_cid"] + "\0x"),                     # 69 ERR_BAD_CLAIM
+               dict(events[0], data=events[0]["data"] + "\0"),                                    # 16 FALSE_DATA
+               dict(events[0], topics=[events[0]["topics"][0] + "\0"] + events[0]["topics"][1:])]  # 15 FALSE_TOPIC
     text = bundle_ref.bundle_json(storage, events, blocks)
+    assert "\\u0000" in text
     b = engine.bundle(text.encode())
     assert (b.n_blocks, b.n_events, b.n_storage) == (len(blocks), len(events), len(storage))
     st, bad = b.witness.verify_cids()
@@ -112,6 +123,7 @@ def test_generate_serialise_parse_verify(tip, engine, oracle):
     pst.close()
     assert np.array_equal(es, want_e), (es.tolist(), want_e.tolist())
     assert np.array_equal(ss, want_s), (ss.tolist(), want_s.tolist())
+    assert ss[n_plain_s:].tolist() == [18, 69, 21, 69] and es[n_plain_e:].tolist() == [69, 16, 15]
     assert (es[: len(gm)] == 1).all() and (ss[: len(sidx)] == 1).all()
     assert (es[len(gm):] != 1).all() and (ss[len(sidx):] != 1).all()
     # with the event filter of the generator
