@@ -16,9 +16,12 @@ that tipset with every input already resident in HBM:
     K6  two-pass event-filter scan of all receipts (topic0 + topic1 + actor_id_filter)
         exec-order reconstruction (TxMeta re-hash + message AMT walks + first-seen dedupe)
         verify_event_proof for every claim (receipt AMT walk + events AMT walk + event compare)
-`value` = claims verified per second.  Multi-GPU: the proof batch is sharded by receipt index — rank r
-owns the receipts, events and claims of its own 1M-receipt shard (weak scaling) — with no data-path
-collective; one RCCL all-gather of the per-shard verdict bytes + CID bitmaps closes each step.
+`value` = claims verified per second.  Multi-GPU (`--gpus N`, one rank per GPU): the SAME tipset is cut into N
+receipt-range shards (strong scaling): rank r plans and places its shard once (untimed, like the
+single-GPU upload) — its receipts' events AMTs and receipts-AMT paths, plus the replicated headers, TxMeta blocks
+and message AMTs — and a step is CID index + K1 + range-restricted scan + verify of the claims routed to it, closed
+by ONE ncclAllGather (RCCL called directly by libipcfp.so) of [header | status bytes | has-match map | CID bitmap].
+`--workload cid|hamt|storage` run BASELINE.json configs[1], [3], [4] instead (single GPU).
 
 torch is plumbing only (HBM residency of inputs, device sync, torch.distributed); every timed
 kernel is launched by libipcfp.so through its C ABI.  DESIGN.md §Measurement has the byte accounting.
@@ -31,12 +34,16 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # the cpu_baseline leg's OpenMP team sleeps between phases
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md §Chip-level parameters)
+VALU_PEAK_TOPS = 78.6  # 32-bit integer lane operations: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+VALU_INSTS_PER_CHUNK = 2083.0  # K1: VALU instructions per wavefront per 128-byte chunk (profiles/r01_final_pmc.txt)
 METRIC = "Merkle proofs verified/sec + HBM GB/s, 1M-receipt synthetic tipset, 1/2/4/8 GPU"
 
 
@@ -73,7 +80,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--receipts", type=int, default=1_000_000, help="receipts per GPU shard")
+    ap.add_argument("--receipts", type=int, default=1_000_000, help="receipts of the tipset (cut into --gpus shards)")
+    ap.add_argument("--workload", choices=["tipset", "cid", "hamt", "storage"], default="tipset",
+                    help="tipset = BASELINE.json configs[2] (the metric's); cid/hamt/storage = configs[1]/[3]/[4]")
+    ap.add_argument("--blocks", type=int, default=100_000, help="--workload cid: number of 1 KiB blocks")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (plan, sub-witness, RCCL all-gather) with a single rank")
     ap.add_argument("--cpu-sample", type=int, default=50_000, help="claims the 1-thread cpu_baseline leg verifies")
     ap.add_argument("--cpu-sample-mt", type=int, default=200_000, help="claims the all-cores cpu_baseline leg verifies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,7 +105,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    if world > 1 or args.force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import ipc_filecoin_proofs_amd as ipcfp
@@ -101,10 +117,23 @@ def main():
 
     eng = ipcfp.Engine(local_rank)
     info = eng.device_info()
+    if args.workload != "tipset":
+        if world > 1:
+            raise SystemExit("--workload %s is a single-GPU line (its shard plan is ipcfp_shard_range + the same "
+                             "entry points; tests/test_gpu_sharding.py)" % args.workload)
+        out = {"cid": run_cid, "hamt": run_hamt, "storage": run_storage}[args.workload](args, eng, info, torch)
+        print(json.dumps(out))
+        eng.close()
+        return
+    if world > 1 or args.force_sharded:
+        run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev)
+        eng.close()
+        dist.destroy_process_group()
+        return
 
-    # ---- this rank's shard of the tipset (weak scaling: a fixed number of receipts per GPU) ----
+    # ---- the tipset ----
     t_gen = time.perf_counter()
-    tip = Tipset(seed=SEED_BASE + 3 + (rank << 24), n_receipts=args.receipts, n_parents=5, dup_permille=20,
+    tip = Tipset(seed=SEED_BASE + 3, n_receipts=args.receipts, n_parents=5, dup_permille=20,
                  n_planted=max(1, args.receipts // 1000), max_events=4, no_events_permille=0, variety=0)
     n_claims = len(tip.claim_exec)
     ts, cl, blob, blob_len = ipcfp.pack_event_claims(
@@ -124,15 +153,6 @@ def main():
     torch.cuda.synchronize()
     w = eng.witness_device(t_bytes.data_ptr(), tip.data.size, t_off.data_ptr(), t_len.data_ptr(), t_cids.data_ptr(),
                            tip.n_blocks)
-    bitmap_bytes = ((tip.n_blocks + 31) // 32) * 4
-    t_bitmap = torch.as_tensor(DevView(w.cid_bitmap_ptr, bitmap_bytes), device=dev)
-    gather = None
-    if world > 1:
-        # shards are generated from different seeds, so their block counts differ by a few: every rank pads its
-        # message to the longest one (an all-gather needs equal sizes) — shard.PaddedGather, tested on gloo
-        from ipc_filecoin_proofs_amd.shard import PaddedGather
-
-        gather = PaddedGather(bitmap_bytes + n_claims, dist, device=dev)
     scan_result = {}
 
     def step():
@@ -143,11 +163,6 @@ def main():
         scan_result["status"], scan_result["matches"] = st, m
         w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len,
                                      t_status.data_ptr())                               # exec order + verify
-        if world > 1:
-            eng.sync()  # K1 runs on the engine's second stream: its bitmap is complete after ctx_sync
-            gather.payload[:bitmap_bytes].copy_(t_bitmap)
-            gather.payload[bitmap_bytes:bitmap_bytes + n_claims].copy_(t_status)
-            gather.run()                                                                 # the one collective
 
     def fence():
         if world > 1:
@@ -230,22 +245,7 @@ def main():
     for k in ("blake2b_cid", "cid_index", "event_scan", "replay", "event_verify", "exec_order"):
         cnt, ms = eng.profile_read(k)
         kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
-    k_launches, k_ms = eng.profile_read("blake2b_cid")
-    k_avg_ms = k_ms / max(k_launches, 1)
-    # algorithmic bytes of one K1 launch: every block's payload + its 40-byte claimed CID + 16 B (offset, len, id)
-    algo_bytes = float(tip.lens.astype(np.float64).sum() + tip.n_blocks * (40 + 16))
-    achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-    # HBM traffic of one K1 launch: FETCH_SIZE needs a rocprofv3 --pmc pass of its own, so the figure is
-    # the committed measurement of this very command (profiles/r01_k1_traffic.json) and only reported
-    # when the workload is the one that was profiled
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_k1_traffic.json")) as f:
-            tr = json.load(f)
-        if tr["workload"]["witness_blocks"] == tip.n_blocks and tr["workload"]["payload_bytes"] == tip.stats["payload_bytes"]:
-            traffic = tr["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    roof = k1_roofline(eng, tip.lens, tip.n_blocks, traffic_file="r01_k1_traffic.json")
 
     if rank == 0:
         out = {
@@ -257,12 +257,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE.json configs[2] (the 1M-receipt tipset the metric is quoted on): %d receipts per GPU (Amtv0<Receipt> + one Amt<StampedEvent> each, 5 parent "
+                "workload": "BASELINE.json configs[2] (the 1M-receipt tipset the metric is quoted on): %d receipts (Amtv0<Receipt> + one Amt<StampedEvent> each, 5 parent "
                             "headers with TxMeta and message AMTs), %d witness blocks, %.3f GB; one EventProof claim per "
                             "receipt; step = CID index + Blake2b-256 CID check of every block + event-filter scan + "
                             "exec-order reconstruction + verify_event_proof of every claim" %
@@ -272,24 +272,11 @@ def main():
                 "witness_blocks_per_gpu": tip.n_blocks,
                 "witness_bytes_per_gpu": tip.stats["payload_bytes"],
                 "scan_matches": int(scan_result["matches"]),
-                "sharding": ("receipt-index shard per rank; one RCCL all-gather of verdict bytes + CID bitmaps per step"
-                             if world > 1 else "single GPU"),
+                "sharding": "single GPU",
                 "device": info["name"],
                 "setup_seconds_untimed": round(t_gen, 2),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_blake2b256_cid",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel_avg_ms": k_avg_ms,
-                "launches": k_launches,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "VALU-bound on gfx950 (≈19 int ops/byte; profiles/r01_ubench_valu_rates.log): see DESIGN.md §K1",
-            },
+            "roofline": roof,
             "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kern.items()},
         }
         if t2 is not None:
@@ -308,6 +295,359 @@ def main():
         dist.destroy_process_group()
 
 
+def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev):
+    """--gpus N > 1: ONE tipset, N receipt-range shards (strong scaling).  Setup (untimed, the analogue of the
+    single-GPU upload): every rank holds the tipset in host memory, uploads it, plans its shard on its own GPU,
+    cuts the shard's witness out and drops the rest.  Timed step: ipc_filecoin_proofs_amd.shard.TipsetShard.step."""
+    import ipc_filecoin_proofs_amd as ipcfp
+    from ipc_filecoin_proofs_amd import shard
+    from tools.synth import SEED_BASE, Tipset
+
+    t_gen = time.perf_counter()
+    tip = Tipset(seed=SEED_BASE + 3, n_receipts=args.receipts, n_parents=5, dup_permille=20,
+                 n_planted=max(1, args.receipts // 1000), max_events=4, no_events_permille=0, variety=0)
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec, tip.claim_event,
+        tip.claim_emitter, tip.exec_order[tip.claim_exec.astype(np.int64)], tip.claim_ntopics, tip.claim_topics,
+        tip.claim_datalen, tip.claim_data)
+    full = eng.witness(tip.data, tip.off, tip.lens, tip.cids)
+    sh = shard.TipsetShard(eng, full, tip.parent_cids, tip.child_cid, tip.receipts_root, world, rank)
+    full.close()
+    sh.route(ts, cl, blob)
+    t_gen = time.perf_counter() - t_gen
+
+    def allreduce_max(v):
+        t = torch.from_numpy(v.copy()).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
+    layout = shard.Layout.agree(sh.counts, allreduce_max)
+    # the communicator of the data path: RCCL through libipcfp.so; its id travels over the host's channel
+    uid = [ipcfp.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    comm = ipcfp.Comm(eng, uid[0], world, rank)
+
+    def dev_bytes(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+
+    d_cl, d_blob, d_hdr = dev_bytes(sh.claims), dev_bytes(sh.blob), dev_bytes(sh.header())
+    d_status = torch.zeros(layout.w_status, dtype=torch.uint8, device=dev)
+    d_has = torch.zeros(layout.w_has, dtype=torch.uint8, device=dev)
+    d_stage = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+    d_recv = torch.zeros(world * layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    filt = (tip.topic0, tip.topic1, tip.filter_actor)
+
+    def step():
+        sh.step(layout, comm, filt, d_cl.data_ptr(), d_blob.data_ptr(), d_status.data_ptr(), d_has.data_ptr(),
+                d_hdr.data_ptr(), d_stage.data_ptr(), d_recv.data_ptr())
+
+    def fence():
+        eng.sync()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    kern = {}
+    for k in ("blake2b_cid", "cid_index", "event_scan", "replay", "event_verify", "exec_order", "allgather"):
+        cnt, ms = eng.profile_read(k)
+        kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
+    # ---- what was timed must be right: every rank merges the gathered messages and checks the WHOLE tipset ----
+    gathered = d_recv.cpu().numpy()
+    positions = [shard.route_claims(cl["exec_index"], *ipcfp.shard_range(sh.n_receipts_total, world, r)) for r in range(world)]
+    merged = shard.merge(gathered, layout, world, positions, len(cl), sh.n_receipts_total)
+    if not (merged["status"] == 1).all() or merged["n_bad_cids"] or merged["scan_status"] != 1:
+        raise SystemExit("bench self-check failed (rank %d): merged verdicts are not all TRUE" % rank)
+    if merged["n_matches"] < len(tip.planted) or not merged["has"][tip.planted.astype(np.int64)].all():
+        raise SystemExit("bench self-check failed (rank %d): the merged scan missed planted matches" % rank)
+    k_launches, k_ms = kern["blake2b_cid"]["launches"], kern["blake2b_cid"]["ms_per_step"] * args.steps
+    k_avg_ms = k_ms / max(k_launches, 1)
+    ids = sh.block_ids
+    algo_bytes = float(tip.lens[ids].astype(np.float64).sum() + len(ids) * 44)
+    achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "blocks": int(sh.witness.n), "claims": int(sh.n_claims),
+                                      "receipts": [int(sh.lo), int(sh.hi)],
+                                      "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kern.items()}})
+    if rank == 0:
+        total_claims = len(cl)
+        out = {
+            "metric": METRIC, "value": total_claims * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[2] (the 1M-receipt tipset the metric is quoted on): ONE tipset of %d "
+                            "receipts (%d witness blocks, %.3f GB, one EventProof claim per receipt) cut into %d "
+                            "receipt-range shards; step = per-rank CID index + Blake2b-256 CID check + range-restricted "
+                            "event scan + exec-order reconstruction (replicated) + verify_event_proof of the rank's "
+                            "claims, closed by one ncclAllGather of %d bytes per rank"
+                            % (args.receipts, tip.n_blocks, tip.stats["payload_bytes"] / 1e9, world, layout.bytes_per_rank),
+                "receipts": args.receipts, "claims": total_claims, "witness_blocks": tip.n_blocks,
+                "sharding": "receipt-range shards of one tipset (SURVEY.md §8e): events AMTs + receipts-AMT paths per "
+                            "rank, headers/TxMeta/message AMTs replicated; one RCCL all-gather per step",
+                "allgather_bytes_per_rank": layout.bytes_per_rank, "scan_matches": merged["n_matches"],
+                "per_rank": per_rank, "device": info["name"], "setup_seconds_untimed": round(t_gen, 2),
+            },
+            "roofline": {"bound": "hbm", "limiter": "valu", "kernel": "k_blake2b256_cid (rank 0's shard)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_avg_ms": k_avg_ms, "launches": k_launches, "algorithmic_bytes_per_launch": algo_bytes},
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kern.items()},
+            "window": "T3 (shards resident in HBM; index rebuilt and every cached enumeration dropped each step)",
+        }
+        print(json.dumps(out))
+    comm.close()
+    sh.close()
+
+
+def k1_roofline(eng, lens, n_blocks, traffic_file=None, extra_note=""):
+    """`roofline` of K1 from the HIP events libipcfp.so recorded on the stream the kernel ran on.  Algorithmic
+    bytes per launch follow SURVEY.md §8(d): len_i + 32 (expected digest) + 12 (offset u64 + len u32) per block."""
+    k_launches, k_ms = eng.profile_read("blake2b_cid")
+    k_avg_ms = k_ms / max(k_launches, 1)
+    algo_bytes = float(np.asarray(lens, dtype=np.float64).sum() + n_blocks * 44)
+    achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+    chunks = float(np.maximum(1, (np.asarray(lens, dtype=np.int64) + 127) // 128).sum())
+    # 2 083 VALU instructions per wavefront per 128-byte chunk (SQ_INSTS_VALU of profiles/r01_final_pmc.txt over the
+    # tipset witness's chunk count); one wavefront instruction = 64 lane operations
+    lane_ops = chunks * VALU_INSTS_PER_CHUNK
+    traffic, src = None, None
+    if traffic_file:
+        try:
+            with open(os.path.join(ROOT, "profiles", traffic_file)) as f:
+                tr = json.load(f)
+            if tr["workload"]["witness_blocks"] == n_blocks:
+                traffic, src = tr["traffic_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE pass of this command; not re-measured in this run)" % traffic_file
+        except (OSError, KeyError, ValueError):
+            pass
+    return {
+        "bound": "hbm", "limiter": "valu", "kernel": "k_blake2b256_cid", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_6290": achieved / 6290.0,
+        "traffic": traffic, "traffic_source": src, "kernel_avg_ms": k_avg_ms, "launches": k_launches,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "valu": {"achieved_Tops": lane_ops / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0, "peak_Tops": VALU_PEAK_TOPS,
+                 "frac": (lane_ops / (k_avg_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS) if k_avg_ms > 0 else 0.0,
+                 "lane_ops_per_launch": lane_ops,
+                 "note": "32-bit integer lane operations; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz. The G function's "
+                         "64-bit adds, v_alignbit and v_perm issue at about half that rate on gfx950 "
+                         "(profiles/r01_ubench_valu_rates.log), which caps the kernel near 2.6 TB/s"},
+        "note": "limited by integer VALU throughput, not by HBM (DESIGN.md §K1)" + extra_note,
+    }
+
+
+def run_cid(args, eng, info, torch):
+    """BASELINE.json configs[1]: N x 1 KiB blocks (59 03 FD + 1021 PRNG bytes), digest bit flipped where i % 1024 == 7."""
+    from tools.synth import SEED_BASE
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    n = args.blocks
+    data, off, lens = make_cfg2(n, SEED_BASE + 2)
+    dig = eng.blake2b256(data, off, lens)
+    cids = np.zeros((n, 40), dtype=np.uint8)
+    cids[:, :6] = np.frombuffer(bytes.fromhex("0171a0e40220"), dtype=np.uint8)
+    cids[:, 6:38] = dig
+    flipped = np.arange(7, n, 1024)
+    cids[flipped, 6] ^= 1
+    w = eng.witness(data, off, lens, cids)
+    for _ in range(args.warmup):
+        w.verify_cids_async()
+    eng.sync()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.verify_cids_async()
+    eng.sync()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    st, nbad = w.cid_results()
+    if nbad != len(flipped) or not (st[flipped] == 0).all() or int(st.sum()) != n - len(flipped):
+        raise SystemExit("bench self-check failed: CID verdicts")
+    roof = k1_roofline(eng, lens, n, extra_note="; %d blocks = %d wavefronts on 1024 SIMDs" % (n, (n + 63) // 64))
+    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[1]: %d Blake2b-256 CID verifications over 1 KiB blocks; step = one "
+                                  "K1 launch over the resident batch (1 proof = 1 CID check)" % n, "blocks": n,
+                      "device": info["name"]},
+           "roofline": roof, "window": "T3"}
+    if not args.no_cpu_baseline:
+        orc, march = oracle_lib.load_native()
+        exp = np.ascontiguousarray(cids[:, 6:38])
+        best = None
+        for t in sorted({1, max(1, orc.num_procs() // 4), max(1, orc.num_procs() // 2), orc.num_procs()}):
+            orc.use_threads(t)
+            t0 = time.perf_counter()
+            ok, good = orc.blake2b256_verify(data, off, lens, exp, threads=t)
+            dt = time.perf_counter() - t0
+            if not np.array_equal(ok, st):
+                raise SystemExit("cpu_baseline: CID verdicts differ")
+            if best is None or n / dt > best[0]:
+                best = (n / dt, t)
+            if t == 1:
+                one = n / dt
+        out["cpu_baseline"] = {"value": best[0], "unit": "proofs/s", "cores": best[1], "kind": "port", "value_1_thread": one,
+                               "sample": "C++ oracle Blake2b-256 over all %d blocks, -march=%s, best thread count" % (n, march)}
+    w.close()
+    return out
+
+
+def _state_tipset():
+    from tools.synth import SEED_BASE, Tipset
+
+    return Tipset(seed=SEED_BASE + 4, n_receipts=8, n_planted=0, n_actors=4_000_000, n_contracts=10_000,
+                  slots_per_contract=256, keep_full_state=0, n_actor_queries=int(65536 * 1.01))
+
+
+def _idaddr(i: int) -> bytes:
+    b = bytearray([0])
+    while True:
+        c = i & 0x7F
+        i >>= 7
+        if i:
+            b.append(c | 0x80)
+        else:
+            b.append(c)
+            return bytes(b)
+
+
+def run_hamt(args, eng, info, torch):
+    """BASELINE.json configs[3]: 4M-actor state tree (HAMT v3, bit width 5), 65 536 present ids + 1 % absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    T = _state_tipset()
+    w = eng.witness(T.data, T.off, T.lens, T.cids)
+    keys = [_idaddr(int(i)) for i in T.query_ids]
+    n = len(keys)
+    for _ in range(args.warmup):
+        w.hamt_get(T.actors_root, 5, "actor_state", keys)
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gs, gl = w.hamt_get(T.actors_root, 5, "actor_state", keys)
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    cnt, ms = eng.profile_read("hamt_get")
+    k_avg_ms = ms / max(cnt, 1)
+    present = T.query_present.astype(bool)
+    if not ((gs[present] == 1).all() and (gs[~present] == 32).all()):
+        raise SystemExit("bench self-check failed: actor gets")
+    # walk bytes per get (SURVEY.md §8d cfg 4 (ii)): per level 4 B bitfield + 43 B link, + <= 3 x 105 B bucket = 0.55 KB
+    algo = n * 550.0
+    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[3]: HAMT state-tree actor lookup, %d actors, %d gets (%d absent), bit "
+                                  "width 5; step = one ipcfp_hamt_get call (keys uploaded, statuses + locations downloaded: "
+                                  "window T2 for the keys, witness resident)" % (4_000_000, n, int((~present).sum())),
+                      "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
+           "roofline": {"bound": "hbm", "limiter": "latency", "kernel": "k_hamt_get", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel_avg_ms": k_avg_ms, "launches": cnt, "algorithmic_bytes_per_launch": algo,
+                        "value_kernel_only_gets_per_s": n / (k_avg_ms * 1e-3),
+                        "note": "0.55 KB walked per get (§8d cfg 4 (ii)); a chain of ~6 dependent node decodes per lane"},
+           "window": "T3 witness / T2 keys"}
+    if not args.no_cpu_baseline:
+        orc, march = oracle_lib.load_native()
+        ost = orc.store(T.data, T.off, T.lens, T.cids, threads=0)
+        orc.use_threads(0)
+        t0 = time.perf_counter()
+        os_, ov = ost.hamt_get(T.actors_root, 5, "actor_state", keys)
+        dt = time.perf_counter() - t0
+        ost.close()
+        if not np.array_equal(os_, gs):
+            raise SystemExit("cpu_baseline: actor-get statuses differ")
+        out["cpu_baseline"] = {"value": n / dt, "unit": "proofs/s", "cores": orc.use_threads(0), "kind": "port",
+                               "sample": "C++ oracle Hamt::get of all %d keys (incl. Python marshalling of the values), "
+                                         "-march=%s, OpenMP all processors" % (n, march)}
+    w.close()
+    return out
+
+
+def run_storage(args, eng, info, torch):
+    """BASELINE.json configs[4]: 10 000 contracts x 256 slots, every StorageProof claim, 0.1 % with a wrong value."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ipc_filecoin_proofs_amd as ipcfp
+    import oracle_lib
+
+    T = _state_tipset()
+    w = eng.witness(T.data, T.off, T.lens, T.cids)
+    n = len(T.sc_actor)
+    cl = ipcfp.pack_storage_claims(T.child_cid, T.state_root, T.child_epoch, T.sc_actor, T.sc_actor_state,
+                                   T.sc_storage_root, T.sc_slot, T.sc_value)
+    wrong = np.arange(500, n, 1000)
+    cl["value"][wrong, 31] ^= 1
+    d_cl = torch.from_numpy(cl.view(np.uint8).reshape(-1)).cuda()
+    d_st = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        w.verify_storage_claims_device(d_cl.data_ptr(), n, d_st.data_ptr())
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.verify_storage_claims_device(d_cl.data_ptr(), n, d_st.data_ptr())
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    cnt, ms = eng.profile_read("storage_verify")
+    k_avg_ms = ms / max(cnt, 1)
+    got = d_st.cpu().numpy()
+    if not ((got[wrong] == 21).all() and int((got == 1).sum()) == n - len(wrong)):
+        raise SystemExit("bench self-check failed: storage verdicts")
+    algo = float(T.stats["payload_bytes"]) + n * 760.0  # §8d cfg 5: unique witness bytes + 0.76 KB walked per proof
+    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[4]: EVM storage proofs, 10 000 contracts x 256 slots = %d claims "
+                                  "(0.1 %% wrong), Keccak slot key + state-tree HAMT get + EVM state + storage HAMT get; "
+                                  "step = one ipcfp_verify_storage_claims_device call, claims resident" % n,
+                      "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
+           "roofline": {"bound": "hbm", "limiter": "latency", "kernel": "k_verify_storage", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel_avg_ms": k_avg_ms, "launches": cnt, "algorithmic_bytes_per_launch": algo},
+           "window": "T3"}
+    if not args.no_cpu_baseline:
+        orc, march = oracle_lib.load_native()
+        ost = orc.store(T.data, T.off, T.lens, T.cids, threads=0)
+        sample = min(n, 400_000)
+        best = None
+        for t in sorted({1, max(1, orc.num_procs() // 4), max(1, orc.num_procs() // 2), orc.num_procs()}):
+            k = sample if t > 1 else 20_000
+            orc.use_threads(t)
+            t0 = time.perf_counter()
+            g = ost.verify_storage_claims_packed(cl[:k], threads=t)
+            dt = time.perf_counter() - t0
+            if not np.array_equal(g, got[:k]):
+                raise SystemExit("cpu_baseline: storage verdicts differ")
+            if best is None or k / dt > best[0]:
+                best = (k / dt, t)
+            if t == 1:
+                one = k / dt
+        ost.close()
+        out["cpu_baseline"] = {"value": best[0], "unit": "proofs/s", "cores": best[1], "kind": "port", "value_1_thread": one,
+                               "sample": "C++ oracle verify_storage_proof (store built once) on the first %d claims, "
+                                         "-march=%s, best thread count" % (sample, march)}
+    w.close()
+    return out
+
+
 def cpu_baseline(tip, gpu_status, sample, sample_mt=None, gpu_cid_status=None, gpu_scan=None):
     """The C++ oracle — a restatement of the reference path; the Rust reference cannot be built in this image —
     compiled on THIS box with -O3 -march=native and timed on its host cores.  Variant B2 of BASELINE.md §2
@@ -322,17 +662,22 @@ def cpu_baseline(tip, gpu_status, sample, sample_mt=None, gpu_cid_status=None, g
     from tools.synth import Tipset
 
     orc, march = oracle_lib.load_native()
-    cores = orc.num_procs()
+    procs = orc.num_procs()
     n = len(tip.claim_exec)
     sample = min(sample, n)
     sample_mt = min(sample_mt or sample, n)
     expect32 = np.ascontiguousarray(tip.cids[:, 6:38])
-    ecs = {1: claims_mod.EventClaims(tip, indices=np.arange(sample))}
-    ecs[0] = ecs[1] if sample_mt == sample else claims_mod.EventClaims(tip, indices=np.arange(sample_mt))
+    ec_small = claims_mod.EventClaims(tip, indices=np.arange(sample))
+    ec_big = ec_small if sample_mt == sample else claims_mod.EventClaims(tip, indices=np.arange(sample_mt))
     ec1 = claims_mod.EventClaims(tip, indices=np.arange(1))
+    # thread counts: 1, then a sweep up to every processor — more threads are not always faster (memory
+    # allocation and NUMA), and the baseline is the BEST all-cores figure, not the one at the largest count
+    sweep = sorted({max(2, procs // 8), max(2, procs // 4), max(2, procs // 2), procs}) if procs > 1 else []
     legs = {}
-    for threads in (1, 0):
+    for threads in [1] + sweep:
         sec = {}
+        if threads > 1:
+            orc.use_threads(threads)  # team start-up and arena growth are not part of any phase
         st = None
         for _ in range(2):  # the second build finds the allocator's arenas grown; keep the better of the two
             if st is not None:
@@ -351,7 +696,7 @@ def cpu_baseline(tip, gpu_status, sample, sample_mt=None, gpu_cid_status=None, g
         t0 = time.perf_counter()
         st.verify_event_proofs(ec1, mode=2, threads=threads)  # builds the execution order kept in the store
         sec["exec_order"] = time.perf_counter() - t0
-        e = ecs[threads]
+        e = ec_small if threads == 1 else ec_big
         t0 = time.perf_counter()
         got = st.verify_event_proofs(e, mode=2, threads=threads)
         sec["verify_sample"] = time.perf_counter() - t0
@@ -374,6 +719,8 @@ def cpu_baseline(tip, gpu_status, sample, sample_mt=None, gpu_cid_status=None, g
         sec["step"] = fixed + sec["verify_sample"] * (n / e.n)
         sec["verify_sample_claims"] = e.n
         legs[threads] = sec
+    best = min(sweep, key=lambda t: legs[t]["step"]) if sweep else 1
+    cores = best
     # ---- variant B1, as written, on a reduced tipset (never extrapolated) ----
     nb1 = 1500
     tb = Tipset(n_receipts=nb1, n_parents=5, dup_permille=20, n_planted=3, max_events=4, no_events_permille=0, variety=0)
@@ -398,19 +745,21 @@ def cpu_baseline(tip, gpu_status, sample, sample_mt=None, gpu_cid_status=None, g
     except OSError:
         pass
     return {
-        "value": n / legs[0]["step"],
+        "value": n / legs[best]["step"],
         "unit": "proofs/s",
         "cores": cores,
         "kind": "port",
         "sample": "C++ oracle (restatement of the reference; the Rust crate cannot be built here), g++ -O3 -march=%s, "
-                  "OpenMP on all %d host processors: sharded store build + Blake2b CID check + two-pass event scan + "
-                  "exec-order on the FULL %d-receipt tipset, verify_event_proof on the first %d of %d claims scaled "
-                  "linearly; store and exec order built once per tipset (BASELINE.md variant B2 all-cores)"
-                  % (march, cores, tip.params["n_receipts"], legs[0]["verify_sample_claims"], n),
-        "seconds": {k: v for k, v in legs[0].items()},
+                  "OpenMP, best of %s threads on %d host processors (%d threads): sharded store build + Blake2b CID check "
+                  "+ two-pass event scan + exec-order on the FULL %d-receipt tipset, verify_event_proof on the first %d of "
+                  "%d claims scaled linearly; store and exec order built once per tipset (BASELINE.md variant B2 all-cores)"
+                  % (march, "/".join(str(t) for t in sweep) or "1", procs, cores, tip.params["n_receipts"],
+                     legs[best]["verify_sample_claims"], n),
+        "seconds": {k: v for k, v in legs[best].items()},
+        "thread_sweep_step_seconds": {str(t): legs[t]["step"] for t in sorted(legs)},
         "value_1_thread": n / legs[1]["step"],
         "seconds_1_thread": {k: v for k, v in legs[1].items()},
-        "scaling_1_to_all": legs[1]["step"] / legs[0]["step"],
+        "scaling_1_to_all": legs[1]["step"] / legs[best]["step"],
         "b1_as_written": {"receipts": nb1, "proofs_per_s": eb.n / t_b1, "seconds": t_b1,
                           "b2_1_thread_same_tipset_proofs_per_s": eb.n / t_b2_small,
                           "note": "reference semantics incl. per-proof execution-order rebuild "

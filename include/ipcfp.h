@@ -145,6 +145,7 @@ enum {
     IPCFP_K_EXEC_ORDER = 10,
     IPCFP_K_BLAKE2B_RAW = 11,
     IPCFP_K_BASE64 = 12,
+    IPCFP_K_ALLGATHER = 13, /* ipcfp_allgather_segments: message packing + ncclAllGather */
     IPCFP_K_COUNT = 16
 };
 int ipcfp_profile_enable(ipcfp_ctx_t* ctx, int on);
@@ -281,6 +282,15 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
                       const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
                       uint8_t* receipt_has_match, uint64_t cap_receipts, uint64_t* n_receipts,
                       ipcfp_event_match_t* matches, uint64_t cap_matches, uint64_t* n_matches, uint32_t* touched_bits);
+
+/* ipcfp_scan_events with DEVICE outputs: receipt_has_match_d (cap_receipts bytes) and matches_d (cap_matches
+ * ipcfp_event_match_t) are HBM buffers of the caller (nullable); status and the two counts come back to the host.
+ * summary_d (nullable): device u64[2] that receives {status, n_matches}, stream-ordered after the scan.
+ * A multi-GPU host all-gathers the map without a round trip through host memory (ipcfp_allgather_segments).     */
+int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* receipts_root40,
+                             const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
+                             void* receipt_has_match_d, uint64_t cap_receipts, uint64_t* n_receipts, void* matches_d,
+                             uint64_t cap_matches, uint64_t* n_matches, void* summary_d);
 
 /* ---- proof claims (string form, exactly the reference's structs) ----------
  * CIDs and hex values are NUL-terminated strings, as in the reference's serde
@@ -471,6 +481,61 @@ int ipcfp_verify_storage_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, con
 /* Rebuild the CID → block index of an existing witness in place (K4), e.g. once per verification
  * pass when the index build is to be charged to that pass.  No allocation.                    */
 int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);
+
+/* ---- one proof batch over the GPUs of a node ----------------------------------------------
+ * The reference verifies a bundle sequentially, proof by proof (src/proofs/verifier.rs:19-28,49-54;
+ * src/proofs/events/verifier.rs:62-71).  Given a read-only witness the proofs are independent: rank r of G takes a
+ * contiguous range of the units (blocks / receipts / keys / claims), verifies it with the entry points above on
+ * its own GPU, and ONE all-gather of the per-rank verdict bytes / bitmaps closes the step.                     */
+
+/* [lo, hi) of shard `shard` when n units are cut into n_shards contiguous ranges (sizes differ by at most one). */
+void ipcfp_shard_range(uint64_t n, uint32_t n_shards, uint32_t shard, uint64_t* lo, uint64_t* hi);
+
+/* Which blocks of `w` — a witness holding a WHOLE tipset — does shard `shard` need to scan the receipts
+ * [*receipt_lo, *receipt_hi) and to verify the EventProof claims about them?  Found like the reference's generator
+ * finds a witness, with a recorder (src/proofs/common/blockstore.rs:26-30):
+ *   every rank   child header, parent headers, their TxMeta and message AMTs (the execution order is global:
+ *                reconstruct_execution_order, src/proofs/events/utils.rs:16-30), the receipts-AMT root;
+ *   this rank    the receipts-AMT nodes on the paths to its receipts and those receipts' events AMTs.
+ *   *status_out  IPCFP_ST_TRUE, or the ERR_* the traversal met first (nothing else is then written)
+ *   *n_receipts  (nullable) the receipts AMT's count;  block_ids: ascending ids, truncated to cap_blocks          */
+int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                            const uint8_t* child_cid40, uint32_t n_shards, uint32_t shard, ipcfp_status_t* status_out,
+                            uint64_t* receipt_lo, uint64_t* receipt_hi, uint64_t* n_receipts, uint32_t* block_ids,
+                            uint64_t cap_blocks, uint64_t* n_blocks);
+
+/* A new witness made of blocks block_ids[0..n) of `src` (device-side copy; block i of the new witness is block
+ * block_ids[i] of src), tagged as the receipt-range shard [receipt_lo, receipt_hi): ipcfp_scan_events walks only
+ * those receipts (receipt_has_match[i - receipt_lo] is receipt i) and ipcfp_verify_event_* resolves them by table.
+ * Pass (0, UINT64_MAX) for an untagged subset (e.g. a block-range shard of a CID batch).                        */
+int ipcfp_witness_create_subset(ipcfp_ctx_t* ctx, ipcfp_witness_t* src, const uint32_t* block_ids, uint64_t n,
+                                uint64_t receipt_lo, uint64_t receipt_hi, ipcfp_witness_t** out);
+/* Tag / read the receipt range of a witness created by other means (drops its cached enumerations).             */
+int ipcfp_witness_set_receipt_range(ipcfp_witness_t* w, uint64_t lo, uint64_t hi);
+void ipcfp_witness_receipt_range(const ipcfp_witness_t* w, uint64_t* lo, uint64_t* hi);
+
+/* The collective: RCCL's ncclAllGather over xGMI, called directly (librccl.so.1 is resolved when the first
+ * communicator is made; single-GPU hosts never need it).  One process per GPU; rank 0 makes the id
+ * (ncclGetUniqueId) and the HOST application carries its 128 bytes to the other ranks over whatever channel it has. */
+#define IPCFP_COMM_ID_BYTES 128
+typedef struct ipcfp_comm ipcfp_comm_t;
+int ipcfp_comm_unique_id(uint8_t id[IPCFP_COMM_ID_BYTES]);
+int ipcfp_comm_create(ipcfp_ctx_t* ctx, const uint8_t id[IPCFP_COMM_ID_BYTES], int n_ranks, int rank,
+                      ipcfp_comm_t** out);
+void ipcfp_comm_destroy(ipcfp_comm_t* comm);
+int ipcfp_comm_rank(const ipcfp_comm_t* comm);
+int ipcfp_comm_size(const ipcfp_comm_t* comm);
+/* recv_d[r * bytes_per_rank ..] = rank r's send_d[0 .. bytes_per_rank), on the context's stream (asynchronous:
+ * ipcfp_ctx_sync or a later synchronous call completes it).  Waits for K1's stream first, so a CID bitmap written
+ * by ipcfp_witness_verify_cids_async may be part of the payload.                                                  */
+int ipcfp_allgather_device(ipcfp_ctx_t* ctx, ipcfp_comm_t* comm, const void* send_d, void* recv_d,
+                           uint64_t bytes_per_rank);
+
+/* The usual step payload lives in several buffers (status bytes, has-match map, CID bitmap): they are packed back to
+ * back into staging_d (bytes_per_rank bytes, zero padded) on the context's stream and all-gathered in the same call —
+ * still ONE collective.  comm may be null (or of size 1): the packed message is then also the result.            */
+int ipcfp_allgather_segments(ipcfp_ctx_t* ctx, ipcfp_comm_t* comm, const void* const* seg_d, const uint64_t* seg_bytes,
+                             uint32_t n_seg, void* staging_d, void* recv_d, uint64_t bytes_per_rank);
 
 /* ---- bundle wire format ----------------------------------------------
  * `UnifiedProofBundle` (src/proofs/common/bundle.rs:39-45) as the JSON serde_json writes for the

@@ -13,6 +13,10 @@ import numpy as np
 
 __all__ = [
     "Engine",
+    "Comm",
+    "shard_range",
+    "comm_unique_id",
+    "allgather_segments",
     "EngineError",
     "Witness",
     "Bundle",
@@ -58,6 +62,7 @@ KERNEL_IDS = {
     "exec_order": 10,
     "blake2b_raw": 11,
     "base64": 12,
+    "allgather": 13,
 }
 
 
@@ -190,6 +195,20 @@ def load_library() -> C.CDLL:
         "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_verify_event_claims": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
+        "ipcfp_shard_range": (None, [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]),
+        "ipcfp_shard_plan_tipset": (i32, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(u64),
+                                          C.POINTER(u64), C.POINTER(u64), vp, u64, C.POINTER(u64)]),
+        "ipcfp_witness_create_subset": (i32, [vp, vp, vp, u64, u64, u64, C.POINTER(vp)]),
+        "ipcfp_witness_set_receipt_range": (i32, [vp, u64, u64]),
+        "ipcfp_witness_receipt_range": (None, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "ipcfp_comm_unique_id": (i32, [vp]),
+        "ipcfp_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "ipcfp_comm_destroy": (None, [vp]),
+        "ipcfp_comm_rank": (i32, [vp]),
+        "ipcfp_comm_size": (i32, [vp]),
+        "ipcfp_allgather_device": (i32, [vp, vp, vp, vp, u64]),
+        "ipcfp_allgather_segments": (i32, [vp, vp, vp, vp, C.c_uint32, vp, vp, u64]),
+        "ipcfp_scan_events_device": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
         "ipcfp_verify_storage_claims_device": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_cid_from_string": (i32, [C.c_char_p, vp]),
         "ipcfp_cid_to_string": (i32, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]),
@@ -347,6 +366,68 @@ class Engine:
 
     def witness_device(self, bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n) -> "Witness":
         return Witness(self, None, None, None, None, device=(bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n))
+
+
+def shard_range(n: int, n_shards: int, shard: int):
+    """[lo, hi) of `shard` when n units are cut into n_shards contiguous ranges (host only, no GPU)."""
+    lo, hi = C.c_uint64(), C.c_uint64()
+    load_library().ipcfp_shard_range(int(n), int(n_shards), int(shard), C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the engine's run-time binding of librccl (rank 0 calls this; the host carries
+    the 128 bytes to the other ranks)."""
+    lib = load_library()
+    buf = np.zeros(128, dtype=np.uint8)
+    rc = lib.ipcfp_comm_unique_id(_p(buf))
+    if rc != 0:
+        raise EngineError(f"comm_unique_id: {lib.ipcfp_strerror(rc).decode()} ({rc})")
+    return buf.tobytes()
+
+
+class Comm:
+    """One rank of an RCCL communicator (``ipcfp_comm_t``) bound to an Engine's GPU and stream."""
+
+    def __init__(self, eng: "Engine", unique_id: bytes, n_ranks: int, rank: int):
+        self.eng = eng
+        self.lib = eng.lib
+        h = C.c_void_p()
+        idb = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        eng._check(self.lib.ipcfp_comm_create(eng.h, _p(idb), int(n_ranks), int(rank), C.byref(h)), "comm_create")
+        self.h = h
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def allgather_device(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int):
+        """ncclAllGather of bytes_per_rank bytes per rank on the engine's stream (asynchronous)."""
+        self.eng._check(self.lib.ipcfp_allgather_device(self.eng.h, self.h, send_ptr, recv_ptr, int(bytes_per_rank)),
+                        "allgather_device")
+
+    def allgather_segments(self, seg_ptrs, seg_bytes, staging_ptr: int, recv_ptr: int, bytes_per_rank: int):
+        allgather_segments(self.eng, self, seg_ptrs, seg_bytes, staging_ptr, recv_ptr, bytes_per_rank)
+
+    def close(self):
+        if getattr(self, "h", None):
+            if self.eng.h:
+                self.lib.ipcfp_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def allgather_segments(eng: "Engine", comm, seg_ptrs, seg_bytes, staging_ptr: int, recv_ptr: int, bytes_per_rank: int):
+    """Pack the device segments back to back into staging (zero padded to bytes_per_rank) and all-gather them —
+    one collective; comm=None: a single rank, the packed message is the result."""
+    n = len(seg_ptrs)
+    ptrs = (C.c_void_p * max(n, 1))(*[int(p) for p in seg_ptrs])
+    lens = (C.c_uint64 * max(n, 1))(*[int(b) for b in seg_bytes])
+    eng._check(eng.lib.ipcfp_allgather_segments(eng.h, comm.h if comm is not None else None,
+                                                C.cast(ptrs, C.c_void_p), C.cast(lens, C.c_void_p), n, staging_ptr,
+                                                recv_ptr, int(bytes_per_rank)), "allgather_segments")
 
 
 def pack_event_claims(parent_cids, child_cid, parent_epoch, child_epoch, exec_index, event_index, emitter,
@@ -658,6 +739,20 @@ class Witness:
             ids = np.nonzero(bits)[0]
         return int(st[0]), has, m, ids
 
+    def scan_events_device(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor, has_ptr: int, cap_receipts: int,
+                           matches_ptr: int = 0, cap_matches: int = 0, summary_ptr: int = 0):
+        """K6 with device outputs (has-match map / match records stay in HBM).  → (status, n_receipts, n_matches)"""
+        root = np.frombuffer(bytes(receipts_root).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        filt = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
+        st = np.zeros(1, dtype=np.uint8)
+        nr, nm = C.c_uint64(), C.c_uint64()
+        a = (0, 0) if actor is None else (1, int(actor))
+        self.eng._check(self.lib.ipcfp_scan_events_device(self.eng.h, self.h, _p(root), _p(filt), a[0], a[1], _p(st),
+                                                          has_ptr or None, int(cap_receipts), C.byref(nr),
+                                                          matches_ptr or None, int(cap_matches), C.byref(nm),
+                                                          summary_ptr or None), "scan_events_device")
+        return int(st[0]), int(nr.value), int(nm.value)
+
     # -- generator side -------------------------------------------------------------------------
     def generate_event_proofs(self, parent_cids, child_cid: bytes, topic0: bytes, topic1: bytes, actor=None):
         """generate_event_proof over this witness as the blockstore.  Returns
@@ -709,6 +804,39 @@ class Witness:
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st)), "verify_event_proofs")
         return st
+
+    # -- one tipset over several GPUs -----------------------------------------------
+    def shard_plan_tipset(self, parent_cids, child_cid: bytes, n_shards: int, shard: int):
+        """Blocks of this (whole-tipset) witness that `shard` of `n_shards` needs.  Returns
+        (status, receipt_lo, receipt_hi, n_receipts, block ids u32[] ascending)."""
+        pc = pack_cids(parent_cids)
+        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        st = np.zeros(1, dtype=np.uint8)
+        lo, hi, nr, nb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ids = np.zeros(max(self.n, 1), dtype=np.uint32)
+        self.eng._check(self.lib.ipcfp_shard_plan_tipset(self.eng.h, self.h, _p(pc), len(parent_cids), _p(child),
+                                                         int(n_shards), int(shard), _p(st), C.byref(lo), C.byref(hi),
+                                                         C.byref(nr), _p(ids), len(ids), C.byref(nb)), "shard_plan_tipset")
+        return int(st[0]), int(lo.value), int(hi.value), int(nr.value), ids[: int(nb.value)].copy()
+
+    def subset(self, block_ids, receipt_lo: int = 0, receipt_hi: int = (1 << 64) - 1) -> "Witness":
+        """A new witness of the listed blocks (device-side copy), tagged as the receipt-range shard [lo, hi)."""
+        ids = np.ascontiguousarray(block_ids, dtype=np.uint32)
+        h = C.c_void_p()
+        self.eng._check(self.lib.ipcfp_witness_create_subset(self.eng.h, self.h, _p(ids), len(ids), int(receipt_lo),
+                                                             int(receipt_hi), C.byref(h)), "witness_create_subset")
+        w = Witness.__new__(Witness)
+        w.eng, w.lib, w.h, w.n = self.eng, self.lib, h, len(ids)
+        return w
+
+    def set_receipt_range(self, lo: int, hi: int):
+        self.eng._check(self.lib.ipcfp_witness_set_receipt_range(self.h, int(lo), int(hi)), "set_receipt_range")
+
+    @property
+    def receipt_range(self):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self.lib.ipcfp_witness_receipt_range(self.h, C.byref(lo), C.byref(hi))
+        return int(lo.value), int(hi.value)
 
     def rebuild_index(self):
         """K4 again, in place (no allocation)."""

@@ -65,9 +65,11 @@ struct ipcfp_ctx {
         void* dst;
         size_t off, n;
         hipStream_t stream;
+        bool hold = false;  // an H2D staged in the page: the slot stays taken until its stream is synchronised
     };
     std::vector<PendingRead> pending;
     int call_depth = 0;
+    hipEvent_t join_event = nullptr;           // main stream ← K1 stream dependency (host/shard.cpp)
     ipcfp::UploadRing* upload_ring = nullptr;  // pinned staging ring of ipcfp::upload (created on first use)
 };
 
@@ -89,8 +91,18 @@ inline hipError_t d2h_small(ipcfp_ctx* ctx, void* dst, const void* src_d, size_t
     if (!ctx->pinned || ctx->pinned_used + need > ctx->pinned_cap) return hipMemcpyAsync(dst, src_d, n, hipMemcpyDeviceToHost, s);
     const size_t off = ctx->pinned_used;
     ctx->pinned_used += need;
-    ctx->pending.push_back({dst, off, n, s});
+    ctx->pending.push_back({dst, off, n, s, false});
     return hipMemcpyAsync(ctx->pinned + off, src_d, n, hipMemcpyDeviceToHost, s);
+}
+// A few bytes host → device through the same pinned page (valid until the next sync_stream of that stream).
+inline hipError_t h2d_small(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t n, hipStream_t s) {
+    const size_t need = (n + 15) & ~size_t(15);
+    if (!ctx->pinned || ctx->pinned_used + need > ctx->pinned_cap) return hipMemcpyAsync(dst_d, src, n, hipMemcpyHostToDevice, s);
+    const size_t off = ctx->pinned_used;
+    ctx->pinned_used += need;
+    std::memcpy(ctx->pinned + off, src, n);
+    ctx->pending.push_back({nullptr, off, 0, s, true});
+    return hipMemcpyAsync(dst_d, ctx->pinned + off, n, hipMemcpyHostToDevice, s);
 }
 // hipStreamSynchronize + delivery of the read-backs queued on that stream.  Every synchronisation of an
 // engine stream goes through here.
@@ -101,7 +113,8 @@ inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
         if (r.stream == s) {
             if (r.dst && e == hipSuccess) std::memcpy(r.dst, ctx->pinned + r.off, r.n);
             r.dst = nullptr;  // delivered (or lost with the failed synchronisation): never written twice
-        } else if (r.dst) {
+            r.hold = false;
+        } else if (r.dst || r.hold) {
             others = true;
         }
     }
@@ -201,7 +214,8 @@ struct EnumCached {
     DevBuf<uint8_t> leaves;  // LeafRef[n]
     uint64_t n = 0;
     uint64_t error = ~0ULL;  // packed first error, ~0 = none
-    bool dense = false;      // leaf i has index i for every i
+    bool dense = false;      // leaf i has index lo + i for every i
+    uint64_t lo = 0, hi = ~0ULL;  // the index range the enumeration was restricted to
 };
 }  // namespace ipcfp
 
@@ -225,5 +239,7 @@ struct ipcfp_witness {
     ipcfp::DevBuf<uint32_t> index_slots;  // table of block ids, 0xffffffff = empty
     uint32_t index_mask = 0;
     bool uniform_chunks = false;  // every block has the same chunk count → identity order
+    // a shard of one tipset (host/shard.cpp): enumerations of a receipts AMT are restricted to [receipt_lo, receipt_hi)
+    uint64_t receipt_lo = 0, receipt_hi = ~0ULL;
     std::vector<std::unique_ptr<ipcfp::EnumCached>> enum_cache;
 };

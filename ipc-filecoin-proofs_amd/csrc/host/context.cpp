@@ -216,6 +216,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     ctx->pool.drain();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->upload_ring) upload_ring_destroy(ctx->upload_ring);
+    if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -27,7 +27,9 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     IPCFP_HIP(ctx, hipMemsetAsync(err.p, 0xff, 8, ctx->stream));  // kNoEnumError
     (void)e0;
     const EnumCached* en = nullptr;
-    int rc = amt_enumerate_cached(ctx, w, root, 0, VK_RECEIPT, &en);  // receipts in index order
+    // receipts in index order; a shard witness (host/shard.cpp) enumerates its own index range only
+    const uint64_t lo = w->receipt_lo, hi = w->receipt_hi;
+    int rc = amt_enumerate_cached(ctx, w, root, 0, VK_RECEIPT, &en, lo, hi);
     if (rc) return rc;
     if (en->error != kNoEnumError) {
         out.status = enum_error_code(en->error);
@@ -38,12 +40,12 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     // receipt indices are ascending: the last leaf gives the size of the per-index byte map
     uint64_t n_idx = 0;
     if (n && en->dense) {
-        n_idx = n;  // leaf i has index i
+        n_idx = n;  // leaf i has index lo + i
     } else if (n) {
         LeafRef last;
         IPCFP_HIP(ctx, d2h_small(ctx, &last, leaves + (n - 1), sizeof last, ctx->stream));
         IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-        n_idx = last.index + 1;
+        n_idx = last.index + 1 - lo;  // the per-index byte map starts at the shard's first index
     }
     DevBuf<uint32_t> counts, offsets;
     DevBuf<uint64_t> scratch, total;
@@ -75,7 +77,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     WitnessView rec = view;
     rec.touched = touched_d;
     rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, counts.p, offsets.p,
-                           cap ? out.matches.p : nullptr, cap, out.has.p, n_idx);
+                           cap ? out.matches.p : nullptr, cap, out.has.p, n_idx, lo);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // delivers nm / e1 when they were not waited for above
     if (e1 != kNoEnumError) {  // PASS 2 ran on a tipset PASS 1 rejected: its output is discarded
@@ -124,6 +126,41 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
                                       hipMemcpyDeviceToHost, ctx->stream));
     if (touched_bits) IPCFP_HIP(ctx, hipMemcpyAsync(touched_bits, touched.p, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    return IPCFP_OK;
+}
+
+// The same scan with DEVICE outputs (a multi-GPU host all-gathers them without a round trip through host memory):
+// receipt_has_match_d (cap_receipts bytes) and matches_d (cap_matches records) are HBM buffers of the caller, or
+// null; the three scalars still come back to the host.
+int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* receipts_root40,
+                             const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
+                             void* receipt_has_match_d, uint64_t cap_receipts, uint64_t* n_receipts, void* matches_d,
+                             uint64_t cap_matches, uint64_t* n_matches, void* summary_d) {
+    if (!ctx || !w || w->ctx != ctx || !receipts_root40 || !filter || !status_out || !n_receipts || !n_matches)
+        return IPCFP_E_INVALID;
+    IPCFP_ENTER(ctx);
+    *n_receipts = *n_matches = 0;
+    *status_out = IPCFP_ST_ERR;
+    ScanResult res;
+    int rc = scan_events_device(ctx, w, key_from_slot(receipts_root40), *filter, has_actor, actor, nullptr, res,
+                                matches_d ? cap_matches : 0);
+    if (rc) return rc;
+    *status_out = ipcfp_status_t(res.status);
+    if (summary_d) {  // {status, n_matches} for the step message of a multi-GPU host
+        const uint64_t sm[2] = {uint64_t(res.status), res.status == IPCFP_ST_TRUE ? res.n_matches : 0};
+        IPCFP_HIP(ctx, h2d_small(ctx, summary_d, sm, sizeof sm, ctx->stream));
+    }
+    if (res.status != IPCFP_ST_TRUE) return IPCFP_OK;
+    *n_receipts = res.n_idx;
+    *n_matches = res.n_matches;
+    if (receipt_has_match_d && res.n_idx)
+        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match_d, res.has.p, res.n_idx < cap_receipts ? res.n_idx : cap_receipts,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    if (matches_d && res.n_matches)
+        IPCFP_HIP(ctx, hipMemcpyAsync(matches_d, res.matches.p,
+                                      (res.n_matches < cap_matches ? res.n_matches : cap_matches) * sizeof(ipcfp_event_match_t),
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // `res` returns its buffers to the pool on exit
     return IPCFP_OK;
 }
 

@@ -132,6 +132,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         tc.exec_slots = nullptr;
         tc.receipt_leaves = nullptr;
         tc.n_receipt_leaves = 0;
+        tc.receipt_first = 0;
         // the execution order is only reached when steps 1-2 can pass for some proof of this context
         const bool reachable = (tc.flags & TC_PARENTS_PARSED) && (tc.flags & TC_CHILD_PARSED) &&
                                tc.child_status == IPCFP_ST_TRUE && tc.parents_match && tc.n_parents > 0 &&
@@ -145,11 +146,12 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         tc.exec_len = 0;  // patched on the device below
         // receipts AMT of this context: enumerate once (shared with ipcfp_scan_events through the witness cache)
         const EnumCached* rc_enum = nullptr;
-        rc = amt_enumerate_cached(ctx, w, tc.receipts_root, 0, VK_RECEIPT, &rc_enum);
+        rc = amt_enumerate_cached(ctx, w, tc.receipts_root, 0, VK_RECEIPT, &rc_enum, w->receipt_lo, w->receipt_hi);
         if (rc) return rc;
         if (rc_enum->error == kNoEnumError && rc_enum->dense) {
             tc.receipt_leaves = reinterpret_cast<const LeafRef*>(rc_enum->leaves.p);
             tc.n_receipt_leaves = rc_enum->n;
+            tc.receipt_first = rc_enum->n ? w->receipt_lo : 0;
         }
     }
     IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,

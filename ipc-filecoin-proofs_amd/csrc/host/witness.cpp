@@ -17,16 +17,15 @@ namespace ipcfp {
 int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w);  // cid_index.hip
 }
 
-namespace {
+namespace ipcfp {
 
 constexpr uint64_t kTailSlack = 256;  // K1 may read one 128-byte chunk past a block's padded end
 
-// Shared tail of both constructors: `raw_bytes_d/raw_off_d` hold the caller's layout on
+// Shared tail of the constructors: `raw_bytes_d/raw_off_d` hold the caller's layout on
 // the device; build the aligned arena (adopting nothing: the witness owns its copy),
 // the lane schedule and the CID index.
-int finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
-                  const uint32_t* len_d_src, const uint8_t* cids_d_src, bool src_is_device_owned_copy) {
-    (void)src_is_device_owned_copy;
+int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
+                          const uint32_t* len_d_src, const uint8_t* cids_d_src) {
     const uint32_t n = uint32_t(w->n);
     IPCFP_HIP(ctx, w->off.alloc(n));
     IPCFP_HIP(ctx, w->len.alloc(n));
@@ -72,7 +71,7 @@ int finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, 
     return IPCFP_OK;
 }
 
-}  // namespace
+}  // namespace ipcfp
 
 extern "C" {
 
@@ -112,7 +111,7 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
         if ((rc = upload(ctx, raw_cids.p, cids40, n * IPCFP_CID_SLOT, ctx->stream))) return rc;
     }
     if (nbytes && (rc = upload(ctx, raw_bytes.p, bytes, nbytes, ctx->stream))) return rc;
-    rc = finish_create(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p, true);
+    rc = witness_finish_create(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p);
     if (rc) return rc;
     *out = w.release();
     return IPCFP_OK;
@@ -130,8 +129,8 @@ int ipcfp_witness_create_device(ipcfp_ctx_t* ctx, const void* bytes_d, uint64_t 
     w->ctx = ctx;
     w->n = n;
     w->nbytes = nbytes;  // upper bound; the device path does not sum lengths on the host
-    int rc = finish_create(ctx, w.get(), static_cast<const uint8_t*>(bytes_d), static_cast<const uint64_t*>(off_d),
-                           static_cast<const uint32_t*>(len_d), static_cast<const uint8_t*>(cids40_d), false);
+    int rc = witness_finish_create(ctx, w.get(), static_cast<const uint8_t*>(bytes_d), static_cast<const uint64_t*>(off_d),
+                                   static_cast<const uint32_t*>(len_d), static_cast<const uint8_t*>(cids40_d));
     if (rc) return rc;
     *out = w.release();
     return IPCFP_OK;

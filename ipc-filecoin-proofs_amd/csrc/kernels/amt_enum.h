@@ -68,16 +68,20 @@ struct AmtEnumResult {
     bool dense = false;             // every AMT held exactly the indices 0..count-1 (the fast path succeeded)
 };
 
+// An enumeration may be restricted to the indices [lo, hi) (a receipt-range shard of one tipset):
+// subtrees that hold no index of the range are neither resolved nor loaded — their blocks live in another
+// shard's witness — while every node that is visited is validated completely.  Meant for ONE root.
+
 // Enumerate `n_roots` AMTs (device array `roots_d`) whose values have type `vkind`.
 // `err_d` is a device u64 initialised by the caller (kNoEnumError or earlier-stage errors); the
 // enumerator atomicMin's into it.  Synchronises the stream twice on the dense path (root shapes; anomaly flag
 // + error word), once more per level on the general path.
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
-                  unsigned long long* err_d, AmtEnumResult& out);
+                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo = 0, uint64_t hi = ~0ULL);
 
 // Enumerate one AMT of the witness, or return the cached enumeration (owned by the witness; valid
 // until ipcfp_witness_rebuild_index).
 int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, int version, int vkind,
-                         const EnumCached** out);
+                         const EnumCached** out, uint64_t lo = 0, uint64_t hi = ~0ULL);
 
 }  // namespace ipcfp

@@ -57,10 +57,29 @@ __device__ __forceinline__ bool enum_read_node(const WitnessView& w, const EnumN
 // interior level L ≥ 1: how many entries does each frontier entry contribute to the next level?
 // `bound` (nullable): device-side number of valid frontier entries when the host launched with a
 // PREDICTED size (speculative path); entries past it count as empty.
+// An index range [lo, hi) restricts an enumeration to the values inside it (a receipt-range shard of one tipset,
+// SURVEY.md §8e): a child whose span does not meet the range is not counted, not resolved and not loaded — its
+// block belongs to another shard's witness.  Nodes that ARE visited are still validated completely.
+struct EnumRange {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ bool span_meets(uint64_t base, uint64_t span, const EnumRange& rg) {
+    const uint64_t end = base + span < base ? ~0ULL : base + span;  // saturating
+    return base < rg.hi && end > rg.lo;
+}
+// slots of node `e` (bitmap in nd) whose child span meets the range
+__device__ __forceinline__ uint32_t links_in_range(const AmtNode& nd, const EnumNode& e, const EnumRange& rg) {
+    const uint64_t span = amt_span(e.bit_width, e.height);
+    uint32_t c = 0;
+    for (uint32_t sub = 0; sub < nd.width; ++sub)
+        if (nd.bit(sub) && span_meets(e.base + uint64_t(sub) * span, span, rg)) ++c;
+    return c;
+}
+
 __global__ __launch_bounds__(256) void k_enum_count(WitnessView w, const EnumNode* __restrict__ frontier, uint32_t n,
                                                     uint32_t level, int vkind, uint32_t* __restrict__ counts,
                                                     unsigned long long* __restrict__ err,
-                                                    const uint64_t* __restrict__ bound) {
+                                                    const uint64_t* __restrict__ bound, EnumRange rg) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     if (bound && t >= *bound) {
@@ -75,7 +94,7 @@ __global__ __launch_bounds__(256) void k_enum_count(WitnessView w, const EnumNod
         } else {
             AmtNode nd;
             if (!enum_read_node(w, e, vkind, nd)) enum_error(err, e.seq, e.base, IPCFP_ST_ERR_DECODE);
-            else c = nd.nlinks ? nd.nlinks : 1;  // a Leaf above height 0 is carried down as-is
+            else c = nd.nlinks ? links_in_range(nd, e, rg) : 1;  // a Leaf above height 0 is carried down as-is
         }
     }
     counts[t] = c;
@@ -89,7 +108,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(WitnessView w, const EnumNo
                                                      uint32_t level, const uint32_t* __restrict__ offsets,
                                                      uint32_t total, EnumNode* __restrict__ next,
                                                      unsigned long long* __restrict__ err,
-                                                     const uint64_t* __restrict__ bound) {
+                                                     const uint64_t* __restrict__ bound, EnumRange rg) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= total) return;
     if (bound && j >= *bound) return;
@@ -117,15 +136,19 @@ __global__ __launch_bounds__(256) void k_enum_expand(WitnessView w, const EnumNo
         next[j] = e;
         return;
     }
-    // the k-th set bit of the bitmap names the slot; step over the k links before ours
-    uint32_t sub = 0, seen = 0;
+    // the k-th set bit whose child meets the range names the slot; step over the links before ours
+    const uint64_t span = amt_span(e.bit_width, e.height);
+    uint32_t sub = 0, seen = 0, before = 0;
     for (;; ++sub) {
         if ((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u) {
-            if (seen == k) break;
-            ++seen;
+            if (span_meets(e.base + uint64_t(sub) * span, span, rg)) {
+                if (seen == k) break;
+                ++seen;
+            }
+            ++before;
         }
     }
-    for (uint32_t q = 0; q < k; ++q) {
+    for (uint32_t q = 0; q < before; ++q) {
         uint32_t m;
         uint64_t a;
         r.head(m, a);  // tag 42
@@ -134,7 +157,6 @@ __global__ __launch_bounds__(256) void k_enum_expand(WitnessView w, const EnumNo
     }
     CidKey key;
     r.read_link_key(key);
-    const uint64_t span = amt_span(e.bit_width, e.height);
     EnumNode c{kNoBlock, 0, e.base + uint64_t(sub) * span, e.seq, uint16_t(e.height - 1), e.bit_width, 0};
     const uint32_t b = witness_find(w, key);
     if (b == kNoBlock) enum_error(err, e.seq, c.base, IPCFP_ST_ERR_MISSING_BLOCK);
@@ -146,7 +168,7 @@ __global__ __launch_bounds__(256) void k_enum_expand(WitnessView w, const EnumNo
 __global__ __launch_bounds__(256) void k_enum_count_leaf(WitnessView w, const EnumNode* __restrict__ frontier,
                                                          uint32_t n, int vkind, uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ err,
-                                                         const uint64_t* __restrict__ bound) {
+                                                         const uint64_t* __restrict__ bound, EnumRange rg) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     if (bound && t >= *bound) {
@@ -159,7 +181,9 @@ __global__ __launch_bounds__(256) void k_enum_count_leaf(WitnessView w, const En
         AmtNode nd;
         if (!enum_read_node(w, e, vkind, nd)) enum_error(err, e.seq, e.base, IPCFP_ST_ERR_DECODE);
         else if (nd.nlinks) enum_error(err, e.seq, e.base, IPCFP_ST_ERR_DECODE);  // link node at height 0
-        else c = nd.nvalues;
+        else
+            for (uint32_t sub = 0; sub < nd.width; ++sub)
+                if (nd.bit(sub) && e.base + sub >= rg.lo && e.base + sub < rg.hi) ++c;
     }
     counts[t] = c;
 }
@@ -167,7 +191,7 @@ __global__ __launch_bounds__(256) void k_enum_count_leaf(WitnessView w, const En
 __global__ __launch_bounds__(256) void k_enum_emit(WitnessView w, const EnumNode* __restrict__ frontier, uint32_t n,
                                                    int vkind, const uint32_t* __restrict__ counts,
                                                    const uint32_t* __restrict__ offsets,
-                                                   LeafRef* __restrict__ leaves, uint64_t cap) {
+                                                   LeafRef* __restrict__ leaves, uint64_t cap, EnumRange rg) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     if (counts[t] == 0) return;
@@ -181,12 +205,12 @@ __global__ __launch_bounds__(256) void k_enum_emit(WitnessView w, const EnumNode
     r.read_bytes(bo, bl);
     (void)r.read_array();  // no links in a leaf
     const uint64_t nv = r.read_array();
-    uint32_t sub = 0;
+    uint32_t sub = 0, k = 0;
     for (uint64_t j = 0; j < nv; ++j) {
         while (!((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
         const uint32_t start = r.pos;
         check_value(r, vkind);
-        leaves[o + uint32_t(j)] = LeafRef{e.block, start, r.pos - start, e.seq, e.base + sub};
+        if (e.base + sub >= rg.lo && e.base + sub < rg.hi) leaves[o + k++] = LeafRef{e.block, start, r.pos - start, e.seq, e.base + sub};
         ++sub;
     }
 }
@@ -204,14 +228,26 @@ __global__ __launch_bounds__(256) void k_enum_emit(WitnessView w, const EnumNode
 struct DenseRoot {
     uint32_t height, bit_width;
     uint64_t count;
+    uint64_t lo, hi;  // the indices to enumerate: [lo, hi) with lo < hi <= count, or (0, 0) for an empty tree
 };
 
-__host__ __device__ inline uint64_t dense_nodes(const DenseRoot& r, uint32_t level) {
+// nodes of `level` (node height) the whole tree has
+__host__ __device__ inline uint64_t dense_total(const DenseRoot& r, uint32_t level) {
     if (r.height < level) return 1;  // rides along until its own level
     const uint64_t shift = uint64_t(r.bit_width) * (level + 1);
     if (shift >= 64) return 1;
     const uint64_t n = (r.count + (1ULL << shift) - 1) >> shift;
     return n ? n : 1;
+}
+// first node of `level` that holds an index of [lo, hi), and how many such nodes there are
+__host__ __device__ inline uint64_t dense_first(const DenseRoot& r, uint32_t level) {
+    const uint64_t shift = uint64_t(r.bit_width) * (level + 1);
+    return (r.height < level || shift >= 64 || r.hi == 0) ? 0 : (r.lo >> shift);
+}
+__host__ __device__ inline uint64_t dense_nodes(const DenseRoot& r, uint32_t level) {
+    const uint64_t shift = uint64_t(r.bit_width) * (level + 1);
+    if (r.height < level || shift >= 64 || r.hi == 0) return 1;
+    return ((r.hi - 1) >> shift) - (r.lo >> shift) + 1;
 }
 
 // frontier entering `level` (≥ 1) → frontier entering level-1; one lane per child
@@ -231,21 +267,25 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
         dr = roots[++r];
         n_here = dense_nodes(dr, level - 1);
     }
-    const uint32_t q = j - next_off;
     if (dr.height < level) {  // rides along
         next[j] = cur[cur_off];
         return;
     }
+    const uint64_t q = dense_first(dr, level - 1) + (j - next_off);  // absolute node number on the child level
     const uint32_t W = 1u << dr.bit_width;
-    const uint32_t p = q >> dr.bit_width, k = q & (W - 1u);
-    const EnumNode e = cur[cur_off + p];
+    const uint64_t p = q >> dr.bit_width;
+    const uint32_t k = uint32_t(q) & (W - 1u);
+    const EnumNode e = cur[cur_off + uint32_t(p - dense_first(dr, level))];
     EnumNode c{kNoBlock, 0, 0, e.seq, uint16_t(level - 1), e.bit_width, 0};
     if (e.block == kNoBlock) {
         next[j] = c;
         return;
     }
-    const uint64_t remaining = n_here - uint64_t(p) * W;
+    const uint64_t remaining = dense_total(dr, level - 1) - p * W;
     const uint32_t m = remaining < W ? uint32_t(remaining) : W;  // links this parent must hold
+    // a parent on the edge of the range has children without a lane: the first / last lane it does have stands in
+    const bool edge_first = j == next_off && k > 0;
+    const bool edge_last = j + 1 == next_off + n_here && k + 1 < m;
     // The parent is validated BY ITS CHILDREN, each lane a share, instead of by one lane parsing all of it (a
     // node of eight links is 350 bytes = 22 dependent chunk loads for that one lane — the latency of a level):
     //   every lane   the node header: array(3), bitmap = exactly the low m bits, links array of m entries;
@@ -278,13 +318,23 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
     }
     const uint32_t mine = r2.pos + 43u * k;
     CidKey key;
-    ok = mine + 43u <= r2.n;  // never read outside the block on the strength of an unverified assumption
+    if (edge_first) {  // links 0..k-1 have no lane of their own here: walk them (each must be the 43-byte form)
+        uint32_t o, l;
+        for (uint32_t i = 0; i < k && r2.ok(); ++i) r2.read_link(o, l);
+        ok = r2.ok() && r2.pos == mine;
+    }
+    ok = ok && mine + 43u <= r2.n;  // never read outside the block on the strength of an unverified assumption
     if (ok) {
         r2.pos = mine;
         r2.read_link_key(key);
         ok = r2.ok() && r2.pos - mine == 43u;
     }
-    if (ok && k == m - 1) {
+    if (ok && edge_last) {  // links k+1..m-1 likewise
+        uint32_t o, l;
+        for (uint32_t i = k + 1; i < m && r2.ok(); ++i) r2.read_link(o, l);
+        ok = r2.ok();
+    }
+    if (ok && (k == m - 1 || edge_last)) {
         ok = r2.read_array() == 0 && r2.ok();
         if (ok && e.node_off == 0) {  // a child block holds exactly this node (the root's tail was checked by amt_load)
             r2.finish();
@@ -310,15 +360,15 @@ __global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumN
     uint64_t n_here = dense_nodes(dr, 0);
     while (t >= node_off0 + n_here) {
         node_off0 += uint32_t(n_here);
-        leaf_off += dr.count;
+        leaf_off += dr.hi - dr.lo;
         dr = roots[++r];
         n_here = dense_nodes(dr, 0);
     }
-    const uint32_t p = t - node_off0;
+    const uint64_t p = dense_first(dr, 0) + (t - node_off0);  // absolute leaf-node number
     const EnumNode e = cur[t];
     if (e.block == kNoBlock) return;  // reported where the link failed to resolve
     const uint32_t W = 1u << dr.bit_width;
-    const uint64_t remaining = dr.count - uint64_t(p) * W;
+    const uint64_t remaining = dr.count - p * W;
     const uint32_t m = remaining < W ? uint32_t(remaining) : W;
     Rd rd = open_block(w, e.block);
     rd.pos = e.node_off;
@@ -338,12 +388,13 @@ __global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumN
     ok = ok && rd.read_array() == 0;  // a leaf holds no links
     const uint64_t nv = rd.read_array();
     ok = ok && rd.ok() && nv == m;
-    LeafRef* out = leaves + leaf_off + uint64_t(p) * W;
+    // every value of the node is type-checked (serde decodes the whole node); the ones inside [lo, hi) are emitted
     for (uint32_t i = 0; ok && i < m; ++i) {
         const uint32_t start = rd.pos;
         check_value(rd, vkind);
         ok = rd.ok();
-        out[i] = LeafRef{e.block, start, rd.pos - start, e.seq, e.base + i};
+        const uint64_t idx = p * W + i;
+        if (ok && idx >= dr.lo && idx < dr.hi) leaves[leaf_off + (idx - dr.lo)] = LeafRef{e.block, start, rd.pos - start, e.seq, e.base + i};
     }
     if (ok && e.node_off == 0) {
         rd.finish();
@@ -386,7 +437,9 @@ static uint64_t amt_span_host(uint32_t bw, uint64_t height) {
 }
 
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
-                  unsigned long long* err_d, AmtEnumResult& out) {
+                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo, uint64_t hi) {
+    const EnumRange rg{lo, hi};
+    const bool whole = lo == 0 && hi == ~0ULL;
     out.n_leaves = 0;
     out.error = kNoEnumError;
     out.leaves.release();
@@ -422,7 +475,11 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             dr[i].count = root_info[2 * size_t(i) + 1];
             if (dr[i].count == 0 && dr[i].height > 0) try_dense = false;  // empty tree with a tall root
             if (dr[i].count > amt_span_host(dr[i].bit_width, dr[i].height + 1)) try_dense = false;
-            n_leaves += dr[i].count;
+            dr[i].lo = lo < dr[i].count ? lo : dr[i].count;
+            dr[i].hi = hi < dr[i].count ? hi : dr[i].count;
+            if (dr[i].count && dr[i].lo >= dr[i].hi) try_dense = false;  // nothing of this tree in the range
+            if (dr[i].count == 0) dr[i].lo = dr[i].hi = 0;
+            n_leaves += dr[i].hi - dr[i].lo;
         }
         std::vector<uint64_t> n_level(max_height + 1, 0);
         for (uint32_t level = 0; level <= max_height && try_dense; ++level) {
@@ -470,7 +527,7 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     }
 
     // ---- speculative pass: every level launched back to back with PREDICTED sizes, one sync at the end ----
-    {
+    if (whole) {
         uint64_t pred_leaves = 0;
         bool sane = true;
         for (size_t i = 0; i + 1 < root_info.size(); i += 2)
@@ -511,11 +568,11 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                     IPCFP_HIP(ctx, hipMemsetAsync(tot, 0, 8, ctx->stream));
                 } else if (level >= 1) {
                     hipLaunchKernelGGL(k_enum_count, dim3(div_up(np, 256)), dim3(256), 0, ctx->stream, view, a.p, np, level,
-                                       vkind, cnt.p, err_spec.p, bound);
+                                       vkind, cnt.p, err_spec.p, bound, rg);
                     rc = launch_scan_u32(ctx, cnt.p, np, offs.p, tot, scr.p);
                 } else {
                     hipLaunchKernelGGL(k_enum_count_leaf, dim3(div_up(np, 256)), dim3(256), 0, ctx->stream, view, a.p, np,
-                                       vkind, cnt.p, err_spec.p, bound);
+                                       vkind, cnt.p, err_spec.p, bound, rg);
                     rc = launch_scan_u32(ctx, cnt.p, np, offs.p, tot, scr.p);
                 }
                 if (rc) return rc;
@@ -524,13 +581,13 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                 if (level >= 1) {
                     if (expect && np)
                         hipLaunchKernelGGL(k_enum_expand, dim3(div_up(expect, 256)), dim3(256), 0, ctx->stream, view, a.p, np,
-                                           level, offs.p, uint32_t(expect), b.p, err_spec.p, tot);
+                                           level, offs.p, uint32_t(expect), b.p, err_spec.p, tot, rg);
                     a.swap(b);
                     bound = tot;
                 } else {
                     if (pred_leaves && np)
                         hipLaunchKernelGGL(k_enum_emit, dim3(div_up(np, 256)), dim3(256), 0, ctx->stream, view, a.p, np, vkind,
-                                           cnt.p, offs.p, out.leaves.p, pred_leaves);
+                                           cnt.p, offs.p, out.leaves.p, pred_leaves, rg);
                     break;
                 }
             }
@@ -556,10 +613,10 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
         IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
         if (level >= 1)
             hipLaunchKernelGGL(k_enum_count, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
-                               vkind, counts.p, err_d, static_cast<const uint64_t*>(nullptr));
+                               vkind, counts.p, err_d, static_cast<const uint64_t*>(nullptr), rg);
         else
             hipLaunchKernelGGL(k_enum_count_leaf, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n,
-                               vkind, counts.p, err_d, static_cast<const uint64_t*>(nullptr));
+                               vkind, counts.p, err_d, static_cast<const uint64_t*>(nullptr), rg);
         int rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total_d.p, scratch.p);
         if (rc) return rc;
         uint64_t total = 0;
@@ -572,7 +629,7 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             IPCFP_HIP(ctx, nxt.alloc(total));
             if (total)
                 hipLaunchKernelGGL(k_enum_expand, dim3(div_up(total, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, level,
-                                   offsets.p, uint32_t(total), nxt.p, err_d, static_cast<const uint64_t*>(nullptr));
+                                   offsets.p, uint32_t(total), nxt.p, err_d, static_cast<const uint64_t*>(nullptr), rg);
             cur.swap(nxt);  // the old frontier returns to the pool; reuse is stream-ordered
             n = uint32_t(total);
             if (n == 0) break;
@@ -581,7 +638,7 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             out.n_leaves = total;
             if (total)
                 hipLaunchKernelGGL(k_enum_emit, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, view, cur.p, n, vkind,
-                                   counts.p, offsets.p, out.leaves.p, total);
+                                   counts.p, offsets.p, out.leaves.p, total, rg);
             break;
         }
     }
@@ -593,17 +650,18 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     return IPCFP_OK;
 }
 
-__global__ __launch_bounds__(256) void k_check_dense(const LeafRef* __restrict__ leaves, uint32_t n,
+__global__ __launch_bounds__(256) void k_check_dense(const LeafRef* __restrict__ leaves, uint32_t n, uint64_t first,
                                                      uint32_t* __restrict__ flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool bad = i < n && leaves[i].index != uint64_t(i);
+    const bool bad = i < n && leaves[i].index != first + uint64_t(i);
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, int version, int vkind,
-                         const EnumCached** out) {
+                         const EnumCached** out, uint64_t lo, uint64_t hi) {
     for (auto& e : w->enum_cache)
-        if (e->version == version && e->vkind == vkind && std::memcmp(e->root, root.w, 40) == 0) {
+        if (e->version == version && e->vkind == vkind && e->lo == lo && e->hi == hi &&
+            std::memcmp(e->root, root.w, 40) == 0) {
             *out = e.get();
             return IPCFP_OK;
         }
@@ -611,6 +669,8 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     std::memcpy(e->root, root.w, 40);
     e->version = version;
     e->vkind = vkind;
+    e->lo = lo;
+    e->hi = hi;
     WitnessView view;
     view.arena = w->arena.p;
     view.off = w->off.p;
@@ -635,14 +695,14 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     (void)e0;
     IPCFP_HIP(ctx, hipMemsetAsync(flag.p, 0, 4, ctx->stream));
     AmtEnumResult en;
-    int rc = amt_enumerate(ctx, view, roots.p, 1, vkind, err.p, en);
+    int rc = amt_enumerate(ctx, view, roots.p, 1, vkind, err.p, en, lo, hi);
     if (rc) return rc;
     e->n = en.n_leaves;
     e->error = en.error;
     uint32_t not_dense = 0;
     if (en.n_leaves && !en.dense) {
         const uint32_t n = uint32_t(en.n_leaves);
-        hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, flag.p);
+        hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, lo, flag.p);
         IPCFP_HIP(ctx, d2h_small(ctx, &not_dense, flag.p, 4, ctx->stream));
         IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
                                                     const uint32_t* __restrict__ counts,
                                                     const uint32_t* __restrict__ offsets,
                                                     EventMatch* __restrict__ matches, uint64_t matches_cap,
-                                                    uint8_t* __restrict__ has_match, uint64_t has_cap) {
+                                                    uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool recording = w.touched != nullptr;
     if (t == 0 && recording) {  // `Amtv0::load(&receipts_root, &rec_receipts)` records the root even without matches (:195-196)
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
     if (t >= n) return;
     const LeafRef leaf = receipts[t];
     const uint32_t c = counts[t];
-    if (leaf.index < has_cap) has_match[leaf.index] = c ? 1 : 0;
+    // one byte per receipt index; a shard's map starts at its first index (has_base = receipt_lo)
+    if (leaf.index >= has_base && leaf.index - has_base < has_cap) has_match[leaf.index - has_base] = c ? 1 : 0;
     if (c == 0) return;
     // `r_amt.get(i)` on the recorder (:249).  Its only observable effect is the recorded path: the index
     // came out of this very AMT's enumeration, which validated every node, so the get cannot return None
@@ -277,14 +278,14 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
 int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
                       uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
                       const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint64_t matches_cap,
-                      uint8_t* has_match_d, uint64_t has_cap) {
+                      uint8_t* has_match_d, uint64_t has_cap, uint64_t has_base) {
     ScanParams sp{filter, actor, has_actor ? 1u : 0u, 0};
     const uint32_t threads = n ? n : 1;
     {
         ProfileScope prof(ctx, IPCFP_K_REPLAY);
         hipLaunchKernelGGL(k_scan_pass2, dim3(div_up(threads, 256)), dim3(256), 0, ctx->stream, w, receipts_root,
                            receipts_d, n, sp, counts_d, offsets_d, static_cast<EventMatch*>(matches_d), matches_cap,
-                           has_match_d, has_cap);
+                           has_match_d, has_cap, has_base);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

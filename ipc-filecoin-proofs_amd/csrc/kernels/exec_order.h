@@ -36,6 +36,7 @@ struct TipsetCtxDev {
     // dense, `Amt::get(exec_index)` is a table lookup — every node on every path was already validated
     const LeafRef* receipt_leaves;
     uint64_t n_receipt_leaves;
+    uint64_t receipt_first;       // index of receipt_leaves[0] (0, or the first receipt of a shard witness)
 };
 
 }  // namespace ipcfp

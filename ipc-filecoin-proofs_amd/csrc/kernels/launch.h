@@ -76,7 +76,7 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
 int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
                       uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
                       const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint64_t matches_cap,
-                      uint8_t* has_match_d, uint64_t has_cap);
+                      uint8_t* has_match_d, uint64_t has_cap, uint64_t has_base = 0);
 
 // --- base64.hip ---
 int launch_base64_decode(ipcfp_ctx* ctx, const uint8_t* text_d, const void* spans_d, uint32_t n_blocks, uint32_t n_units,
@@ -92,6 +92,13 @@ int launch_mark_cids(ipcfp_ctx* ctx, const WitnessView& w, const CidKey* keys_d,
 int launch_gather_keys(ipcfp_ctx* ctx, const CidKey* table_d, uint64_t table_len, const uint64_t* index_d, uint32_t n,
                        CidKey* out_d, uint32_t* oor_d);
 int launch_gather_block_cids(ipcfp_ctx* ctx, const uint8_t* cids_d, const uint32_t* ids_d, uint32_t n, CidKey* out_d);
+
+// --- shard.hip ---
+int launch_plan_receipts(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint64_t lo, uint32_t n);
+int launch_amt_root_info(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, int version, int vkind, uint64_t* out_d);
+int launch_subset_tables(ipcfp_ctx* ctx, const uint32_t* ids_d, uint32_t n, uint32_t n_src, const uint64_t* src_off,
+                         const uint32_t* src_len, const uint8_t* src_cids, uint64_t* off_d, uint32_t* len_d,
+                         uint8_t* cids_d, uint32_t* bad_d);
 
 // device view of a witness (host helper, witness.cpp)
 WitnessView witness_view(const ipcfp_witness* w, uint32_t* touched_bits = nullptr);

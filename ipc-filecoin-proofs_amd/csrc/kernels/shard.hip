@@ -1,0 +1,145 @@
+// csrc/kernels/shard.hip — one tipset over several GPUs: the planner's marking pass and the
+// gathers that cut a shard's witness out of the whole one.
+//
+// The reference verifies a bundle proof by proof on one thread (src/proofs/verifier.rs:19-28,49-54,
+// src/proofs/events/verifier.rs:62-71).  Proofs are independent given a read-only witness, so rank r of G takes
+// the receipts [lo, hi) of the tipset — their events AMTs, the receipts-AMT nodes on the paths to them (the upper
+// nodes end up on every rank) — plus what every proof needs: the headers, the TxMeta blocks and the message AMTs
+// the execution order is rebuilt from.  Which blocks those are is found the way the reference's generator finds a
+// witness: by walking with a RecordingBlockStore (src/proofs/common/blockstore.rs:26-30) — here the `touched`
+// bitmap of the WitnessView.
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "amt_enum.h"
+#include "events_dev.h"
+#include "launch.h"
+
+namespace ipcfp {
+
+// lane i: the path to receipt lo + i in the receipts AMT, and the whole events AMT of that receipt
+__global__ __launch_bounds__(256) void k_plan_receipts(WitnessView rec, CidKey receipts_root, uint64_t lo, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    AmtRootInfo rinfo;
+    if (amt_load(rec, receipts_root, 0, VK_RECEIPT, rinfo) != IPCFP_ST_TRUE) return;
+    ValueLoc rl;
+    if (amt_get(rec, rinfo, VK_RECEIPT, lo + t, rl) != IPCFP_ST_TRUE) return;
+    Rd r;
+    r.init(rec.arena + rec.off[rl.block] + rl.off, rl.len);
+    uint32_t o, l;
+    r.expect_array(4);
+    (void)r.read_uint();
+    r.read_bytes(o, l);
+    (void)r.read_uint();
+    if (!r.ok() || r.at_null()) return;
+    CidKey ev_root;
+    r.read_link_key(ev_root);
+    if (!r.ok()) return;
+    AmtRootInfo einfo;
+    if (amt_load(rec, ev_root, 3, VK_STAMPED_EVENT, einfo) != IPCFP_ST_TRUE) return;
+    if (einfo.height == 0) return;  // the root block is the whole tree
+    // depth-first over the links; a node that fails to decode is recorded and not descended into
+    constexpr int kMaxDepth = 8;
+    if (einfo.height >= kMaxDepth) return;
+    uint32_t blk[kMaxDepth], noff[kMaxDepth], next_sub[kMaxDepth];
+    int depth = 0;
+    blk[0] = einfo.block;
+    noff[0] = einfo.node_off;
+    next_sub[0] = 0;
+    const uint32_t bw = einfo.bit_width, width = 1u << bw;
+    while (depth >= 0) {
+        const uint64_t height = einfo.height - uint64_t(depth);
+        Rd nr = open_block(rec, blk[depth]);
+        nr.pos = noff[depth];
+        nr.expect_array(3);
+        uint32_t bo, bl;
+        nr.read_bytes(bo, bl);
+        const uint64_t nl = nr.read_array();
+        if (!nr.ok() || nl == 0 || height == 0 || bl != (width + 7) / 8) {
+            --depth;
+            continue;
+        }
+        uint32_t sub = next_sub[depth], ordinal = 0;
+        for (uint32_t i = 0; i < sub && i < width; ++i) ordinal += (nr.at(bo + (i >> 3)) >> (i & 7)) & 1u;
+        while (sub < width && !((nr.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
+        if (sub >= width || ordinal >= nl) {
+            --depth;
+            continue;
+        }
+        next_sub[depth] = sub + 1;
+        CidKey key;
+        for (uint32_t k = 0; k <= ordinal && nr.ok(); ++k) nr.read_link_key(key);
+        if (!nr.ok()) {
+            --depth;
+            continue;
+        }
+        const uint32_t child = witness_find(rec, key);  // records it
+        if (child == kNoBlock || depth + 1 >= kMaxDepth) continue;
+        ++depth;
+        blk[depth] = child;
+        noff[depth] = 0;
+        next_sub[depth] = 0;
+    }
+}
+
+// Amt::load of one root → {status, height, count, bit width}
+__global__ void k_amt_root_info(WitnessView w, CidKey root, int version, int vkind, uint64_t* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    AmtRootInfo info;
+    info.height = info.count = 0;
+    info.bit_width = 0;
+    const uint32_t st = amt_load(w, root, version, vkind, info);
+    out[0] = st;
+    out[1] = info.height;
+    out[2] = info.count;
+    out[3] = info.bit_width;
+}
+
+// tables of a sub-witness: entry i describes block ids[i] of the source witness
+__global__ __launch_bounds__(256) void k_subset_tables(const uint32_t* __restrict__ ids, uint32_t n, uint32_t n_src,
+                                                       const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
+                                                       const uint8_t* __restrict__ src_cids, uint64_t* __restrict__ off,
+                                                       uint32_t* __restrict__ len, uint8_t* __restrict__ cids,
+                                                       uint32_t* __restrict__ bad) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t id = ids[t];
+    if (id >= n_src) {
+        atomicOr(bad, 1u);
+        off[t] = 0;
+        len[t] = 0;
+        return;
+    }
+    off[t] = src_off[id];
+    len[t] = src_len[id];
+    const uint64_t* s = reinterpret_cast<const uint64_t*>(src_cids + 40ull * id);
+    uint64_t* d = reinterpret_cast<uint64_t*>(cids + 40ull * t);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] = s[k];
+}
+
+int launch_plan_receipts(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint64_t lo, uint32_t n) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_plan_receipts, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, rec, receipts_root, lo, n);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_amt_root_info(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, int version, int vkind, uint64_t* out_d) {
+    hipLaunchKernelGGL(k_amt_root_info, dim3(1), dim3(64), 0, ctx->stream, w, root, version, vkind, out_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_subset_tables(ipcfp_ctx* ctx, const uint32_t* ids_d, uint32_t n, uint32_t n_src, const uint64_t* src_off,
+                         const uint32_t* src_len, const uint8_t* src_cids, uint64_t* off_d, uint32_t* len_d,
+                         uint8_t* cids_d, uint32_t* bad_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_subset_tables, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, ids_d, n, n_src, src_off, src_len,
+                       src_cids, off_d, len_d, cids_d, bad_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

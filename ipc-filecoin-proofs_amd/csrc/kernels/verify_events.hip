@@ -346,10 +346,10 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     // Step 4: verify_receipt_and_event (:207-254)
     uint32_t st;
     ValueLoc rloc;
-    if (tc.receipt_leaves && c.exec_index < tc.n_receipt_leaves) {
+    if (tc.receipt_leaves && c.exec_index >= tc.receipt_first && c.exec_index - tc.receipt_first < tc.n_receipt_leaves) {
         // the receipts AMT was enumerated (and thereby fully validated) for this context: load + get
         // of a present index cannot fail and yields exactly this leaf                                        // :220-224
-        const LeafRef l = tc.receipt_leaves[c.exec_index];
+        const LeafRef l = tc.receipt_leaves[c.exec_index - tc.receipt_first];
         rloc = ValueLoc{l.block, l.off, l.len};
     } else {
         AmtRootInfo receipts;

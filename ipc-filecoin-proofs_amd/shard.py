@@ -1,72 +1,163 @@
-"""Shard planning and result gathering for multi-GPU runs (one process per GPU).
+"""One tipset over the GPUs of a node: host-side orchestration above the C ABI.
 
-The hot path shards by receipt / key / block index with no data-path exchange:
-every rank verifies the claims of its own contiguous index range against its own witness shard,
-and ONE all-gather of the per-shard verdict bytes / bitmaps produces the global result.  The
-collective is `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
-CPU tests); this module is plumbing and contains no compute.
+The reference verifies a bundle proof by proof (src/proofs/verifier.rs:19-28,49-54,
+src/proofs/events/verifier.rs:62-71).  Here rank r of G
+
+  * plans   — `ipcfp_shard_plan_tipset`: the blocks it needs for the receipts [lo, hi) of the tipset (their events
+              AMTs + the receipts-AMT paths; headers, TxMeta and message AMTs replicated),
+  * places  — `ipcfp_witness_create_subset`: its own witness, tagged with the range,
+  * routes  — the claims whose exec_index falls in [lo, hi),
+  * steps   — CID index, K1, range-restricted scan, verify_event_proof of its claims — all through the same
+              entry points a single-GPU host uses,
+  * gathers — ONE `ncclAllGather` (RCCL, called directly by libipcfp.so) of
+              [header | status bytes | has-match map | CID bitmap] per rank,
+
+and `merge` lays the gathered messages out by claim position / receipt index.  Everything on the data path is
+behind the C ABI; this module only sequences the calls (a Rust host would do the same over ffi.rs).  The widths of
+the message parts must be agreed once at setup over the host's own channel (`Layout.agree`).
 """
 from __future__ import annotations
 
 import numpy as np
 
+from . import binding as B
 
-def shard_bounds(n_items: int, world: int):
-    """Contiguous, near-equal index ranges [(lo, hi)] * world; the first n_items % world get one extra."""
-    base, extra = divmod(n_items, world)
-    out, lo = [], 0
-    for r in range(world):
-        hi = lo + base + (1 if r < extra else 0)
-        out.append((lo, hi))
-        lo = hi
-    return out
+HEADER_BYTES = 64  # u64 x 8: n_claims, n_receipts, n_blocks, scan_status, n_matches, n_bad_cids(filled by merge), lo, hi
 
 
-def gather_bytes(local: np.ndarray, n_items: int, dist, device="cpu"):
-    """All-gather per-shard byte arrays laid out by shard_bounds(n_items, world) into the global array.
-    Shards differ by at most one element, so every rank sends max-shard bytes (one collective)."""
-    import torch
+class Layout:
+    """Byte layout of one rank's message: widths are the maxima over ranks, so every rank sends the same size."""
 
-    world = dist.get_world_size()
-    bounds = shard_bounds(n_items, world)
-    width = max(hi - lo for lo, hi in bounds)
-    buf = torch.zeros(width, dtype=torch.uint8, device=device)
-    buf[: len(local)] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint8)).to(device)
-    out = torch.empty(world * width, dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(world, width)
-    return np.concatenate([out[r, : hi - lo] for r, (lo, hi) in enumerate(bounds)])
+    def __init__(self, max_claims: int, max_receipts: int, max_blocks: int):
+        self.w_status = (int(max_claims) + 15) & ~15
+        self.w_has = (int(max_receipts) + 15) & ~15
+        self.w_bits = ((int(max_blocks) + 31) // 32 * 4 + 15) & ~15
+        self.off_status = HEADER_BYTES
+        self.off_has = self.off_status + self.w_status
+        self.off_bits = self.off_has + self.w_has
+        self.bytes_per_rank = self.off_bits + self.w_bits
 
-
-def pack_bits(flags: np.ndarray) -> np.ndarray:
-    """bool/0-1 bytes → little-endian bitmap bytes (bit i of byte i//8), the form the engine's
-    CID bitmap has."""
-    return np.packbits(np.asarray(flags, dtype=np.uint8), bitorder="little")
+    @staticmethod
+    def agree(local_counts, allreduce_max):
+        """local_counts = (n_claims, n_receipts, n_blocks) of this rank; allreduce_max: the host's channel
+        (e.g. torch.distributed all_reduce MAX over a 3-vector, or the identity for one rank)."""
+        return Layout(*[int(x) for x in allreduce_max(np.asarray(local_counts, dtype=np.int64))])
 
 
-class PaddedGather:
-    """The per-step collective of bench.py: every rank contributes one message of ITS OWN length (shards are
-    generated independently, so block counts differ slightly); messages are padded to the longest one,
-    agreed once at setup, and all-gathered into a [world, width] tensor."""
+def route_claims(exec_index: np.ndarray, lo: int, hi: int) -> np.ndarray:
+    """Positions of the claims this rank verifies: exec_index in [lo, hi)."""
+    e = np.asarray(exec_index, dtype=np.uint64)
+    return np.nonzero((e >= np.uint64(lo)) & (e < np.uint64(hi)))[0]
 
-    def __init__(self, local_len: int, dist, device="cpu"):
-        import torch
 
-        self.dist = dist
-        self.world = dist.get_world_size()
-        t = torch.tensor([int(local_len)], dtype=torch.int64, device=device)
-        lens = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world)]
-        dist.all_gather(lens, t)
-        self.lens = [int(x.item()) for x in lens]
-        self.width = max(self.lens)
-        self.payload = torch.zeros(self.width, dtype=torch.uint8, device=device)
-        self.gathered = torch.empty(self.world * self.width, dtype=torch.uint8, device=device)
+def merge(gathered: np.ndarray, layout: Layout, n_ranks: int, claim_positions, n_claims_total: int, n_receipts_total: int):
+    """gathered: u8[n_ranks * bytes_per_rank] (host copy of the all-gather result).
+    claim_positions[r]: positions (in the caller's claim order) of the claims rank r verified.
+    → dict(status u8[n_claims_total], has u8[n_receipts_total], scan_status, n_matches, n_bad_cids, per_rank)."""
+    g = np.asarray(gathered, dtype=np.uint8).reshape(n_ranks, layout.bytes_per_rank)
+    status = np.full(n_claims_total, 255, dtype=np.uint8)
+    has = np.zeros(n_receipts_total, dtype=np.uint8)
+    scan_status, n_matches, n_bad, per_rank = 1, 0, 0, []
+    for r in range(n_ranks):
+        hdr = g[r, :HEADER_BYTES].view(np.uint64)
+        nc, nr, nb, sst, nm, _, lo, hi = [int(x) for x in hdr]
+        pos = np.asarray(claim_positions[r])
+        assert len(pos) == nc, "claim routing differs from what the rank reported"
+        status[pos] = g[r, layout.off_status: layout.off_status + nc]
+        has[lo: lo + nr] = g[r, layout.off_has: layout.off_has + nr]
+        bits = np.unpackbits(g[r, layout.off_bits: layout.off_bits + (nb + 31) // 32 * 4], bitorder="little")[:nb]
+        bad = int(nb - bits.sum())
+        # the first Err in traversal order is the one of the lowest receipt range
+        if scan_status == 1 and sst != 1:
+            scan_status = sst
+        n_matches += nm
+        n_bad += bad
+        per_rank.append({"claims": nc, "receipts": nr, "blocks": nb, "scan_status": sst, "matches": nm, "bad_cids": bad,
+                         "lo": lo, "hi": hi})
+    return {"status": status, "has": has, "scan_status": scan_status, "n_matches": n_matches, "n_bad_cids": n_bad,
+            "per_rank": per_rank}
 
-    def run(self):
-        """One all-gather of `payload` (the caller fills payload[:local_len] beforehand)."""
-        self.dist.all_gather_into_tensor(self.gathered, self.payload)
 
-    def message(self, rank: int):
-        """Rank `rank`'s unpadded message out of the last gather."""
-        lo = rank * self.width
-        return self.gathered[lo: lo + self.lens[rank]]
+def gather_ranges(blob: np.ndarray, starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Concatenation of blob[starts[i] : starts[i] + lens[i]] (vectorised)."""
+    lens = np.asarray(lens, dtype=np.int64)
+    starts = np.asarray(starts, dtype=np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.uint8)
+    first = np.cumsum(lens) - lens
+    idx = np.repeat(starts - first, lens) + np.arange(total, dtype=np.int64)
+    return np.asarray(blob, dtype=np.uint8)[idx]
+
+
+def subset_packed_claims(claims: np.ndarray, blob: np.ndarray, positions: np.ndarray):
+    """The packed claims at `positions` with a blob of their own (ipcfp_event_claim_t[], include/ipcfp.h):
+    → (claims copy with topics_off / data_off rewritten, blob u8[] + 64 B slack, blob_len)."""
+    c = np.ascontiguousarray(claims[positions]).copy()
+    tl = c["n_topics"].astype(np.int64) * 33
+    dl = c["data_len"].astype(np.int64)
+    t_bytes = gather_ranges(blob, c["topics_off"], tl)
+    d_bytes = gather_ranges(blob, c["data_off"], dl)
+    t_first = np.cumsum(tl) - tl
+    d_first = np.cumsum(dl) - dl + int(tl.sum())
+    c["topics_off"] = t_first
+    c["data_off"] = d_first
+    out = np.zeros(len(t_bytes) + len(d_bytes) + 64, dtype=np.uint8)
+    out[: len(t_bytes)] = t_bytes
+    out[len(t_bytes): len(t_bytes) + len(d_bytes)] = d_bytes
+    return c, out, len(t_bytes) + len(d_bytes)
+
+
+class TipsetShard:
+    """Rank `shard` of `n_shards` for one tipset.  `full` is a Witness holding the whole tipset on this rank's GPU
+    (setup only: it may be closed once the shard exists)."""
+
+    def __init__(self, eng: B.Engine, full: B.Witness, parent_cids, child_cid: bytes, receipts_root: bytes,
+                 n_shards: int, shard: int):
+        self.eng, self.n_shards, self.shard = eng, int(n_shards), int(shard)
+        st, lo, hi, n_receipts, ids = full.shard_plan_tipset(parent_cids, child_cid, n_shards, shard)
+        if st != 1:
+            raise B.EngineError(f"shard plan failed with status {st}")
+        self.lo, self.hi, self.n_receipts_total, self.block_ids = lo, hi, n_receipts, ids
+        self.witness = full.subset(ids, lo, hi)
+        self.receipts_root = bytes(receipts_root)
+        self.parent_cids, self.child_cid = parent_cids, child_cid
+
+    def route(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray):
+        """This rank's share of a packed claim batch: claims whose exec_index is one of its receipts."""
+        self.tipsets = np.ascontiguousarray(tipsets)
+        self.positions = route_claims(claims["exec_index"], self.lo, self.hi)
+        self.claims, self.blob, self.blob_len = subset_packed_claims(claims, blob, self.positions)
+        self.n_claims = len(self.positions)
+        return self.claims, self.blob, self.blob_len
+
+    @property
+    def counts(self):
+        return (getattr(self, "n_claims", 0), self.hi - self.lo, self.witness.n)
+
+    def header(self) -> np.ndarray:
+        """The static part of the step message's header (scan status / match count are written by the scan)."""
+        return np.array([self.n_claims, self.hi - self.lo, self.witness.n, 0, 0, 0, self.lo, self.hi], dtype=np.uint64)
+
+    def step(self, layout: Layout, comm, filt, claims_ptr: int, blob_ptr: int, status_ptr: int, has_ptr: int,
+             header_ptr: int, staging_ptr: int, recv_ptr: int):
+        """One verification pass of this shard + the one collective.  All pointers are HBM buffers of the caller:
+        claims/blob (the routed claims), status (layout.w_status bytes), has (layout.w_has bytes), header (64 B,
+        initialised from header()), staging (bytes_per_rank), recv (n_ranks * bytes_per_rank).  Asynchronous
+        after the verify call returns: the gathered result is complete after eng.sync()."""
+        topic0, topic1, actor = filt
+        w = self.witness
+        w.rebuild_index()                                                                    # K4
+        w.verify_cids_async()                                                                # K1 (second stream)
+        st, nr, nm = w.scan_events_device(self.receipts_root, topic0, topic1, actor, has_ptr, layout.w_has,
+                                          summary_ptr=header_ptr + 24)                       # K6, range-restricted
+        if self.n_claims:
+            w.verify_event_claims_device(self.tipsets, claims_ptr, self.n_claims, blob_ptr, self.blob_len, status_ptr)
+        bits_bytes = (w.n + 31) // 32 * 4
+        B.allgather_segments(self.eng, comm, [header_ptr, status_ptr, has_ptr, w.cid_bitmap_ptr],
+                             [HEADER_BYTES, layout.w_status, layout.w_has, bits_bytes], staging_ptr, recv_ptr,
+                             layout.bytes_per_rank)                                          # the ONE collective
+        return st, nr, nm
+
+    def close(self):
+        self.witness.close()

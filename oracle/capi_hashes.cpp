@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 
+#include "amt.hpp"
 #include "hashes.hpp"
 
 extern "C" {
@@ -45,7 +46,7 @@ uint64_t orc_blake2b256_verify(const uint8_t* bytes, const uint64_t* off, const 
 // the same check on `threads` OpenMP threads (0 = every processor): baseline variant B2 all-cores
 uint64_t orc_blake2b256_verify_mt(const uint8_t* bytes, const uint64_t* off, const uint32_t* len,
                                   const uint8_t* expect32, uint64_t n, uint8_t* ok, int threads) {
-    omp_set_num_threads(threads > 0 ? threads : omp_get_num_procs());
+    orc::use_threads(threads);
     uint64_t good = 0;
 #pragma omp parallel for schedule(dynamic, 1024) reduction(+ : good)
     for (int64_t i = 0; i < int64_t(n); ++i) {

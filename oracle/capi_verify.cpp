@@ -114,6 +114,7 @@ void* orc_store_create_mt(const uint8_t* bytes, const uint64_t* off, const uint3
 void orc_store_destroy(void* s) { delete static_cast<Store*>(s); }
 uint64_t orc_store_size(void* s) { return static_cast<Store*>(s)->bs.size(); }
 int orc_num_procs(void) { return omp_get_num_procs(); }
+int orc_use_threads(int threads) { return use_threads(threads); }  // the count `threads` resolves to
 
 // mode 0: exactly as written — sequential, exec order rebuilt per proof (events/verifier.rs:190).
 // mode 1: "fair" baseline — exec order computed once per distinct parent tipset key and looked

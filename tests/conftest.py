@@ -8,6 +8,11 @@ import sys
 
 import pytest
 
+# the oracle's OpenMP team: sleep when idle (a 256-processor box otherwise spins between calls) and stay small —
+# the parity tests need the oracle's answers, not its peak throughput (bench.py sets its own thread counts)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("IPCFP_ORACLE_MAX_THREADS", "48")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

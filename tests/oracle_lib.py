@@ -43,6 +43,8 @@ class Oracle:
         lib.orc_store_size.argtypes = [vp]
         lib.orc_num_procs.restype = C.c_int
         lib.orc_num_procs.argtypes = []
+        lib.orc_use_threads.restype = C.c_int
+        lib.orc_use_threads.argtypes = [C.c_int]
         lib.orc_blake2b256_verify_mt.restype = u64
         lib.orc_blake2b256_verify_mt.argtypes = [vp, vp, vp, vp, u64, vp, C.c_int]
         lib.orc_scan_events_mt.restype = C.c_uint8
@@ -110,6 +112,11 @@ class Oracle:
 
     def num_procs(self) -> int:
         return int(self.lib.orc_num_procs())
+
+    def use_threads(self, threads: int) -> int:
+        """The OpenMP thread count `threads` resolves to (0 = every processor, capped by IPCFP_ORACLE_MAX_THREADS);
+        also grows the worker threads' malloc arenas ahead of the first parallel phase."""
+        return int(self.lib.orc_use_threads(threads))
 
     def hash_batch(self, kind: str, data, off, lens):
         k = {"blake2b256": 0, "keccak256": 1, "sha256": 2}[kind]

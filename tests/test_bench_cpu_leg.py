@@ -29,6 +29,7 @@ def test_cpu_baseline_record(oracle):
     n = len(tip.claim_exec)
     assert abs(rec["value"] - n / rec["seconds"]["step"]) < 1e-6 * rec["value"]
     assert "3000-receipt" in rec["sample"] and "first 2000 of" in rec["sample"] and "all-cores" in rec["sample"]
+    assert str(rec["cores"]) in rec["thread_sweep_step_seconds"] and "1" in rec["thread_sweep_step_seconds"]
     # a wrong GPU verdict is caught by the leg
     bad = status.copy()
     bad[5] = 0

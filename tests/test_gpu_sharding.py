@@ -1,0 +1,154 @@
+"""GPU: one tipset cut into G receipt-range shards — plan, sub-witness, routed claims, range-restricted
+scan, verify, packed step message — run as G LOGICAL shards on the one GPU here; the merged result must equal the
+unsharded engine's, bit for bit, and the oracle's.  The RCCL path is exercised with a 1-rank communicator (the
+run-time binding of librccl, ncclCommInitRank, ncclAllGather on the engine's stream)."""
+import numpy as np
+import pytest
+import torch
+
+import ipc_filecoin_proofs_amd as ipcfp
+from ipc_filecoin_proofs_amd import shard
+from tools.synth import Tipset
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+
+
+def run_shards(engine, tip, G, ts, cl, blob, comm=None, tamper=None):
+    """Every shard of G in turn on this GPU; returns (merged result, list of TipsetShard counts)."""
+    data = tip.data if tamper is None else tamper
+    full = engine.witness(data, tip.off, tip.lens, tip.cids)
+    shards = [shard.TipsetShard(engine, full, tip.parent_cids, tip.child_cid, tip.receipts_root, G, r) for r in range(G)]
+    for s in shards:
+        s.route(ts, cl, blob)
+    layout = shard.Layout(max(s.n_claims for s in shards), max(s.hi - s.lo for s in shards),
+                          max(s.witness.n for s in shards))
+    msgs, ids = [], []
+    for s in shards:
+        d_cl, d_blob = dev(s.claims), dev(s.blob)
+        d_status = torch.zeros(layout.w_status, dtype=torch.uint8, device="cuda")
+        d_has = torch.zeros(layout.w_has, dtype=torch.uint8, device="cuda")
+        d_hdr = dev(s.header())
+        d_stage = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device="cuda")
+        d_recv = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        s.step(layout, comm, (tip.topic0, tip.topic1, tip.filter_actor), d_cl.data_ptr(), d_blob.data_ptr(),
+               d_status.data_ptr(), d_has.data_ptr(), d_hdr.data_ptr(), d_stage.data_ptr(), d_recv.data_ptr())
+        engine.sync()
+        msgs.append(d_recv.cpu().numpy())
+        ids.append(s.block_ids)
+    merged = shard.merge(np.concatenate(msgs), layout, G, [s.positions for s in shards], len(cl), shards[0].n_receipts_total)
+    counts = [(s.n_claims, s.hi - s.lo, s.witness.n) for s in shards]
+    for s in shards:
+        s.close()
+    full.close()
+    return merged, counts, ids
+
+
+@pytest.fixture(scope="module")
+def tip():
+    return Tipset(n_receipts=40_000, n_parents=4, dup_permille=30, n_planted=40, max_events=4, no_events_permille=50,
+                  variety=1, seed=77)
+
+
+@pytest.fixture(scope="module")
+def claims_packed(tip):
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec, tip.claim_event,
+        tip.claim_emitter, tip.exec_order[tip.claim_exec.astype(np.int64)], tip.claim_ntopics, tip.claim_topics,
+        tip.claim_datalen, tip.claim_data)
+    n = len(cl)
+    liars = np.arange(5, n, 17)
+    cl["exec_index"][liars[0::3]] += 1
+    cl["emitter"][liars[1::3]] ^= 1
+    blob[cl["data_off"][liars[2::3]]] ^= 0x40
+    return ts, cl, blob, blob_len
+
+
+def test_shard_range_is_a_partition():
+    for n in (0, 1, 7, 1000, 1_000_000, (1 << 64) - 1):
+        for G in (1, 2, 3, 8, 64):
+            prev = 0
+            for r in range(G):
+                lo, hi = ipcfp.shard_range(n, G, r)
+                assert lo == prev and hi >= lo and hi - lo in (n // G, n // G + 1)
+                prev = hi
+            assert prev == n
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_logical_shards_equal_the_unsharded_result(engine, oracle, tip, claims_packed, G):
+    ts, cl, blob, blob_len = claims_packed
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        want = w.verify_event_claims(ts, cl, blob, blob_len)
+        ws, whas, wm, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
+    merged, counts, ids = run_shards(engine, tip, G, ts, cl, blob)
+    assert np.array_equal(merged["status"], want) and (want != 1).sum() > 100
+    assert merged["scan_status"] == ws == 1 and np.array_equal(merged["has"], whas) and merged["n_matches"] == len(wm)
+    assert merged["n_bad_cids"] == 0
+    # the oracle agrees with both
+    ost = oracle.store(tip.data, tip.off, tip.lens, tip.cids, threads=0)
+    assert np.array_equal(ost.verify_event_claims_packed(ts, cl, blob, threads=0), want)
+    ost.close()
+    if G > 1:
+        # placement: every rank holds the replicated part, and the shards together are the blocks a full pass touches
+        common = set(ids[0].tolist())
+        for x in ids[1:]:
+            common &= set(x.tolist())
+        assert len(common) > 0 and max(c[2] for c in counts) < tip.n_blocks
+        per_rank_receipts = [c[1] for c in counts]
+        assert sum(per_rank_receipts) == 40_000 and max(per_rank_receipts) - min(per_rank_receipts) <= 1
+
+
+def test_a_tampered_block_is_reported_by_the_shard_that_holds_it(engine, tip, claims_packed):
+    ts, cl, blob, _ = claims_packed
+    data = tip.data.copy()
+    # an events-AMT block of the last receipt range: flip a byte of its payload
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        _, lo, hi, _, ids_last = w.shard_plan_tipset(tip.parent_cids, tip.child_cid, 4, 3)
+        _, _, _, _, ids_first = w.shard_plan_tipset(tip.parent_cids, tip.child_cid, 4, 0)
+    only_last = np.setdiff1d(ids_last, ids_first)
+    victim = int(only_last[len(only_last) // 2])
+    data[int(tip.off[victim]) + int(tip.lens[victim]) - 1] ^= 0x01
+    merged, _, _ = run_shards(engine, tip, 4, ts, cl, blob, tamper=data)
+    bad = [r["bad_cids"] for r in merged["per_rank"]]
+    assert bad == [0, 0, 0, 1] and merged["n_bad_cids"] == 1
+
+
+def test_misrouted_claim_is_an_error_not_a_verdict(engine, tip, claims_packed):
+    """A claim about a receipt outside the shard's range cannot be judged there: its receipt path is not part of the
+    shard's witness → ERR_MISSING_BLOCK (the router's mistake surfaces, it is never a silent Ok(false))."""
+    ts, cl, blob, blob_len = claims_packed
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as full:
+        s = shard.TipsetShard(engine, full, tip.parent_cids, tip.child_cid, tip.receipts_root, 4, 1)
+        honest = np.nonzero(np.isin(np.arange(len(cl)), np.arange(5, len(cl), 17), invert=True))[0]
+        far = honest[honest > 35_000][:8]          # receipts of shard 3
+        own = shard.route_claims(cl["exec_index"], s.lo, s.hi)[:8]
+        c2, b2, bl2 = shard.subset_packed_claims(cl, blob, np.concatenate([own, far]))
+        got = s.witness.verify_event_claims(ts, c2, b2, bl2)
+        s.close()
+    assert (got[8:] == 65).all() and set(got[:8].tolist()) <= {1, 8, 12, 16}
+
+
+def test_rccl_single_rank_allgather(engine):
+    uid = ipcfp.comm_unique_id()
+    assert len(uid) == 128
+    comm = ipcfp.Comm(engine, uid, 1, 0)
+    a = torch.arange(0, 200, dtype=torch.uint8, device="cuda")
+    b = torch.full((56,), 7, dtype=torch.uint8, device="cuda")
+    stage = torch.zeros(512, dtype=torch.uint8, device="cuda")
+    recv = torch.zeros(512, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    comm.allgather_device(a.data_ptr(), recv.data_ptr(), 200)
+    engine.sync()
+    assert torch.equal(recv[:200], a)
+    comm.allgather_segments([a.data_ptr(), b.data_ptr()], [200, 56], stage.data_ptr(), recv.data_ptr(), 512)
+    engine.sync()
+    want = torch.zeros(512, dtype=torch.uint8, device="cuda")
+    want[:200] = a
+    want[200:256] = 7
+    assert torch.equal(recv, want) and torch.equal(stage, want)
+    comm.close()
