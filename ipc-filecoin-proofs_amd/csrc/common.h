@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "ipcfp.h"
+#include "kernels/event_table.h"
 
 namespace ipcfp {
 
@@ -217,6 +218,16 @@ struct EnumCached {
     bool dense = false;      // leaf i has index lo + i for every i
     uint64_t lo = 0, hi = ~0ULL;  // the index range the enumeration was restricted to
 };
+// The event table of one receipts AMT (range) of the witness (kernels/event_table.h).  Valid until the witness
+// index is rebuilt.
+struct EventTableCached {
+    uint64_t root[5];
+    uint64_t lo = 0, hi = ~0ULL;
+    DevBuf<ReceiptRec> receipts;  // one per enumerated receipt leaf
+    DevBuf<EventRec> events;
+    uint64_t n = 0;
+    EventTableView view() const { return EventTableView{receipts.p, events.p}; }
+};
 }  // namespace ipcfp
 
 // The opaque witness of the C ABI: the whole witness resident in HBM as SoA.
@@ -242,4 +253,6 @@ struct ipcfp_witness {
     // a shard of one tipset (host/shard.cpp): enumerations of a receipts AMT are restricted to [receipt_lo, receipt_hi)
     uint64_t receipt_lo = 0, receipt_hi = ~0ULL;
     std::vector<std::unique_ptr<ipcfp::EnumCached>> enum_cache;
+    std::vector<std::unique_ptr<ipcfp::EventTableCached>> table_cache;
+    bool use_event_table = true;  // env IPCFP_EVENT_TABLE=0: every scan / claim walks the blocks (A/B measurements)
 };

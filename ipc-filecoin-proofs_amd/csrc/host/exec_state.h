@@ -45,6 +45,13 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
                        int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out,
                        uint64_t cap_matches = kAllMatches);
 
+// The event table of the receipts AMT `root` (range = the witness's receipt range): the cached one, or a new one.
+// With `filter` the building pass also counts that filter's matches per receipt into counts_d (and reports the
+// first failing receipt through err_d, as PASS 1 does); *built tells whether it did.  `en` = the enumeration.
+int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en,
+                    const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, uint32_t* counts_d,
+                    unsigned long long* err_d, const EventTableCached** out, bool* built);
+
 CidKey key_from_slot(const uint8_t* slot40);
 
 }  // namespace ipcfp

@@ -1,6 +1,8 @@
 // csrc/host/scan_events.cpp — `find_matching_events` over the HBM-resident tipset
 // (src/proofs/events/generator.rs:180-307): enumerate the receipts AMT, PASS 1, prefix-sum, PASS 2.
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../common.h"
@@ -15,6 +17,47 @@ CidKey key_from_slot(const uint8_t* slot40);
 }
 
 namespace ipcfp {
+
+int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en,
+                    const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, uint32_t* counts_d,
+                    unsigned long long* err_d, const EventTableCached** out, bool* built) {
+    *built = false;
+    for (auto& t : w->table_cache)
+        if (t->lo == w->receipt_lo && t->hi == w->receipt_hi && std::memcmp(t->root, root.w, 40) == 0) {
+            *out = t.get();
+            return IPCFP_OK;
+        }
+    std::unique_ptr<EventTableCached> t(new EventTableCached());
+    std::memcpy(t->root, root.w, 40);
+    t->lo = w->receipt_lo;
+    t->hi = w->receipt_hi;
+    t->n = en->n;
+    const uint64_t n = en->n;
+    // record pool: generous for real tipsets (a few events per receipt), bounded by what the witness could hold;
+    // a receipt that finds the pool exhausted is simply walked (RK_WALK)
+    uint64_t cap = std::max<uint64_t>(4 * n + 1024, w->nbytes / 24);
+    cap = std::min<uint64_t>(cap, 64 * n + 1024);
+    cap = std::min<uint64_t>(cap, 0xfffffff0ull);
+    IPCFP_HIP(ctx, t->receipts.alloc(n));
+    IPCFP_HIP(ctx, t->events.alloc(cap));
+    DevBuf<uint32_t> used;
+    DevBuf<unsigned long long> err_local;
+    IPCFP_HIP(ctx, used.alloc(1));
+    IPCFP_HIP(ctx, hipMemsetAsync(used.p, 0, 4, ctx->stream));
+    if (!err_d) {
+        IPCFP_HIP(ctx, err_local.alloc(1));
+        IPCFP_HIP(ctx, hipMemsetAsync(err_local.p, 0xff, 8, ctx->stream));
+        err_d = err_local.p;
+    }
+    const WitnessView view = witness_view(w);
+    int rc = launch_event_table(ctx, view, reinterpret_cast<const LeafRef*>(en->leaves.p), uint32_t(n), filter, has_actor,
+                                actor, t->receipts.p, t->events.p, uint32_t(cap), used.p, counts_d, err_d);
+    if (rc) return rc;
+    *built = true;
+    *out = t.get();
+    w->table_cache.push_back(std::move(t));
+    return IPCFP_OK;  // `used` / `err_local` return to the pool; reuse is ordered on the stream
+}
 
 // PASS 1 + prefix sum + PASS 2 on the device.  `touched_d` (nullable, device, words = ceil(n/32)) is
 // OR-ed into, so a caller can accumulate one recorder across several steps (generate_event_proof).
@@ -55,8 +98,23 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     IPCFP_HIP(ctx, total.alloc(1));
     IPCFP_HIP(ctx, out.has.alloc(n_idx));
     if (n_idx) IPCFP_HIP(ctx, hipMemsetAsync(out.has.p, 0, n_idx, ctx->stream));
-    rc = launch_scan_pass1(ctx, view, leaves, n, filter, has_actor, actor, counts.p, err.p);
-    if (rc) return rc;
+    // PASS 1: with the events tabulated once per witness (kernels/event_table.h) — the first scan builds the table
+    // and counts in one kernel, a later one (another filter) counts from the records
+    EventTableView tview{nullptr, nullptr};
+    if (w->use_event_table && n) {
+        const EventTableCached* table = nullptr;
+        bool built = false;
+        rc = event_table_get(ctx, w, root, en, &filter, has_actor, actor, counts.p, err.p, &table, &built);
+        if (rc) return rc;
+        tview = table->view();
+        if (!built) {
+            rc = launch_count_from_table(ctx, view, leaves, n, filter, has_actor, actor, tview, counts.p, err.p);
+            if (rc) return rc;
+        }
+    } else {
+        rc = launch_scan_pass1(ctx, view, leaves, n, filter, has_actor, actor, counts.p, err.p);
+        if (rc) return rc;
+    }
     rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total.p, scratch.p);
     if (rc) return rc;
     uint64_t nm = 0;
@@ -77,7 +135,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     WitnessView rec = view;
     rec.touched = touched_d;
     rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, counts.p, offsets.p,
-                           cap ? out.matches.p : nullptr, cap, out.has.p, n_idx, lo);
+                           cap ? out.matches.p : nullptr, cap, out.has.p, n_idx, lo, tview.receipts ? &tview : nullptr);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // delivers nm / e1 when they were not waited for above
     if (e1 != kNoEnumError) {  // PASS 2 ran on a tipset PASS 1 rejected: its output is discarded

@@ -237,6 +237,7 @@ int ipcfp_witness_set_receipt_range(ipcfp_witness_t* w, uint64_t lo, uint64_t hi
     w->receipt_lo = lo;
     w->receipt_hi = hi;
     w->enum_cache.clear();
+    w->table_cache.clear();
     return IPCFP_OK;
 }
 

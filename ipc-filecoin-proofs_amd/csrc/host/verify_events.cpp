@@ -133,6 +133,8 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         tc.receipt_leaves = nullptr;
         tc.n_receipt_leaves = 0;
         tc.receipt_first = 0;
+        tc.receipt_recs = nullptr;
+        tc.event_recs = nullptr;
         // the execution order is only reached when steps 1-2 can pass for some proof of this context
         const bool reachable = (tc.flags & TC_PARENTS_PARSED) && (tc.flags & TC_CHILD_PARSED) &&
                                tc.child_status == IPCFP_ST_TRUE && tc.parents_match && tc.n_parents > 0 &&
@@ -152,6 +154,15 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
             tc.receipt_leaves = reinterpret_cast<const LeafRef*>(rc_enum->leaves.p);
             tc.n_receipt_leaves = rc_enum->n;
             tc.receipt_first = rc_enum->n ? w->receipt_lo : 0;
+            // ... and their events tabulated once (shared with the scan through the witness cache)
+            if (w->use_event_table && rc_enum->n) {
+                const EventTableCached* table = nullptr;
+                bool built = false;
+                rc = event_table_get(ctx, w, tc.receipts_root, rc_enum, nullptr, 0, 0, nullptr, nullptr, &table, &built);
+                if (rc) return rc;
+                tc.receipt_recs = table->receipts.p;
+                tc.event_recs = table->events.p;
+            }
         }
     }
     IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,

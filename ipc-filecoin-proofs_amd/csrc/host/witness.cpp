@@ -4,6 +4,7 @@
 // (src/proofs/events/verifier.rs:79-89, src/proofs/storage/verifier.rs:68-78), rebuilt
 // per storage proof by the reference (src/proofs/verifier.rs:19-28); here it is built
 // once per bundle and stays resident.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -27,6 +28,7 @@ constexpr uint64_t kTailSlack = 256;  // K1 may read one 128-byte chunk past a b
 int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
                           const uint32_t* len_d_src, const uint8_t* cids_d_src) {
     const uint32_t n = uint32_t(w->n);
+    if (const char* e = std::getenv("IPCFP_EVENT_TABLE")) w->use_event_table = std::atoi(e) != 0;
     IPCFP_HIP(ctx, w->off.alloc(n));
     IPCFP_HIP(ctx, w->len.alloc(n));
     IPCFP_HIP(ctx, w->cids.alloc(size_t(n) * IPCFP_CID_SLOT));
@@ -187,7 +189,8 @@ int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
     IPCFP_ENTER(ctx);
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    w->enum_cache.clear();  // enumerations are derived from the index
+    w->enum_cache.clear();  // enumerations and event tables are derived from the index
+    w->table_cache.clear();
     return witness_build_index(ctx, w);
 }
 

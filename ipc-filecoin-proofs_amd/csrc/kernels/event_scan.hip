@@ -14,6 +14,7 @@
 
 #include "../common.h"
 #include "amt_enum.h"
+#include "event_table.h"
 #include "events_dev.h"
 #include "launch.h"
 
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
                                                     const uint32_t* __restrict__ counts,
                                                     const uint32_t* __restrict__ offsets,
                                                     EventMatch* __restrict__ matches, uint64_t matches_cap,
-                                                    uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base) {
+                                                    uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base,
+                                                    const ReceiptRec* __restrict__ skip_tabulated) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool recording = w.touched != nullptr;
     if (t == 0 && recording) {  // `Amtv0::load(&receipts_root, &rec_receipts)` records the root even without matches (:195-196)
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
     // one byte per receipt index; a shard's map starts at its first index (has_base = receipt_lo)
     if (leaf.index >= has_base && leaf.index - has_base < has_cap) has_match[leaf.index - has_base] = c ? 1 : 0;
     if (c == 0) return;
+    if (skip_tabulated && skip_tabulated[t].kind == RK_TABLE) return;  // k_scan_pass2_table wrote its matches
     // `r_amt.get(i)` on the recorder (:249).  Its only observable effect is the recorded path: the index
     // came out of this very AMT's enumeration, which validated every node, so the get cannot return None
     // or Err — without a recorder there is nothing to do.
@@ -261,6 +264,231 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The event table (event_table.h): PASS 1 that also leaves a record per event.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool rec_matches(const uint8_t* __restrict__ arena, const EventRec& e, const ScanParams& sp) {
+    if (sp.has_actor && e.emitter != sp.actor) return false;
+    const uint32_t nt = uint32_t(e.base_flags >> kEvTopicShift) & 0xffu;
+    if (!(e.base_flags & kEvIsLog) || nt < 2) return false;
+    const uint8_t* item = arena + (e.base_flags & kEvBaseMask);
+    const uint8_t* t0 = item + e.topic_rel[0];
+    const uint8_t* t1 = (e.base_flags & kEvCaseA) ? t0 + 32 : item + e.topic_rel[1];
+    uint64_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint64_t a, b, fa, fb;
+        __builtin_memcpy(&a, t0 + 8 * k, 8);
+        __builtin_memcpy(&b, t1 + 8 * k, 8);
+        __builtin_memcpy(&fa, sp.filter.topic0 + 8 * k, 8);
+        __builtin_memcpy(&fb, sp.filter.topic1 + 8 * k, 8);
+        diff |= (a ^ fa) | (b ^ fb);
+    }
+    return diff == 0;
+}
+
+// One receipt per lane: decode its events AMT (leaf root) once, write the records, count the filter's matches.
+// `count_matches` = 0 builds the table only (a verify call that no scan preceded).
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_event_table(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+                                                     ScanParams sp, int count_matches, ReceiptRec* __restrict__ rrecs,
+                                                     EventRec* __restrict__ erecs, uint32_t cap_events,
+                                                     uint32_t* __restrict__ pool_used, uint32_t* __restrict__ counts,
+                                                     unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < n;
+    ReceiptRec rr{RK_NO_EVENTS, 0, 0, kNoBlock, 0};
+    uint32_t c = 0;
+    CidKey ev_root;
+    // ---- stage 1: the root block's header, so that the record segment can be reserved before the events are read ----
+    Rd r;
+    r.init(w.arena, 0);
+    uint32_t nv = 0;
+    bool table = false;
+    if (live && receipt_events_root(w, receipts[t], ev_root)) {
+        const uint32_t b = witness_find(w, ev_root);
+        rr.block = b;
+        if (b == kNoBlock) {
+            rr.kind = IPCFP_ST_ERR_MISSING_BLOCK;
+        } else {
+            r = open_block(w, b);
+            r.expect_array(4);
+            const uint64_t bw = r.read_uint();
+            if (r.ok() && (bw < 1 || bw > kAmtMaxBitWidth)) r.fail();
+            const uint64_t height = r.read_uint();
+            (void)r.read_uint();  // count: not checked by load or for_each
+            rr.kind = RK_WALK;
+            if (r.ok() && height == 0 && bw <= 6) {
+                const uint32_t width = 1u << uint32_t(bw);
+                r.expect_array(3);
+                uint32_t bo, bl;
+                r.read_bytes(bo, bl);
+                uint64_t bits = 0;
+                if (r.ok() && bl == (width + 7) / 8) {
+                    bits = r.peek64(bo);
+                    if (bl < 8) bits &= (1ull << (8u * bl)) - 1ull;
+                    if (width < 64) bits &= (1ull << width) - 1ull;
+                    const uint64_t nl = r.read_array();
+                    const uint64_t nvals = r.ok() && nl == 0 ? r.read_array() : ~0ull;
+                    if (r.ok() && nl == 0 && nvals == uint64_t(__popcll(bits))) {
+                        table = true;
+                        nv = uint32_t(nvals);
+                        rr.bitmap = bits;
+                    }
+                }
+            }
+            // any irregularity (decode error included) is left to the general walk below, which names the outcome
+        }
+    }
+    // reserve nv records: one atomic per wavefront
+    {
+        const uint32_t want = table ? nv : 0;
+        uint32_t before = want;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(before, d, 64);
+            if (lane >= d) before += up;
+        }
+        const uint32_t wave_total = __shfl(before, 63, 64);
+        uint32_t base = 0;
+        if (lane == 63 && wave_total) base = atomicAdd(pool_used, wave_total);
+        base = __shfl(base, 63, 64);
+        rr.first = base + before - want;
+        if (table && uint64_t(rr.first) + nv > cap_events) table = false;  // pool exhausted: walk this one
+    }
+    if (!live) return;
+    if (table) {
+        // ---- stage 2: the events, each decoded once (the decode IS the per-value type check of Amt::load) ----
+        bool oversize = false;
+        const uint64_t block_base = w.off[rr.block];
+        for (uint32_t j = 0; j < nv && r.ok(); ++j) {
+            const uint32_t start = r.pos;
+            uint64_t emitter;
+            EvmLogLoc log;
+            decode_event_log(r, emitter, log);
+            if (!r.ok()) break;
+            EventRec e;
+            const uint32_t len = r.pos - start;
+            uint64_t flags = (uint64_t(log.n_topics & 0xffu) << kEvTopicShift) | (log.is_log ? kEvIsLog : 0) |
+                             (log.case_a ? kEvCaseA : 0);
+            oversize |= len > 0xffffu || log.n_topics > 255u;
+            e.base_flags = ((block_base + start) & kEvBaseMask) | flags;
+            e.emitter = emitter;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e.topic_rel[q] = uint16_t(log.topic_off[q] >= start ? log.topic_off[q] - start : 0);
+            e.data_rel = uint16_t(log.data.present ? log.data.off - start : 0);
+            e.ev_len = uint16_t(len);
+            e.data_len = log.data.present ? log.data.len : 0;
+            erecs[rr.first + j] = e;
+            if (count_matches && !(sp.has_actor && emitter != sp.actor) && log_matches(r, log, sp.filter)) ++c;
+        }
+        r.finish();
+        if (!r.ok()) {
+            rr.kind = IPCFP_ST_ERR_DECODE;
+            c = 0;
+        } else {
+            rr.kind = oversize ? uint32_t(RK_WALK) : uint32_t(RK_TABLE);
+        }
+    } else if (rr.kind == RK_WALK) {
+        // ---- the general route: names decode errors, counts matches of tall / wide / oversized trees ----
+        uint32_t st = IPCFP_ST_TRUE;
+        auto visit = [&](uint64_t, uint32_t, Rd& er) {
+            uint64_t emitter;
+            EvmLogLoc log;
+            decode_event_log(er, emitter, log);
+            if (!count_matches || (sp.has_actor && emitter != sp.actor)) return;
+            if (log_matches(er, log, sp.filter)) ++c;
+        };
+        bool handled;
+        st = amt3_for_each_leaf_root(w, ev_root, handled, visit);
+        if (!handled) {
+            c = 0;
+            AmtRootInfo info;
+            st = amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info);
+            if (st == IPCFP_ST_TRUE) st = amt_for_each_lane(w, info, VK_STAMPED_EVENT, visit);
+        }
+        if (st != IPCFP_ST_TRUE) {  // the scan stops here; a verify call walks this receipt itself (kind stays RK_WALK)
+            atomicMin(err, (unsigned long long)pack_enum_error(1, t, st));
+            c = 0;
+        }
+    }
+    if (rr.kind >= 64) atomicMin(err, (unsigned long long)pack_enum_error(1, t, rr.kind));
+    rrecs[t] = rr;
+    if (counts) counts[t] = c;
+}
+
+// the match count of a (new) filter from an existing table; receipts the table does not cover are walked
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_count_from_table(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+                                                          ScanParams sp, const ReceiptRec* __restrict__ rrecs,
+                                                          const EventRec* __restrict__ erecs, uint32_t* __restrict__ counts,
+                                                          unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const ReceiptRec rr = rrecs[t];
+    uint32_t c = 0;
+    if (rr.kind == RK_TABLE) {
+        const uint32_t ne = __popcll(rr.bitmap);
+        for (uint32_t j = 0; j < ne; ++j)
+            if (rec_matches(w.arena, erecs[rr.first + j], sp)) ++c;
+    } else if (rr.kind == RK_WALK) {
+        CidKey ev_root;
+        if (receipt_events_root(w, receipts[t], ev_root)) {
+            auto visit = [&](uint64_t, uint32_t, Rd& er) {
+                uint64_t emitter;
+                EvmLogLoc log;
+                decode_event_log(er, emitter, log);
+                if (sp.has_actor && emitter != sp.actor) return;
+                if (log_matches(er, log, sp.filter)) ++c;
+            };
+            bool handled;
+            uint32_t st = amt3_for_each_leaf_root(w, ev_root, handled, visit);
+            if (!handled) {
+                c = 0;
+                AmtRootInfo info;
+                st = amt_load(w, ev_root, 3, VK_STAMPED_EVENT, info);
+                if (st == IPCFP_ST_TRUE) st = amt_for_each_lane(w, info, VK_STAMPED_EVENT, visit);
+            }
+            if (st != IPCFP_ST_TRUE) {
+                atomicMin(err, (unsigned long long)pack_enum_error(1, t, st));
+                c = 0;
+            }
+        }
+    } else if (rr.kind >= 64) {
+        atomicMin(err, (unsigned long long)pack_enum_error(1, t, rr.kind));
+    }
+    counts[t] = c;
+}
+
+// PASS 2 without a recorder: the matches of tabulated receipts come straight from the records
+__global__ __launch_bounds__(256) void k_scan_pass2_table(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+                                                          ScanParams sp, const ReceiptRec* __restrict__ rrecs,
+                                                          const EventRec* __restrict__ erecs,
+                                                          const uint32_t* __restrict__ counts,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          EventMatch* __restrict__ matches, uint64_t matches_cap,
+                                                          uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t c = counts[t];
+    const uint64_t index = receipts[t].index;
+    if (index >= has_base && index - has_base < has_cap) has_match[index - has_base] = c ? 1 : 0;
+    if (c == 0) return;
+    const ReceiptRec rr = rrecs[t];
+    if (rr.kind != RK_TABLE || !matches) return;  // the rest is k_scan_pass2's (general walk)
+    uint32_t k = 0, ord = 0;
+    const uint32_t o = offsets[t];
+    const uint64_t block_base = w.off[rr.block];
+    for (uint32_t j = 0; j < 64; ++j) {
+        if (!((rr.bitmap >> j) & 1ull)) continue;
+        const EventRec e = erecs[rr.first + ord++];
+        if (!rec_matches(w.arena, e, sp)) continue;
+        if (k < c && uint64_t(o) + k < matches_cap)
+            matches[o + k] = EventMatch{index, j, e.emitter,
+                                        ValueLoc{rr.block, uint32_t((e.base_flags & kEvBaseMask) - block_base), e.ev_len}, 0};
+        ++k;
+    }
+}
+
 int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
                       const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, uint32_t* counts_d,
                       unsigned long long* err_d) {
@@ -275,17 +503,54 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
     return IPCFP_OK;
 }
 
+int launch_event_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                       const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ReceiptRec* rrecs_d,
+                       EventRec* erecs_d, uint32_t cap_events, uint32_t* pool_used_d, uint32_t* counts_d,
+                       unsigned long long* err_d) {
+    if (n == 0) return IPCFP_OK;
+    ScanParams sp{};
+    if (filter) sp = ScanParams{*filter, actor, has_actor ? 1u : 0u, 0};
+    {
+        ProfileScope prof(ctx, IPCFP_K_EVENT_SCAN);
+        hipLaunchKernelGGL(k_event_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n, sp,
+                           filter ? 1 : 0, rrecs_d, erecs_d, cap_events, pool_used_d, counts_d, err_d);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_count_from_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                            const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, const EventTableView& table,
+                            uint32_t* counts_d, unsigned long long* err_d) {
+    if (n == 0) return IPCFP_OK;
+    ScanParams sp{filter, actor, has_actor ? 1u : 0u, 0};
+    {
+        ProfileScope prof(ctx, IPCFP_K_EVENT_SCAN);
+        hipLaunchKernelGGL(k_count_from_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n, sp,
+                           table.receipts, table.events, counts_d, err_d);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
                       uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
                       const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint64_t matches_cap,
-                      uint8_t* has_match_d, uint64_t has_cap, uint64_t has_base) {
+                      uint8_t* has_match_d, uint64_t has_cap, uint64_t has_base, const EventTableView* table) {
     ScanParams sp{filter, actor, has_actor ? 1u : 0u, 0};
     const uint32_t threads = n ? n : 1;
     {
         ProfileScope prof(ctx, IPCFP_K_REPLAY);
+        // without a recorder the matches of tabulated receipts are read off the records; the walking kernel then
+        // only serves the receipts the table does not cover
+        const bool use_table = table && table->receipts && !w.touched && n;
+        if (use_table)
+            hipLaunchKernelGGL(k_scan_pass2_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n, sp,
+                               table->receipts, table->events, counts_d, offsets_d, static_cast<EventMatch*>(matches_d),
+                               matches_cap, has_match_d, has_cap, has_base);
         hipLaunchKernelGGL(k_scan_pass2, dim3(div_up(threads, 256)), dim3(256), 0, ctx->stream, w, receipts_root,
                            receipts_d, n, sp, counts_d, offsets_d, static_cast<EventMatch*>(matches_d), matches_cap,
-                           has_match_d, has_cap, has_base);
+                           has_match_d, has_cap, has_base, use_table ? table->receipts : nullptr);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

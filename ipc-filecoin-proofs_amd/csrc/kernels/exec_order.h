@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "amt_enum.h"
+#include "event_table.h"
 #include "types_dev.h"
 
 namespace ipcfp {
@@ -37,6 +38,9 @@ struct TipsetCtxDev {
     const LeafRef* receipt_leaves;
     uint64_t n_receipt_leaves;
     uint64_t receipt_first;       // index of receipt_leaves[0] (0, or the first receipt of a shard witness)
+    // the event table of those receipts (event_table.h), aligned with receipt_leaves; null: walk every claim
+    const ReceiptRec* receipt_recs;
+    const EventRec* event_recs;
 };
 
 }  // namespace ipcfp

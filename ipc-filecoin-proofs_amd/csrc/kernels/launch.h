@@ -53,6 +53,9 @@ int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* 
 // --- verify_events.hip ---
 struct TipsetCtxDev;
 struct AmtRootSpec;
+struct ReceiptRec;
+struct EventRec;
+struct EventTableView;
 struct LeafRef;
 struct EventClaimPacked;
 int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n);
@@ -76,7 +79,16 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
 int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receipts_root, const LeafRef* receipts_d,
                       uint32_t n, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor,
                       const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint64_t matches_cap,
-                      uint8_t* has_match_d, uint64_t has_cap, uint64_t has_base = 0);
+                      uint8_t* has_match_d, uint64_t has_cap, uint64_t has_base = 0,
+                      const EventTableView* table = nullptr);
+// the event table (event_table.h): PASS 1 that leaves a record per event (filter nullable: build only)
+int launch_event_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                       const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ReceiptRec* rrecs_d,
+                       EventRec* erecs_d, uint32_t cap_events, uint32_t* pool_used_d, uint32_t* counts_d,
+                       unsigned long long* err_d);
+int launch_count_from_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                            const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, const EventTableView& table,
+                            uint32_t* counts_d, unsigned long long* err_d);
 
 // --- base64.hip ---
 int launch_base64_decode(ipcfp_ctx* ctx, const uint8_t* text_d, const void* spans_d, uint32_t n_blocks, uint32_t n_units,

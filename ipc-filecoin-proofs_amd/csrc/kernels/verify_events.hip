@@ -322,6 +322,46 @@ __device__ __forceinline__ bool ev_trusted(const ipcfp_trust_policy_t& t, long l
     return epoch >= t.min_epoch && epoch <= t.max_epoch;
 }
 
+// verify_event_data_matches (+ the built-in check_event) on a tabulated event: bytes at known addresses
+__device__ __forceinline__ bool bytes_equal_global(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t n) {
+    uint64_t diff = 0;
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, a + i, 8);
+        __builtin_memcpy(&y, b + i, 8);
+        diff |= x ^ y;
+    }
+    for (; i < n; ++i) diff |= uint64_t(a[i] ^ b[i]);
+    return diff == 0;
+}
+
+__device__ __forceinline__ uint32_t verify_event_record(const WitnessView& w, const EventClaimPacked& c, const EventRec& e,
+                                                        const uint8_t* __restrict__ blob, const ipcfp_event_filter_t& filter,
+                                                        bool has_filter) {
+    if (e.emitter != c.emitter) return IPCFP_ST_FALSE_EMITTER;                                                // :262
+    if (!(e.base_flags & kEvIsLog)) return IPCFP_ST_FALSE_NOT_EVM_LOG;                                        // :267
+    const uint32_t nt = uint32_t(e.base_flags >> kEvTopicShift) & 0xffu;
+    if (nt != c.n_topics) return IPCFP_ST_FALSE_TOPIC_COUNT;                                                  // :272
+    const uint8_t* item = w.arena + (e.base_flags & kEvBaseMask);
+    const bool case_a = (e.base_flags & kEvCaseA) != 0;
+    for (uint32_t i = 0; i < nt; ++i) {                                                                       // :276-281
+        const uint8_t* claimed = blob + c.topics_off + 33u * i;
+        if (!claimed[0]) return IPCFP_ST_FALSE_TOPIC;  // the claimed string is not "0x" + 64 hex digits
+        const uint32_t rel = case_a ? uint32_t(e.topic_rel[0]) + 32u * i : uint32_t(e.topic_rel[i & 3u]);
+        if (!bytes_equal_global(item + rel, claimed + 1, 32)) return IPCFP_ST_FALSE_TOPIC;
+    }
+    if (!(c.flags & EC_DATA_MATCHABLE) || c.data_len != e.data_len) return IPCFP_ST_FALSE_DATA;               // :284-287
+    if (!bytes_equal_global(item + e.data_rel, blob + c.data_off, c.data_len)) return IPCFP_ST_FALSE_DATA;
+    if (has_filter) {                                                                                         // :247-251
+        if (nt < 2) return IPCFP_ST_FALSE_FILTER;
+        const uint32_t r1 = case_a ? uint32_t(e.topic_rel[0]) + 32u : uint32_t(e.topic_rel[1]);
+        if (!bytes_equal_global(item + e.topic_rel[0], filter.topic0, 32) || !bytes_equal_global(item + r1, filter.topic1, 32))
+            return IPCFP_ST_FALSE_FILTER;
+    }
+    return IPCFP_ST_TRUE;
+}
+
 __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const EventClaimPacked& c,
                                                      const TipsetCtxDev& tc, const uint8_t* __restrict__ blob,
                                                      const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t& filter,
@@ -349,7 +389,21 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     if (tc.receipt_leaves && c.exec_index >= tc.receipt_first && c.exec_index - tc.receipt_first < tc.n_receipt_leaves) {
         // the receipts AMT was enumerated (and thereby fully validated) for this context: load + get
         // of a present index cannot fail and yields exactly this leaf                                        // :220-224
-        const LeafRef l = tc.receipt_leaves[c.exec_index - tc.receipt_first];
+        const uint64_t slot = c.exec_index - tc.receipt_first;
+        if (tc.receipt_recs) {
+            // ... and its events were tabulated (event_table.h): what `Amt::load(events_root)`, `get(event_index)`,
+            // extract_evm_log and the compares below observe is all in the records
+            const ReceiptRec rr = tc.receipt_recs[slot];
+            if (rr.kind == RK_NO_EVENTS) return IPCFP_ST_FALSE_NO_EVENTS_ROOT;                                // :229
+            if (rr.kind >= 64) return rr.kind;                                                                // :234 Err
+            if (rr.kind == RK_TABLE) {
+                if (c.event_index == ~0ULL) return IPCFP_ST_ERR;                                              // > MAX_INDEX
+                if (c.event_index >= 64 || !((rr.bitmap >> c.event_index) & 1ull)) return IPCFP_ST_FALSE_NO_EVENT;  // :237
+                const EventRec e = tc.event_recs[rr.first + __popcll(rr.bitmap & ((1ull << c.event_index) - 1ull))];
+                return verify_event_record(w, c, e, blob, filter, has_filter);
+            }
+        }
+        const LeafRef l = tc.receipt_leaves[slot];
         rloc = ValueLoc{l.block, l.off, l.len};
     } else {
         AmtRootInfo receipts;
