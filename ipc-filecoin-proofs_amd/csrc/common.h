@@ -71,6 +71,8 @@ struct ipcfp_ctx {
     std::vector<PendingRead> pending;
     int call_depth = 0;
     hipEvent_t join_event = nullptr;           // main stream ← K1 stream dependency (host/shard.cpp)
+    hipEvent_t spin_event = nullptr;           // wait_stream's polling event
+    bool spin_sync = true;                     // env IPCFP_SPIN_SYNC=0: always block in hipStreamSynchronize
     ipcfp::UploadRing* upload_ring = nullptr;  // pinned staging ring of ipcfp::upload (created on first use)
 };
 
@@ -107,8 +109,14 @@ inline hipError_t h2d_small(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t
 }
 // hipStreamSynchronize + delivery of the read-backs queued on that stream.  Every synchronisation of an
 // engine stream goes through here.
+// The wait itself: hipStreamSynchronize parks the thread and is woken by an interrupt — 30-70 µs before the host runs
+// again, and a verification pass waits for the device several times (tree shapes, match counts).  Polling an event
+// keeps the thread on the core and sees the completion within a few microseconds (ctx->spin_sync, default on; a
+// wait that lasts longer than ~2 ms falls back to the blocking call).
+hipError_t wait_stream(ipcfp_ctx* ctx, hipStream_t s);
+
 inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
-    const hipError_t e = hipStreamSynchronize(s);
+    const hipError_t e = wait_stream(ctx, s);
     bool others = false;
     for (auto& r : ctx->pending) {
         if (r.stream == s) {

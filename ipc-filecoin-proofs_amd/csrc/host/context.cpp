@@ -20,6 +20,19 @@ int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...) {
 
 thread_local DevPool* g_tls_pool = nullptr;
 
+hipError_t wait_stream(ipcfp_ctx* ctx, hipStream_t s) {
+    if (!ctx->spin_sync) return hipStreamSynchronize(s);
+    if (!ctx->spin_event && hipEventCreateWithFlags(&ctx->spin_event, hipEventDisableTiming) != hipSuccess)
+        return hipStreamSynchronize(s);
+    hipError_t e = hipEventRecord(ctx->spin_event, s);
+    if (e != hipSuccess) return e;
+    for (uint32_t spins = 0;; ++spins) {
+        e = hipEventQuery(ctx->spin_event);
+        if (e != hipErrorNotReady) return e;
+        if (spins > 200000) return hipStreamSynchronize(s);  // a long wait: give the core back
+    }
+}
+
 hipError_t DevPool::take(void** out, size_t bytes, size_t* cap) {
     const size_t want = (bytes + 255) & ~size_t(255);
     // best fit among cached buffers that are not wastefully large
@@ -190,6 +203,7 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
                 ctx->stream_k1 = ctx->stream;
         }
     }
+    if (const char* e = std::getenv("IPCFP_SPIN_SYNC")) ctx->spin_sync = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = std::atoi(e) == 1 ? 1 : 0;
     if (const char* e = std::getenv("IPCFP_B2B_WG")) {
         const int wg = std::atoi(e);
@@ -217,6 +231,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->upload_ring) upload_ring_destroy(ctx->upload_ring);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
+    if (ctx->spin_event) (void)hipEventDestroy(ctx->spin_event);
     if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -228,8 +243,8 @@ void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx) { return ctx ? reinterpret_cast<void*>(
 
 int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
     if (!ctx) return IPCFP_E_INVALID;
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
+    IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream));
+    IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream_k1));
     return IPCFP_OK;
 }
 

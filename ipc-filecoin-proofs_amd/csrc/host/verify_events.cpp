@@ -43,7 +43,7 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
         if (rc) return rc;
     }
     AmtEnumResult en;
-    rc = amt_enumerate(ctx, view, ex.roots.p, 2 * n_parents, VK_CID, ex.err.p, en);
+    rc = amt_enumerate(ctx, view, ex.roots.p, 2 * n_parents, VK_CID, ex.err.p, en, 0, ~0ULL, &ex.keys);
     if (rc) return rc;
     const unsigned long long e = en.error;  // read back by the enumerator: stage-1 errors and its own, merged
     ex.status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
@@ -54,12 +54,12 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     uint32_t size = 64;
     while (size < 2ull * n) size <<= 1;
     ex.mask = size - 1;
-    IPCFP_HIP(ctx, ex.keys.alloc(n));
+    if (!en.keys_written) IPCFP_HIP(ctx, ex.keys.alloc(n));
     IPCFP_HIP(ctx, ex.slots.alloc(size));
     IPCFP_HIP(ctx, ex.first.alloc(n));
     IPCFP_HIP(ctx, ex.pos.alloc(n));
     IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 4, ctx->stream));
-    rc = launch_exec_dedup(ctx, view, en.leaves.p, n, ex.keys.p, ex.slots.p, ex.mask, ex.first.p);
+    rc = launch_exec_dedup(ctx, view, en.keys_written ? nullptr : en.leaves.p, n, ex.keys.p, ex.slots.p, ex.mask, ex.first.p);
     if (rc) return rc;
     DevBuf<uint64_t> scratch;
     IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));

@@ -66,6 +66,7 @@ struct AmtEnumResult {
     uint64_t n_leaves = 0;
     uint64_t error = kNoEnumError;  // packed first error (after the final sync)
     bool dense = false;             // every AMT held exactly the indices 0..count-1 (the fast path succeeded)
+    bool keys_written = false;      // the values (links) went to the caller's key buffer instead of `leaves`
 };
 
 // An enumeration may be restricted to the indices [lo, hi) (a receipt-range shard of one tipset):
@@ -77,7 +78,8 @@ struct AmtEnumResult {
 // enumerator atomicMin's into it.  Synchronises the stream twice on the dense path (root shapes; anomaly flag
 // + error word), once more per level on the general path.
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
-                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo = 0, uint64_t hi = ~0ULL);
+                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo = 0, uint64_t hi = ~0ULL,
+                  DevBuf<CidKey>* keys_out = nullptr);  // VK_CID on the dense path: the links as witness keys, no LeafRefs
 
 // Enumerate one AMT of the witness, or return the cached enumeration (owned by the witness; valid
 // until ipcfp_witness_rebuild_index).

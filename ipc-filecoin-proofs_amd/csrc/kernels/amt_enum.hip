@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
 // leaf level: one lane per leaf node validates it in one pass and writes its values' locations
 __global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumNode* __restrict__ cur,
                                                       const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t n_nodes,
-                                                      int vkind, LeafRef* __restrict__ leaves, uint32_t* __restrict__ anomaly) {
+                                                      int vkind, LeafRef* __restrict__ leaves, uint32_t* __restrict__ anomaly,
+                                                      CidKey* __restrict__ keys_out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_nodes) return;
     uint32_t r = 0, node_off0 = 0;
@@ -391,10 +392,19 @@ __global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumN
     // every value of the node is type-checked (serde decodes the whole node); the ones inside [lo, hi) are emitted
     for (uint32_t i = 0; ok && i < m; ++i) {
         const uint32_t start = rd.pos;
-        check_value(rd, vkind);
-        ok = rd.ok();
         const uint64_t idx = p * W + i;
-        if (ok && idx >= dr.lo && idx < dr.hi) leaves[leaf_off + (idx - dr.lo)] = LeafRef{e.block, start, rd.pos - start, e.seq, e.base + i};
+        if (keys_out) {
+            // Amtv0<Cid>: the value IS a link — validate it and hand its CID out as a witness key in the same pass
+            // (the execution-order reconstruction needs the keys, not the locations)
+            CidKey key;
+            rd.read_link_key(key);
+            ok = rd.ok();
+            if (ok && idx >= dr.lo && idx < dr.hi) keys_out[leaf_off + (idx - dr.lo)] = key;
+        } else {
+            check_value(rd, vkind);
+            ok = rd.ok();
+        }
+        if (ok && leaves && idx >= dr.lo && idx < dr.hi) leaves[leaf_off + (idx - dr.lo)] = LeafRef{e.block, start, rd.pos - start, e.seq, e.base + i};
     }
     if (ok && e.node_off == 0) {
         rd.finish();
@@ -437,7 +447,8 @@ static uint64_t amt_span_host(uint32_t bw, uint64_t height) {
 }
 
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
-                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo, uint64_t hi) {
+                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo, uint64_t hi, DevBuf<CidKey>* keys_out) {
+    out.keys_written = false;
     const EnumRange rg{lo, hi};
     const bool whole = lo == 0 && hi == ~0ULL;
     out.n_leaves = 0;
@@ -497,7 +508,9 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             IPCFP_HIP(ctx, b.alloc(biggest));
             IPCFP_HIP(ctx, dr_d.alloc(n_roots));
             IPCFP_HIP(ctx, anomaly.alloc(1));
-            IPCFP_HIP(ctx, out.leaves.alloc(n_leaves));
+            const bool want_keys = keys_out && vkind == VK_CID;
+            if (want_keys) IPCFP_HIP(ctx, keys_out->alloc(n_leaves));
+            else IPCFP_HIP(ctx, out.leaves.alloc(n_leaves));
             IPCFP_HIP(ctx, hipMemsetAsync(anomaly.p, 0, 4, ctx->stream));
             IPCFP_HIP(ctx, hipMemcpyAsync(dr_d.p, dr.data(), size_t(n_roots) * sizeof(DenseRoot), hipMemcpyHostToDevice, ctx->stream));
             const EnumNode* src = cur.p;
@@ -509,7 +522,8 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                 a.swap(b);  // `src` now lives in b; the next level writes a
             }
             hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_level[0], 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p,
-                               n_roots, uint32_t(n_level[0]), vkind, out.leaves.p, anomaly.p);
+                               n_roots, uint32_t(n_level[0]), vkind, want_keys ? nullptr : out.leaves.p, anomaly.p,
+                               want_keys ? keys_out->p : nullptr);
             uint32_t bad = 0;
             unsigned long long e = kNoEnumError;  // err_d is untouched here: report what earlier stages left in it
             IPCFP_HIP(ctx, d2h_small(ctx, &bad, anomaly.p, 4, ctx->stream));
@@ -520,9 +534,11 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                 out.n_leaves = n_leaves;
                 out.error = e;
                 out.dense = true;
+                out.keys_written = want_keys;
                 return IPCFP_OK;
             }
             out.leaves.release();
+            if (want_keys) keys_out->release();
         }
     }
 

@@ -513,7 +513,7 @@ int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leave
                       uint32_t* slots_d, uint32_t mask, uint32_t* first_d) {
     if (n == 0) return IPCFP_OK;
     const dim3 g(div_up(n, 256)), b(256);
-    hipLaunchKernelGGL(k_exec_keys, g, b, 0, ctx->stream, w, leaves_d, n, keys_d);
+    if (leaves_d) hipLaunchKernelGGL(k_exec_keys, g, b, 0, ctx->stream, w, leaves_d, n, keys_d);  // else: keys came with the enumeration
     hipLaunchKernelGGL(k_exec_insert, g, b, 0, ctx->stream, keys_d, n, slots_d, mask);
     hipLaunchKernelGGL(k_exec_first, g, b, 0, ctx->stream, keys_d, n, slots_d, mask, first_d);
     IPCFP_HIP(ctx, hipGetLastError());

@@ -89,7 +89,8 @@ def test_damaged_events_blocks(engine, oracle):
     ts, cl, blob, blob_len = packed(tip, lie=False)
     with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
         _, _, m, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=None, want_touched=False)
-    for victim_row, damage in ((40, "key"), (len(m) // 2, "type"), (len(m) - 3, "truncate")):
+    assert len(m) >= 6
+    for victim_row, damage in ((1, "key"), (len(m) // 2, "type"), (len(m) - 2, "truncate")):
         rec = m[victim_row]
         b, off = int(rec["block"]), int(rec["off"])
         data = tip.data.copy()
