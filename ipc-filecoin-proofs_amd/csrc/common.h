@@ -70,6 +70,19 @@ struct ipcfp_ctx {
     };
     std::vector<PendingRead> pending;
     int call_depth = 0;
+    // --- the call's control block: every flag, counter and error word a verification call hands to its kernels lives
+    // in ONE small device buffer, initialised by one copy from a pinned template (first half zeros, second half
+    // 0xff) and read back by one copy — a dozen hipMemsetAsync / hipMemcpyAsync of a few bytes each cost ~10 µs
+    // apiece as kernels of their own (profiles/r02_timeline_before_ctl.txt)
+    uint8_t* ctl_dev = nullptr;
+    uint8_t* ctl_host = nullptr;               // pinned: [template 2·kCtlHalf][mirror 2·kCtlHalf]
+    uint32_t ctl_used_zero = 0, ctl_used_ff = 0;
+    bool ctl_primed = false;
+    struct CtlRead {
+        void* dst;
+        uint32_t off, n;
+    };
+    std::vector<CtlRead> ctl_reads;            // words wanted on the host at the next synchronisation of the main stream
     hipEvent_t join_event = nullptr;           // main stream ← K1 stream dependency (host/shard.cpp)
     hipEvent_t spin_event = nullptr;           // wait_stream's polling event
     bool spin_sync = true;                     // env IPCFP_SPIN_SYNC=0: always block in hipStreamSynchronize
@@ -87,6 +100,39 @@ int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...);
             return ::ipcfp::set_error((ctx), IPCFP_E_HIP, "%s failed: %s (%s:%d)", #call,       \
                                       hipGetErrorString(_e), __FILE__, __LINE__);               \
     } while (0)
+
+constexpr uint32_t kCtlHalf = 1024;
+
+// `bytes` (multiple of 8) of the call's control block, pre-set to zero (`ff` = false) or to 0xff bytes; nullptr when the
+// block is used up or absent (the caller then allocates and memsets as before).
+inline void* ctl_take(ipcfp_ctx* ctx, uint32_t bytes, bool ff) {
+    if (!ctx->ctl_dev) return nullptr;
+    bytes = (bytes + 7u) & ~7u;
+    uint32_t& used = ff ? ctx->ctl_used_ff : ctx->ctl_used_zero;
+    if (used + bytes > kCtlHalf) return nullptr;
+    if (!ctx->ctl_primed) {
+        if (hipMemcpyAsync(ctx->ctl_dev, ctx->ctl_host, 2 * kCtlHalf, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return nullptr;
+        ctx->ctl_primed = true;
+    }
+    void* p = ctx->ctl_dev + (ff ? kCtlHalf : 0u) + used;
+    used += bytes;
+    return p;
+}
+// Queue ONE read-back of the whole block on the main stream; after sync_stream every word is available through ctl_value.
+inline hipError_t ctl_fetch(ipcfp_ctx* ctx) {
+    if (!ctx->ctl_dev || !ctx->ctl_primed) return hipSuccess;
+    return hipMemcpyAsync(ctx->ctl_host + 2 * kCtlHalf, ctx->ctl_dev, 2 * kCtlHalf, hipMemcpyDeviceToHost, ctx->stream);
+}
+inline bool ctl_owns(const ipcfp_ctx* ctx, const void* dev_ptr) {
+    const uint8_t* p = static_cast<const uint8_t*>(dev_ptr);
+    return ctx->ctl_dev && p >= ctx->ctl_dev && p < ctx->ctl_dev + 2 * kCtlHalf;
+}
+template <typename T>
+inline T ctl_value(const ipcfp_ctx* ctx, const void* dev_ptr) {
+    T v;
+    std::memcpy(&v, ctx->ctl_host + 2 * kCtlHalf + (static_cast<const uint8_t*>(dev_ptr) - ctx->ctl_dev), sizeof(T));
+    return v;
+}
 
 // Queue an asynchronous read-back of n bytes; `dst` is valid after the next sync_stream on `s`.
 inline hipError_t d2h_small(ipcfp_ctx* ctx, void* dst, const void* src_d, size_t n, hipStream_t s) {
@@ -116,7 +162,14 @@ inline hipError_t h2d_small(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t
 hipError_t wait_stream(ipcfp_ctx* ctx, hipStream_t s);
 
 inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
+    const bool ctl = s == ctx->stream && !ctx->ctl_reads.empty();
+    if (ctl) (void)ctl_fetch(ctx);  // one copy for every control word the host asked for
     const hipError_t e = wait_stream(ctx, s);
+    if (ctl) {
+        if (e == hipSuccess)
+            for (auto& r : ctx->ctl_reads) std::memcpy(r.dst, ctx->ctl_host + 2 * kCtlHalf + r.off, r.n);
+        ctx->ctl_reads.clear();
+    }
     bool others = false;
     for (auto& r : ctx->pending) {
         if (r.stream == s) {
@@ -189,6 +242,26 @@ struct DevBuf {
     }
 };
 
+// `count` control words for the kernels of this call, pre-set to zero or to 0xff bytes: a slice of the control block
+// when there is room, else `own` (allocated and memset here).
+template <typename T>
+inline hipError_t ctl_words(ipcfp_ctx* ctx, DevBuf<T>& own, T*& p, size_t count, bool ff) {
+    p = static_cast<T*>(ctl_take(ctx, uint32_t(count * sizeof(T)), ff));
+    if (p) return hipSuccess;
+    hipError_t e = own.alloc(count);
+    if (e != hipSuccess) return e;
+    p = own.p;
+    return hipMemsetAsync(own.p, ff ? 0xff : 0, count * sizeof(T), ctx->stream);
+}
+// `*dst` = the device value at p after the next sync_stream of the main stream (p: a control word or any device address)
+inline hipError_t ctl_read(ipcfp_ctx* ctx, void* dst, const void* p, size_t n) {
+    if (ctl_owns(ctx, p)) {
+        ctx->ctl_reads.push_back({dst, uint32_t(static_cast<const uint8_t*>(p) - ctx->ctl_dev), uint32_t(n)});
+        return hipSuccess;
+    }
+    return d2h_small(ctx, dst, p, n, ctx->stream);
+}
+
 // Binds the calling thread to a context for the duration of one C-ABI call: device selection and
 // the allocation pool DevBufs draw from.
 struct CallScope {
@@ -199,6 +272,9 @@ struct CallScope {
         if (c->call_depth++ == 0) {  // read-backs a failed call left behind point at dead stack frames
             c->pending.clear();
             c->pinned_used = 0;
+            c->ctl_used_zero = c->ctl_used_ff = 0;
+            c->ctl_primed = false;
+            c->ctl_reads.clear();
         }
     }
     ~CallScope() {

@@ -213,6 +213,19 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
         ctx->pinned_cap = 64 * 1024;
     else
         ctx->pinned = nullptr;  // read-backs fall back to pageable copies
+    // the control block and its pinned template / mirror (IPCFP_CTL_BLOCK=0: individual memsets and copies)
+    const char* ctl_env = std::getenv("IPCFP_CTL_BLOCK");
+    if (!(ctl_env && std::atoi(ctl_env) == 0) &&
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->ctl_host), 4 * kCtlHalf, hipHostMallocDefault) == hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->ctl_dev), 2 * kCtlHalf) == hipSuccess) {
+            std::memset(ctx->ctl_host, 0, kCtlHalf);
+            std::memset(ctx->ctl_host + kCtlHalf, 0xff, kCtlHalf);
+        } else {
+            (void)hipHostFree(ctx->ctl_host);
+            ctx->ctl_host = nullptr;
+            ctx->ctl_dev = nullptr;
+        }
+    }
     *out = ctx;
     return IPCFP_OK;
 }
@@ -229,6 +242,8 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     ctx->pool.drain();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
+    if (ctx->ctl_dev) (void)hipFree(ctx->ctl_dev);
     if (ctx->upload_ring) upload_ring_destroy(ctx->upload_ring);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->spin_event) (void)hipEventDestroy(ctx->spin_event);

@@ -9,12 +9,14 @@ namespace ipcfp {
 // device buffers of one context's execution order
 struct ExecState {
     DevBuf<CidKey> keys;        // raw for_each sequence
-    DevBuf<uint32_t> slots;     // hash table → first raw position
+    DevBuf<unsigned long long> slots;  // hash table: {key fingerprint, first raw position}
     DevBuf<uint32_t> first;     // 1 where the raw position is a first occurrence
     DevBuf<uint32_t> pos;       // exclusive scan of `first` → execution index
-    DevBuf<uint64_t> total;     // device: number of distinct messages (= exec_len)
+    struct Word64 { uint64_t* p = nullptr; } total;           // device: number of distinct messages (= exec_len)
+    struct WordErr { unsigned long long* p = nullptr; } err;  // packed first error of the whole reconstruction
+    DevBuf<uint64_t> total_own;                 // backing store when the call's control block is full
+    DevBuf<unsigned long long> err_own;
     DevBuf<AmtRootSpec> roots;  // stage 1 output: the BLS / secp message AMT roots of every parent block
-    DevBuf<unsigned long long> err;  // packed first error of the whole reconstruction
     uint32_t mask = 0;
     uint64_t raw_len = 0, exec_len = 0;
     uint32_t status = IPCFP_ST_ERR;

@@ -40,15 +40,12 @@ int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const 
     cap = std::min<uint64_t>(cap, 0xfffffff0ull);
     IPCFP_HIP(ctx, t->receipts.alloc(n));
     IPCFP_HIP(ctx, t->events.alloc(cap));
-    DevBuf<uint32_t> used;
-    DevBuf<unsigned long long> err_local;
-    IPCFP_HIP(ctx, used.alloc(1));
-    IPCFP_HIP(ctx, hipMemsetAsync(used.p, 0, 4, ctx->stream));
-    if (!err_d) {
-        IPCFP_HIP(ctx, err_local.alloc(1));
-        IPCFP_HIP(ctx, hipMemsetAsync(err_local.p, 0xff, 8, ctx->stream));
-        err_d = err_local.p;
-    }
+    DevBuf<uint32_t> used_own;
+    DevBuf<unsigned long long> err_own;
+    uint32_t* used_p = nullptr;
+    IPCFP_HIP(ctx, ctl_words(ctx, used_own, used_p, 1, false));
+    struct { uint32_t* p; } used{used_p};
+    if (!err_d) IPCFP_HIP(ctx, ctl_words(ctx, err_own, err_d, 1, true));
     const WitnessView view = witness_view(w);
     int rc = launch_event_table(ctx, view, reinterpret_cast<const LeafRef*>(en->leaves.p), uint32_t(n), filter, has_actor,
                                 actor, t->receipts.p, t->events.p, uint32_t(cap), used.p, counts_d, err_d);
@@ -64,11 +61,10 @@ int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const 
 int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const ipcfp_event_filter_t& filter,
                        int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out, uint64_t cap_matches) {
     const WitnessView view = witness_view(w);
-    DevBuf<unsigned long long> err;
-    IPCFP_HIP(ctx, err.alloc(1));
-    unsigned long long e0 = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemsetAsync(err.p, 0xff, 8, ctx->stream));  // kNoEnumError
-    (void)e0;
+    DevBuf<unsigned long long> err_own;
+    unsigned long long* err_p = nullptr;  // kNoEnumError
+    IPCFP_HIP(ctx, ctl_words(ctx, err_own, err_p, 1, true));
+    struct { unsigned long long* p; } err{err_p};
     const EnumCached* en = nullptr;
     // receipts in index order; a shard witness (host/shard.cpp) enumerates its own index range only
     const uint64_t lo = w->receipt_lo, hi = w->receipt_hi;
@@ -91,11 +87,13 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         n_idx = last.index + 1 - lo;  // the per-index byte map starts at the shard's first index
     }
     DevBuf<uint32_t> counts, offsets;
-    DevBuf<uint64_t> scratch, total;
+    DevBuf<uint64_t> scratch, total_own;
+    uint64_t* total_p = nullptr;
     IPCFP_HIP(ctx, counts.alloc(n));
     IPCFP_HIP(ctx, offsets.alloc(n));
     IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
-    IPCFP_HIP(ctx, total.alloc(1));
+    IPCFP_HIP(ctx, ctl_words(ctx, total_own, total_p, 1, false));
+    struct { uint64_t* p; } total{total_p};
     IPCFP_HIP(ctx, out.has.alloc(n_idx));
     if (n_idx) IPCFP_HIP(ctx, hipMemsetAsync(out.has.p, 0, n_idx, ctx->stream));
     // PASS 1: with the events tabulated once per witness (kernels/event_table.h) — the first scan builds the table
@@ -119,8 +117,8 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     if (rc) return rc;
     uint64_t nm = 0;
     unsigned long long e1 = kNoEnumError;
-    IPCFP_HIP(ctx, d2h_small(ctx, &nm, total.p, 8, ctx->stream));
-    IPCFP_HIP(ctx, d2h_small(ctx, &e1, err.p, 8, ctx->stream));
+    IPCFP_HIP(ctx, ctl_read(ctx, &nm, total.p, 8));
+    IPCFP_HIP(ctx, ctl_read(ctx, &e1, err.p, 8));
     uint64_t cap = cap_matches;
     if (cap_matches > (1ull << 26)) {  // unknown (kAllMatches) or too big to reserve blindly:
         // size the match list to the count — one more synchronisation

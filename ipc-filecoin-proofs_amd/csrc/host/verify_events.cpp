@@ -27,8 +27,7 @@ CidKey key_from_slot(const uint8_t* slot40);
 
 int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents) {
     IPCFP_HIP(ctx, ex.roots.alloc(2 * size_t(n_parents) + 1));
-    IPCFP_HIP(ctx, ex.err.alloc(1));
-    IPCFP_HIP(ctx, hipMemsetAsync(ex.err.p, 0xff, 8, ctx->stream));  // kNoEnumError
+    IPCFP_HIP(ctx, ctl_words(ctx, ex.err_own, ex.err.p, 1, true));  // kNoEnumError
     return IPCFP_OK;
 }
 
@@ -58,18 +57,18 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     IPCFP_HIP(ctx, ex.slots.alloc(size));
     IPCFP_HIP(ctx, ex.first.alloc(n));
     IPCFP_HIP(ctx, ex.pos.alloc(n));
-    IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 4, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 8, ctx->stream));
     rc = launch_exec_dedup(ctx, view, en.keys_written ? nullptr : en.leaves.p, n, ex.keys.p, ex.slots.p, ex.mask, ex.first.p);
     if (rc) return rc;
     DevBuf<uint64_t> scratch;
     IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
-    IPCFP_HIP(ctx, ex.total.alloc(1));
+    IPCFP_HIP(ctx, ctl_words(ctx, ex.total_own, ex.total.p, 1, false));
     rc = launch_scan_u32(ctx, ex.first.p, n, ex.pos.p, ex.total.p, scratch.p);
     if (rc) return rc;
     // `en.leaves` and `scratch` go back to the pool here; reuse is ordered on the one stream
     if (!host_len) return IPCFP_OK;
     uint64_t distinct = 0;
-    IPCFP_HIP(ctx, d2h_small(ctx, &distinct, ex.total.p, 8, ctx->stream));
+    IPCFP_HIP(ctx, ctl_read(ctx, &distinct, ex.total.p, 8));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     ex.exec_len = distinct;
     return IPCFP_OK;
@@ -85,8 +84,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     const WitnessView view = witness_view(w);
     DevBuf<TipsetCtxDev> tcs_d;
     IPCFP_HIP(ctx, tcs_d.alloc(tcs.size()));
-    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
-                                  ctx->stream));
+    IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
     // The tipset prologue — header facts of every context and stage 1 of every execution order (parent
     // headers, TxMeta re-hash, message AMT roots) — is one launch.  The execution order is prepared for every
     // context whose claim strings parsed, before the header facts are known on the host; a context that fails
@@ -111,7 +109,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     }
     DevBuf<PrepareJob> jobs_d;
     IPCFP_HIP(ctx, jobs_d.alloc(jobs.size()));
-    IPCFP_HIP(ctx, hipMemcpyAsync(jobs_d.p, jobs.data(), jobs.size() * sizeof(PrepareJob), hipMemcpyHostToDevice, ctx->stream));
+    IPCFP_HIP(ctx, h2d_small(ctx, jobs_d.p, jobs.data(), jobs.size() * sizeof(PrepareJob), ctx->stream));
     rc = launch_tipset_prepare(ctx, view, jobs_d.p, uint32_t(jobs.size()));
     if (rc) return rc;
     // the header facts come back with the first synchronisation below (the enumerator's), not one of their own
@@ -165,8 +163,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
             }
         }
     }
-    IPCFP_HIP(ctx, hipMemcpyAsync(tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), hipMemcpyHostToDevice,
-                                  ctx->stream));
+    IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
     for (size_t k = 0; k < tcs.size(); ++k)
         if (tcs[k].exec_slots && execs[k]->status == IPCFP_ST_TRUE && execs[k]->total.p) {
             rc = launch_set_exec_len(ctx, tcs_d.p + k, execs[k]->total.p);

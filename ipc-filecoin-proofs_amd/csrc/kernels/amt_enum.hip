@@ -457,20 +457,20 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     if (n_roots == 0) return IPCFP_OK;
     ProfileScope prof(ctx, IPCFP_K_EXEC_ORDER);
     DevBuf<EnumNode> cur, nxt;
-    DevBuf<uint32_t> counts, offsets, small;
-    DevBuf<uint64_t> scratch, total_d;
+    DevBuf<uint32_t> counts, offsets, small_own;
+    DevBuf<uint64_t> scratch, total_d, root_info_own;
     IPCFP_HIP(ctx, cur.alloc(n_roots));
-    IPCFP_HIP(ctx, small.alloc(4));
     IPCFP_HIP(ctx, total_d.alloc(2));
-    IPCFP_HIP(ctx, hipMemsetAsync(small.p, 0, 16, ctx->stream));
-    DevBuf<uint64_t> root_info_d;
-    IPCFP_HIP(ctx, root_info_d.alloc(2 * size_t(n_roots)));
+    uint32_t* small = nullptr;      // [0] = max height; [2] = anomaly flag of the dense path
+    uint64_t* root_info_d = nullptr;
+    IPCFP_HIP(ctx, ctl_words(ctx, small_own, small, 4, false));
+    IPCFP_HIP(ctx, ctl_words(ctx, root_info_own, root_info_d, 2 * size_t(n_roots), false));
     hipLaunchKernelGGL(k_enum_roots, dim3(div_up(n_roots, 64)), dim3(64), 0, ctx->stream, view, roots_d, n_roots, vkind,
-                       cur.p, small.p, err_d, root_info_d.p);
+                       cur.p, small, err_d, root_info_d);
     uint32_t max_height = 0;
     std::vector<uint64_t> root_info(2 * size_t(n_roots));
-    IPCFP_HIP(ctx, d2h_small(ctx, &max_height, small.p, 4, ctx->stream));
-    IPCFP_HIP(ctx, d2h_small(ctx, root_info.data(), root_info_d.p, root_info.size() * 8, ctx->stream));
+    IPCFP_HIP(ctx, ctl_read(ctx, &max_height, small, 4));
+    IPCFP_HIP(ctx, ctl_read(ctx, root_info.data(), root_info_d, root_info.size() * 8));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
 
     // ---- dense fast path: the tree's shape follows from the roots; one kernel per level ----
@@ -501,18 +501,16 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
         if (try_dense) {
             DevBuf<EnumNode> a, b;
             DevBuf<DenseRoot> dr_d;
-            DevBuf<uint32_t> anomaly;
+            struct { uint32_t* p; } anomaly{small + 2};  // still zero: nothing has written it
             uint64_t biggest = n_roots;
             for (auto v : n_level) biggest = v > biggest ? v : biggest;
             IPCFP_HIP(ctx, a.alloc(biggest));
             IPCFP_HIP(ctx, b.alloc(biggest));
             IPCFP_HIP(ctx, dr_d.alloc(n_roots));
-            IPCFP_HIP(ctx, anomaly.alloc(1));
             const bool want_keys = keys_out && vkind == VK_CID;
             if (want_keys) IPCFP_HIP(ctx, keys_out->alloc(n_leaves));
             else IPCFP_HIP(ctx, out.leaves.alloc(n_leaves));
-            IPCFP_HIP(ctx, hipMemsetAsync(anomaly.p, 0, 4, ctx->stream));
-            IPCFP_HIP(ctx, hipMemcpyAsync(dr_d.p, dr.data(), size_t(n_roots) * sizeof(DenseRoot), hipMemcpyHostToDevice, ctx->stream));
+            IPCFP_HIP(ctx, h2d_small(ctx, dr_d.p, dr.data(), size_t(n_roots) * sizeof(DenseRoot), ctx->stream));
             const EnumNode* src = cur.p;
             for (uint32_t level = max_height; level >= 1; --level) {
                 const uint32_t nn = uint32_t(n_level[level - 1]);
@@ -526,8 +524,8 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                                want_keys ? keys_out->p : nullptr);
             uint32_t bad = 0;
             unsigned long long e = kNoEnumError;  // err_d is untouched here: report what earlier stages left in it
-            IPCFP_HIP(ctx, d2h_small(ctx, &bad, anomaly.p, 4, ctx->stream));
-            IPCFP_HIP(ctx, d2h_small(ctx, &e, err_d, 8, ctx->stream));
+            IPCFP_HIP(ctx, ctl_read(ctx, &bad, anomaly.p, 4));
+            IPCFP_HIP(ctx, ctl_read(ctx, &e, err_d, 8));
             IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
             IPCFP_HIP(ctx, hipGetLastError());
             if (!bad) {
@@ -697,19 +695,19 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     view.n = uint32_t(w->n);
     view.touched = nullptr;
     DevBuf<AmtRootSpec> roots;
-    DevBuf<unsigned long long> err;
-    DevBuf<uint32_t> flag;
+    DevBuf<unsigned long long> err_own;
+    DevBuf<uint32_t> flag_own;
+    unsigned long long* err_p = nullptr;  // kNoEnumError
+    uint32_t* flag_p = nullptr;
     IPCFP_HIP(ctx, roots.alloc(1));
-    IPCFP_HIP(ctx, err.alloc(1));
-    IPCFP_HIP(ctx, flag.alloc(1));
+    IPCFP_HIP(ctx, ctl_words(ctx, err_own, err_p, 1, true));
+    IPCFP_HIP(ctx, ctl_words(ctx, flag_own, flag_p, 1, false));
+    struct { unsigned long long* p; } err{err_p};
+    struct { uint32_t* p; } flag{flag_p};
     AmtRootSpec spec{};
     spec.root = root;
     spec.version = uint32_t(version);
-    unsigned long long e0 = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemcpyAsync(roots.p, &spec, sizeof spec, hipMemcpyHostToDevice, ctx->stream));
-    IPCFP_HIP(ctx, hipMemsetAsync(err.p, 0xff, 8, ctx->stream));  // kNoEnumError
-    (void)e0;
-    IPCFP_HIP(ctx, hipMemsetAsync(flag.p, 0, 4, ctx->stream));
+    IPCFP_HIP(ctx, h2d_small(ctx, roots.p, &spec, sizeof spec, ctx->stream));
     AmtEnumResult en;
     int rc = amt_enumerate(ctx, view, roots.p, 1, vkind, err.p, en, lo, hi);
     if (rc) return rc;
@@ -719,7 +717,7 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     if (en.n_leaves && !en.dense) {
         const uint32_t n = uint32_t(en.n_leaves);
         hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, lo, flag.p);
-        IPCFP_HIP(ctx, d2h_small(ctx, &not_dense, flag.p, 4, ctx->stream));
+        IPCFP_HIP(ctx, ctl_read(ctx, &not_dense, flag.p, 4));
         IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     }
     e->dense = !not_dense;

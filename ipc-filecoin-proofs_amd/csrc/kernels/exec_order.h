@@ -29,7 +29,7 @@ struct TipsetCtxDev {
     // execution order (filled by the host after the enumeration)
     uint32_t exec_status;      // TRUE or the first ERR_* of reconstruct_execution_order
     uint32_t exec_mask;        // hash-table size - 1
-    const uint32_t* exec_slots;   // open addressing over message CIDs → FIRST position in the raw sequence
+    const unsigned long long* exec_slots;  // open addressing over message CIDs: {fingerprint, FIRST raw position}
     const CidKey* exec_keys;      // raw for_each sequence (with duplicates)
     const uint32_t* exec_pos;     // raw position → execution index (valid where the position is a first occurrence)
     uint64_t exec_len;            // number of distinct messages

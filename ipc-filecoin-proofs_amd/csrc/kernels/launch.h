@@ -65,7 +65,7 @@ int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
                       unsigned long long* err_d, int verify_txmeta = 1);
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,
-                      uint32_t* slots_d, uint32_t mask, uint32_t* first_d);
+                      unsigned long long* slots_d, uint32_t mask, uint32_t* first_d);
 int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const uint32_t* first_d,
                         const uint32_t* pos_d, CidKey* out_d);
 int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,

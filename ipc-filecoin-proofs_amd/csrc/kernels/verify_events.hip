@@ -263,45 +263,69 @@ __global__ __launch_bounds__(256) void k_exec_keys(WitnessView w, const LeafRef*
     keys[t] = k;
 }
 
-// stage 3: `seen.insert(c)` — the table keeps, per distinct CID, the SMALLEST raw position
+// stage 3: `seen.insert(c)` — the table keeps, per distinct CID, the SMALLEST raw position.
+// A slot is one u64: fingerprint (low half of the key's 64-bit hash) in the high word, raw position in the low
+// word.  A probe compares fingerprints first and reads the 40-byte key behind a slot only when they agree — at load
+// 0.5 half of all inserts pass an occupied slot, and each of those used to be a random 40-byte read.
+constexpr unsigned long long kEmptySlot64 = ~0ULL;
+
 __global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ keys, uint32_t n,
-                                                     uint32_t* __restrict__ slots, uint32_t mask) {
+                                                     unsigned long long* __restrict__ slots, uint32_t mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const CidKey key = keys[i];
-    uint32_t s = cid_hash(key) & mask;
+    const uint64_t h = cid_hash64(key);
+    const unsigned long long mine = ((unsigned long long)uint32_t(h) << 32) | i;
+    uint32_t s = uint32_t(h >> 32) & mask;
     for (;;) {
-        uint32_t cur = slots[s];
-        if (cur == kNoBlock) {
-            cur = atomicCAS(&slots[s], kNoBlock, i);
-            if (cur == kNoBlock) return;
+        unsigned long long cur = slots[s];
+        if (cur == kEmptySlot64) {
+            cur = atomicCAS(&slots[s], kEmptySlot64, mine);
+            if (cur == kEmptySlot64) return;
         }
-        if (cid_equal(keys[cur], key)) {
-            atomicMin(&slots[s], i);
+        if (uint32_t(cur >> 32) == uint32_t(h) && cid_equal(keys[uint32_t(cur)], key)) {
+            atomicMin(&slots[s], mine);  // same fingerprint: the minimum is the smaller position
             return;
         }
         s = (s + 1) & mask;
     }
 }
 
-__device__ __forceinline__ uint32_t exec_find(const uint32_t* slots, uint32_t mask, const CidKey* keys,
+__device__ __forceinline__ uint32_t exec_find(const unsigned long long* slots, uint32_t mask, const CidKey* keys,
                                               const CidKey& key) {
-    uint32_t s = cid_hash(key) & mask;
+    const uint64_t h = cid_hash64(key);
+    uint32_t s = uint32_t(h >> 32) & mask;
     for (;;) {
-        const uint32_t cur = slots[s];
-        if (cur == kNoBlock) return kNoBlock;
-        if (cid_equal(keys[cur], key)) return cur;
+        const unsigned long long cur = slots[s];
+        if (cur == kEmptySlot64) return kNoBlock;
+        if (uint32_t(cur >> 32) == uint32_t(h) && cid_equal(keys[uint32_t(cur)], key)) return uint32_t(cur);
         s = (s + 1) & mask;
     }
 }
 
 // stage 4: first[i] = 1 iff position i is the first occurrence of its CID (`if seen.insert(*c) { out.push(*c) }`)
 __global__ __launch_bounds__(256) void k_exec_first(const CidKey* __restrict__ keys, uint32_t n,
-                                                    const uint32_t* __restrict__ slots, uint32_t mask,
+                                                    const unsigned long long* __restrict__ slots, uint32_t mask,
                                                     uint32_t* __restrict__ first) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    first[i] = exec_find(slots, mask, keys, keys[i]) == i ? 1u : 0u;
+    const CidKey key = keys[i];
+    const uint64_t h = cid_hash64(key);
+    uint32_t s = uint32_t(h >> 32) & mask;
+    uint32_t f = 0;
+    for (;;) {
+        const unsigned long long cur = slots[s];
+        if (cur == kEmptySlot64) break;  // cannot happen after stage 3; kept as a stop
+        if (uint32_t(cur >> 32) == uint32_t(h)) {
+            if (uint32_t(cur) == i) {  // the slot is this position's own: no key to read
+                f = 1;
+                break;
+            }
+            if (cid_equal(keys[uint32_t(cur)], key)) break;  // an earlier position holds the same CID
+        }
+        s = (s + 1) & mask;
+    }
+    first[i] = f;
 }
 
 // the distinct CIDs in execution order (ipcfp_exec_order)
@@ -510,7 +534,7 @@ int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* 
 }
 
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,
-                      uint32_t* slots_d, uint32_t mask, uint32_t* first_d) {
+                      unsigned long long* slots_d, uint32_t mask, uint32_t* first_d) {
     if (n == 0) return IPCFP_OK;
     const dim3 g(div_up(n, 256)), b(256);
     if (leaves_d) hipLaunchKernelGGL(k_exec_keys, g, b, 0, ctx->stream, w, leaves_d, n, keys_d);  // else: keys came with the enumeration

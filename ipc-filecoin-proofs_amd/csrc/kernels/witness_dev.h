@@ -35,6 +35,13 @@ __device__ __forceinline__ uint32_t cid_hash(const CidKey& k) {
     return uint32_t(x >> 32);
 }
 
+// the full 64-bit mix: high half selects the slot (cid_hash), low half is an independent fingerprint
+__device__ __forceinline__ uint64_t cid_hash64(const CidKey& k) {
+    uint64_t x = k.w[0] ^ ((k.w[1] << 13) | (k.w[1] >> 51)) ^ ((k.w[2] << 27) | (k.w[2] >> 37)) ^
+                 ((k.w[3] << 41) | (k.w[3] >> 23)) ^ k.w[4];
+    return x * 0x9E3779B97F4A7C15ULL;
+}
+
 __device__ __forceinline__ CidKey load_cid_slot(const uint8_t* cids, uint32_t i) {
     const uint64_t* p = reinterpret_cast<const uint64_t*>(cids + 40ull * i);
     CidKey k;
