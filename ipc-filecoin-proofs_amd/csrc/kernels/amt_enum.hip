@@ -250,11 +250,13 @@ __host__ __device__ inline uint64_t dense_nodes(const DenseRoot& r, uint32_t lev
     return ((r.hi - 1) >> shift) - (r.lo >> shift) + 1;
 }
 
-// frontier entering `level` (≥ 1) → frontier entering level-1; one lane per child (child j of n_next)
-__device__ __forceinline__ void dense_child(const WitnessView& w, const EnumNode* __restrict__ cur,
-                                            const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t level,
-                                            uint32_t j, int vkind, EnumNode* __restrict__ next,
-                                            uint32_t* __restrict__ anomaly) {
+// frontier entering `level` (≥ 1) → frontier entering level-1; one lane per child
+__global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNode* __restrict__ cur,
+                                                     const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t level,
+                                                     uint32_t n_next, int vkind, EnumNode* __restrict__ next,
+                                                     uint32_t* __restrict__ anomaly) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_next) return;
     // which root, and where its entries start on both levels
     uint32_t r = 0, cur_off = 0, next_off = 0;
     DenseRoot dr = roots[0];
@@ -344,115 +346,6 @@ __device__ __forceinline__ void dense_child(const WitnessView& w, const EnumNode
     if (b == kNoBlock) atomicOr(anomaly, 1u);
     c.block = b;
     next[j] = c;
-}
-
-__global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNode* __restrict__ cur,
-                                                     const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t level,
-                                                     uint32_t n_next, int vkind, EnumNode* __restrict__ next,
-                                                     uint32_t* __restrict__ anomaly) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_next) return;
-    dense_child(w, cur, roots, n_roots, level, j, vkind, next, anomaly);
-}
-
-// The top of the trees in ONE launch.  The upper levels of an AMT are a handful of nodes each (1, 8, 64, … for bit
-// width 3) and a launch per level costs far more than its work; here one workgroup loads every root (Amt::load, one
-// lane per root), derives the dense shape on the device, and walks the levels down while they are small — a
-// __syncthreads() between levels instead of a kernel boundary.  The frontier it stops at and the shape table stay in
-// HBM for the per-level kernels that take over; the host reads the roots' shapes back to size those launches.
-constexpr uint32_t kTopThreads = 1024;
-constexpr uint32_t kTopMaxNodes = 4096;   // a level with more nodes than this gets a launch of its own
-constexpr uint32_t kTopMaxRoots = 32;
-
-struct TopState {         // written by k_enum_top, read by the host
-    uint32_t max_height;
-    uint32_t stop_level;  // the frontier in `out` ENTERS this level (== max_height: no level was walked)
-    uint32_t dense_ok;    // 0: some root rules the dense path out (dead root, empty tall tree, lying count, empty range)
-    uint32_t n_out;       // entries of that frontier
-};
-
-__global__ __launch_bounds__(kTopThreads) void k_enum_top(WitnessView w, const AmtRootSpec* __restrict__ specs, uint32_t n_roots,
-                                                          int vkind, uint64_t lo, uint64_t hi, EnumNode* __restrict__ roots_frontier,
-                                                          EnumNode* __restrict__ buf_a, EnumNode* __restrict__ buf_b,
-                                                          DenseRoot* __restrict__ dr_out, uint64_t* __restrict__ root_info,
-                                                          TopState* __restrict__ state, uint32_t* __restrict__ anomaly,
-                                                          unsigned long long* __restrict__ err) {
-    __shared__ DenseRoot dr[kTopMaxRoots];
-    __shared__ uint32_t s_max_height, s_dense_ok;
-    const uint32_t t = threadIdx.x;
-    if (t == 0) {
-        s_max_height = 0;
-        s_dense_ok = 1;
-    }
-    __syncthreads();
-    // ---- the roots: Amt::load, one lane per root (k_enum_roots) ----
-    if (t < n_roots) {
-        const AmtRootSpec spec = specs[t];
-        EnumNode e{kNoBlock, 0, 0, spec.seq, 0, 0, 0};
-        root_info[2 * t] = ~0ULL;  // dead
-        root_info[2 * t + 1] = 0;
-        DenseRoot d{0, 0, 0, 0, 0};
-        bool ok = false;
-        if (!spec.skip) {
-            AmtRootInfo info;
-            const uint32_t st = amt_load(w, spec.root, int(spec.version), vkind, info);
-            if (st != IPCFP_ST_TRUE) {
-                enum_error(err, spec.seq, 0, st);
-            } else {
-                e.block = info.block;
-                e.node_off = info.node_off;
-                e.height = uint16_t(info.height);
-                e.bit_width = uint8_t(info.bit_width);
-                atomicMax(&s_max_height, uint32_t(info.height));
-                root_info[2 * t] = uint64_t(uint32_t(info.height)) | (uint64_t(info.bit_width) << 32);
-                root_info[2 * t + 1] = info.count;
-                d.height = uint32_t(info.height);
-                d.bit_width = info.bit_width;
-                d.count = info.count;
-                d.lo = lo < d.count ? lo : d.count;
-                d.hi = hi < d.count ? hi : d.count;
-                ok = !(d.count == 0 && d.height > 0) && d.count <= amt_span(d.bit_width, uint64_t(d.height) + 1) &&
-                     !(d.count && d.lo >= d.hi);
-                if (d.count == 0) d.lo = d.hi = 0;
-            }
-        }
-        if (!ok) s_dense_ok = 0;
-        dr[t] = d;
-        dr_out[t] = d;
-        roots_frontier[t] = e;
-        buf_a[t] = e;
-    }
-    __syncthreads();
-    const uint32_t max_height = s_max_height;
-    uint32_t level = max_height, n_cur = n_roots;
-    const EnumNode* cur = buf_a;
-    EnumNode* nxt = buf_b;
-    if (s_dense_ok && n_roots <= kTopMaxRoots) {
-        while (level >= 1) {
-            uint64_t n_next = 0;
-            for (uint32_t r = 0; r < n_roots; ++r) n_next += dense_nodes(dr[r], level - 1);
-            uint64_t n_here = 0;
-            for (uint32_t r = 0; r < n_roots; ++r) n_here += dense_nodes(dr[r], level);
-            if (n_next > kTopMaxNodes || n_here != n_cur) break;  // (n_here != n_cur cannot happen: the top level is one node per root)
-            for (uint32_t j = t; j < uint32_t(n_next); j += kTopThreads) dense_child(w, cur, dr, n_roots, level, j, vkind, nxt, anomaly);
-            __threadfence_block();
-            __syncthreads();
-            const EnumNode* sw = cur;
-            cur = nxt;
-            nxt = const_cast<EnumNode*>(sw);
-            n_cur = uint32_t(n_next);
-            --level;
-        }
-    }
-    if (t == 0) {
-        state->max_height = max_height;
-        state->stop_level = level;
-        state->dense_ok = s_dense_ok;
-        state->n_out = n_cur;
-    }
-    // the frontier the walk stopped at goes to buf_a (the host continues from there)
-    if (cur != buf_a)
-        for (uint32_t j = t; j < n_cur; j += kTopThreads) buf_a[j] = cur[j];
 }
 
 // leaf level: one lane per leaf node validates it in one pass and writes its values' locations
@@ -572,31 +465,13 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     uint64_t* root_info_d = nullptr;
     IPCFP_HIP(ctx, ctl_words(ctx, small_own, small, 4, false));
     IPCFP_HIP(ctx, ctl_words(ctx, root_info_own, root_info_d, 2 * size_t(n_roots), false));
-    // the roots — and, in the same launch, the small upper levels of the dense shape (k_enum_top)
-    const bool use_top = n_roots <= kTopMaxRoots;
-    DevBuf<EnumNode> top_a, top_b;
-    DevBuf<DenseRoot> dr_top;
-    DevBuf<TopState> state_own;
-    TopState* state_d = nullptr;
-    TopState top{0, 0, 0, 0};
-    if (use_top) {
-        IPCFP_HIP(ctx, top_a.alloc(kTopMaxNodes));
-        IPCFP_HIP(ctx, top_b.alloc(kTopMaxNodes));
-        IPCFP_HIP(ctx, dr_top.alloc(n_roots));
-        IPCFP_HIP(ctx, ctl_words(ctx, state_own, state_d, 1, false));
-        hipLaunchKernelGGL(k_enum_top, dim3(1), dim3(kTopThreads), 0, ctx->stream, view, roots_d, n_roots, vkind, lo, hi, cur.p,
-                           top_a.p, top_b.p, dr_top.p, root_info_d, state_d, small + 2, err_d);
-        IPCFP_HIP(ctx, ctl_read(ctx, &top, state_d, sizeof top));
-    } else {
-        hipLaunchKernelGGL(k_enum_roots, dim3(div_up(n_roots, 64)), dim3(64), 0, ctx->stream, view, roots_d, n_roots, vkind,
-                           cur.p, small, err_d, root_info_d);
-    }
+    hipLaunchKernelGGL(k_enum_roots, dim3(div_up(n_roots, 64)), dim3(64), 0, ctx->stream, view, roots_d, n_roots, vkind,
+                       cur.p, small, err_d, root_info_d);
     uint32_t max_height = 0;
     std::vector<uint64_t> root_info(2 * size_t(n_roots));
-    if (!use_top) IPCFP_HIP(ctx, ctl_read(ctx, &max_height, small, 4));
+    IPCFP_HIP(ctx, ctl_read(ctx, &max_height, small, 4));
     IPCFP_HIP(ctx, ctl_read(ctx, root_info.data(), root_info_d, root_info.size() * 8));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    if (use_top) max_height = top.max_height;
 
     // ---- dense fast path: the tree's shape follows from the roots; one kernel per level ----
     out.dense = false;
@@ -635,21 +510,16 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             const bool want_keys = keys_out && vkind == VK_CID;
             if (want_keys) IPCFP_HIP(ctx, keys_out->alloc(n_leaves));
             else IPCFP_HIP(ctx, out.leaves.alloc(n_leaves));
-            // the top kernel left the shape table on the device and walked the levels down to top.stop_level
-            const bool from_top = use_top && top.dense_ok && top.stop_level <= max_height &&
-                                  top.n_out == n_level[top.stop_level];
-            const DenseRoot* dr_p = dr_d.p;
-            if (from_top) dr_p = dr_top.p;
-            else IPCFP_HIP(ctx, h2d_small(ctx, dr_d.p, dr.data(), size_t(n_roots) * sizeof(DenseRoot), ctx->stream));
-            const EnumNode* src = from_top ? top_a.p : cur.p;
-            for (uint32_t level = from_top ? top.stop_level : max_height; level >= 1; --level) {
+            IPCFP_HIP(ctx, h2d_small(ctx, dr_d.p, dr.data(), size_t(n_roots) * sizeof(DenseRoot), ctx->stream));
+            const EnumNode* src = cur.p;
+            for (uint32_t level = max_height; level >= 1; --level) {
                 const uint32_t nn = uint32_t(n_level[level - 1]);
-                hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, dr_p, n_roots,
+                hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p, n_roots,
                                    level, nn, vkind, a.p, anomaly.p);
                 src = a.p;
                 a.swap(b);  // `src` now lives in b; the next level writes a
             }
-            hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_level[0], 256)), dim3(256), 0, ctx->stream, view, src, dr_p,
+            hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_level[0], 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p,
                                n_roots, uint32_t(n_level[0]), vkind, want_keys ? nullptr : out.leaves.p, anomaly.p,
                                want_keys ? keys_out->p : nullptr);
             uint32_t bad = 0;
