@@ -204,7 +204,7 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
         }
     }
     if (const char* e = std::getenv("IPCFP_SPIN_SYNC")) ctx->spin_sync = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = std::atoi(e) == 1 ? 1 : 0;
+    if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = (std::atoi(e) >= 0 && std::atoi(e) <= 3) ? std::atoi(e) : 0;
     if (const char* e = std::getenv("IPCFP_B2B_WG")) {
         const int wg = std::atoi(e);
         if (wg == 64 || wg == 128 || wg == 192 || wg == 256) ctx->b2b_wg = uint32_t(wg);

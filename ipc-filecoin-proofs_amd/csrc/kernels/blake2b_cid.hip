@@ -64,6 +64,33 @@ __device__ __forceinline__ void hash_block(const uint8_t* __restrict__ arena, ui
     b2b::compress<MODE>(h, m, t, true);
 }
 
+// The LDS-message variant of hash_block: the chunk being compressed lives in LDS ([word][lane]), the next one is
+// prefetched into registers while it is compressed.
+template <int WG>
+__device__ __forceinline__ void hash_block_lds(const uint8_t* __restrict__ arena, uint64_t o, uint32_t L, uint64_t h[8],
+                                               uint64_t (*sm)[WG]) {
+    b2b::init256(h);
+    const uint8_t* p = arena + o;
+    const uint32_t nfull = chunk_count(L) - 1;  // non-final chunks
+    uint64_t* lm = &sm[0][threadIdx.x];
+    uint64_t m[16];
+    b2b::load_chunk(m, p);
+    uint64_t t = 0;
+    for (uint32_t c = 0; c < nfull; ++c) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lm[k * WG] = m[k];
+        b2b::load_chunk(m, p + 128ull * (c + 1));  // in flight while the staged chunk is compressed
+        t += 128;
+        b2b::compress_lds(h, lm, WG, t, false);
+    }
+    const uint32_t rem = L - nfull * 128u;
+    b2b::mask_tail(m, rem);
+    t += rem;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lm[k * WG] = m[k];
+    b2b::compress_lds(h, lm, WG, t, true);
+}
+
 // K1's per-lane metadata, stored in SCHEDULE order so a wavefront reads it coalesced.
 struct K1Meta {
     uint64_t off;   // arena offset of the block
@@ -92,6 +119,36 @@ __global__ __launch_bounds__(256, IPCFP_K1_WAVES) void k_blake2b256_cid(const ui
     if (is_b2b) {
         uint64_t h[8];
         hash_block<MODE>(arena, mt.off, mt.len, h);
+        const uint64_t e0 = (w0 >> 48) | (w1 << 16);
+        const uint64_t e1 = (w1 >> 48) | (w2 << 16);
+        const uint64_t e2 = (w2 >> 48) | (w3 << 16);
+        const uint64_t e3 = (w3 >> 48) | (w4 << 16);
+        const bool ok = ((h[0] ^ e0) | (h[1] ^ e1) | (h[2] ^ e2) | (h[3] ^ e3)) == 0;
+        st = ok ? IPCFP_CID_OK : IPCFP_CID_MISMATCH;
+        if (ok) atomicOr(&ok_bits[i >> 5], 1u << (i & 31));
+        else atomicAdd(&counters[0], 1ull);
+    }
+    status[i] = st;
+}
+
+// K1 with the message words staged in LDS (IPCFP_B2B_MODE=3): same outputs, 64 threads per workgroup.
+__global__ __launch_bounds__(64, 5) void k_blake2b256_cid_lds(const uint8_t* __restrict__ arena, const K1Meta* __restrict__ meta,
+                                                              const uint8_t* __restrict__ sched_cids40, uint32_t n,
+                                                              uint32_t* __restrict__ ok_bits, uint8_t* __restrict__ status,
+                                                              unsigned long long* __restrict__ counters) {
+    __shared__ uint64_t sm[16][64];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const K1Meta mt = meta[t];
+    const uint32_t i = mt.id;
+    const uint64_t* cw = reinterpret_cast<const uint64_t*>(sched_cids40 + 40ull * t);
+    const uint64_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3], w4 = cw[4];
+    const bool is_b2b = ((w0 & 0x0000FFFFFFFF00FFULL) == 0x00002002e4a00001ULL) && ((w0 & 0x8000ULL) == 0) &&
+                        ((w4 >> 48) == 0);
+    uint8_t st = IPCFP_CID_UNCHECKED;
+    if (is_b2b) {
+        uint64_t h[8];
+        hash_block_lds<64>(arena, mt.off, mt.len, h, sm);
         const uint64_t e0 = (w0 >> 48) | (w1 << 16);
         const uint64_t e1 = (w1 >> 48) | (w2 << 16);
         const uint64_t e2 = (w2 >> 48) | (w3 << 16);
@@ -257,6 +314,12 @@ int launch_blake2b256_cid(ipcfp_ctx* ctx, const uint8_t* arena, const void* meta
         const K1Meta* m = static_cast<const K1Meta*>(meta);
         if (ctx->b2b_mode == 1)
             hipLaunchKernelGGL(k_blake2b256_cid<1>, dim3(div_up(n, wg)), dim3(wg), 0, s, arena, m, sched_cids40, n, ok_bits,
+                               status, counters);
+        else if (ctx->b2b_mode == 2)
+            hipLaunchKernelGGL(k_blake2b256_cid<2>, dim3(div_up(n, wg)), dim3(wg), 0, s, arena, m, sched_cids40, n, ok_bits,
+                               status, counters);
+        else if (ctx->b2b_mode == 3)
+            hipLaunchKernelGGL(k_blake2b256_cid_lds, dim3(div_up(n, 64)), dim3(64), 0, s, arena, m, sched_cids40, n, ok_bits,
                                status, counters);
         else
             hipLaunchKernelGGL(k_blake2b256_cid<0>, dim3(div_up(n, wg)), dim3(wg), 0, s, arena, m, sched_cids40, n, ok_bits,

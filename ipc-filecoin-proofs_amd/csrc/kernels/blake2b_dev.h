@@ -44,7 +44,7 @@ __device__ __forceinline__ uint64_t rotr(uint64_t x) {
 // MODE 1: explicit v_add_co_u32 / v_addc_co_u32 pair (A/B-measured on MI355X).
 template <int MODE>
 __device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b) {
-    if constexpr (MODE == 0) {
+    if constexpr (MODE != 1) {
         return a + b;
     } else {
         uint32_t lo, hi;
@@ -76,6 +76,14 @@ __device__ __forceinline__ void init256(uint64_t h[8]) {
     h[7] = IPCFP_B2B_IV7;
 }
 
+// rotr 63 = rotl 1.  MODE 2: as (x << 1) + (x >> 63) — one 32-bit shift and one v_lshl_add_u64 instead of two
+// v_alignbit_b32 (A/B-measured on MI355X: profiles/r02_k1_variants.log).
+template <int MODE>
+__device__ __forceinline__ uint64_t rotr63(uint64_t x) {
+    if constexpr (MODE == 2) return (x << 1) + (x >> 63);
+    else return rotr<63>(x);
+}
+
 #define IPCFP_B2B_G(a, b, c, d, x, y)          \
     a = add64<MODE>(add64<MODE>(a, b), (x));   \
     d = rotr<32>(d ^ a);                       \
@@ -84,7 +92,7 @@ __device__ __forceinline__ void init256(uint64_t h[8]) {
     a = add64<MODE>(add64<MODE>(a, b), (y));   \
     d = rotr<16>(d ^ a);                       \
     c = add64<MODE>(c, d);                     \
-    b = rotr<63>(b ^ c);
+    b = rotr63<MODE>(b ^ c);
 
 #define IPCFP_B2B_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
     IPCFP_B2B_G(v0, v4, v8, v12, m[s0], m[s1])                                                \
@@ -116,6 +124,49 @@ __device__ __forceinline__ void compress(uint64_t h[8], const uint64_t m[16], ui
     IPCFP_B2B_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
     IPCFP_B2B_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
     IPCFP_B2B_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    h[0] ^= v0 ^ v8;
+    h[1] ^= v1 ^ v9;
+    h[2] ^= v2 ^ v10;
+    h[3] ^= v3 ^ v11;
+    h[4] ^= v4 ^ v12;
+    h[5] ^= v5 ^ v13;
+    h[6] ^= v6 ^ v14;
+    h[7] ^= v7 ^ v15;
+}
+
+// The same compression with the 16 message words staged in LDS ([word][lane], conflict-free): 32 VGPRs fewer per
+// lane, i.e. one or two more wavefronts per SIMD (north-star's "message schedule staged in LDS"; A/B-measured —
+// profiles/r02_k1_variants.log).  `lm` points at this lane's word 0; word w is lm[w * stride].
+__device__ __forceinline__ void compress_lds(uint64_t h[8], const uint64_t* lm, uint32_t stride, uint64_t t, bool last) {
+    constexpr int MODE = 0;
+    uint64_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+    uint64_t v8 = IPCFP_B2B_IV0, v9 = IPCFP_B2B_IV1, v10 = IPCFP_B2B_IV2, v11 = IPCFP_B2B_IV3;
+    uint64_t v12 = IPCFP_B2B_IV4 ^ t, v13 = IPCFP_B2B_IV5;
+    uint64_t v14 = last ? ~IPCFP_B2B_IV6 : IPCFP_B2B_IV6, v15 = IPCFP_B2B_IV7;
+#define m(i) lm[(i) * stride]
+#define IPCFP_B2B_ROUND_L(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    IPCFP_B2B_G(v0, v4, v8, v12, m(s0), m(s1))                                                  \
+    IPCFP_B2B_G(v1, v5, v9, v13, m(s2), m(s3))                                                  \
+    IPCFP_B2B_G(v2, v6, v10, v14, m(s4), m(s5))                                                 \
+    IPCFP_B2B_G(v3, v7, v11, v15, m(s6), m(s7))                                                 \
+    IPCFP_B2B_G(v0, v5, v10, v15, m(s8), m(s9))                                                 \
+    IPCFP_B2B_G(v1, v6, v11, v12, m(s10), m(s11))                                               \
+    IPCFP_B2B_G(v2, v7, v8, v13, m(s12), m(s13))                                                \
+    IPCFP_B2B_G(v3, v4, v9, v14, m(s14), m(s15))
+    IPCFP_B2B_ROUND_L(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    IPCFP_B2B_ROUND_L(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    IPCFP_B2B_ROUND_L(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    IPCFP_B2B_ROUND_L(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    IPCFP_B2B_ROUND_L(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    IPCFP_B2B_ROUND_L(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    IPCFP_B2B_ROUND_L(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    IPCFP_B2B_ROUND_L(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    IPCFP_B2B_ROUND_L(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    IPCFP_B2B_ROUND_L(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    IPCFP_B2B_ROUND_L(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    IPCFP_B2B_ROUND_L(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+#undef IPCFP_B2B_ROUND_L
+#undef m
     h[0] ^= v0 ^ v8;
     h[1] ^= v1 ^ v9;
     h[2] ^= v2 ^ v10;

@@ -42,9 +42,10 @@ def run(mode, wg, n, reps=10, block=1024, extra_env=None):
 
 
 if __name__ == "__main__":
-    for n in (100_000, 1_000_000):
-        for mode in (0, 1):
-            for wg in (64, 256):
-                run(mode, wg, n)
-    run(0, 64, 4_000_000, reps=5)
-    run(0, 64, 1_000_000, block=256)
+    # modes: 0 = hipcc's u64 adds + v_alignbit rotates (default), 1 = explicit carry adds, 2 = rot63 as shift + add,
+    #        3 = message words staged in LDS (5 waves/SIMD)
+    for n in (100_000, 1_000_000, 4_000_000):
+        for mode in (0, 2, 3, 1):
+            run(mode, 64, n, reps=5 if n > 1_000_000 else 10)
+    for mode in (0, 2, 3):
+        run(mode, 64, 1_000_000, block=341)
