@@ -1,20 +1,51 @@
-//! bindings/rust/ffi.rs — the Rust side of the drop-in boundary (NOT compiled in this repository:
-//! the build image has no Rust toolchain; this is the file a maintainer of
-//! consensus-shipyard/ipc-filecoin-proofs adds as `src/gpu/ffi.rs`, with `libipcfp.so` on the link
-//! path: `println!("cargo:rustc-link-lib=dylib=ipcfp")` in build.rs).
+//! bindings/rust/ffi.rs — the Rust side of the drop-in boundary.
 //!
-//! Declarations mirror `include/ipcfp.h` one to one; the safe wrappers keep the reference's names and
-//! signatures (`verify_event_proof`, `verify_storage_proof`), so `src/proofs/verifier.rs` only swaps
-//! which function it calls.
+//! NOT compiled in this repository (the build image has no Rust toolchain): this is the module a maintainer of
+//! consensus-shipyard/ipc-filecoin-proofs adds as `src/gpu/mod.rs` (with `ffi_sys.rs` beside it as
+//! `src/gpu/ffi_sys.rs`) and `println!("cargo:rustc-link-lib=dylib=ipcfp")` in build.rs.
+//!
+//! * `ffi_sys.rs` — GENERATED from `include/ipcfp.h` (tools/gen_rust_ffi.py): the raw declaration of every symbol.
+//! * this file — the `#[repr(C)]` mirrors of the header's structs and the safe wrappers, which keep the reference's
+//!   names, argument meaning and error behaviour:
+//!     `load_witness_store`            src/proofs/events/verifier.rs:79-89
+//!     `verify_event_proof`            src/proofs/events/verifier.rs:51-74 (built-in filter) — `verify_event_proof_with`
+//!                                     for an arbitrary `check_event` closure (:247-251)
+//!     `verify_storage_proof`          src/proofs/storage/verifier.rs:24-63
+//!     `verify_proof_bundle[_json]`    src/proofs/verifier.rs:12-62
+//!     `generate_proof_bundle`         src/proofs/generator.rs:25-95
+//!     `impl Blockstore for Witness`   src/proofs/common/blockstore.rs:26-39 (get / put_keyed / has)
+//!   A string with an interior NUL cannot cross a C ABI; the reference would fail to parse it (CID fields) or find it
+//!   unequal (compared fields), so the wrappers replace NUL by 0x01 — a byte that is in no multibase / hex alphabet
+//!   either — instead of panicking (`c_string`).
 #![allow(non_camel_case_types)]
-use std::ffi::{c_char, c_int, c_void, CString};
+use std::cell::RefCell;
+use std::ffi::{c_char, c_int, CStr, CString};
 
 use anyhow::{anyhow, Result};
+use cid::Cid;
+use fvm_ipld_blockstore::Blockstore;
 
+pub mod ffi_sys;
+pub use ffi_sys::*;
+
+use crate::proofs::common::bundle::{ProofBlock, UnifiedProofBundle};
+use crate::proofs::events::bundle::{EventData, EventProof, EventProofBundle};
+use crate::proofs::generator::{EventProofSpec, StorageProofSpec};
+use crate::proofs::storage::bundle::StorageProof;
+use crate::proofs::trust::TrustPolicy;
+
+// ---- opaque handles -----------------------------------------------------------------------------------------------
 #[repr(C)] pub struct ipcfp_ctx_t { _p: [u8; 0] }
 #[repr(C)] pub struct ipcfp_witness_t { _p: [u8; 0] }
 #[repr(C)] pub struct ipcfp_bundle_t { _p: [u8; 0] }
 #[repr(C)] pub struct ipcfp_packed_events_t { _p: [u8; 0] }
+#[repr(C)] pub struct ipcfp_comm_t { _p: [u8; 0] }
+
+// ---- PODs of include/ipcfp.h --------------------------------------------------------------------------------------
+pub const IPCFP_CID_SLOT: usize = 40;
+pub const IPCFP_MAX_PARENTS: usize = 16;
+pub const IPCFP_ST_TRUE: u8 = 1;
+pub const IPCFP_ST_FALSE_FILTER: u8 = 17;
 
 #[repr(C)]
 pub struct ipcfp_event_proof_t {
@@ -44,138 +75,304 @@ pub struct ipcfp_storage_proof_t {
     pub value: *const c_char,
 }
 
-#[repr(C)] pub struct ipcfp_event_filter_t { pub topic0: [u8; 32], pub topic1: [u8; 32] }
-#[repr(C)] pub struct ipcfp_value_loc_t { pub block: u32, pub off: u32, pub len: u32 }
-#[repr(C)] pub struct ipcfp_event_match_t { pub exec_index: u64, pub event_index: u64, pub emitter: u64,
-                                            pub event: ipcfp_value_loc_t, pub reserved: u32 }
-#[repr(C)] pub struct ipcfp_generated_storage_t { pub parent_state_root: [u8; 40], pub actor_state_cid: [u8; 40],
-                                                  pub storage_root: [u8; 40], pub value: [u8; 32], pub status: u32,
-                                                  pub reserved: u32 }
-#[repr(C)] pub struct ipcfp_trust_policy_t { pub kind: c_int, pub ec_chain_empty: c_int, pub min_epoch: i64, pub max_epoch: i64 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct ipcfp_event_filter_t { pub topic0: [u8; 32], pub topic1: [u8; 32] }
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct ipcfp_value_loc_t { pub block: u32, pub off: u32, pub len: u32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct ipcfp_event_match_t { pub exec_index: u64, pub event_index: u64, pub emitter: u64,
+                                                                   pub event: ipcfp_value_loc_t, pub reserved: u32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct ipcfp_generated_storage_t { pub parent_state_root: [u8; 40], pub actor_state_cid: [u8; 40],
+                                                                         pub storage_root: [u8; 40], pub value: [u8; 32],
+                                                                         pub status: u32, pub reserved: u32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct ipcfp_trust_policy_t { pub kind: c_int, pub ec_chain_empty: c_int, pub min_epoch: i64, pub max_epoch: i64 }
+#[repr(C)] pub struct ipcfp_tipset_ref_t { pub flags: u32, pub n_parents: u32, pub child: [u8; 40], pub parents: [[u8; 40]; IPCFP_MAX_PARENTS] }
+#[repr(C)] pub struct ipcfp_event_claim_t { pub parent_epoch: i64, pub child_epoch: i64, pub exec_index: u64, pub event_index: u64,
+                                            pub emitter: u64, pub message_cid: [u8; 40], pub tipset: u32, pub flags: u32,
+                                            pub n_topics: u32, pub topics_off: u32, pub data_off: u32, pub data_len: u32 }
+#[repr(C)] pub struct ipcfp_storage_claim_t { pub child_epoch: i64, pub actor_id: u64, pub child: [u8; 40], pub state_root: [u8; 40],
+                                              pub actor_state: [u8; 40], pub storage_root: [u8; 40], pub slot: [u8; 32],
+                                              pub value: [u8; 32], pub flags: u32, pub reserved: u32 }
+#[repr(C)] pub struct ipcfp_storage_proof_spec_t { pub actor_id: u64, pub slot: [u8; 32] }
+#[repr(C)] pub struct ipcfp_event_proof_spec_t { pub event_signature: *const c_char, pub topic_1: *const c_char,
+                                                 pub actor_id_filter: u64, pub has_actor_id_filter: u8 }
 
-extern "C" {
-    pub fn ipcfp_ctx_create(device: c_int, out: *mut *mut ipcfp_ctx_t) -> c_int;
-    pub fn ipcfp_ctx_destroy(ctx: *mut ipcfp_ctx_t);
-    pub fn ipcfp_last_error(ctx: *const ipcfp_ctx_t) -> *const c_char;
-    pub fn ipcfp_witness_create(ctx: *mut ipcfp_ctx_t, bytes: *const u8, nbytes: u64, off: *const u64, len: *const u32,
-                                cids40: *const u8, n: u64, out: *mut *mut ipcfp_witness_t) -> c_int;
-    pub fn ipcfp_witness_destroy(w: *mut ipcfp_witness_t);
-    pub fn ipcfp_witness_verify_cids(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, status: *mut u8, n_bad: *mut u64) -> c_int;
-    pub fn ipcfp_create_event_filter(ctx: *mut ipcfp_ctx_t, sig: *const c_char, subnet: *const c_char,
-                                     out: *mut ipcfp_event_filter_t) -> c_int;
-    pub fn ipcfp_verify_event_proofs(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, proofs: *const ipcfp_event_proof_t,
-                                     n: u64, trust: *const ipcfp_trust_policy_t, filter: *const ipcfp_event_filter_t,
-                                     status: *mut u8) -> c_int;
-    pub fn ipcfp_verify_storage_proofs(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, proofs: *const ipcfp_storage_proof_t,
-                                       n: u64, trust: *const ipcfp_trust_policy_t, status: *mut u8) -> c_int;
-    pub fn ipcfp_generate_event_proofs(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, parent_cids40: *const u8, n_parents: u32,
-                                       child_cid40: *const u8, filter: *const ipcfp_event_filter_t, has_actor: c_int, actor: u64,
-                                       status_out: *mut u8, matches: *mut ipcfp_event_match_t, message_cids40: *mut u8,
-                                       cap_proofs: u64, n_proofs: *mut u64, witness_block_ids: *mut u32, witness_cids40: *mut u8,
-                                       cap_blocks: u64, n_blocks: *mut u64) -> c_int;
-    pub fn ipcfp_generate_storage_proofs(ctx: *mut ipcfp_ctx_t, w: *mut ipcfp_witness_t, child_cid40: *const u8,
-                                         actor_ids: *const u64, slots32: *const u8, n: u64, out: *mut ipcfp_generated_storage_t,
-                                         witness_block_ids: *mut u32, witness_cids40: *mut u8, cap_blocks: u64,
-                                         n_blocks: *mut u64) -> c_int;
-    pub fn ipcfp_bundle_parse_json(ctx: *mut ipcfp_ctx_t, json: *const c_char, len: u64, flags: u32,
-                                   out: *mut *mut ipcfp_bundle_t) -> c_int;
-    pub fn ipcfp_bundle_destroy(b: *mut ipcfp_bundle_t);
-    pub fn ipcfp_bundle_event_count(b: *const ipcfp_bundle_t) -> u64;
-    pub fn ipcfp_bundle_storage_count(b: *const ipcfp_bundle_t) -> u64;
-    pub fn ipcfp_verify_proof_bundle(ctx: *mut ipcfp_ctx_t, b: *mut ipcfp_bundle_t, trust: *const ipcfp_trust_policy_t,
-                                     filter: *const ipcfp_event_filter_t, storage_status: *mut u8,
-                                     event_status: *mut u8) -> c_int;
-    // host-only, parallel lowering of the reference's structs to the packed claim form (no device involved)
-    pub fn ipcfp_pack_event_proofs(proofs: *const ipcfp_event_proof_t, n: u64, out: *mut *mut ipcfp_packed_events_t) -> c_int;
-    pub fn ipcfp_packed_events_destroy(p: *mut ipcfp_packed_events_t);
-    pub fn ipcfp_pack_storage_proofs(proofs: *const ipcfp_storage_proof_t, n: u64, claims: *mut u8 /* n × ipcfp_storage_claim_t */) -> c_int;
-    // … the remaining primitives (ipcfp_amt_get, ipcfp_hamt_get, ipcfp_scan_events, ipcfp_exec_order,
-    //   ipcfp_*_batch, ipcfp_verify_event_claims_device, profiling) bind the same way.
+// ---- helpers --------------------------------------------------------------------------------------------------------
+/// A Rust string as a C string.  An interior NUL (legal in a JSON claim: "\u0000") becomes 0x01: like NUL it is in no
+/// multibase / hex alphabet and equals no character of a canonical form, so every parse and compare keeps its outcome.
+fn c_string(s: &str) -> CString {
+    let bytes: Vec<u8> = s.bytes().map(|b| if b == 0 { 1 } else { b }).collect();
+    CString::new(bytes).expect("no interior NUL left")
 }
 
-/// `status >= 64` is `Err`; the reference aborts the whole bundle at the first one
+fn cid_slot(c: &Cid) -> Result<[u8; 40]> {
+    let b = c.to_bytes();
+    if b.len() > IPCFP_CID_SLOT { return Err(anyhow!("CID longer than {IPCFP_CID_SLOT} bytes: {c}")); }
+    let mut slot = [0u8; 40];
+    slot[..b.len()].copy_from_slice(&b);
+    Ok(slot)
+}
+
+fn cid_from_slot(slot: &[u8; 40]) -> Result<Cid> {
+    // a binary CID is self-delimiting: Cid::read_bytes stops after the multihash
+    Ok(Cid::read_bytes(&slot[..])?)
+}
+
+/// `status >= 64` is `Err`; the reference aborts at the first one in proof order
 /// (src/proofs/events/verifier.rs:62-71, src/proofs/verifier.rs:19-28).
 fn statuses_to_result(st: &[u8]) -> Result<Vec<bool>> {
     if let Some((i, s)) = st.iter().enumerate().find(|(_, s)| **s >= 64) {
         return Err(anyhow!("proof {i}: verification error (ipcfp status {s})"));
     }
-    Ok(st.iter().map(|s| *s == 1).collect())
+    Ok(st.iter().map(|s| *s == IPCFP_ST_TRUE).collect())
 }
 
+/// `TrustPolicy` (src/proofs/trust/mod.rs:8-16,53-78) as the POD the engine evaluates: both variants are pure
+/// functions of the epoch (AcceptAll; F3Certificate = the EC chain's epoch range, src/cert.rs:52-64).
+pub fn trust_pod(p: &TrustPolicy) -> ipcfp_trust_policy_t {
+    match p {
+        TrustPolicy::AcceptAll => ipcfp_trust_policy_t { kind: 0, ec_chain_empty: 0, min_epoch: 0, max_epoch: 0 },
+        TrustPolicy::F3Certificate(cert) => match (cert.ec_chain.first(), cert.ec_chain.last()) {
+            (Some(a), Some(b)) => ipcfp_trust_policy_t { kind: 1, ec_chain_empty: 0, min_epoch: a.epoch, max_epoch: b.epoch },
+            _ => ipcfp_trust_policy_t { kind: 1, ec_chain_empty: 1, min_epoch: 0, max_epoch: 0 },
+        },
+    }
+}
+
+// ---- engine / witness -------------------------------------------------------------------------------------------------
 pub struct Engine { ctx: *mut ipcfp_ctx_t }
-pub struct Witness<'e> { eng: &'e Engine, w: *mut ipcfp_witness_t }
+/// The HBM-resident witness store.  `&self` methods with interior state, like the trait it implements
+/// (`fvm_ipld_blockstore::Blockstore` takes `&self`); not `Sync` — one thread at a time, as the C ABI requires.
+pub struct Witness<'e> { eng: &'e Engine, w: RefCell<*mut ipcfp_witness_t> }
 
 impl Engine {
     pub fn new(device: i32) -> Result<Self> {
         let mut ctx = std::ptr::null_mut();
         match unsafe { ipcfp_ctx_create(device, &mut ctx) } { 0 => Ok(Self { ctx }), rc => Err(anyhow!("ipcfp_ctx_create: {rc}")) }
     }
-    /// replaces `load_witness_store(blocks)` (src/proofs/events/verifier.rs:79-89)
-    pub fn load_witness_store(&self, blocks: &[crate::proofs::common::bundle::ProofBlock]) -> Result<Witness<'_>> {
+    fn err(&self, what: &str, rc: c_int) -> anyhow::Error {
+        let msg = unsafe { CStr::from_ptr(ipcfp_last_error(self.ctx)) }.to_string_lossy().into_owned();
+        anyhow!("{what}: {rc} {msg}")
+    }
+
+    /// replaces `load_witness_store(blocks)` (src/proofs/events/verifier.rs:79-89, src/proofs/storage/verifier.rs:68-78)
+    pub fn load_witness_store(&self, blocks: &[ProofBlock]) -> Result<Witness<'_>> {
         let (mut bytes, mut off, mut len, mut cids) = (Vec::new(), Vec::new(), Vec::new(), Vec::new());
         for b in blocks {
-            off.push(bytes.len() as u64); len.push(b.data.len() as u32); bytes.extend_from_slice(&b.data);
-            let mut slot = [0u8; 40]; let c = b.cid.to_bytes();
-            if c.len() > 40 { return Err(anyhow!("CID longer than 40 bytes")); }
-            slot[..c.len()].copy_from_slice(&c); cids.extend_from_slice(&slot);
+            off.push(bytes.len() as u64);
+            len.push(u32::try_from(b.data.len())?);
+            bytes.extend_from_slice(&b.data);
+            cids.extend_from_slice(&cid_slot(&b.cid)?);
         }
         let mut w = std::ptr::null_mut();
         let rc = unsafe { ipcfp_witness_create(self.ctx, bytes.as_ptr(), bytes.len() as u64, off.as_ptr(), len.as_ptr(),
                                                cids.as_ptr(), blocks.len() as u64, &mut w) };
-        if rc != 0 { return Err(anyhow!("ipcfp_witness_create: {rc}")); }
-        Ok(Witness { eng: self, w })
+        if rc != 0 { return Err(self.err("ipcfp_witness_create", rc)); }
+        Ok(Witness { eng: self, w: RefCell::new(w) })
     }
-}
-impl Engine {
-    /// `serde_json::from_str::<UnifiedProofBundle>(text)` + `verify_proof_bundle(&bundle, policy, filter)`
-    /// (src/proofs/verifier.rs:12-62) without materialising the blocks on the host: the base64 of every
-    /// `ProofBlock.data` is decoded on the device straight into the witness arena.
-    pub fn verify_proof_bundle_json(&self, text: &str, trust: &ipcfp_trust_policy_t,
+
+    /// `create_event_filter(event_sig, subnet_id)` (src/proofs/events/verifier.rs:28-39) as the POD the device applies
+    pub fn create_event_filter(&self, event_sig: &str, subnet_id: &str) -> Result<ipcfp_event_filter_t> {
+        let (s, t) = (c_string(event_sig), c_string(subnet_id));
+        let mut f = ipcfp_event_filter_t { topic0: [0; 32], topic1: [0; 32] };
+        match unsafe { ipcfp_create_event_filter(self.ctx, s.as_ptr(), t.as_ptr(), &mut f) } { 0 => Ok(f), rc => Err(self.err("ipcfp_create_event_filter", rc)) }
+    }
+
+    /// drop-in for `verify_proof_bundle(&bundle, policy, filter)` (src/proofs/verifier.rs:12-62): one witness per
+    /// bundle (the reference rebuilds it per storage proof), storage proofs first, the first `Err` aborts.
+    pub fn verify_proof_bundle(&self, bundle: &UnifiedProofBundle, policy: &TrustPolicy,
+                               filter: Option<&ipcfp_event_filter_t>) -> Result<(Vec<bool>, Vec<bool>)> {
+        let witness = self.load_witness_store(&bundle.blocks)?;
+        let trust = trust_pod(policy);
+        let storage = witness.verify_storage_proof(&bundle.storage_proofs, &trust)?;
+        let events = witness.verify_event_proof(&EventProofBundle { proofs: bundle.event_proofs.clone(), blocks: vec![] },
+                                                &trust, filter)?;
+        Ok((storage, events))
+    }
+
+    /// `serde_json::from_str::<UnifiedProofBundle>(text)` + `verify_proof_bundle` without materialising the blocks on
+    /// the host: the base64 of every `ProofBlock.data` is decoded on the device straight into the witness arena.
+    pub fn verify_proof_bundle_json(&self, text: &str, policy: &TrustPolicy,
                                     filter: Option<&ipcfp_event_filter_t>) -> Result<(Vec<bool>, Vec<bool>)> {
+        let trust = trust_pod(policy);
         let mut b = std::ptr::null_mut();
         let rc = unsafe { ipcfp_bundle_parse_json(self.ctx, text.as_ptr() as *const c_char, text.len() as u64, 0, &mut b) };
-        if rc != 0 { return Err(anyhow!("bundle JSON: {rc}")); }
+        if rc != 0 { return Err(self.err("bundle JSON", rc)); }
         let (ns, ne) = unsafe { (ipcfp_bundle_storage_count(b) as usize, ipcfp_bundle_event_count(b) as usize) };
         let (mut ss, mut es) = (vec![0u8; ns.max(1)], vec![0u8; ne.max(1)]);
-        let rc = unsafe { ipcfp_verify_proof_bundle(self.ctx, b, trust, filter.map_or(std::ptr::null(), |f| f as *const _),
+        let rc = unsafe { ipcfp_verify_proof_bundle(self.ctx, b, &trust, filter.map_or(std::ptr::null(), |f| f as *const _),
                                                     ss.as_mut_ptr(), es.as_mut_ptr()) };
         unsafe { ipcfp_bundle_destroy(b) };
-        if rc != 0 { return Err(anyhow!("ipcfp_verify_proof_bundle: {rc}")); }
-        // storage proofs are checked first and the first Err aborts (verifier.rs:19-28)
+        if rc != 0 { return Err(self.err("ipcfp_verify_proof_bundle", rc)); }
         Ok((statuses_to_result(&ss[..ns])?, statuses_to_result(&es[..ne])?))
     }
 }
 impl Drop for Engine { fn drop(&mut self) { unsafe { ipcfp_ctx_destroy(self.ctx) } } }
-impl Drop for Witness<'_> { fn drop(&mut self) { unsafe { ipcfp_witness_destroy(self.w) } } }
+impl Drop for Witness<'_> { fn drop(&mut self) { unsafe { ipcfp_witness_destroy(*self.w.borrow()) } } }
 
 impl Witness<'_> {
-    /// drop-in for `verify_event_proof` (src/proofs/events/verifier.rs:51-56).  The trust closures are
-    /// pure in (epoch, cid) for `TrustPolicy::{AcceptAll, F3Certificate}` and travel as a POD; an
-    /// arbitrary `check_event` closure still runs on the host over the statuses that come back TRUE.
-    pub fn verify_event_proof(&self, bundle: &crate::proofs::events::bundle::EventProofBundle,
-                              trust: &ipcfp_trust_policy_t, filter: Option<&ipcfp_event_filter_t>) -> Result<Vec<bool>> {
-        let keep: Vec<_> = bundle.proofs.iter().map(CProof::new).collect();   // owns the CStrings
+    fn raw(&self) -> *mut ipcfp_witness_t { *self.w.borrow() }
+
+    /// K1: Blake2b-256 of every block against its CID — the check `MemoryBlockstore` never makes
+    pub fn verify_cids(&self) -> Result<u64> {
+        let mut bad = 0u64;
+        match unsafe { ipcfp_witness_verify_cids(self.eng.ctx, self.raw(), std::ptr::null_mut(), &mut bad) } { 0 => Ok(bad), rc => Err(self.eng.err("ipcfp_witness_verify_cids", rc)) }
+    }
+
+    /// drop-in for `verify_event_proof` with the built-in `create_event_filter` closure (or none)
+    /// (src/proofs/events/verifier.rs:51-74).
+    pub fn verify_event_proof(&self, bundle: &EventProofBundle, trust: &ipcfp_trust_policy_t,
+                              filter: Option<&ipcfp_event_filter_t>) -> Result<Vec<bool>> {
+        let keep: Vec<_> = bundle.proofs.iter().map(CEventProof::new).collect();  // owns the C strings
         let raw: Vec<ipcfp_event_proof_t> = keep.iter().map(|k| k.raw()).collect();
         let mut st = vec![0u8; raw.len()];
-        let rc = unsafe { ipcfp_verify_event_proofs(self.eng.ctx, self.w, raw.as_ptr(), raw.len() as u64, trust,
+        let rc = unsafe { ipcfp_verify_event_proofs(self.eng.ctx, self.raw(), raw.as_ptr(), raw.len() as u64, trust,
                                                     filter.map_or(std::ptr::null(), |f| f as *const _), st.as_mut_ptr()) };
-        if rc != 0 { return Err(anyhow!("ipcfp_verify_event_proofs: {rc}")); }
+        if rc != 0 { return Err(self.eng.err("ipcfp_verify_event_proofs", rc)); }
         statuses_to_result(&st)
+    }
+
+    /// `verify_event_proof(.., Some(&check_event))` for an ARBITRARY closure (src/proofs/events/verifier.rs:51-56,
+    /// applied at :247-251): the device verifies everything up to and including `verify_event_data_matches`, reports
+    /// where each proof's `StampedEvent` lies, and the closure runs here over the decoded events of the proofs that
+    /// are still true — `Ok(false)` where it declines, exactly where the reference calls it.
+    pub fn verify_event_proof_with(&self, bundle: &EventProofBundle, trust: &ipcfp_trust_policy_t,
+                                   check_event: &dyn Fn(&fvm_shared::event::ActorEvent) -> bool) -> Result<Vec<bool>> {
+        let keep: Vec<_> = bundle.proofs.iter().map(CEventProof::new).collect();
+        let raw: Vec<ipcfp_event_proof_t> = keep.iter().map(|k| k.raw()).collect();
+        let n = raw.len();
+        let (mut st, mut loc) = (vec![0u8; n], vec![ipcfp_value_loc_t::default(); n]);
+        let rc = unsafe { ipcfp_verify_event_proofs_located(self.eng.ctx, self.raw(), raw.as_ptr(), n as u64, trust, std::ptr::null(),
+                                                            st.as_mut_ptr(), loc.as_mut_ptr()) };
+        if rc != 0 { return Err(self.eng.err("ipcfp_verify_event_proofs_located", rc)); }
+        let stride = loc.iter().map(|l| l.len as usize).max().unwrap_or(0).max(1);
+        let mut bytes = vec![0u8; n * stride];
+        let rc = unsafe { ipcfp_witness_read_values(self.eng.ctx, self.raw(), loc.as_ptr(), n as u64, bytes.as_mut_ptr(), stride as u64) };
+        if rc != 0 { return Err(self.eng.err("ipcfp_witness_read_values", rc)); }
+        for i in 0..n {
+            if st[i] != IPCFP_ST_TRUE { continue; }
+            let raw_event = &bytes[i * stride..i * stride + loc[i].len as usize];
+            let stamped: fvm_shared::event::StampedEvent = fvm_ipld_encoding::from_slice(raw_event)?;  // already validated on the device
+            if !check_event(&stamped.event) { st[i] = IPCFP_ST_FALSE_FILTER; }
+        }
+        statuses_to_result(&st)
+    }
+
+    /// drop-in for `verify_storage_proof` over all storage proofs of a bundle (src/proofs/storage/verifier.rs:24-63;
+    /// the loop of src/proofs/verifier.rs:19-28 — the witness is NOT rebuilt per proof).
+    pub fn verify_storage_proof(&self, proofs: &[StorageProof], trust: &ipcfp_trust_policy_t) -> Result<Vec<bool>> {
+        let keep: Vec<_> = proofs.iter().map(CStorageProof::new).collect();
+        let raw: Vec<ipcfp_storage_proof_t> = keep.iter().map(|k| k.raw()).collect();
+        let mut st = vec![0u8; raw.len()];
+        let rc = unsafe { ipcfp_verify_storage_proofs(self.eng.ctx, self.raw(), raw.as_ptr(), raw.len() as u64, trust, st.as_mut_ptr()) };
+        if rc != 0 { return Err(self.eng.err("ipcfp_verify_storage_proofs", rc)); }
+        statuses_to_result(&st)
+    }
+
+    /// `generate_proof_bundle` (src/proofs/generator.rs:25-95) with this witness in the role of the RPC block store:
+    /// every block the generators may load must be resident.  Returns the bundle with `blocks` in
+    /// `BTreeSet<(Cid, Vec<u8>)>` order.
+    pub fn generate_proof_bundle(&self, parent_cids: &[Cid], parent_epoch: i64, child_cid: &Cid, child_epoch: i64,
+                                 storage_specs: &[StorageProofSpec], event_specs: &[EventProofSpec]) -> Result<UnifiedProofBundle> {
+        let mut pc = Vec::new();
+        for c in parent_cids { pc.extend_from_slice(&cid_slot(c)?); }
+        let child = cid_slot(child_cid)?;
+        let ss: Vec<ipcfp_storage_proof_spec_t> = storage_specs.iter().map(|s| ipcfp_storage_proof_spec_t { actor_id: s.actor_id, slot: s.slot.0 }).collect();
+        let keep: Vec<(CString, CString)> = event_specs.iter().map(|e| (c_string(&e.event_signature), c_string(&e.topic_1))).collect();
+        let es: Vec<ipcfp_event_proof_spec_t> = event_specs.iter().zip(&keep).map(|(e, k)| ipcfp_event_proof_spec_t {
+            event_signature: k.0.as_ptr(), topic_1: k.1.as_ptr(), actor_id_filter: e.actor_id_filter.unwrap_or(0),
+            has_actor_id_filter: e.actor_id_filter.is_some() as u8 }).collect();
+        let n_blocks_max = unsafe { ipcfp_witness_block_count(self.raw()) } as usize;
+        let cap_p = 1usize << 16;
+        let mut sout = vec![unsafe { std::mem::zeroed::<ipcfp_generated_storage_t>() }; ss.len().max(1)];
+        let mut est = vec![0u8; es.len().max(1)];
+        let mut matches = vec![unsafe { std::mem::zeroed::<ipcfp_event_match_t>() }; cap_p];
+        let (mut msg, mut spec_of) = (vec![0u8; cap_p * 40], vec![0u32; cap_p]);
+        let (mut ids, mut wcids) = (vec![0u32; n_blocks_max.max(1)], vec![0u8; n_blocks_max.max(1) * 40]);
+        let (mut n_p, mut n_b, mut first_err) = (0u64, 0u64, 0u64);
+        let rc = unsafe { ipcfp_generate_proof_bundle(self.eng.ctx, self.raw(), pc.as_ptr(), parent_cids.len() as u32, child.as_ptr(),
+                                                      ss.as_ptr(), ss.len() as u64, es.as_ptr(), es.len() as u64, sout.as_mut_ptr(),
+                                                      est.as_mut_ptr(), matches.as_mut_ptr(), msg.as_mut_ptr(), spec_of.as_mut_ptr(),
+                                                      cap_p as u64, &mut n_p, ids.as_mut_ptr(), wcids.as_mut_ptr(), ids.len() as u64,
+                                                      &mut n_b, &mut first_err) };
+        if rc != 0 { return Err(self.eng.err("ipcfp_generate_proof_bundle", rc)); }
+        if first_err != u64::MAX { return Err(anyhow!("proof spec {first_err} failed (the reference's `?` aborts the bundle there)")); }
+        if n_p as usize > cap_p { return Err(anyhow!("{n_p} event proofs exceed the wrapper's buffer")); }
+        // claim strings exactly as the generators format them (storage/generator.rs:158-178, events/generator.rs:274-293)
+        let hex0x = |b: &[u8]| format!("0x{}", hex::encode(b));
+        let mut storage_proofs = Vec::new();
+        for (s, o) in storage_specs.iter().zip(&sout) {
+            storage_proofs.push(StorageProof {
+                child_epoch, child_block_cid: child_cid.to_string(), parent_state_root: cid_from_slot(&o.parent_state_root)?.to_string(),
+                actor_id: s.actor_id, actor_state_cid: cid_from_slot(&o.actor_state_cid)?.to_string(),
+                storage_root: cid_from_slot(&o.storage_root)?.to_string(), slot: hex0x(&s.slot.0), value: hex0x(&o.value) });
+        }
+        let locs: Vec<ipcfp_value_loc_t> = matches[..n_p as usize].iter().map(|m| m.event).collect();
+        let stride = locs.iter().map(|l| l.len as usize).max().unwrap_or(0).max(1);
+        let mut ev_bytes = vec![0u8; locs.len().max(1) * stride];
+        if !locs.is_empty() {
+            let rc = unsafe { ipcfp_witness_read_values(self.eng.ctx, self.raw(), locs.as_ptr(), locs.len() as u64, ev_bytes.as_mut_ptr(), stride as u64) };
+            if rc != 0 { return Err(self.eng.err("ipcfp_witness_read_values", rc)); }
+        }
+        let mut event_proofs = Vec::new();
+        for (k, m) in matches[..n_p as usize].iter().enumerate() {
+            let stamped: fvm_shared::event::StampedEvent = fvm_ipld_encoding::from_slice(&ev_bytes[k * stride..k * stride + m.event.len as usize])?;
+            let log = crate::proofs::common::evm::extract_evm_log(&stamped.event).ok_or_else(|| anyhow!("matched event is not an EVM log"))?;
+            let mut slot = [0u8; 40];
+            slot.copy_from_slice(&msg[k * 40..k * 40 + 40]);
+            event_proofs.push(EventProof {
+                parent_epoch, child_epoch, parent_tipset_cids: parent_cids.iter().map(|c| c.to_string()).collect(),
+                child_block_cid: child_cid.to_string(), message_cid: cid_from_slot(&slot)?.to_string(),
+                exec_index: m.exec_index, event_index: m.event_index,
+                event_data: EventData { emitter: m.emitter, topics: log.topics.iter().map(|t| hex0x(t)).collect(), data: hex0x(&log.data) } });
+        }
+        let mut blocks = Vec::new();
+        for k in 0..n_b as usize {
+            let mut slot = [0u8; 40];
+            slot.copy_from_slice(&wcids[k * 40..k * 40 + 40]);
+            let cid = cid_from_slot(&slot)?;
+            let data = self.get(&cid)?.ok_or_else(|| anyhow!("materialize: block {cid} vanished"))?;
+            blocks.push(ProofBlock { cid, data });
+        }
+        Ok(UnifiedProofBundle { storage_proofs, event_proofs, blocks })
     }
 }
 
-/// Owns the NUL-terminated copies of one EventProof's strings.
-struct CProof { parents: Vec<CString>, parent_ptrs: Vec<*const c_char>, child: CString, msg: CString,
-                topics: Vec<CString>, topic_ptrs: Vec<*const c_char>, data: CString,
-                epochs: (i64, i64), idx: (u64, u64), emitter: u64 }
-impl CProof {
-    fn new(p: &crate::proofs::events::bundle::EventProof) -> Self {
-        let parents: Vec<CString> = p.parent_tipset_cids.iter().map(|s| CString::new(s.as_str()).unwrap()).collect();
-        let topics: Vec<CString> = p.event_data.topics.iter().map(|s| CString::new(s.as_str()).unwrap()).collect();
+/// The witness as the trait every fvm_ipld_amt / fvm_ipld_hamt call goes through
+/// (src/proofs/common/blockstore.rs:26-39): unmodified AMT / HAMT callers can sit on the HBM-resident store.
+impl Blockstore for Witness<'_> {
+    fn get(&self, k: &Cid) -> Result<Option<Vec<u8>>> {
+        let slot = cid_slot(k)?;
+        let (mut len, mut found) = (0u64, 0 as c_int);
+        let rc = unsafe { ipcfp_witness_get(self.eng.ctx, self.raw(), slot.as_ptr(), std::ptr::null_mut(), 0, &mut len, &mut found) };
+        if rc != 0 { return Err(self.eng.err("ipcfp_witness_get", rc)); }
+        if found == 0 { return Ok(None); }
+        let mut out = vec![0u8; len as usize];
+        let rc = unsafe { ipcfp_witness_get(self.eng.ctx, self.raw(), slot.as_ptr(), out.as_mut_ptr(), len, &mut len, &mut found) };
+        if rc != 0 { return Err(self.eng.err("ipcfp_witness_get", rc)); }
+        Ok(Some(out))
+    }
+    fn put_keyed(&self, k: &Cid, v: &[u8]) -> Result<()> {
+        let slot = cid_slot(k)?;
+        let (off, len) = ([0u64], [u32::try_from(v.len())?]);
+        match unsafe { ipcfp_witness_put_keyed(self.eng.ctx, self.raw(), slot.as_ptr(), v.as_ptr(), off.as_ptr(), len.as_ptr(), 1) } { 0 => Ok(()), rc => Err(self.eng.err("ipcfp_witness_put_keyed", rc)) }
+    }
+    fn has(&self, k: &Cid) -> Result<bool> {
+        let slot = cid_slot(k)?;
+        let mut has = 0u8;
+        match unsafe { ipcfp_witness_has(self.eng.ctx, self.raw(), slot.as_ptr(), 1, &mut has, std::ptr::null_mut()) } { 0 => Ok(has != 0), rc => Err(self.eng.err("ipcfp_witness_has", rc)) }
+    }
+}
+
+// ---- owned C views of the claim structs -----------------------------------------------------------------------------
+/// Owns the NUL-terminated copies of one EventProof's strings (src/proofs/events/bundle.rs:5-23).
+struct CEventProof { parents: Vec<CString>, parent_ptrs: Vec<*const c_char>, child: CString, msg: CString,
+                     topics: Vec<CString>, topic_ptrs: Vec<*const c_char>, data: CString,
+                     epochs: (i64, i64), idx: (u64, u64), emitter: u64 }
+impl CEventProof {
+    fn new(p: &EventProof) -> Self {
+        let parents: Vec<CString> = p.parent_tipset_cids.iter().map(|s| c_string(s)).collect();
+        let topics: Vec<CString> = p.event_data.topics.iter().map(|s| c_string(s)).collect();
         Self { parent_ptrs: parents.iter().map(|c| c.as_ptr()).collect(), parents,
-               child: CString::new(p.child_block_cid.as_str()).unwrap(), msg: CString::new(p.message_cid.as_str()).unwrap(),
-               topic_ptrs: topics.iter().map(|c| c.as_ptr()).collect(), topics,
-               data: CString::new(p.event_data.data.as_str()).unwrap(),
+               child: c_string(&p.child_block_cid), msg: c_string(&p.message_cid),
+               topic_ptrs: topics.iter().map(|c| c.as_ptr()).collect(), topics, data: c_string(&p.event_data.data),
                epochs: (p.parent_epoch, p.child_epoch), idx: (p.exec_index, p.event_index), emitter: p.event_data.emitter }
     }
     fn raw(&self) -> ipcfp_event_proof_t {
@@ -184,5 +381,20 @@ impl CProof {
             child_block_cid: self.child.as_ptr(), message_cid: self.msg.as_ptr(), exec_index: self.idx.0,
             event_index: self.idx.1, emitter: self.emitter, topics: self.topic_ptrs.as_ptr(),
             n_topics: self.topic_ptrs.len() as u32, data: self.data.as_ptr() }
+    }
+}
+
+/// Owns the C strings of one StorageProof (src/proofs/storage/bundle.rs:5-14).
+struct CStorageProof { s: [CString; 6], child_epoch: i64, actor_id: u64 }
+impl CStorageProof {
+    fn new(p: &StorageProof) -> Self {
+        Self { s: [c_string(&p.child_block_cid), c_string(&p.parent_state_root), c_string(&p.actor_state_cid),
+                   c_string(&p.storage_root), c_string(&p.slot), c_string(&p.value)],
+               child_epoch: p.child_epoch, actor_id: p.actor_id }
+    }
+    fn raw(&self) -> ipcfp_storage_proof_t {
+        ipcfp_storage_proof_t { child_epoch: self.child_epoch, child_block_cid: self.s[0].as_ptr(), parent_state_root: self.s[1].as_ptr(),
+            actor_id: self.actor_id, actor_state_cid: self.s[2].as_ptr(), storage_root: self.s[3].as_ptr(),
+            slot: self.s[4].as_ptr(), value: self.s[5].as_ptr() }
     }
 }

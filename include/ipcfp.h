@@ -195,6 +195,23 @@ int ipcfp_witness_cid_results(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
 void* ipcfp_witness_cid_bitmap_device(ipcfp_witness_t* w);
 void* ipcfp_witness_cid_status_device(ipcfp_witness_t* w);
 
+/* ---- the witness as a Blockstore -------------------------------------------------------------------------------
+ * `fvm_ipld_blockstore::Blockstore { get, put_keyed, has }` — the trait the reference's stores implement
+ * (src/proofs/common/blockstore.rs:26-39, src/client/blockstore.rs:20-37, src/client/cached_blockstore.rs:53-85) and
+ * every fvm_ipld_amt / fvm_ipld_hamt call goes through.  bindings/rust/ffi.rs implements the trait over these, so
+ * unmodified AMT/HAMT callers can sit on the HBM-resident store.
+ *   has        has[i] = 1 iff cids40[i] is in the witness (block_ids[i] = its id, 0xffffffff if absent; both nullable)
+ *   get        Ok(None): *found = 0.  Ok(Some(v)): *found = 1, *len = v.len(), the first min(*len, cap) bytes in out
+ *              (an owned copy, as the trait returns; call with cap = 0 to size the buffer)
+ *   put_keyed  n blocks at once; `MemoryBlockstore::put_keyed` semantics: the data is NOT hashed, an existing CID is
+ *              replaced.  The witness is re-laid out (block ids of existing blocks are kept, new ones are appended).  */
+int ipcfp_witness_has(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* cids40, uint64_t n, uint8_t* has,
+                      uint32_t* block_ids);
+int ipcfp_witness_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* cid40, uint8_t* out, uint64_t cap,
+                      uint64_t* len, int* found);
+int ipcfp_witness_put_keyed(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* cids40, const uint8_t* bytes,
+                            const uint64_t* off, const uint32_t* len, uint64_t n);
+
 /* ---- batch hashes (host buffers in, host digests out) --------------------
  * message i = bytes[off[i] .. off[i]+len[i]); out32 receives n × 32 bytes.
  *   blake2b256 : multihash-codetable Code::Blake2b256       (events/utils.rs:65)
@@ -227,6 +244,11 @@ enum {
     IPCFP_V_VEC_U8 = 4,        /* Hamt<_, Vec<u8>>      storage/decode.rs:79,86,92       */
     IPCFP_V_ANY = 5            /* any well-formed item                                    */
 };
+
+/* Bytes of located values (from the walk primitives, the scan's matches or ipcfp_verify_event_proofs_located): value i
+ * is copied to out[i * stride ..), truncated to stride; entries with block == 0xffffffff are skipped.            */
+int ipcfp_witness_read_values(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_value_loc_t* locs, uint64_t n,
+                              uint8_t* out, uint64_t stride);
 
 /* K5 — `Amt::load(root).get(index[i])` for a batch of indices (version 0 = Amtv0, 3 = Amt).
  * status[i] ∈ {IPCFP_ST_TRUE, IPCFP_ST_NOT_FOUND, IPCFP_ST_ERR_*}; loc nullable.
@@ -369,6 +391,33 @@ int ipcfp_generate_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ui
                                   ipcfp_generated_storage_t* out, uint32_t* witness_block_ids, uint8_t* witness_cids40,
                                   uint64_t cap_blocks, uint64_t* n_blocks);
 
+/* `generate_proof_bundle` (src/proofs/generator.rs:25-95) against the resident tipset: every StorageProofSpec, then
+ * every EventProofSpec (:12-22), one bundle.  The RPC block cache the reference shares between the specs is the
+ * witness itself; what remains is the union of the recorded blocks, which the reference keeps in a
+ * `BTreeSet<(Cid, Vec<u8>)>` (:34,52-54,75-77,85-88): ids in `Cid: Ord` order, each block once.
+ *   storage_out[i]           claim fields + status of storage spec i (ERR_*: generate_proof_bundle returns that Err)
+ *   event_status[j]          IPCFP_ST_TRUE or the ERR_* of event spec j
+ *   matches / message_cids40 / match_spec   the EventProofs of all specs in spec order (match_spec[k] = j)
+ *   *first_error             index of the first failing spec in the reference's order (storage specs first, then
+ *                            n_storage + j), or UINT64_MAX: the reference aborts there and returns nothing        */
+typedef struct ipcfp_storage_proof_spec {
+    uint64_t actor_id;
+    uint8_t slot[32];
+} ipcfp_storage_proof_spec_t;
+typedef struct ipcfp_event_proof_spec {
+    const char* event_signature; /* e.g. "NewTopDownMessage(bytes32,uint256)" */
+    const char* topic_1;         /* subnet id; ascii_to_bytes32 (src/proofs/common/evm.rs:72-78) */
+    uint64_t actor_id_filter;
+    uint8_t has_actor_id_filter;
+} ipcfp_event_proof_spec_t;
+int ipcfp_generate_proof_bundle(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                                const uint8_t* child_cid40, const ipcfp_storage_proof_spec_t* storage_specs,
+                                uint64_t n_storage, const ipcfp_event_proof_spec_t* event_specs, uint64_t n_events,
+                                ipcfp_generated_storage_t* storage_out, ipcfp_status_t* event_status,
+                                ipcfp_event_match_t* matches, uint8_t* message_cids40, uint32_t* match_spec,
+                                uint64_t cap_proofs, uint64_t* n_proofs, uint32_t* witness_block_ids,
+                                uint8_t* witness_cids40, uint64_t cap_blocks, uint64_t* n_blocks, uint64_t* first_error);
+
 /* `TrustPolicy` (src/proofs/trust/mod.rs:8-16,53-78): the predicate is evaluated on the
  * host, before the device call, because it is a pure function of (epoch, cid).  */
 typedef struct ipcfp_trust_policy {
@@ -386,6 +435,16 @@ typedef struct ipcfp_trust_policy {
 int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
                               const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
                               ipcfp_status_t* status);
+
+/* The same, also reporting WHERE each proof's StampedEvent lies (event_loc[i].block == 0xffffffff when proof i did
+ * not get that far).  This is the door for an ARBITRARY host closure `check_event: &dyn Fn(&ActorEvent) -> bool`
+ * (src/proofs/events/verifier.rs:51-56, applied at :247-251): call with filter = NULL, read the located events of the
+ * proofs whose status is TRUE (ipcfp_witness_read_values), run the closure on the host, and turn a `false` into
+ * IPCFP_ST_FALSE_FILTER — bindings/rust/ffi.rs::verify_event_proof_with does exactly that.                      */
+int ipcfp_verify_event_proofs_located(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs,
+                                      uint64_t n, const ipcfp_trust_policy_t* trust,
+                                      const ipcfp_event_filter_t* filter, ipcfp_status_t* status,
+                                      ipcfp_value_loc_t* event_loc);
 
 /* `verify_storage_proof` (src/proofs/storage/verifier.rs:24-63) over a batch. */
 int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_storage_proof_t* proofs,

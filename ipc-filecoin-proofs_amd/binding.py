@@ -13,6 +13,8 @@ import numpy as np
 
 __all__ = [
     "Engine",
+    "EventProofSpec",
+    "STORAGE_SPEC_DTYPE",
     "Comm",
     "shard_range",
     "comm_unique_id",
@@ -132,6 +134,16 @@ GEN_STORAGE_DTYPE = np.dtype([("parent_state_root", np.uint8, 40), ("actor_state
                               ("reserved", np.uint32)])
 
 
+STORAGE_SPEC_DTYPE = np.dtype([("actor_id", np.uint64), ("slot", np.uint8, 32)])
+
+
+class EventProofSpec(C.Structure):
+    """ipcfp_event_proof_spec_t == EventProofSpec (src/proofs/generator.rs:17-22)"""
+
+    _fields_ = [("event_signature", C.c_char_p), ("topic_1", C.c_char_p), ("actor_id_filter", C.c_uint64),
+                ("has_actor_id_filter", C.c_uint8)]
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -195,6 +207,13 @@ def load_library() -> C.CDLL:
         "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_verify_event_claims": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
+        "ipcfp_witness_has": (i32, [vp, vp, vp, u64, vp, vp]),
+        "ipcfp_witness_get": (i32, [vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(i32)]),
+        "ipcfp_witness_put_keyed": (i32, [vp, vp, vp, vp, vp, vp, u64]),
+        "ipcfp_witness_read_values": (i32, [vp, vp, vp, u64, vp, u64]),
+        "ipcfp_verify_event_proofs_located": (i32, [vp, vp, vp, u64, vp, vp, vp, vp]),
+        "ipcfp_generate_proof_bundle": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, vp, u64, vp, vp, vp, vp, vp, u64,
+                                              C.POINTER(u64), vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
         "ipcfp_shard_range": (None, [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]),
         "ipcfp_shard_plan_tipset": (i32, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(u64),
                                           C.POINTER(u64), C.POINTER(u64), vp, u64, C.POINTER(u64)]),
@@ -837,6 +856,87 @@ class Witness:
         lo, hi = C.c_uint64(), C.c_uint64()
         self.lib.ipcfp_witness_receipt_range(self.h, C.byref(lo), C.byref(hi))
         return int(lo.value), int(hi.value)
+
+    # -- Blockstore face (get / has / put_keyed) ---------------------------------------------------
+    def has(self, cids):
+        """cids: list[bytes] → (has u8[n], block ids u32[n] with 0xffffffff for absent)."""
+        pc = pack_cids(cids)
+        has = np.zeros(len(cids), dtype=np.uint8)
+        ids = np.zeros(len(cids), dtype=np.uint32)
+        self.eng._check(self.lib.ipcfp_witness_has(self.eng.h, self.h, _p(pc), len(cids), _p(has), _p(ids)), "witness_has")
+        return has, ids
+
+    def get(self, cid: bytes):
+        """Blockstore::get → bytes, or None."""
+        c = np.frombuffer(bytes(cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        ln, found = C.c_uint64(), C.c_int()
+        self.eng._check(self.lib.ipcfp_witness_get(self.eng.h, self.h, _p(c), None, 0, C.byref(ln), C.byref(found)), "witness_get")
+        if not found.value:
+            return None
+        out = np.zeros(max(int(ln.value), 1), dtype=np.uint8)
+        self.eng._check(self.lib.ipcfp_witness_get(self.eng.h, self.h, _p(c), _p(out), len(out), C.byref(ln), C.byref(found)), "witness_get")
+        return out[: int(ln.value)].tobytes()
+
+    def put_keyed(self, cids, blocks):
+        """MemoryBlockstore::put_keyed for a batch: no hashing, an existing CID is replaced."""
+        data, off, lens = _table(blocks)
+        pc = pack_cids(cids)
+        self.eng._check(self.lib.ipcfp_witness_put_keyed(self.eng.h, self.h, _p(pc), _p(data), _p(off), _p(lens), len(cids)),
+                        "witness_put_keyed")
+        self.n = self.block_count
+
+    def read_values(self, locs: np.ndarray, stride: int = 1024):
+        """Bytes of located values (LOC_DTYPE / the block, off, len fields of MATCH_DTYPE) → list[bytes | None]."""
+        l = np.zeros(len(locs), dtype=LOC_DTYPE)
+        for f in ("block", "off", "len"):
+            l[f] = locs[f]
+        out = np.zeros((max(len(l), 1), stride), dtype=np.uint8)
+        self.eng._check(self.lib.ipcfp_witness_read_values(self.eng.h, self.h, _p(l), len(l), _p(out), stride), "read_values")
+        return [None if l["block"][i] == 0xFFFFFFFF else out[i, : min(int(l["len"][i]), stride)].tobytes() for i in range(len(l))]
+
+    def verify_event_proofs_located(self, claims_arr, n, trust=None, filt=None):
+        """verify_event_proof + where each proof's StampedEvent lies (for a host check_event closure)."""
+        st = np.zeros(n, dtype=np.uint8)
+        loc = np.zeros(n, dtype=LOC_DTYPE)
+        self.eng._check(self.lib.ipcfp_verify_event_proofs_located(
+            self.eng.h, self.h, C.cast(claims_arr, C.c_void_p), n,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st), _p(loc)), "verify_event_proofs_located")
+        return st, loc
+
+    def generate_proof_bundle(self, parent_cids, child_cid: bytes, storage_specs, event_specs):
+        """generate_proof_bundle.  storage_specs: [(actor_id, slot32)], event_specs: [(signature, topic_1, actor|None)].
+        → dict(storage GEN_STORAGE_DTYPE[], event_status, matches, message_cids, match_spec, block_ids (Cid order),
+               first_error | None)"""
+        pc = pack_cids(parent_cids)
+        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        ss = np.zeros(len(storage_specs), dtype=STORAGE_SPEC_DTYPE)
+        for i, (a, slot) in enumerate(storage_specs):
+            ss["actor_id"][i] = a
+            ss["slot"][i] = np.frombuffer(bytes(slot), dtype=np.uint8)
+        es = (EventProofSpec * max(len(event_specs), 1))()
+        keep = []
+        for j, (sig, t1, actor) in enumerate(event_specs):
+            keep += [sig.encode(), t1.encode()]
+            es[j].event_signature, es[j].topic_1 = keep[-2], keep[-1]
+            es[j].has_actor_id_filter = 0 if actor is None else 1
+            es[j].actor_id_filter = 0 if actor is None else int(actor)
+        sout = np.zeros(max(len(ss), 1), dtype=GEN_STORAGE_DTYPE)
+        est = np.zeros(max(len(event_specs), 1), dtype=np.uint8)
+        cap_p, cap_b = 1 << 16, max(self.n, 1)
+        m = np.zeros(cap_p, dtype=MATCH_DTYPE)
+        mc = np.zeros((cap_p, CID_SLOT), dtype=np.uint8)
+        ms = np.zeros(cap_p, dtype=np.uint32)
+        ids = np.zeros(cap_b, dtype=np.uint32)
+        npf, nb, fe = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.eng._check(self.lib.ipcfp_generate_proof_bundle(
+            self.eng.h, self.h, _p(pc), len(parent_cids), _p(child), _p(ss), len(ss), C.cast(es, C.c_void_p),
+            len(event_specs), _p(sout), _p(est), _p(m), _p(mc), _p(ms), cap_p, C.byref(npf), _p(ids), None, cap_b,
+            C.byref(nb), C.byref(fe)), "generate_proof_bundle")
+        k = min(int(npf.value), cap_p)
+        return {"storage": sout[: len(ss)], "event_status": est[: len(event_specs)], "matches": m[:k], "message_cids": mc[:k],
+                "match_spec": ms[:k], "block_ids": ids[: int(nb.value)],
+                "first_error": None if fe.value == (1 << 64) - 1 else int(fe.value)}
 
     def rebuild_index(self):
         """K4 again, in place (no allocation)."""

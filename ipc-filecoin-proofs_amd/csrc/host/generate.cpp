@@ -271,4 +271,99 @@ int ipcfp_generate_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ui
     return materialize(ctx, w, touched.p, witness_block_ids, witness_cids40, cap_blocks, n_blocks);
 }
 
+int ipcfp_generate_proof_bundle(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                                const uint8_t* child_cid40, const ipcfp_storage_proof_spec_t* storage_specs,
+                                uint64_t n_storage, const ipcfp_event_proof_spec_t* event_specs, uint64_t n_events,
+                                ipcfp_generated_storage_t* storage_out, ipcfp_status_t* event_status,
+                                ipcfp_event_match_t* matches, uint8_t* message_cids40, uint32_t* match_spec,
+                                uint64_t cap_proofs, uint64_t* n_proofs, uint32_t* witness_block_ids,
+                                uint8_t* witness_cids40, uint64_t cap_blocks, uint64_t* n_blocks, uint64_t* first_error) {
+    if (!ctx || !w || w->ctx != ctx || !child_cid40 || !n_proofs || !n_blocks || !first_error ||
+        (n_storage && (!storage_specs || !storage_out)) || (n_events && (!event_specs || !event_status)))
+        return IPCFP_E_INVALID;
+    *n_proofs = *n_blocks = 0;
+    *first_error = ~0ULL;
+    std::vector<uint32_t> all_ids;  // the union, de-duplicated below (BTreeSet<(Cid, Vec<u8>)>, generator.rs:34)
+    // ---- storage specs (generator.rs:42-56) ----
+    if (n_storage) {
+        std::vector<uint64_t> actors(n_storage);
+        std::vector<uint8_t> slots(n_storage * 32);
+        for (uint64_t i = 0; i < n_storage; ++i) {
+            actors[i] = storage_specs[i].actor_id;
+            std::memcpy(slots.data() + 32 * i, storage_specs[i].slot, 32);
+        }
+        std::vector<uint32_t> ids(w->n ? w->n : 1);
+        uint64_t nb = 0;
+        int rc = ipcfp_generate_storage_proofs(ctx, w, child_cid40, actors.data(), slots.data(), n_storage, storage_out,
+                                               ids.data(), nullptr, ids.size(), &nb);
+        if (rc) return rc;
+        for (uint64_t i = 0; i < n_storage; ++i)
+            if (storage_out[i].status != IPCFP_ST_TRUE) {
+                *first_error = i;
+                return IPCFP_OK;  // `generate_storage_proof(..).await?` (generator.rs:48-49)
+            }
+        all_ids.assign(ids.begin(), ids.begin() + nb);
+    }
+    // ---- event specs (generator.rs:59-80) ----
+    uint64_t np = 0;
+    for (uint64_t j = 0; j < n_events; ++j) {
+        const ipcfp_event_proof_spec_t& sp = event_specs[j];
+        ipcfp_event_filter_t filter;
+        int rc = ipcfp_create_event_filter(ctx, sp.event_signature ? sp.event_signature : "", sp.topic_1 ? sp.topic_1 : "", &filter);
+        if (rc) return rc;
+        // size, then fill
+        ipcfp_status_t st = IPCFP_ST_ERR;
+        uint64_t n_p = 0, n_b = 0;
+        rc = ipcfp_generate_event_proofs(ctx, w, parent_cids40, n_parents, child_cid40, &filter, sp.has_actor_id_filter ? 1 : 0,
+                                         sp.actor_id_filter, &st, nullptr, nullptr, 0, &n_p, nullptr, nullptr, 0, &n_b);
+        if (rc) return rc;
+        event_status[j] = st;
+        if (st != IPCFP_ST_TRUE) {
+            *first_error = n_storage + j;
+            return IPCFP_OK;  // `generate_event_proof(..).await?` (generator.rs:65-74)
+        }
+        std::vector<ipcfp_event_match_t> m(n_p ? n_p : 1);
+        std::vector<uint8_t> mc((n_p ? n_p : 1) * IPCFP_CID_SLOT);
+        std::vector<uint32_t> ids(n_b ? n_b : 1);
+        rc = ipcfp_generate_event_proofs(ctx, w, parent_cids40, n_parents, child_cid40, &filter, sp.has_actor_id_filter ? 1 : 0,
+                                         sp.actor_id_filter, &st, m.data(), mc.data(), n_p, &n_p, ids.data(), nullptr, n_b, &n_b);
+        if (rc) return rc;
+        for (uint64_t k = 0; k < n_p; ++k, ++np) {
+            if (np >= cap_proofs) continue;
+            if (matches) matches[np] = m[k];
+            if (message_cids40) std::memcpy(message_cids40 + np * IPCFP_CID_SLOT, mc.data() + k * IPCFP_CID_SLOT, IPCFP_CID_SLOT);
+            if (match_spec) match_spec[np] = uint32_t(j);
+        }
+        all_ids.insert(all_ids.end(), ids.begin(), ids.begin() + n_b);
+    }
+    *n_proofs = np;
+    // ---- the union in `Cid: Ord` order, each block once (generator.rs:84-88) ----
+    std::sort(all_ids.begin(), all_ids.end());
+    all_ids.erase(std::unique(all_ids.begin(), all_ids.end()), all_ids.end());
+    const uint32_t n = uint32_t(all_ids.size());
+    *n_blocks = n;
+    if (n == 0) return IPCFP_OK;
+    IPCFP_ENTER(ctx);
+    DevBuf<uint32_t> ids_d;
+    DevBuf<CidKey> keys_d;
+    IPCFP_HIP(ctx, ids_d.alloc(n));
+    IPCFP_HIP(ctx, keys_d.alloc(n));
+    IPCFP_HIP(ctx, hipMemcpyAsync(ids_d.p, all_ids.data(), size_t(n) * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_gather_block_cids(ctx, w->cids.p, ids_d.p, n, keys_d.p);
+    if (rc) return rc;
+    std::vector<uint8_t> cids(size_t(n) * IPCFP_CID_SLOT);
+    IPCFP_HIP(ctx, hipMemcpyAsync(cids.data(), keys_d.p, cids.size(), hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    std::vector<uint32_t> perm(n);
+    for (uint32_t i = 0; i < n; ++i) perm[i] = i;
+    std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
+        return cid_slot_less(cids.data() + size_t(a) * IPCFP_CID_SLOT, cids.data() + size_t(b) * IPCFP_CID_SLOT);
+    });
+    for (uint64_t i = 0; i < n && i < cap_blocks; ++i) {
+        if (witness_block_ids) witness_block_ids[i] = all_ids[perm[i]];
+        if (witness_cids40) std::memcpy(witness_cids40 + i * IPCFP_CID_SLOT, cids.data() + size_t(perm[i]) * IPCFP_CID_SLOT, IPCFP_CID_SLOT);
+    }
+    return IPCFP_OK;
+}
+
 }  // extern "C"

@@ -79,7 +79,7 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
 // (header facts, execution order) and verify the batch.  `claims_d`, `blob_d`, `status_d` are device.
 int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
                   uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
-                  const ipcfp_event_filter_t* filter, uint8_t* status_d) {
+                  const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d = nullptr) {
     static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
     const WitnessView view = witness_view(w);
     DevBuf<TipsetCtxDev> tcs_d;
@@ -170,7 +170,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
             if (rc) return rc;
         }
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, uint32_t(tcs.size()), blob_d, blob_len,
-                              trust ? *trust : accept_all, filter, status_d);
+                              trust ? *trust : accept_all, filter, status_d, where_d);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // contexts / exec tables are released on return
     return IPCFP_OK;
@@ -181,9 +181,30 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
 
 extern "C" {
 
+static int verify_event_proofs_impl(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
+                                    const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                                    ipcfp_status_t* status, ipcfp_value_loc_t* event_loc);
+
 int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
                               const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
                               ipcfp_status_t* status) {
+    return verify_event_proofs_impl(ctx, w, proofs, n, trust, filter, status, nullptr);
+}
+
+// The same, also reporting WHERE each proof's event lies (event_loc[i].block == 0xffffffff when the proof did not get
+// that far): the door for an arbitrary host `check_event(&ActorEvent)` closure (events/verifier.rs:51-56,247-251) —
+// the wrapper reads the located bytes (ipcfp_witness_read_values), runs the closure over the proofs whose status is
+// TRUE, and turns a `false` into IPCFP_ST_FALSE_FILTER.
+int ipcfp_verify_event_proofs_located(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
+                                      const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                                      ipcfp_status_t* status, ipcfp_value_loc_t* event_loc) {
+    if (n && !event_loc) return IPCFP_E_INVALID;
+    return verify_event_proofs_impl(ctx, w, proofs, n, trust, filter, status, event_loc);
+}
+
+static int verify_event_proofs_impl(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
+                                    const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                                    ipcfp_status_t* status, ipcfp_value_loc_t* event_loc) {
     if (!ctx || !w || w->ctx != ctx || (n && (!proofs || !status))) return IPCFP_E_INVALID;
     if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
     if (n == 0) return IPCFP_OK;
@@ -216,8 +237,11 @@ int ipcfp_verify_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     IPCFP_HIP(ctx, hipMemcpyAsync(cd.p, packed.data(), n * sizeof(EventClaimPacked), hipMemcpyHostToDevice, ctx->stream));
     if (!blob.empty())
         IPCFP_HIP(ctx, hipMemcpyAsync(bd.p, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
-    int rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, blob.size(), trust, filter, sd.p);
+    DevBuf<ipcfp_value_loc_t> ld;
+    if (event_loc) IPCFP_HIP(ctx, ld.alloc(n));
+    int rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, blob.size(), trust, filter, sd.p, event_loc ? ld.p : nullptr);
     if (rc) return rc;
+    if (event_loc) IPCFP_HIP(ctx, hipMemcpyAsync(event_loc, ld.p, n * sizeof(ipcfp_value_loc_t), hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;

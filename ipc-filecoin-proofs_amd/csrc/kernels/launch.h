@@ -70,7 +70,8 @@ int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const 
                         const uint32_t* pos_d, CidKey* out_d);
 int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
                          const TipsetCtxDev* ctxs_d, uint32_t n_ctxs, const uint8_t* blob_d, uint64_t blob_len,
-                         const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d);
+                         const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d,
+                         void* where_d = nullptr);
 
 // --- event_scan.hip (K6 scan, K8 replay bitmap) ---
 int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
@@ -107,6 +108,8 @@ int launch_gather_block_cids(ipcfp_ctx* ctx, const uint8_t* cids_d, const uint32
 
 // --- shard.hip ---
 int launch_plan_receipts(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint64_t lo, uint32_t n);
+int launch_find_blocks(ipcfp_ctx* ctx, const WitnessView& w, const CidKey* keys_d, uint32_t n, uint32_t* ids_d);
+int launch_absolute_offsets(ipcfp_ctx* ctx, const uint64_t* off_d, uint32_t n, uint64_t base, uint64_t* out_d);
 int launch_amt_root_info(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, int version, int vkind, uint64_t* out_d);
 int launch_subset_tables(ipcfp_ctx* ctx, const uint32_t* ids_d, uint32_t n, uint32_t n_src, const uint64_t* src_off,
                          const uint32_t* src_len, const uint8_t* src_cids, uint64_t* off_d, uint32_t* len_d,

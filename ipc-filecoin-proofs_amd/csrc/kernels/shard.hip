@@ -119,6 +119,34 @@ __global__ __launch_bounds__(256) void k_subset_tables(const uint32_t* __restric
     for (int k = 0; k < 5; ++k) d[k] = s[k];
 }
 
+// Blockstore::has / get: CID → block id (kNoBlock: absent)
+__global__ __launch_bounds__(256) void k_find_blocks(WitnessView w, const CidKey* __restrict__ keys, uint32_t n,
+                                                     uint32_t* __restrict__ ids) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) ids[t] = witness_find(w, keys[t]);
+}
+
+// out[i] = base + off[i]: arena offsets as absolute device addresses (ipcfp_witness_put_keyed's source table)
+__global__ __launch_bounds__(256) void k_absolute_offsets(const uint64_t* __restrict__ off, uint32_t n, uint64_t base,
+                                                          uint64_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = base + off[t];
+}
+
+int launch_find_blocks(ipcfp_ctx* ctx, const WitnessView& w, const CidKey* keys_d, uint32_t n, uint32_t* ids_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_find_blocks, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, keys_d, n, ids_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_absolute_offsets(ipcfp_ctx* ctx, const uint64_t* off_d, uint32_t n, uint64_t base, uint64_t* out_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_absolute_offsets, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, off_d, n, base, out_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 int launch_plan_receipts(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint64_t lo, uint32_t n) {
     if (n == 0) return IPCFP_OK;
     hipLaunchKernelGGL(k_plan_receipts, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, rec, receipts_root, lo, n);

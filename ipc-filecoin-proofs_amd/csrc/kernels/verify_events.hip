@@ -386,10 +386,12 @@ __device__ __forceinline__ uint32_t verify_event_record(const WitnessView& w, co
     return IPCFP_ST_TRUE;
 }
 
+// `where` (nullable) receives the location of the StampedEvent the claim names once the proof has reached it
+// (block = 0xffffffff otherwise): a host `check_event` closure runs over those bytes (events/verifier.rs:247-251).
 __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const EventClaimPacked& c,
                                                      const TipsetCtxDev& tc, const uint8_t* __restrict__ blob,
                                                      const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t& filter,
-                                                     bool has_filter) {
+                                                     bool has_filter, ValueLoc* where) {
     // Step 1: verify_trust_anchors (events/verifier.rs:124-144)
     if (!(tc.flags & TC_PARENTS_PARSED) || !(tc.flags & TC_CHILD_PARSED)) return IPCFP_ST_ERR_BAD_CLAIM;  // :130-131
     if (!ev_trusted(trust, c.parent_epoch)) return IPCFP_ST_FALSE_UNTRUSTED_PARENT;                          // :134
@@ -424,6 +426,7 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
                 if (c.event_index == ~0ULL) return IPCFP_ST_ERR;                                              // > MAX_INDEX
                 if (c.event_index >= 64 || !((rr.bitmap >> c.event_index) & 1ull)) return IPCFP_ST_FALSE_NO_EVENT;  // :237
                 const EventRec e = tc.event_recs[rr.first + __popcll(rr.bitmap & ((1ull << c.event_index) - 1ull))];
+                if (where) *where = ValueLoc{rr.block, uint32_t((e.base_flags & kEvBaseMask) - w.off[rr.block]), e.ev_len};
                 return verify_event_record(w, c, e, blob, filter, has_filter);
             }
         }
@@ -451,6 +454,7 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     st = amt_load_get(w, events_root, 3, VK_STAMPED_EVENT, c.event_index, eloc);                              // :234-237
     if (st == IPCFP_ST_NOT_FOUND) return IPCFP_ST_FALSE_NO_EVENT;
     if (st != IPCFP_ST_TRUE) return st;
+    if (where) *where = eloc;
     // verify_event_data_matches (:257-290)
     Rd er;
     er.init(w.arena + w.off[eloc.block] + eloc.off, eloc.len);
@@ -483,15 +487,16 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(Witness
                                                        const uint8_t* __restrict__ blob, uint64_t blob_len,
                                                        ipcfp_trust_policy_t trust,
                                                        ipcfp_event_filter_t filter, int has_filter,
-                                                       uint8_t* __restrict__ status) {
+                                                       uint8_t* __restrict__ status, ValueLoc* __restrict__ where) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const EventClaimPacked& c = claims[t];
-    if (!claim_in_bounds(c, n_ctxs, blob_len)) {
-        status[t] = IPCFP_ST_ERR_BAD_CLAIM;
-        return;
-    }
-    status[t] = uint8_t(verify_event_one(w, c, ctxs[c.context], blob, trust, filter, has_filter != 0));
+    ValueLoc loc{kNoBlock, 0, 0};
+    uint32_t st = IPCFP_ST_ERR_BAD_CLAIM;
+    if (claim_in_bounds(c, n_ctxs, blob_len))
+        st = verify_event_one(w, c, ctxs[c.context], blob, trust, filter, has_filter != 0, where ? &loc : nullptr);
+    status[t] = uint8_t(st);
+    if (where) where[t] = loc;
 }
 
 // exec_len of a context = the total of the first-occurrence scan, copied on the device so the host
@@ -555,14 +560,15 @@ int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const 
 
 int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
                          const TipsetCtxDev* ctxs_d, uint32_t n_ctxs, const uint8_t* blob_d, uint64_t blob_len,
-                         const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d) {
+                         const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d,
+                         void* where_d) {
     if (n == 0) return IPCFP_OK;
     ipcfp_event_filter_t f{};
     if (filter) f = *filter;
     {
         ProfileScope prof(ctx, IPCFP_K_EVENT_VERIFY);
         hipLaunchKernelGGL(k_verify_events, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, claims_d, n, ctxs_d,
-                           n_ctxs, blob_d, blob_len, trust, f, filter ? 1 : 0, status_d);
+                           n_ctxs, blob_d, blob_len, trust, f, filter ? 1 : 0, status_d, static_cast<ValueLoc*>(where_d));
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
