@@ -157,10 +157,12 @@ def main():
 
     def step():
         w.rebuild_index()                                                               # K4
-        w.verify_cids_async()                                                           # K1
         st, _, m, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
                                     want_touched=False, counts_only=True)               # K6
         scan_result["status"], scan_result["matches"] = st, m
+        # K1 is independent of everything else in the step and VALU-bound: it is queued (own stream) where the
+        # main stream turns to the verify call's memory-bound kernels, not beside the block-order event parse
+        w.verify_cids_async()                                                           # K1
         w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len,
                                      t_status.data_ptr())                               # exec order + verify
 
@@ -212,9 +214,9 @@ def main():
             ta = time.perf_counter()
             w2 = eng.witness(tip.data, tip.off, tip.lens, tip.cids)
             tb = time.perf_counter()
-            w2.verify_cids_async()
             st2, _, nm2, _ = w2.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
                                             want_touched=False, counts_only=True)
+            w2.verify_cids_async()
             tc_ = time.perf_counter()
             status2 = w2.verify_event_claims(ts, cl, blob, blob_len)
             td = time.perf_counter()

@@ -45,6 +45,8 @@ struct ipcfp_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream_k1 = nullptr;  // K1 (VALU-bound hashing) runs beside the latency-bound walk kernels
+    hipStream_t stream_aux = nullptr; // the block-order event parse (k_block_events) runs beside both
+    hipEvent_t aux_event = nullptr;   // main stream ← aux stream dependency (host/scan_events.cpp)
     std::string last_error;
     hipDeviceProp_t props{};
     ipcfp::DevPool pool;
@@ -222,6 +224,14 @@ struct DevBuf {
         cap = 0;
         owner = nullptr;
     }
+    // an allocation of its own (never pooled): buffers that another stream writes while the main stream's pooled
+    // scratch is still in flight
+    hipError_t alloc_unpooled(size_t n) {
+        release();
+        count = n;
+        cap = (n ? n : 1) * sizeof(T);
+        return hipMalloc(reinterpret_cast<void**>(&p), cap);
+    }
     hipError_t alloc(size_t n) {
         release();
         count = n;
@@ -308,9 +318,9 @@ struct EventTableCached {
     uint64_t root[5];
     uint64_t lo = 0, hi = ~0ULL;
     DevBuf<ReceiptRec> receipts;  // one per enumerated receipt leaf
-    DevBuf<EventRec> events;
+    const EventRec* events = nullptr;  // the witness's block table owns the records (ipcfp_witness::bt_events)
     uint64_t n = 0;
-    EventTableView view() const { return EventTableView{receipts.p, events.p}; }
+    EventTableView view() const { return EventTableView{receipts.p, events}; }
 };
 }  // namespace ipcfp
 
@@ -339,4 +349,13 @@ struct ipcfp_witness {
     std::vector<std::unique_ptr<ipcfp::EnumCached>> enum_cache;
     std::vector<std::unique_ptr<ipcfp::EventTableCached>> table_cache;
     bool use_event_table = true;  // env IPCFP_EVENT_TABLE=0: every scan / claim walks the blocks (A/B measurements)
+    // the block table (kernels/event_table.h, k_block_events): one BlockRec per block + the EventRec pool.  The
+    // buffers are the witness's own and live as long as it does; `bt_valid` is dropped with the index.
+    ipcfp::DevBuf<ipcfp::BlockRec> bt_blocks;
+    ipcfp::DevBuf<ipcfp::EventRec> bt_events;
+    ipcfp::DevBuf<uint32_t> bt_used;
+    bool bt_valid = false;    // k_block_events has been queued (aux stream) for the current arena
+    bool bt_joined = false;   // ... and the main stream waits for it
+    bool bt_has_filter = false;
+    ipcfp::ScanParams bt_filter{};  // the filter whose matches BlockRec::kind_matches counts
 };

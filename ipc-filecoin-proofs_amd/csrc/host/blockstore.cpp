@@ -147,6 +147,10 @@ int ipcfp_witness_put_keyed(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream_k1));
     w->enum_cache.clear();
     w->table_cache.clear();
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));  // the block table describes the old arena
+    w->bt_valid = w->bt_joined = false;
+    w->bt_blocks.release();
+    w->bt_events.release();
     w->n = nw->n;
     w->nbytes = nw->nbytes;
     w->arena_bytes = nw->arena_bytes;

@@ -103,6 +103,7 @@ static int drain_launches(ipcfp_ctx* ctx) {
     if (ctx->launches.empty()) return IPCFP_OK;
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
+    IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
     for (auto& l : ctx->launches) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, l.start, l.stop) == hipSuccess && l.kernel_id >= 0 &&
@@ -203,6 +204,18 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
                 ctx->stream_k1 = ctx->stream;
         }
     }
+    // the block-order event parse on a stream of its own (IPCFP_AUX_STREAM=0: on the main stream, in order)
+    ctx->stream_aux = ctx->stream;
+    {
+        const char* e = std::getenv("IPCFP_AUX_STREAM");
+        if (!(e && std::atoi(e) == 0) && hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking) != hipSuccess)
+            ctx->stream_aux = ctx->stream;
+        if (hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming) != hipSuccess) {
+            if (ctx->stream_aux != ctx->stream) (void)hipStreamDestroy(ctx->stream_aux);
+            ctx->stream_aux = ctx->stream;
+            ctx->aux_event = nullptr;
+        }
+    }
     if (const char* e = std::getenv("IPCFP_SPIN_SYNC")) ctx->spin_sync = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = (std::atoi(e) >= 0 && std::atoi(e) <= 3) ? std::atoi(e) : 0;
     if (const char* e = std::getenv("IPCFP_B2B_WG")) {
@@ -235,6 +248,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream_k1);
+    (void)hipStreamSynchronize(ctx->stream_aux);
     for (auto& l : ctx->launches) {
         (void)hipEventDestroy(l.start);
         (void)hipEventDestroy(l.stop);
@@ -247,6 +261,8 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (ctx->upload_ring) upload_ring_destroy(ctx->upload_ring);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->spin_event) (void)hipEventDestroy(ctx->spin_event);
+    if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
+    if (ctx->stream_aux != ctx->stream) (void)hipStreamDestroy(ctx->stream_aux);
     if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -260,6 +276,7 @@ int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
     if (!ctx) return IPCFP_E_INVALID;
     IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream));
     IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream_k1));
+    if (ctx->stream_aux != ctx->stream) IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream_aux));
     return IPCFP_OK;
 }
 

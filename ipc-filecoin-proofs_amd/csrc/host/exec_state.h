@@ -12,6 +12,7 @@ struct ExecState {
     DevBuf<unsigned long long> slots;  // hash table: {key fingerprint, first raw position}
     DevBuf<uint32_t> first;     // 1 where the raw position is a first occurrence
     DevBuf<uint32_t> pos;       // exclusive scan of `first` → execution index
+    DevBuf<uint32_t> inv;       // execution index → raw position (filled by launch_exec_finish on the verify path)
     struct Word64 { uint64_t* p = nullptr; } total;           // device: number of distinct messages (= exec_len)
     struct WordErr { unsigned long long* p = nullptr; } err;  // packed first error of the whole reconstruction
     DevBuf<uint64_t> total_own;                 // backing store when the call's control block is full
@@ -53,6 +54,9 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
 int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en,
                     const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, uint32_t* counts_d,
                     unsigned long long* err_d, const EventTableCached** out, bool* built);
+
+// queue the block-order event parse of the witness on the aux stream unless its block table exists (scan_events.cpp)
+int block_table_prefetch(ipcfp_ctx* ctx, ipcfp_witness* w, const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor);
 
 CidKey key_from_slot(const uint8_t* slot40);
 

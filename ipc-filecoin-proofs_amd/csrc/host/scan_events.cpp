@@ -18,6 +18,35 @@ CidKey key_from_slot(const uint8_t* slot40);
 
 namespace ipcfp {
 
+// Queue k_block_events for the witness (aux stream) unless its block table is already there.  `filter` (nullable):
+// the scan filter whose matches the pass counts per block.  Called at the START of a scan / verify call, before the
+// main stream's own work is queued, so that the parse runs beside the receipts enumeration (and K1).
+int block_table_prefetch(ipcfp_ctx* ctx, ipcfp_witness* w, const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor) {
+    if (!w->use_event_table || w->n == 0 || w->bt_valid) return IPCFP_OK;
+    const uint64_t n = w->n;
+    if (!w->bt_blocks.p) {
+        // record pool: generous for real tipsets (an event is > 64 encoded bytes), bounded by what the witness could
+        // hold; a block that finds the pool exhausted is simply left to the walkers (RK_WALK)
+        uint64_t cap = std::max<uint64_t>(4 * n + 1024, w->nbytes / 64);
+        cap = std::min<uint64_t>(cap, 0xfffffff0ull);
+        IPCFP_HIP(ctx, w->bt_blocks.alloc_unpooled(n));
+        IPCFP_HIP(ctx, w->bt_events.alloc_unpooled(cap));
+        IPCFP_HIP(ctx, w->bt_used.alloc_unpooled(1));
+    }
+    hipStream_t s = ctx->stream_aux;
+    IPCFP_HIP(ctx, hipMemsetAsync(w->bt_used.p, 0, 4, s));
+    w->bt_has_filter = filter != nullptr;
+    w->bt_filter = ScanParams{};
+    if (filter) w->bt_filter = ScanParams{*filter, has_actor ? actor : 0, has_actor ? 1u : 0u, 0};
+    int rc = launch_block_events(ctx, s, w->arena.p, w->k1_meta.p, uint32_t(n), filter, has_actor, actor, w->bt_blocks.p,
+                                 w->bt_events.p, uint32_t(w->bt_events.count), w->bt_used.p);
+    if (rc) return rc;
+    w->bt_valid = true;
+    w->bt_joined = s == ctx->stream;
+    if (!w->bt_joined) IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, s));
+    return IPCFP_OK;
+}
+
 int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en,
                     const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, uint32_t* counts_d,
                     unsigned long long* err_d, const EventTableCached** out, bool* built) {
@@ -27,33 +56,37 @@ int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const 
             *out = t.get();
             return IPCFP_OK;
         }
+    int rc = block_table_prefetch(ctx, w, filter, has_actor, actor);  // (queued long ago by the callers that care)
+    if (rc) return rc;
+    if (!w->bt_joined) {
+        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
+        w->bt_joined = true;
+    }
     std::unique_ptr<EventTableCached> t(new EventTableCached());
     std::memcpy(t->root, root.w, 40);
     t->lo = w->receipt_lo;
     t->hi = w->receipt_hi;
     t->n = en->n;
+    t->events = w->bt_events.p;
     const uint64_t n = en->n;
-    // record pool: generous for real tipsets (a few events per receipt), bounded by what the witness could hold;
-    // a receipt that finds the pool exhausted is simply walked (RK_WALK)
-    uint64_t cap = std::max<uint64_t>(4 * n + 1024, w->nbytes / 24);
-    cap = std::min<uint64_t>(cap, 64 * n + 1024);
-    cap = std::min<uint64_t>(cap, 0xfffffff0ull);
     IPCFP_HIP(ctx, t->receipts.alloc(n));
-    IPCFP_HIP(ctx, t->events.alloc(cap));
-    DevBuf<uint32_t> used_own;
     DevBuf<unsigned long long> err_own;
-    uint32_t* used_p = nullptr;
-    IPCFP_HIP(ctx, ctl_words(ctx, used_own, used_p, 1, false));
-    struct { uint32_t* p; } used{used_p};
     if (!err_d) IPCFP_HIP(ctx, ctl_words(ctx, err_own, err_d, 1, true));
+    // the per-block match counts are this scan's iff the block pass ran with this very filter
+    bool counted = false;
+    if (filter && counts_d && w->bt_has_filter) {
+        const ScanParams want{*filter, has_actor ? actor : 0, has_actor ? 1u : 0u, 0};
+        counted = std::memcmp(&want, &w->bt_filter, sizeof want) == 0;
+    }
     const WitnessView view = witness_view(w);
-    int rc = launch_event_table(ctx, view, reinterpret_cast<const LeafRef*>(en->leaves.p), uint32_t(n), filter, has_actor,
-                                actor, t->receipts.p, t->events.p, uint32_t(cap), used.p, counts_d, err_d);
+    rc = launch_receipt_events(ctx, view, reinterpret_cast<const LeafRef*>(en->leaves.p), uint32_t(n),
+                               counted ? filter : nullptr, has_actor, actor, w->bt_blocks.p, t->receipts.p,
+                               counted ? counts_d : nullptr, err_d);
     if (rc) return rc;
-    *built = true;
+    *built = counted;
     *out = t.get();
     w->table_cache.push_back(std::move(t));
-    return IPCFP_OK;  // `used` / `err_local` return to the pool; reuse is ordered on the stream
+    return IPCFP_OK;  // `err_own` returns to the pool; reuse is ordered on the stream
 }
 
 // PASS 1 + prefix sum + PASS 2 on the device.  `touched_d` (nullable, device, words = ceil(n/32)) is
@@ -61,6 +94,9 @@ int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const 
 int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const ipcfp_event_filter_t& filter,
                        int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out, uint64_t cap_matches) {
     const WitnessView view = witness_view(w);
+    // the block-order event parse starts now, beside everything below up to the table lookup
+    int rc0 = block_table_prefetch(ctx, w, &filter, has_actor, actor);
+    if (rc0) return rc0;
     DevBuf<unsigned long long> err_own;
     unsigned long long* err_p = nullptr;  // kNoEnumError
     IPCFP_HIP(ctx, ctl_words(ctx, err_own, err_p, 1, true));

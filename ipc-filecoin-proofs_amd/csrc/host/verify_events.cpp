@@ -82,6 +82,9 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
                   const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d = nullptr) {
     static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
     const WitnessView view = witness_view(w);
+    // when no scan has tabulated the events yet, the block-order parse runs beside the whole tipset prologue
+    int rc_bt = block_table_prefetch(ctx, w, nullptr, 0, 0);
+    if (rc_bt) return rc_bt;
     DevBuf<TipsetCtxDev> tcs_d;
     IPCFP_HIP(ctx, tcs_d.alloc(tcs.size()));
     IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
@@ -128,6 +131,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         tc = facts[k];
         tc.exec_status = IPCFP_ST_ERR_BAD_CLAIM;
         tc.exec_slots = nullptr;
+        tc.exec_inv = nullptr;
         tc.receipt_leaves = nullptr;
         tc.n_receipt_leaves = 0;
         tc.receipt_first = 0;
@@ -143,6 +147,11 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         tc.exec_slots = execs[k]->slots.p;
         tc.exec_keys = execs[k]->keys.p;
         tc.exec_pos = execs[k]->pos.p;
+        tc.exec_inv = nullptr;
+        if (execs[k]->status == IPCFP_ST_TRUE && execs[k]->total.p) {
+            IPCFP_HIP(ctx, execs[k]->inv.alloc(execs[k]->raw_len));
+            tc.exec_inv = execs[k]->inv.p;
+        }
         tc.exec_len = 0;  // patched on the device below
         // receipts AMT of this context: enumerate once (shared with ipcfp_scan_events through the witness cache)
         const EnumCached* rc_enum = nullptr;
@@ -159,18 +168,21 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
                 rc = event_table_get(ctx, w, tc.receipts_root, rc_enum, nullptr, 0, 0, nullptr, nullptr, &table, &built);
                 if (rc) return rc;
                 tc.receipt_recs = table->receipts.p;
-                tc.event_recs = table->events.p;
+                tc.event_recs = table->events;
             }
         }
     }
     IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, tcs.data(), tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
     for (size_t k = 0; k < tcs.size(); ++k)
         if (tcs[k].exec_slots && execs[k]->status == IPCFP_ST_TRUE && execs[k]->total.p) {
-            rc = launch_set_exec_len(ctx, tcs_d.p + k, execs[k]->total.p);
+            rc = launch_exec_finish(ctx, tcs_d.p + k, execs[k]->total.p, execs[k]->first.p, execs[k]->pos.p,
+                                    uint32_t(execs[k]->raw_len), execs[k]->inv.p);
             if (rc) return rc;
         }
+    bool tabulated = false;
+    for (auto& tc : tcs) tabulated = tabulated || tc.receipt_recs != nullptr;
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, uint32_t(tcs.size()), blob_d, blob_len,
-                              trust ? *trust : accept_all, filter, status_d, where_d);
+                              trust ? *trust : accept_all, filter, status_d, where_d, tabulated);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // contexts / exec tables are released on return
     return IPCFP_OK;

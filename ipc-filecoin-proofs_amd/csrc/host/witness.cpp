@@ -144,6 +144,7 @@ void ipcfp_witness_destroy(ipcfp_witness_t* w) {
         (void)hipSetDevice(w->ctx->device);
         (void)hipStreamSynchronize(w->ctx->stream);
         (void)hipStreamSynchronize(w->ctx->stream_k1);
+        (void)hipStreamSynchronize(w->ctx->stream_aux);
     }
     delete w;
 }
@@ -191,6 +192,9 @@ int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     w->enum_cache.clear();  // enumerations and event tables are derived from the index
     w->table_cache.clear();
+    // the block table is not (it is a function of the arena alone), but a rebuild means "start over": it goes as well
+    if (w->bt_valid && !w->bt_joined) IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+    w->bt_valid = w->bt_joined = false;
     return witness_build_index(ctx, w);
 }
 

@@ -91,12 +91,7 @@ __device__ __forceinline__ void hash_block_lds(const uint8_t* __restrict__ arena
     b2b::compress_lds(h, lm, WG, t, true);
 }
 
-// K1's per-lane metadata, stored in SCHEDULE order so a wavefront reads it coalesced.
-struct K1Meta {
-    uint64_t off;   // arena offset of the block
-    uint32_t len;
-    uint32_t id;    // block id (position in the caller's tables)
-};
+// K1's per-lane metadata (K1Meta, witness_dev.h) is stored in SCHEDULE order so a wavefront reads it coalesced.
 
 template <int MODE>
 __global__ __launch_bounds__(256, IPCFP_K1_WAVES) void k_blake2b256_cid(const uint8_t* __restrict__ arena,

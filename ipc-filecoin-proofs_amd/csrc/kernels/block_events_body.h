@@ -1,0 +1,90 @@
+// csrc/kernels/block_events_body.h — one block parsed as the root of an events AMT (event_table.h, step 1): the part
+// the variants of k_block_events share.  The including unit configures the reader (IPCFP_RD_LDS / IPCFP_LINE_STAGE).
+#pragma once
+#include "cbor_dev.h"
+#include "event_log_dev.h"
+#include "event_table.h"
+
+namespace ipcfp {
+
+// EVERY lane of the wavefront calls this (the record reservation is a wave-level prefix sum); the lanes with `mine`
+// parse the block their reader sits on.  On success br becomes RK_TABLE; it is left alone otherwise (RK_WALK).
+__device__ __forceinline__ void block_events_parse(Rd& r, bool mine, uint64_t arena_off, const ScanParams& sp, int count_matches,
+                                                   EventRec* __restrict__ erecs, uint32_t cap_events,
+                                                   uint32_t* __restrict__ pool_used, uint32_t lane, BlockRec& br) {
+    // ---- header first, so the record segment can be reserved before the events are read ----
+    uint32_t nv = 0;
+    uint64_t bits = 0;
+    bool table = false;
+    if (mine) {
+        r.expect_array(4);
+        const uint64_t bw = r.read_uint();
+        if (r.ok() && (bw < 1 || bw > 6)) r.fail();
+        const uint64_t height = r.read_uint();
+        (void)r.read_uint();  // count: checked by neither load nor for_each
+        if (r.ok() && height == 0) {
+            const uint32_t width = 1u << uint32_t(bw);
+            r.expect_array(3);
+            uint32_t bo, bl;
+            r.read_bytes(bo, bl);
+            if (r.ok() && bl == (width + 7) / 8) {
+                bits = r.peek64(bo);
+                if (bl < 8) bits &= (1ull << (8u * bl)) - 1ull;
+                if (width < 64) bits &= (1ull << width) - 1ull;
+                const uint64_t nl = r.read_array();
+                const uint64_t nvals = r.ok() && nl == 0 ? r.read_array() : ~0ull;
+                if (r.ok() && nl == 0 && nvals == uint64_t(__popcll(bits))) {
+                    table = true;
+                    nv = uint32_t(nvals);
+                }
+            }
+        }
+    }
+    // reserve nv records: one atomic per wavefront and batch
+    uint32_t rec_first;
+    {
+        const uint32_t want = table ? nv : 0;
+        uint32_t incl = want;
+    #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= uint32_t(d)) incl += up;
+        }
+        const uint32_t wave_total = __shfl(incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == 63 && wave_total) base = atomicAdd(pool_used, wave_total);
+        base = __shfl(base, 63, 64);
+        rec_first = base + incl - want;
+        if (table && uint64_t(rec_first) + nv > cap_events) table = false;  // pool exhausted: the receipt walks
+    }
+    if (table) {
+        // ---- the events, each decoded once (the decode IS the per-value type check of Amt::load) ----
+        bool oversize = false;
+        uint32_t c = 0;
+        for (uint32_t j = 0; j < nv && r.ok(); ++j) {
+            const uint32_t start = r.pos;
+            uint64_t emitter;
+            EvmLogLoc log;
+            decode_event_log(r, emitter, log);
+            if (!r.ok()) break;
+            EventRec e;
+            const uint32_t len = r.pos - start;
+            const uint64_t flags = (uint64_t(log.n_topics & 0xffu) << kEvTopicShift) | (log.is_log ? kEvIsLog : 0) |
+                                   (log.case_a ? kEvCaseA : 0);
+            oversize |= len > 0xffffu || log.n_topics > 255u;
+            e.base_flags = ((arena_off + start) & kEvBaseMask) | flags;
+            e.emitter = emitter;
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) e.topic_rel[q] = uint16_t(log.topic_off[q] >= start ? log.topic_off[q] - start : 0);
+            e.data_rel = uint16_t(log.data.present ? log.data.off - start : 0);
+            e.ev_len = uint16_t(len);
+            e.data_len = log.data.present ? log.data.len : 0;
+            erecs[rec_first + j] = e;
+            if (count_matches && !(sp.has_actor && emitter != sp.actor) && log_matches(r, log, sp.filter)) ++c;
+        }
+        r.finish();
+        if (r.ok() && !oversize) br = BlockRec{uint32_t(RK_TABLE) | (c << 8), rec_first, bits};
+    }
+}
+
+}  // namespace ipcfp

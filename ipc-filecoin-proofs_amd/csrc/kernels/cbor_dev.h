@@ -64,8 +64,25 @@ __device__ __noinline__ bool utf8_ok_bytes(const uint8_t* s, uint32_t len) {
 #define IPCFP_LINE_STAGE 0
 #endif
 
+// IPCFP_RD_LDS = 1 (a per-translation-unit choice as well): every reader of that unit parses bytes that a wavefront
+// staged in LDS (block_events.hip).  The pointers are typed into the LDS address space, so a chunk load is ONE
+// ds_read_b128 (≈64 cycles) instead of a flat / global load; nothing else in the reader changes.
+#ifndef IPCFP_RD_LDS
+#define IPCFP_RD_LDS 0
+#endif
+#if IPCFP_RD_LDS
+#define IPCFP_RD_AS __attribute__((address_space(3)))
+#if IPCFP_LINE_STAGE
+#error "IPCFP_LINE_STAGE stages global lines in LDS; a reader that already sits in LDS has nothing to stage"
+#endif
+#else
+#define IPCFP_RD_AS
+#endif
+
+typedef unsigned long long rd_chunk_t __attribute__((ext_vector_type(2)));  // one 16-byte window chunk
+
 struct Rd {
-    const uint8_t* p;
+    const IPCFP_RD_AS uint8_t* p;
     uint32_t n;
     uint32_t pos;
     uint32_t err;
@@ -78,20 +95,20 @@ struct Rd {
     // straddles into the next chunk the low word of the old chunk is never needed again.  Blocks sit
     // line-aligned in the arena with tail slack, so the chunk after the one that holds an item's last
     // byte never leaves the arena.
-    const ulonglong2* base16;  // p rounded down to 16 bytes
+    const IPCFP_RD_AS rd_chunk_t* base16;  // p rounded down to 16 bytes
     uint32_t bias;             // p - base16
     uint32_t cwi;              // index of the current chunk (0xfffffff0: none)
     uint32_t phi;              // index of the chunk whose high word is in `ph` (0xffffffff: none)
     uint64_t lo, hi, ph;
     bool stage;                // chunk loads go through the lane's LDS line slot (IPCFP_LINE_STAGE builds only)
 
-    __device__ __forceinline__ void init(const uint8_t* data, uint32_t len) {
+    __device__ __forceinline__ void init(const IPCFP_RD_AS uint8_t* data, uint32_t len) {
         p = data;
         n = len;
         pos = 0;
         err = 0;
-        const uintptr_t a = reinterpret_cast<uintptr_t>(data);
-        base16 = reinterpret_cast<const ulonglong2*>(a & ~uintptr_t(15));
+        const uintptr_t a = (uintptr_t)data;
+        base16 = (const IPCFP_RD_AS rd_chunk_t*)(a & ~uintptr_t(15));
         bias = uint32_t(a & 15);
         cwi = 0xfffffff0u;
         phi = 0xffffffffu;
@@ -110,14 +127,23 @@ struct Rd {
         bool stage;
     };
     // make chunk ci the current one (moving forward by one chunk keeps the old high word)
-    __device__ __forceinline__ static void slide(Win& w, const ulonglong2* base16, uint32_t ci) {
+    __device__ __forceinline__ static void slide(Win& w, const IPCFP_RD_AS rd_chunk_t* base16, uint32_t ci) {
         if (ci == w.cwi) return;
         const bool next = ci == w.cwi + 1;
         w.ph = next ? w.hi : w.ph;
         w.phi = next ? w.cwi : 0xffffffffu;
-        const ulonglong2 v = (IPCFP_LINE_STAGE && w.stage) ? staged_chunk(base16 + ci) : base16[ci];
-        w.lo = v.x;
-        w.hi = v.y;
+#if IPCFP_LINE_STAGE
+        if (w.stage) {
+            const ulonglong2 v = staged_chunk(reinterpret_cast<const ulonglong2*>(base16 + ci));
+            w.lo = v.x;
+            w.hi = v.y;
+        } else
+#endif
+        {
+            const rd_chunk_t v = base16[ci];
+            w.lo = v.x;
+            w.hi = v.y;
+        }
         w.cwi = ci;
     }
     // ---- per-lane line staging (IPCFP_LINE_STAGE) -------------------------------------------------------
@@ -180,6 +206,18 @@ struct Rd {
         hi = w.hi;
         ph = w.ph;
     }
+#if IPCFP_RD_LDS
+    // A reader that sits in LDS needs no window: a byte is one ds_read_u8, eight unaligned bytes one ds_read_b64
+    // (gfx950 serves unaligned LDS accesses).  The window above exists to cut the NUMBER of global load instructions;
+    // what it costs is instructions — ≈10 k VALU per wavefront of 64 receipts in k_scan_pass1 / k_event_table, which
+    // is what those kernels were bound by (profiles/r01_final_pmc.txt: 15 % of the wave cycles wait for memory).
+    __device__ __forceinline__ uint32_t at(uint32_t i) { return p[i]; }
+    __device__ __forceinline__ uint64_t peek64(uint32_t i) {
+        uint64_t v;
+        __builtin_memcpy(&v, p + i, 8);
+        return v;
+    }
+#else
     // byte i of the item (i < n, or inside the block's padded tail)
     __device__ __forceinline__ uint32_t at(uint32_t i) {
         const uint32_t j = i + bias;
@@ -219,6 +257,7 @@ struct Rd {
         // (second << 1) << (63 - sh) is second << (64 - sh), and 0 for sh == 0: no branch on sh
         return (first >> sh) | ((second << 1) << (63u - sh));
     }
+#endif
     // the CID bytes [off, off+len) as a witness key (len ≤ 40): five unaligned words, tail masked
     __device__ __forceinline__ CidKey key_at(uint32_t off, uint32_t len) {
         CidKey k;
@@ -349,7 +388,7 @@ struct Rd {
             for (uint32_t i = 0; i < len; ++i) hi |= at(off + i);
             if (hi < 0x80) return true;
         }
-        return utf8_ok_bytes(p + off, len);
+        return utf8_ok_bytes((const uint8_t*)(p + off), len);  // (an LDS reader hands out the generic address)
     }
     __device__ __forceinline__ void read_text(uint32_t& off, uint32_t& len) {
         off = len = 0;

@@ -167,13 +167,6 @@ __device__ __forceinline__ bool receipt_events_root(const WitnessView& w, const 
     return true;
 }
 
-struct ScanParams {
-    ipcfp_event_filter_t filter;
-    uint64_t actor;
-    uint32_t has_actor;
-    uint32_t pad;
-};
-
 // PASS 1: counts[t] = number of matching events of receipt leaf t
 __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_scan_pass1(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
                                                     ScanParams sp, uint32_t* __restrict__ counts,
@@ -216,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
                                                     EventMatch* __restrict__ matches, uint64_t matches_cap,
                                                     uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base,
                                                     const ReceiptRec* __restrict__ skip_tabulated) {
+    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool recording = w.touched != nullptr;
     if (t == 0 && recording) {  // `Amtv0::load(&receipts_root, &rec_receipts)` records the root even without matches (:195-196)
@@ -287,111 +281,55 @@ __device__ __forceinline__ bool rec_matches(const uint8_t* __restrict__ arena, c
     return diff == 0;
 }
 
-// One receipt per lane: decode its events AMT (leaf root) once, write the records, count the filter's matches.
-// `count_matches` = 0 builds the table only (a verify call that no scan preceded).
-__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_event_table(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
-                                                     ScanParams sp, int count_matches, ReceiptRec* __restrict__ rrecs,
-                                                     EventRec* __restrict__ erecs, uint32_t cap_events,
-                                                     uint32_t* __restrict__ pool_used, uint32_t* __restrict__ counts,
-                                                     unsigned long long* __restrict__ err) {
+// One receipt per lane: events_root → block id → the block's record (k_block_events) → ReceiptRec and, when the table
+// was built with this scan's filter, the match count.  No block is parsed here except the receipt value itself; a
+// receipt whose block the table does not cover is marked for k_receipt_walk (counts[t] = kWalkPending).
+constexpr uint32_t kWalkPending = 0xffffffffu;
+
+__global__ __launch_bounds__(256) void k_receipt_events(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+                                                        int count_matches, const BlockRec* __restrict__ brecs,
+                                                        ReceiptRec* __restrict__ rrecs, uint32_t* __restrict__ counts,
+                                                        unsigned long long* __restrict__ err) {
+    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < n;
+    if (t >= n) return;
     ReceiptRec rr{RK_NO_EVENTS, 0, 0, kNoBlock, 0};
     uint32_t c = 0;
     CidKey ev_root;
-    // ---- stage 1: the root block's header, so that the record segment can be reserved before the events are read ----
-    Rd r;
-    r.init(w.arena, 0);
-    uint32_t nv = 0;
-    bool table = false;
-    if (live && receipt_events_root(w, receipts[t], ev_root)) {
+    if (receipt_events_root(w, receipts[t], ev_root)) {
         const uint32_t b = witness_find(w, ev_root);
         rr.block = b;
         if (b == kNoBlock) {
             rr.kind = IPCFP_ST_ERR_MISSING_BLOCK;
+            atomicMin(err, (unsigned long long)pack_enum_error(1, t, rr.kind));
         } else {
-            r = open_block(w, b);
-            r.expect_array(4);
-            const uint64_t bw = r.read_uint();
-            if (r.ok() && (bw < 1 || bw > kAmtMaxBitWidth)) r.fail();
-            const uint64_t height = r.read_uint();
-            (void)r.read_uint();  // count: not checked by load or for_each
-            rr.kind = RK_WALK;
-            if (r.ok() && height == 0 && bw <= 6) {
-                const uint32_t width = 1u << uint32_t(bw);
-                r.expect_array(3);
-                uint32_t bo, bl;
-                r.read_bytes(bo, bl);
-                uint64_t bits = 0;
-                if (r.ok() && bl == (width + 7) / 8) {
-                    bits = r.peek64(bo);
-                    if (bl < 8) bits &= (1ull << (8u * bl)) - 1ull;
-                    if (width < 64) bits &= (1ull << width) - 1ull;
-                    const uint64_t nl = r.read_array();
-                    const uint64_t nvals = r.ok() && nl == 0 ? r.read_array() : ~0ull;
-                    if (r.ok() && nl == 0 && nvals == uint64_t(__popcll(bits))) {
-                        table = true;
-                        nv = uint32_t(nvals);
-                        rr.bitmap = bits;
-                    }
-                }
+            const BlockRec br = brecs[b];
+            if ((br.kind_matches & 0xffu) == RK_TABLE) {
+                rr.kind = RK_TABLE;
+                rr.first = br.first;
+                rr.bitmap = br.bitmap;
+                c = count_matches ? br.kind_matches >> 8 : 0u;
+            } else {
+                rr.kind = RK_WALK;
+                c = kWalkPending;
             }
-            // any irregularity (decode error included) is left to the general walk below, which names the outcome
         }
     }
-    // reserve nv records: one atomic per wavefront
-    {
-        const uint32_t want = table ? nv : 0;
-        uint32_t before = want;
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(before, d, 64);
-            if (lane >= d) before += up;
-        }
-        const uint32_t wave_total = __shfl(before, 63, 64);
-        uint32_t base = 0;
-        if (lane == 63 && wave_total) base = atomicAdd(pool_used, wave_total);
-        base = __shfl(base, 63, 64);
-        rr.first = base + before - want;
-        if (table && uint64_t(rr.first) + nv > cap_events) table = false;  // pool exhausted: walk this one
-    }
-    if (!live) return;
-    if (table) {
-        // ---- stage 2: the events, each decoded once (the decode IS the per-value type check of Amt::load) ----
-        bool oversize = false;
-        const uint64_t block_base = w.off[rr.block];
-        for (uint32_t j = 0; j < nv && r.ok(); ++j) {
-            const uint32_t start = r.pos;
-            uint64_t emitter;
-            EvmLogLoc log;
-            decode_event_log(r, emitter, log);
-            if (!r.ok()) break;
-            EventRec e;
-            const uint32_t len = r.pos - start;
-            uint64_t flags = (uint64_t(log.n_topics & 0xffu) << kEvTopicShift) | (log.is_log ? kEvIsLog : 0) |
-                             (log.case_a ? kEvCaseA : 0);
-            oversize |= len > 0xffffu || log.n_topics > 255u;
-            e.base_flags = ((block_base + start) & kEvBaseMask) | flags;
-            e.emitter = emitter;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e.topic_rel[q] = uint16_t(log.topic_off[q] >= start ? log.topic_off[q] - start : 0);
-            e.data_rel = uint16_t(log.data.present ? log.data.off - start : 0);
-            e.ev_len = uint16_t(len);
-            e.data_len = log.data.present ? log.data.len : 0;
-            erecs[rr.first + j] = e;
-            if (count_matches && !(sp.has_actor && emitter != sp.actor) && log_matches(r, log, sp.filter)) ++c;
-        }
-        r.finish();
-        if (!r.ok()) {
-            rr.kind = IPCFP_ST_ERR_DECODE;
-            c = 0;
-        } else {
-            rr.kind = oversize ? uint32_t(RK_WALK) : uint32_t(RK_TABLE);
-        }
-    } else if (rr.kind == RK_WALK) {
-        // ---- the general route: names decode errors, counts matches of tall / wide / oversized trees ----
-        uint32_t st = IPCFP_ST_TRUE;
+    rrecs[t] = rr;
+    if (counts) counts[t] = c;
+}
+
+// The general route for the receipts k_receipt_events could not settle from the table: names decode errors, counts
+// the matches of tall / wide / oversized trees.  Every other lane leaves at once.
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_receipt_walk(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+                                                      ScanParams sp, int count_matches, const ReceiptRec* __restrict__ rrecs,
+                                                      uint32_t* __restrict__ counts, unsigned long long* __restrict__ err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (counts ? counts[t] != kWalkPending : rrecs[t].kind != RK_WALK) return;
+    uint32_t c = 0;
+    CidKey ev_root;
+    if (receipt_events_root(w, receipts[t], ev_root)) {
         auto visit = [&](uint64_t, uint32_t, Rd& er) {
             uint64_t emitter;
             EvmLogLoc log;
@@ -400,7 +338,7 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_event_table(WitnessVi
             if (log_matches(er, log, sp.filter)) ++c;
         };
         bool handled;
-        st = amt3_for_each_leaf_root(w, ev_root, handled, visit);
+        uint32_t st = amt3_for_each_leaf_root(w, ev_root, handled, visit);
         if (!handled) {
             c = 0;
             AmtRootInfo info;
@@ -412,8 +350,6 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_event_table(WitnessVi
             c = 0;
         }
     }
-    if (rr.kind >= 64) atomicMin(err, (unsigned long long)pack_enum_error(1, t, rr.kind));
-    rrecs[t] = rr;
     if (counts) counts[t] = c;
 }
 
@@ -467,6 +403,7 @@ __global__ __launch_bounds__(256) void k_scan_pass2_table(WitnessView w, const L
                                                           const uint32_t* __restrict__ offsets,
                                                           EventMatch* __restrict__ matches, uint64_t matches_cap,
                                                           uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base) {
+    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t c = counts[t];
@@ -503,17 +440,18 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
     return IPCFP_OK;
 }
 
-int launch_event_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
-                       const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ReceiptRec* rrecs_d,
-                       EventRec* erecs_d, uint32_t cap_events, uint32_t* pool_used_d, uint32_t* counts_d,
-                       unsigned long long* err_d) {
+int launch_receipt_events(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                          const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, const BlockRec* brecs_d,
+                          ReceiptRec* rrecs_d, uint32_t* counts_d, unsigned long long* err_d) {
     if (n == 0) return IPCFP_OK;
     ScanParams sp{};
     if (filter) sp = ScanParams{*filter, actor, has_actor ? 1u : 0u, 0};
     {
         ProfileScope prof(ctx, IPCFP_K_EVENT_SCAN);
-        hipLaunchKernelGGL(k_event_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n, sp,
-                           filter ? 1 : 0, rrecs_d, erecs_d, cap_events, pool_used_d, counts_d, err_d);
+        hipLaunchKernelGGL(k_receipt_events, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n,
+                           filter ? 1 : 0, brecs_d, rrecs_d, counts_d, err_d);
+        hipLaunchKernelGGL(k_receipt_walk, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n, sp,
+                           filter ? 1 : 0, rrecs_d, counts_d, err_d);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

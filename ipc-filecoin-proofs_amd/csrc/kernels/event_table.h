@@ -16,6 +16,8 @@
 #pragma once
 #include <cstdint>
 
+#include "ipcfp.h"
+
 namespace ipcfp {
 
 enum : uint32_t {
@@ -47,6 +49,30 @@ static_assert(sizeof(EventRec) == 32 && sizeof(ReceiptRec) == 24, "record layout
 constexpr uint64_t kEvBaseMask = (1ull << 48) - 1;
 constexpr int kEvTopicShift = 48;
 constexpr uint64_t kEvIsLog = 1ull << 56, kEvCaseA = 1ull << 57;
+
+// The table is built in two steps.
+//   k_block_events (block_events.hip)  EVERY block of the witness, in arena order, is parsed as if it were the root of
+//     an events AMT: a wavefront copies the contiguous arena span of its 64 blocks into LDS with coalesced 16-byte
+//     loads and every lane parses its own block out of LDS (the reader's chunk load is a ds_read_b128).  It needs
+//     nothing but the arena — neither the CID index nor the receipts — so it runs on its own stream beside K1 and
+//     the receipts enumeration.  Outcome per block: a BlockRec.  A block that is not exactly the tabulated shape
+//     (or is no events AMT at all) is RK_WALK, which decides nothing.
+//   k_receipt_events (event_scan.hip)  one receipt per lane: events_root → block id → BlockRec → ReceiptRec.
+//     Receipts whose block is RK_WALK take the general walkers (k_receipt_walk), as before.
+struct BlockRec {
+    uint32_t kind_matches;  // bits 0..7: RK_TABLE | RK_WALK; bits 8..31: events matching the filter the table was built with
+    uint32_t first;         // index of the first EventRec
+    uint64_t bitmap;
+};
+static_assert(sizeof(BlockRec) == 16, "record layout");
+
+// filter of one scan (EventMatcher + the optional emitter filter, src/proofs/events/generator.rs:25-40,220-224)
+struct ScanParams {
+    ipcfp_event_filter_t filter;
+    uint64_t actor;
+    uint32_t has_actor;
+    uint32_t pad;
+};
 
 // device view handed to the kernels (null pointers: no table)
 struct EventTableView {

@@ -32,6 +32,7 @@ struct TipsetCtxDev {
     const unsigned long long* exec_slots;  // open addressing over message CIDs: {fingerprint, FIRST raw position}
     const CidKey* exec_keys;      // raw for_each sequence (with duplicates)
     const uint32_t* exec_pos;     // raw position → execution index (valid where the position is a first occurrence)
+    const uint32_t* exec_inv;     // execution index → raw position of that message's first occurrence (k_exec_finish)
     uint64_t exec_len;            // number of distinct messages
     // receipts AMT enumerated once per context (amt_enum.hip): when it decoded without error and is
     // dense, `Amt::get(exec_index)` is a table lookup — every node on every path was already validated

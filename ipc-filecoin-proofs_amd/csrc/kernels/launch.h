@@ -59,7 +59,8 @@ struct EventTableView;
 struct LeafRef;
 struct EventClaimPacked;
 int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n);
-int launch_set_exec_len(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d);
+int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d, const uint32_t* first_d,
+                       const uint32_t* pos_d, uint32_t n, uint32_t* inv_d);
 // jobs_d: device array of {TipsetCtxDev* ctx, AmtRootSpec* roots (nullable), unsigned long long* err}
 int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs_d, uint32_t n_jobs);
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
@@ -71,7 +72,12 @@ int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const 
 int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
                          const TipsetCtxDev* ctxs_d, uint32_t n_ctxs, const uint8_t* blob_d, uint64_t blob_len,
                          const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d,
-                         void* where_d = nullptr);
+                         void* where_d = nullptr, bool tabulated = false);
+// --- verify_table.hip --- the claims the event table settles (everything else is left kStPending)
+int launch_verify_events_table(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
+                               const TipsetCtxDev* ctxs_d, uint32_t n_ctxs, const uint8_t* blob_d, uint64_t blob_len,
+                               const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t& filter, int has_filter,
+                               uint8_t* status_d, void* where_d);
 
 // --- event_scan.hip (K6 scan, K8 replay bitmap) ---
 int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
@@ -82,11 +88,16 @@ int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receip
                       const uint32_t* counts_d, const uint32_t* offsets_d, void* matches_d, uint64_t matches_cap,
                       uint8_t* has_match_d, uint64_t has_cap, uint64_t has_base = 0,
                       const EventTableView* table = nullptr);
-// the event table (event_table.h): PASS 1 that leaves a record per event (filter nullable: build only)
-int launch_event_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
-                       const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ReceiptRec* rrecs_d,
-                       EventRec* erecs_d, uint32_t cap_events, uint32_t* pool_used_d, uint32_t* counts_d,
-                       unsigned long long* err_d);
+// the event table (event_table.h), step 2: receipt → its block's record (filter nullable: no match counts); the
+// receipts the block table does not cover are walked
+struct BlockRec;
+int launch_receipt_events(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
+                          const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, const BlockRec* brecs_d,
+                          ReceiptRec* rrecs_d, uint32_t* counts_d, unsigned long long* err_d);
+// --- block_events.hip --- step 1: every block parsed out of LDS in arena order, on `stream` (meta_d: K1Meta[n])
+int launch_block_events(ipcfp_ctx* ctx, hipStream_t stream, const uint8_t* arena, const void* meta_d, uint32_t n,
+                        const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, BlockRec* brecs_d,
+                        EventRec* erecs_d, uint32_t cap_events, uint32_t* pool_used_d);
 int launch_count_from_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
                             const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, const EventTableView& table,
                             uint32_t* counts_d, unsigned long long* err_d);

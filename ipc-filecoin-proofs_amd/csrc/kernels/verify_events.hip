@@ -13,6 +13,7 @@
 #include "events_dev.h"
 #include "exec_order.h"
 #include "launch.h"
+#include "verify_dev.h"
 
 namespace ipcfp {
 
@@ -123,6 +124,7 @@ __device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtx
 }
 
 __global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
+    IPCFP_LATENCY_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     const uint32_t t = blockIdx.x >> 1;
     if (t >= n) return;
@@ -226,6 +228,7 @@ __device__ __forceinline__ void exec_roots_body(const WitnessView& w, const Tips
 __global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx,
                                                    AmtRootSpec* __restrict__ roots,
                                                    unsigned long long* __restrict__ err, int verify_txmeta) {
+    IPCFP_LATENCY_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     exec_roots_body(w, ctx, roots, err, verify_txmeta, blockIdx.x, lds);
 }
@@ -242,6 +245,7 @@ struct PrepareJob {
 constexpr uint32_t kPrepareSlots = 2 + kMaxParents;
 
 __global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, const PrepareJob* __restrict__ jobs, uint32_t n_jobs) {
+    IPCFP_LATENCY_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(256) void k_exec_keys(WitnessView w, const LeafRef*
 // A slot is one u64: fingerprint (low half of the key's 64-bit hash) in the high word, raw position in the low
 // word.  A probe compares fingerprints first and reads the 40-byte key behind a slot only when they agree — at load
 // 0.5 half of all inserts pass an occupied slot, and each of those used to be a random 40-byte read.
-constexpr unsigned long long kEmptySlot64 = ~0ULL;
 
 __global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ keys, uint32_t n,
                                                      unsigned long long* __restrict__ slots, uint32_t mask) {
+    IPCFP_LATENCY_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const CidKey key = keys[i];
@@ -291,22 +295,11 @@ __global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ 
     }
 }
 
-__device__ __forceinline__ uint32_t exec_find(const unsigned long long* slots, uint32_t mask, const CidKey* keys,
-                                              const CidKey& key) {
-    const uint64_t h = cid_hash64(key);
-    uint32_t s = uint32_t(h >> 32) & mask;
-    for (;;) {
-        const unsigned long long cur = slots[s];
-        if (cur == kEmptySlot64) return kNoBlock;
-        if (uint32_t(cur >> 32) == uint32_t(h) && cid_equal(keys[uint32_t(cur)], key)) return uint32_t(cur);
-        s = (s + 1) & mask;
-    }
-}
-
 // stage 4: first[i] = 1 iff position i is the first occurrence of its CID (`if seen.insert(*c) { out.push(*c) }`)
 __global__ __launch_bounds__(256) void k_exec_first(const CidKey* __restrict__ keys, uint32_t n,
                                                     const unsigned long long* __restrict__ slots, uint32_t mask,
                                                     uint32_t* __restrict__ first) {
+    IPCFP_LATENCY_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const CidKey key = keys[i];
@@ -338,77 +331,17 @@ __global__ __launch_bounds__(256) void k_exec_compact(const CidKey* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// one proof per lane
+// one proof per lane (the checks every route shares live in verify_dev.h)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ bool ev_trusted(const ipcfp_trust_policy_t& t, long long epoch) {
-    if (t.kind == 0) return true;
-    if (t.ec_chain_empty) return false;
-    return epoch >= t.min_epoch && epoch <= t.max_epoch;
-}
-
-// verify_event_data_matches (+ the built-in check_event) on a tabulated event: bytes at known addresses
-__device__ __forceinline__ bool bytes_equal_global(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t n) {
-    uint64_t diff = 0;
-    uint32_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t x, y;
-        __builtin_memcpy(&x, a + i, 8);
-        __builtin_memcpy(&y, b + i, 8);
-        diff |= x ^ y;
-    }
-    for (; i < n; ++i) diff |= uint64_t(a[i] ^ b[i]);
-    return diff == 0;
-}
-
-__device__ __forceinline__ uint32_t verify_event_record(const WitnessView& w, const EventClaimPacked& c, const EventRec& e,
-                                                        const uint8_t* __restrict__ blob, const ipcfp_event_filter_t& filter,
-                                                        bool has_filter) {
-    if (e.emitter != c.emitter) return IPCFP_ST_FALSE_EMITTER;                                                // :262
-    if (!(e.base_flags & kEvIsLog)) return IPCFP_ST_FALSE_NOT_EVM_LOG;                                        // :267
-    const uint32_t nt = uint32_t(e.base_flags >> kEvTopicShift) & 0xffu;
-    if (nt != c.n_topics) return IPCFP_ST_FALSE_TOPIC_COUNT;                                                  // :272
-    const uint8_t* item = w.arena + (e.base_flags & kEvBaseMask);
-    const bool case_a = (e.base_flags & kEvCaseA) != 0;
-    for (uint32_t i = 0; i < nt; ++i) {                                                                       // :276-281
-        const uint8_t* claimed = blob + c.topics_off + 33u * i;
-        if (!claimed[0]) return IPCFP_ST_FALSE_TOPIC;  // the claimed string is not "0x" + 64 hex digits
-        const uint32_t rel = case_a ? uint32_t(e.topic_rel[0]) + 32u * i : uint32_t(e.topic_rel[i & 3u]);
-        if (!bytes_equal_global(item + rel, claimed + 1, 32)) return IPCFP_ST_FALSE_TOPIC;
-    }
-    if (!(c.flags & EC_DATA_MATCHABLE) || c.data_len != e.data_len) return IPCFP_ST_FALSE_DATA;               // :284-287
-    if (!bytes_equal_global(item + e.data_rel, blob + c.data_off, c.data_len)) return IPCFP_ST_FALSE_DATA;
-    if (has_filter) {                                                                                         // :247-251
-        if (nt < 2) return IPCFP_ST_FALSE_FILTER;
-        const uint32_t r1 = case_a ? uint32_t(e.topic_rel[0]) + 32u : uint32_t(e.topic_rel[1]);
-        if (!bytes_equal_global(item + e.topic_rel[0], filter.topic0, 32) || !bytes_equal_global(item + r1, filter.topic1, 32))
-            return IPCFP_ST_FALSE_FILTER;
-    }
-    return IPCFP_ST_TRUE;
-}
-
 // `where` (nullable) receives the location of the StampedEvent the claim names once the proof has reached it
 // (block = 0xffffffff otherwise): a host `check_event` closure runs over those bytes (events/verifier.rs:247-251).
 __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const EventClaimPacked& c,
                                                      const TipsetCtxDev& tc, const uint8_t* __restrict__ blob,
                                                      const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t& filter,
                                                      bool has_filter, ValueLoc* where) {
-    // Step 1: verify_trust_anchors (events/verifier.rs:124-144)
-    if (!(tc.flags & TC_PARENTS_PARSED) || !(tc.flags & TC_CHILD_PARSED)) return IPCFP_ST_ERR_BAD_CLAIM;  // :130-131
-    if (!ev_trusted(trust, c.parent_epoch)) return IPCFP_ST_FALSE_UNTRUSTED_PARENT;                          // :134
-    if (!ev_trusted(trust, c.child_epoch)) return IPCFP_ST_FALSE_UNTRUSTED_CHILD;                            // :139
-    // Step 2: verify_header_consistency (:147-181)
-    if (tc.child_status != IPCFP_ST_TRUE) return tc.child_status;                                             // :155-158
-    if (!tc.parents_match) return IPCFP_ST_FALSE_PARENTS_MISMATCH;                                            // :161
-    if (tc.child_height != c.child_epoch) return IPCFP_ST_FALSE_CHILD_EPOCH;                                  // :166
-    if (tc.n_parents == 0) return IPCFP_ST_ERR_EMPTY_PARENTS;                                                 // :172 (panic)
-    if (tc.parent0_status != IPCFP_ST_TRUE) return tc.parent0_status;                                         // :171-174
-    if (tc.parent0_height != c.parent_epoch) return IPCFP_ST_FALSE_PARENT_EPOCH;                              // :176
-    // Step 3: verify_execution_order (:184-204)
-    if (tc.exec_status != IPCFP_ST_TRUE) return tc.exec_status;                                               // :190
-    if (!(c.flags & EC_MSG_PARSED)) return IPCFP_ST_ERR_BAD_CLAIM;                                            // :193
-    const uint32_t raw = tc.exec_slots ? exec_find(tc.exec_slots, tc.exec_mask, tc.exec_keys, c.message) : kNoBlock;
-    if (raw == kNoBlock) return IPCFP_ST_FALSE_MSG_NOT_IN_EXEC;                                               // :194
-    if (uint64_t(tc.exec_pos[raw]) != c.exec_index) return IPCFP_ST_FALSE_EXEC_INDEX;                         // :199
+    // Steps 1-3: trust anchors, header consistency, execution order (verify_dev.h)
+    const uint32_t pre = verify_event_prefix(c, tc, trust);
+    if (pre != IPCFP_ST_TRUE) return pre;
     // Step 4: verify_receipt_and_event (:207-254)
     uint32_t st;
     ValueLoc rloc;
@@ -417,18 +350,10 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
         // of a present index cannot fail and yields exactly this leaf                                        // :220-224
         const uint64_t slot = c.exec_index - tc.receipt_first;
         if (tc.receipt_recs) {
-            // ... and its events were tabulated (event_table.h): what `Amt::load(events_root)`, `get(event_index)`,
-            // extract_evm_log and the compares below observe is all in the records
-            const ReceiptRec rr = tc.receipt_recs[slot];
-            if (rr.kind == RK_NO_EVENTS) return IPCFP_ST_FALSE_NO_EVENTS_ROOT;                                // :229
-            if (rr.kind >= 64) return rr.kind;                                                                // :234 Err
-            if (rr.kind == RK_TABLE) {
-                if (c.event_index == ~0ULL) return IPCFP_ST_ERR;                                              // > MAX_INDEX
-                if (c.event_index >= 64 || !((rr.bitmap >> c.event_index) & 1ull)) return IPCFP_ST_FALSE_NO_EVENT;  // :237
-                const EventRec e = tc.event_recs[rr.first + __popcll(rr.bitmap & ((1ull << c.event_index) - 1ull))];
-                if (where) *where = ValueLoc{rr.block, uint32_t((e.base_flags & kEvBaseMask) - w.off[rr.block]), e.ev_len};
-                return verify_event_record(w, c, e, blob, filter, has_filter);
-            }
+            // ... and its events were tabulated (event_table.h): normally k_verify_events_table has settled the claim
+            bool settled;
+            const uint32_t ts = verify_event_from_table(w, c, tc, blob, filter, has_filter, where, settled);
+            if (settled) return ts;
         }
         const LeafRef l = tc.receipt_leaves[slot];
         rloc = ValueLoc{l.block, l.off, l.len};
@@ -475,21 +400,16 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
     return IPCFP_ST_TRUE;
 }
 
-// A packed claim that points outside the tipset table or the blob (only a caller of the packed entry points can
-// build one; the string lowering cannot) is answered with ERR_BAD_CLAIM instead of being followed.
-__device__ __forceinline__ bool claim_in_bounds(const EventClaimPacked& c, uint32_t n_ctxs, uint64_t blob_len) {
-    return c.context < n_ctxs && c.n_topics <= (1u << 20) && uint64_t(c.topics_off) + 33ull * c.n_topics <= blob_len &&
-           uint64_t(c.data_off) + c.data_len <= blob_len;
-}
-
 __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(WitnessView w, const EventClaimPacked* __restrict__ claims,
                                                        uint32_t n, const TipsetCtxDev* __restrict__ ctxs, uint32_t n_ctxs,
                                                        const uint8_t* __restrict__ blob, uint64_t blob_len,
                                                        ipcfp_trust_policy_t trust,
                                                        ipcfp_event_filter_t filter, int has_filter,
-                                                       uint8_t* __restrict__ status, ValueLoc* __restrict__ where) {
+                                                       uint8_t* __restrict__ status, ValueLoc* __restrict__ where,
+                                                       int pending_only) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (pending_only && status[t] != kStPending) return;  // settled from the event table (verify_table.hip)
     const EventClaimPacked& c = claims[t];
     ValueLoc loc{kNoBlock, 0, 0};
     uint32_t st = IPCFP_ST_ERR_BAD_CLAIM;
@@ -501,8 +421,16 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(Witness
 
 // exec_len of a context = the total of the first-occurrence scan, copied on the device so the host
 // never waits for it
-__global__ void k_set_exec_len(TipsetCtxDev* __restrict__ c, const uint64_t* __restrict__ total) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) c->exec_len = *total;
+// ... and the inverse of exec_pos: inv[execution index] = raw position of the message's first occurrence.  A claim
+// names (exec_index, message): `exec_keys[inv[exec_index]] == message` settles `position(message) == exec_index`
+// with two reads that run along with the claims instead of a hash probe (three reads somewhere in 60 MB).
+__global__ __launch_bounds__(256) void k_exec_finish(TipsetCtxDev* __restrict__ c, const uint64_t* __restrict__ total,
+                                                     const uint32_t* __restrict__ first, const uint32_t* __restrict__ pos,
+                                                     uint32_t n, uint32_t* __restrict__ inv) {
+    IPCFP_LATENCY_PRIO();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) c->exec_len = *total;
+    if (i < n && first[i]) inv[pos[i]] = i;
 }
 
 // ------------------------------ launchers -----------------------------------
@@ -514,8 +442,10 @@ int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs
     return IPCFP_OK;
 }
 
-int launch_set_exec_len(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d) {
-    hipLaunchKernelGGL(k_set_exec_len, dim3(1), dim3(64), 0, ctx->stream, ctx_d, total_d);
+int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d, const uint32_t* first_d,
+                       const uint32_t* pos_d, uint32_t n, uint32_t* inv_d) {
+    hipLaunchKernelGGL(k_exec_finish, dim3(n ? div_up(n, 256) : 1), dim3(256), 0, ctx->stream, ctx_d, total_d, first_d, pos_d,
+                       n, inv_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
@@ -561,14 +491,22 @@ int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const 
 int launch_verify_events(ipcfp_ctx* ctx, const WitnessView& w, const EventClaimPacked* claims_d, uint32_t n,
                          const TipsetCtxDev* ctxs_d, uint32_t n_ctxs, const uint8_t* blob_d, uint64_t blob_len,
                          const ipcfp_trust_policy_t& trust, const ipcfp_event_filter_t* filter, uint8_t* status_d,
-                         void* where_d) {
+                         void* where_d, bool tabulated) {
     if (n == 0) return IPCFP_OK;
     ipcfp_event_filter_t f{};
     if (filter) f = *filter;
     {
         ProfileScope prof(ctx, IPCFP_K_EVENT_VERIFY);
+        // claims whose receipt's events are tabulated are settled by a kernel that parses nothing; the general
+        // walker then only serves what that one left pending
+        if (tabulated) {
+            int rc = launch_verify_events_table(ctx, w, claims_d, n, ctxs_d, n_ctxs, blob_d, blob_len, trust, f, filter ? 1 : 0,
+                                                status_d, where_d);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(k_verify_events, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, claims_d, n, ctxs_d,
-                           n_ctxs, blob_d, blob_len, trust, f, filter ? 1 : 0, status_d, static_cast<ValueLoc*>(where_d));
+                           n_ctxs, blob_d, blob_len, trust, f, filter ? 1 : 0, status_d, static_cast<ValueLoc*>(where_d),
+                           tabulated ? 1 : 0);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

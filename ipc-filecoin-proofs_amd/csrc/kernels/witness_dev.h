@@ -11,6 +11,12 @@ namespace ipcfp {
 
 constexpr uint32_t kNoBlock = 0xffffffffu;
 
+// The kernels of the main stream are chains of short dependent steps, and they run beside K1 and the block-order
+// event parse (VALU-heavy, streams of their own).  With equal priority a wave of k_tipset_prepare gets every fourth
+// issue slot of its SIMD while K1 is resident (87 -> 250 us measured); raised issue priority keeps the chain at the
+// speed it has alone, and costs the throughput kernels nothing they can measure.
+#define IPCFP_LATENCY_PRIO() __builtin_amdgcn_s_setprio(2)
+
 struct WitnessView {
     const uint8_t* arena;    // every block on its own 128-byte line(s), + 256 B tail slack
     const uint64_t* off;     // n
@@ -22,6 +28,14 @@ struct WitnessView {
     // K8 recording: when non-null, every lookup of a CID present in the witness sets
     // bit `block id` (RecordingBlockStore::get, src/proofs/common/blockstore.rs:26-30)
     uint32_t* touched;
+};
+
+// One block in SCHEDULE order = arena order (blocks sorted by 128-byte line count, each class contiguous): what K1
+// and the block-order event parser read, coalesced.
+struct K1Meta {
+    uint64_t off;   // arena offset of the block
+    uint32_t len;
+    uint32_t id;    // block id (position in the caller's tables)
 };
 
 struct CidKey {
