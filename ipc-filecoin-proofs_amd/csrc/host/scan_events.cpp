@@ -31,10 +31,10 @@ int block_table_prefetch(ipcfp_ctx* ctx, ipcfp_witness* w, const ipcfp_event_fil
         cap = std::min<uint64_t>(cap, 0xfffffff0ull);
         IPCFP_HIP(ctx, w->bt_blocks.alloc_unpooled(n));
         IPCFP_HIP(ctx, w->bt_events.alloc_unpooled(cap));
-        IPCFP_HIP(ctx, w->bt_used.alloc_unpooled(1));
+        IPCFP_HIP(ctx, w->bt_used.alloc_unpooled(size_t(kPoolParts) * kPoolCounterStride));
     }
     hipStream_t s = ctx->stream_aux;
-    IPCFP_HIP(ctx, hipMemsetAsync(w->bt_used.p, 0, 4, s));
+    IPCFP_HIP(ctx, hipMemsetAsync(w->bt_used.p, 0, size_t(kPoolParts) * kPoolCounterStride * 4, s));
     w->bt_has_filter = filter != nullptr;
     w->bt_filter = ScanParams{};
     if (filter) w->bt_filter = ScanParams{*filter, has_actor ? actor : 0, has_actor ? 1u : 0u, 0};

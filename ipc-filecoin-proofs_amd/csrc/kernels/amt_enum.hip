@@ -21,7 +21,6 @@ __global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootS
                                                    uint32_t* __restrict__ max_height,
                                                    unsigned long long* __restrict__ err,
                                                    uint64_t* __restrict__ root_info /* n × {height|bw<<32, count} */) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const AmtRootSpec spec = roots[t];
@@ -256,7 +255,6 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
                                                      const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t level,
                                                      uint32_t n_next, int vkind, EnumNode* __restrict__ next,
                                                      uint32_t* __restrict__ anomaly) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_next) return;
     // which root, and where its entries start on both levels
@@ -355,7 +353,6 @@ __global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumN
                                                       const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t n_nodes,
                                                       int vkind, LeafRef* __restrict__ leaves, uint32_t* __restrict__ anomaly,
                                                       CidKey* __restrict__ keys_out) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_nodes) return;
     uint32_t r = 0, node_off0 = 0;

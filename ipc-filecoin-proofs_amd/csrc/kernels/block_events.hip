@@ -65,10 +65,10 @@ __global__ __launch_bounds__(64) void k_block_events(const uint8_t* __restrict__
     const uint64_t prev_end = (uint64_t(uint32_t(__shfl_up(uint32_t(my_end >> 32), 1, 64))) << 32) |
                               uint32_t(__shfl_up(uint32_t(my_end), 1, 64));
     const bool follows = lane > 0 && prev_end == m.off;
-    // what a batch must hold of this block when it is the last one: its bytes in whole chunks plus one chunk of the
-    // reader's window read-ahead (the last block's line padding is not needed; the arena's tail slack covers the read)
-    const uint32_t tail = ((m.len + 15u) & ~15u) + 16u;
-    const bool stageable = live && (m.off & 127ull) == 0 && m.len <= kStageChunks * 16u - 16u;
+    // what a batch must hold of this block when it is the last one: its bytes in whole chunks plus two chunks of the
+    // reader's read-ahead (the last block's line padding is not needed; the arena's tail slack covers the read)
+    const uint32_t tail = ((m.len + 15u) & ~15u) + 32u;
+    const bool stageable = live && (m.off & 127ull) == 0 && m.len <= kStageChunks * 16u - 32u;
     BlockRec br{RK_WALK, 0, 0};
     uint64_t todo = __ballot(stageable);
     while (todo) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void k_block_events(const uint8_t* __restrict__
         // ---- parse out of LDS (block_events_body.h) ----
         Rd r;
         r.init((lds_bytes_t)(stage) + (mine ? uint32_t(rel64) : 0u), mine ? m.len : 0u);
-        block_events_parse(r, mine, m.off, sp, count_matches, erecs, cap_events, pool_used, lane, br);
+        block_events_parse(r, mine, m.off, sp, count_matches, erecs, cap_events, pool_parts(n), pool_used, blockIdx.x, lane, br);
         todo &= ~(((stop < 64u ? (1ull << stop) : 0ull) - 1ull) & ~((1ull << first) - 1ull));
         __syncthreads();  // the next batch overwrites the stage
     }
@@ -126,7 +126,7 @@ int launch_block_events(ipcfp_ctx* ctx, hipStream_t stream, const uint8_t* arena
     if (filter) sp = ScanParams{*filter, actor, has_actor ? 1u : 0u, 0};
     static const int mode = [] {
         const char* e = std::getenv("IPCFP_BLOCK_EVENTS_MODE");
-        return e ? std::atoi(e) : 0;
+        return e ? std::atoi(e) : 2;
     }();
     static const uint32_t stage_chunks = [] {
         const char* e = std::getenv("IPCFP_BLOCK_STAGE_KB");

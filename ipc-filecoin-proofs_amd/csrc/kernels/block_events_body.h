@@ -10,8 +10,9 @@ namespace ipcfp {
 // EVERY lane of the wavefront calls this (the record reservation is a wave-level prefix sum); the lanes with `mine`
 // parse the block their reader sits on.  On success br becomes RK_TABLE; it is left alone otherwise (RK_WALK).
 __device__ __forceinline__ void block_events_parse(Rd& r, bool mine, uint64_t arena_off, const ScanParams& sp, int count_matches,
-                                                   EventRec* __restrict__ erecs, uint32_t cap_events,
-                                                   uint32_t* __restrict__ pool_used, uint32_t lane, BlockRec& br) {
+                                                   EventRec* __restrict__ erecs, uint32_t cap_events, uint32_t n_parts,
+                                                   uint32_t* __restrict__ pool_used, uint32_t wave_no, uint32_t lane,
+                                                   BlockRec& br) {
     // ---- header first, so the record segment can be reserved before the events are read ----
     uint32_t nv = 0;
     uint64_t bits = 0;
@@ -52,10 +53,12 @@ __device__ __forceinline__ void block_events_parse(Rd& r, bool mine, uint64_t ar
         }
         const uint32_t wave_total = __shfl(incl, 63, 64);
         uint32_t base = 0;
-        if (lane == 63 && wave_total) base = atomicAdd(pool_used, wave_total);
+        const uint32_t part = wave_no % n_parts, part_cap = cap_events / n_parts;
+        if (lane == 63 && wave_total) base = atomicAdd(pool_used + part * kPoolCounterStride, wave_total);
         base = __shfl(base, 63, 64);
         rec_first = base + incl - want;
-        if (table && uint64_t(rec_first) + nv > cap_events) table = false;  // pool exhausted: the receipt walks
+        if (table && uint64_t(rec_first) + nv > part_cap) table = false;  // partition exhausted: the receipt walks
+        rec_first += part * part_cap;
     }
     if (table) {
         // ---- the events, each decoded once (the decode IS the per-value type check of Amt::load) ----

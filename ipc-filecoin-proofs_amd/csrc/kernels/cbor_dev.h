@@ -212,10 +212,24 @@ struct Rd {
     // what it costs is instructions — ≈10 k VALU per wavefront of 64 receipts in k_scan_pass1 / k_event_table, which
     // is what those kernels were bound by (profiles/r01_final_pmc.txt: 15 % of the wave cycles wait for memory).
     __device__ __forceinline__ uint32_t at(uint32_t i) { return p[i]; }
+    // Eight bytes at any offset = the two ALIGNED words around them (one ds_read2_b64), funnel-shifted.  gfx950 does
+    // serve an unaligned ds_read_b64, but by replaying it: SQ_LDS_UNALIGNED_STALL was 6x the LDS instruction cycles
+    // of k_block_events with the one-instruction form (profiles/r02_pmc_block_events.txt).
     __device__ __forceinline__ uint64_t peek64(uint32_t i) {
-        uint64_t v;
-        __builtin_memcpy(&v, p + i, 8);
-        return v;
+        const uint32_t a = uint32_t(uintptr_t(p + i));
+        const IPCFP_RD_AS uint64_t* q = (const IPCFP_RD_AS uint64_t*)(uintptr_t(a & ~7u));
+        const uint64_t lo = q[0], hi = q[1];
+        const uint32_t sh = (a & 7u) * 8u;
+        return (lo >> sh) | ((hi << 1) << (63u - sh));
+    }
+    // sixteen bytes at any offset as two words: three aligned words
+    __device__ __forceinline__ void peek128(uint32_t i, uint64_t& w0, uint64_t& w1) {
+        const uint32_t a = uint32_t(uintptr_t(p + i));
+        const IPCFP_RD_AS uint64_t* q = (const IPCFP_RD_AS uint64_t*)(uintptr_t(a & ~7u));
+        const uint64_t q0 = q[0], q1 = q[1], q2 = q[2];
+        const uint32_t sh = (a & 7u) * 8u;
+        w0 = (q0 >> sh) | ((q1 << 1) << (63u - sh));
+        w1 = (q1 >> sh) | ((q2 << 1) << (63u - sh));
     }
 #else
     // byte i of the item (i < n, or inside the block's padded tail)
@@ -256,6 +270,10 @@ struct Rd {
         keep(w);
         // (second << 1) << (63 - sh) is second << (64 - sh), and 0 for sh == 0: no branch on sh
         return (first >> sh) | ((second << 1) << (63u - sh));
+    }
+    __device__ __forceinline__ void peek128(uint32_t i, uint64_t& w0, uint64_t& w1) {
+        w0 = peek64(i);
+        w1 = peek64(i + 8u);
     }
 #endif
     // the CID bytes [off, off+len) as a witness key (len ≤ 40): five unaligned words, tail masked
@@ -316,6 +334,31 @@ struct Rd {
     }
 
     // item header → major type, argument
+#if IPCFP_RD_LDS
+    // In LDS there is nothing to protect a failed reader from: the fetch is clamped into the item and the outcome is
+    // selected, so that the whole header decode is straight-line code — a lane whose reader has failed, or sits on
+    // another kind of item, costs its wavefront no branch.  Same results as the version below.
+    __device__ __forceinline__ void head(uint32_t& major, uint64_t& arg) {
+        const bool in = pos < n;
+        const uint32_t at_pos = in ? pos : 0u;
+        const uint64_t raw = peek64(at_pos);
+        const uint32_t b = uint32_t(raw) & 0xffu;
+        const uint32_t m = b >> 5, ai = b & 31u;
+        const bool imm = ai < 24;
+        const uint32_t nb = imm ? 0u : (1u << ((ai - 24u) & 3u));
+        bool bad = !in || ai > 27;
+        bad |= m == 7 && (imm ? !(ai >= 20 && ai <= 22) : ai != 27);
+        bad |= in && nb > n - at_pos - 1;
+        uint64_t be = __builtin_bswap64(raw >> 8);
+        be |= nb == 8 ? uint64_t(at(at_pos + 8)) : 0ull;  // (reads inside the stage: the item plus its slack)
+        const uint64_t v = imm ? uint64_t(ai) : (nb == 8 ? be : (be >> ((64u - 8u * nb) & 63u)));
+        const bool good = !err && !bad;
+        err = err ? err : (bad ? uint32_t(IPCFP_ST_ERR_DECODE) : 0u);
+        pos += good ? 1u + nb : 0u;
+        major = good ? m : 8u;
+        arg = good ? v : 0ull;
+    }
+#else
     __device__ __forceinline__ void head(uint32_t& major, uint64_t& arg) {
         major = 8;  // invalid
         arg = 0;
@@ -344,6 +387,7 @@ struct Rd {
         major = m;
         arg = v;
     }
+#endif
 
     __device__ __forceinline__ uint64_t read_uint() {
         uint32_t m;
@@ -383,10 +427,15 @@ struct Rd {
     // UTF-8 validity of the text at [off, off+len): short ASCII keys ("t1", "d", "topics", "root" …)
     // are settled from the window; anything else takes the out-of-line validator.
     __device__ __forceinline__ bool text_ok(uint32_t off, uint32_t len) {
-        if (len <= 8) {
+        if (len <= 8) {  // all ASCII?
+#if IPCFP_RD_LDS
+            const uint64_t m = len == 8 ? ~0ull : ((1ull << (8u * len)) - 1ull);  // one fetch, the rest masked off
+            if (len == 0 || (peek64(off) & m & 0x8080808080808080ull) == 0) return true;
+#else
             uint32_t hi = 0;
             for (uint32_t i = 0; i < len; ++i) hi |= at(off + i);
             if (hi < 0x80) return true;
+#endif
         }
         return utf8_ok_bytes((const uint8_t*)(p + off), len);  // (an LDS reader hands out the generic address)
     }

@@ -31,6 +31,50 @@ struct EvmLogLoc {
     }
 };
 
+// One entry `[flags, key, codec, value]` in the shape FVM writes it, decoded from the 16 bytes at the reader's
+// position without a branch: 0x84, a one-byte flags uint, a text key of at most 6 ASCII bytes, a codec uint with an
+// immediate or one-byte argument, a byte string with a 1-3 byte header.  All of it is what the general decode below
+// accepts for these very bytes (same offsets, same lengths); any other spelling — a non-minimal integer, a longer or
+// non-ASCII key, a value that overruns the item — returns false with the reader untouched and the general decode
+// takes the entry (and names the error, if it is one).  An entry is five CBOR headers; decoded one by one they are
+// ≈400 instructions and two dozen branches per entry, which is what the event kernels were spending their time on.
+__device__ __forceinline__ bool decode_entry_fast(Rd& r, uint32_t& ko, uint32_t& kl, uint32_t& vo, uint32_t& vl) {
+    const uint32_t p0 = r.pos;
+    if (r.err || r.n - p0 < 6u || p0 > r.n) return false;  // (the shortest entry is 84 00 60 00 40)
+    uint64_t w0, w1;
+    r.peek128(p0, w0, w1);
+    const uint32_t b0 = uint32_t(w0) & 0xffu, b1 = uint32_t(w0 >> 8) & 0xffu, b2 = uint32_t(w0 >> 16) & 0xffu;
+    const uint32_t klen = b2 - 0x60u;                        // key length when b2 is a short text header
+    bool ok = b0 == 0x84u && b1 < 0x18u && klen <= 6u;
+    const uint32_t kq = klen <= 6u ? klen : 0u;
+    const uint64_t kbytes = (w0 >> 24) | (w1 << 40);         // bytes 3..10
+    const uint64_t kmask = (1ull << (8u * kq)) - 1ull;
+    ok = ok && (kbytes & kmask & 0x8080808080808080ull) == 0;  // ASCII ⇒ valid UTF-8
+    const uint32_t c = 3u + kq;                              // offset of the codec header: 3..9
+    const uint32_t c_lo = c < 8u ? c : 7u, c_hi = c < 8u ? 0u : c - 8u;  // (both arms are computed: keep the shifts defined)
+    const uint64_t rest = c < 8u ? ((w0 >> (8u * c_lo)) | ((w1 << 1) << (63u - 8u * c_lo))) : (w1 >> (8u * c_hi));  // bytes c..
+    const uint32_t r0 = uint32_t(rest) & 0xffu;
+    const uint32_t cl = r0 < 0x18u ? 1u : 2u;
+    ok = ok && r0 <= 0x18u;
+    const uint64_t v = rest >> (8u * cl);
+    const uint32_t vb = uint32_t(v) & 0xffu;
+    const bool v_imm = vb >= 0x40u && vb <= 0x57u, v_1 = vb == 0x58u, v_2 = vb == 0x59u;
+    ok = ok && (v_imm || v_1 || v_2);
+    const uint32_t hl = v_imm ? 1u : (v_1 ? 2u : 3u);
+    const uint32_t len1 = uint32_t(v >> 8) & 0xffu;
+    const uint32_t len2 = (len1 << 8) | (uint32_t(v >> 16) & 0xffu);  // big-endian u16
+    const uint32_t len = v_imm ? vb - 0x40u : (v_1 ? len1 : len2);
+    const uint32_t value_at = p0 + c + cl + hl;
+    ok = ok && value_at <= r.n && len <= r.n - value_at;
+    if (!ok) return false;
+    ko = p0 + 3u;
+    kl = kq;
+    vo = value_at;
+    vl = len;
+    r.pos = value_at + len;
+    return true;
+}
+
 // Decode one StampedEvent `[emitter, [[flags, key, codec, value]…]]` located at r (already
 // type-checked by the AMT walk) and extract the EVM log view.  Offsets are relative to r.p.
 __device__ __forceinline__ void decode_event_log(Rd& r, uint64_t& emitter, EvmLogLoc& log) {
@@ -41,26 +85,28 @@ __device__ __forceinline__ void decode_event_log(Rd& r, uint64_t& emitter, EvmLo
     const uint64_t ne = r.read_array();
     for (uint64_t i = 0; i < ne && r.ok(); ++i) {
         uint32_t ko, kl, vo, vl;
-        r.expect_array(4);
-        (void)r.read_uint();
-        r.read_text(ko, kl);
-        (void)r.read_uint();
-        r.read_bytes(vo, vl);
-        if (!r.ok()) break;
-        // keys that matter are at most 6 bytes: fetch them once
-        uint32_t k[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) k[q] = uint32_t(q) < kl ? r.at(ko + q) : 0u;
+        if (!decode_entry_fast(r, ko, kl, vo, vl)) {
+            r.expect_array(4);
+            (void)r.read_uint();
+            r.read_text(ko, kl);
+            (void)r.read_uint();
+            r.read_bytes(vo, vl);
+            if (!r.ok()) break;
+        }
+        // keys that matter are at most 6 bytes: ONE fetch, compared as little-endian words; every outcome is a
+        // select (the lanes of a wavefront sit on different keys: a branch per key would run them all)
+        const uint64_t kw = kl <= 6 ? (r.peek64(ko) & ((1ull << (8u * (kl & 7u))) - 1ull)) : 0ull;
         const ByteRange v{vo, vl, true};
-        if (kl == 1 && k[0] == 'd') d = v;
-        else if (kl == 2 && k[0] == 't' && k[1] >= '1' && k[1] <= '4') {
-            // t[k[1]-'1'] without dynamic register indexing
-            const uint32_t which = k[1] - '1';
+        const bool is_d = kl == 1 && kw == 0x64ull;                                   // "d"
+        const bool is_data = kl == 4 && kw == 0x61746164ull;                          // "data"
+        const bool is_topics = kl == 6 && kw == 0x736369706f74ull;                    // "topics"
+        const uint32_t digit = uint32_t(kw >> 8) & 0xffu;
+        const bool is_t = kl == 2 && (kw & 0xffull) == 0x74ull && digit >= '1' && digit <= '4';  // "t1".."t4"
+        d = is_d ? v : d;
+        data = is_data ? v : data;
+        topics = is_topics ? v : topics;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (which == uint32_t(q)) t[q] = v;
-        } else if (kl == 4 && k[0] == 'd' && k[1] == 'a' && k[2] == 't' && k[3] == 'a') data = v;
-        else if (kl == 6 && k[0] == 't' && k[1] == 'o' && k[2] == 'p' && k[3] == 'i' && k[4] == 'c' && k[5] == 's') topics = v;
+        for (int q = 0; q < 4; ++q) t[q] = (is_t && digit == uint32_t('1' + q)) ? v : t[q];
     }
     log.is_log = false;
     log.case_a = false;

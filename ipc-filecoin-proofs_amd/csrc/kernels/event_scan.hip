@@ -209,7 +209,6 @@ __global__ __launch_bounds__(256, 2) void k_scan_pass2(WitnessView w, CidKey rec
                                                     EventMatch* __restrict__ matches, uint64_t matches_cap,
                                                     uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base,
                                                     const ReceiptRec* __restrict__ skip_tabulated) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool recording = w.touched != nullptr;
     if (t == 0 && recording) {  // `Amtv0::load(&receipts_root, &rec_receipts)` records the root even without matches (:195-196)
@@ -290,7 +289,6 @@ __global__ __launch_bounds__(256) void k_receipt_events(WitnessView w, const Lea
                                                         int count_matches, const BlockRec* __restrict__ brecs,
                                                         ReceiptRec* __restrict__ rrecs, uint32_t* __restrict__ counts,
                                                         unsigned long long* __restrict__ err) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     ReceiptRec rr{RK_NO_EVENTS, 0, 0, kNoBlock, 0};
@@ -403,7 +401,6 @@ __global__ __launch_bounds__(256) void k_scan_pass2_table(WitnessView w, const L
                                                           const uint32_t* __restrict__ offsets,
                                                           EventMatch* __restrict__ matches, uint64_t matches_cap,
                                                           uint8_t* __restrict__ has_match, uint64_t has_cap, uint64_t has_base) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t c = counts[t];

@@ -14,6 +14,8 @@
 // (FVM writes bit width 5) holding events of less than 64 KB.  Anything else is marked RK_WALK and takes the
 // general walkers (event_scan.hip, walk_dev.h), so outcomes never depend on the table.
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 
 #include "ipcfp.h"
@@ -65,6 +67,16 @@ struct BlockRec {
     uint64_t bitmap;
 };
 static_assert(sizeof(BlockRec) == 16, "record layout");
+
+// The EventRec pool is cut into kPoolParts equal partitions, each with its own fill counter on its own 128-byte line:
+// a wavefront reserves the records of its blocks with ONE atomic on the counter of partition (wavefront number mod
+// kPoolParts).  One counter for the whole pool made every wavefront of the chip wait in line at a single L2 address.
+constexpr uint32_t kPoolParts = 256;  // at most; a small witness uses one partition per wavefront (pool_parts below)
+__host__ __device__ inline uint32_t pool_parts(uint32_t n_blocks) {
+    const uint32_t waves = (n_blocks + 63u) / 64u;
+    return waves < 1u ? 1u : (waves > kPoolParts ? kPoolParts : waves);
+}
+constexpr uint32_t kPoolCounterStride = 32;  // uint32 words between two counters
 
 // filter of one scan (EventMatcher + the optional emitter filter, src/proofs/events/generator.rs:25-40,220-224)
 struct ScanParams {

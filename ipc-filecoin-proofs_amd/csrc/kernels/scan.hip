@@ -11,7 +11,6 @@ namespace ipcfp {
 
 __global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t n,
                                                         uint64_t* __restrict__ tile_sums) {
-    IPCFP_LATENCY_PRIO();
     __shared__ uint64_t smem[17];
     const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
     uint64_t s = 0;
@@ -25,7 +24,6 @@ __global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* __restri
 
 __global__ __launch_bounds__(1024) void k_scan_tiles_u64(uint64_t* __restrict__ tile_sums, uint32_t ntiles,
                                                          uint64_t* __restrict__ total_out) {
-    IPCFP_LATENCY_PRIO();
     __shared__ uint64_t smem[17];
     uint64_t carry = 0;
     for (uint32_t base = 0; base < ntiles; base += 1024) {
@@ -42,7 +40,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles_u64(uint64_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
                                                     const uint64_t* __restrict__ tile_base,
                                                     uint32_t* __restrict__ out) {
-    IPCFP_LATENCY_PRIO();
     __shared__ uint64_t smem[17];
     const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
     uint32_t r[4];
@@ -64,7 +61,6 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 // n ≤ 4096: the whole scan in one workgroup, one launch (most tree levels are this small)
 __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict__ in, uint32_t n,
                                                      uint32_t* __restrict__ out, uint64_t* __restrict__ total_out) {
-    IPCFP_LATENCY_PRIO();
     __shared__ uint64_t smem[17];
     const uint32_t base = threadIdx.x * 4u;
     uint32_t r[4];

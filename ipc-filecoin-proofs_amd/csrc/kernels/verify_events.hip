@@ -124,7 +124,6 @@ __device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtx
 }
 
 __global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
-    IPCFP_LATENCY_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     const uint32_t t = blockIdx.x >> 1;
     if (t >= n) return;
@@ -228,7 +227,6 @@ __device__ __forceinline__ void exec_roots_body(const WitnessView& w, const Tips
 __global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx,
                                                    AmtRootSpec* __restrict__ roots,
                                                    unsigned long long* __restrict__ err, int verify_txmeta) {
-    IPCFP_LATENCY_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     exec_roots_body(w, ctx, roots, err, verify_txmeta, blockIdx.x, lds);
 }
@@ -245,7 +243,6 @@ struct PrepareJob {
 constexpr uint32_t kPrepareSlots = 2 + kMaxParents;
 
 __global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, const PrepareJob* __restrict__ jobs, uint32_t n_jobs) {
-    IPCFP_LATENCY_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
@@ -274,7 +271,6 @@ __global__ __launch_bounds__(256) void k_exec_keys(WitnessView w, const LeafRef*
 
 __global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ keys, uint32_t n,
                                                      unsigned long long* __restrict__ slots, uint32_t mask) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const CidKey key = keys[i];
@@ -299,7 +295,6 @@ __global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ 
 __global__ __launch_bounds__(256) void k_exec_first(const CidKey* __restrict__ keys, uint32_t n,
                                                     const unsigned long long* __restrict__ slots, uint32_t mask,
                                                     uint32_t* __restrict__ first) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const CidKey key = keys[i];
@@ -427,7 +422,6 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_verify_events(Witness
 __global__ __launch_bounds__(256) void k_exec_finish(TipsetCtxDev* __restrict__ c, const uint64_t* __restrict__ total,
                                                      const uint32_t* __restrict__ first, const uint32_t* __restrict__ pos,
                                                      uint32_t n, uint32_t* __restrict__ inv) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) c->exec_len = *total;
     if (i < n && first[i]) inv[pos[i]] = i;

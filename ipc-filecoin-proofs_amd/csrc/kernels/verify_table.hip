@@ -28,7 +28,6 @@ __global__ __launch_bounds__(256) void k_verify_events_table(WitnessView w, cons
                                                              ipcfp_trust_policy_t trust, ipcfp_event_filter_t filter,
                                                              int has_filter, uint8_t* __restrict__ status,
                                                              ValueLoc* __restrict__ where) {
-    IPCFP_LATENCY_PRIO();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t < n;
     EventClaimPacked c;

@@ -11,11 +11,9 @@ namespace ipcfp {
 
 constexpr uint32_t kNoBlock = 0xffffffffu;
 
-// The kernels of the main stream are chains of short dependent steps, and they run beside K1 and the block-order
-// event parse (VALU-heavy, streams of their own).  With equal priority a wave of k_tipset_prepare gets every fourth
-// issue slot of its SIMD while K1 is resident (87 -> 250 us measured); raised issue priority keeps the chain at the
-// speed it has alone, and costs the throughput kernels nothing they can measure.
-#define IPCFP_LATENCY_PRIO() __builtin_amdgcn_s_setprio(2)
+// (Raising the issue priority of the main-stream kernels with s_setprio, so that K1 and the block-order event parse
+// beside them would not stretch their dependent steps, was measured and made every one of them SLOWER — AMT levels
+// 15 -> 30 us, k_tipset_prepare 87 -> 200 us, with or without a neighbour: profiles/r02_experiments.md.)
 
 struct WitnessView {
     const uint8_t* arena;    // every block on its own 128-byte line(s), + 256 B tail slack
