@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50_000, help="claims the 1-thread cpu_baseline leg verifies")
     ap.add_argument("--cpu-sample-mt", type=int, default=200_000, help="claims the all-cores cpu_baseline leg verifies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", default="K,V,S",
+                    help="order of the three calls of a tipset step after the index rebuild: K = CID check (K1, asynchronous), "
+                         "V = verify_event_proof batch (incl. execution order), S = event-filter scan")
     ap.add_argument("--t2-reps", type=int, default=3, help="repetitions of the PCIe-inclusive window (0 = skip)")
     args = ap.parse_args()
 
@@ -155,16 +158,22 @@ def main():
                            tip.n_blocks)
     scan_result = {}
 
+    order = args.order.split(",")
+
     def step():
         w.rebuild_index()                                                               # K4
-        st, _, m, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
-                                    want_touched=False, counts_only=True)               # K6
-        scan_result["status"], scan_result["matches"] = st, m
-        # K1 is independent of everything else in the step and VALU-bound: it is queued (own stream) where the
-        # main stream turns to the verify call's memory-bound kernels, not beside the block-order event parse
-        w.verify_cids_async()                                                           # K1
-        w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len,
-                                     t_status.data_ptr())                               # exec order + verify
+        for what in order:
+            if what == "S":
+                st, _, m, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                            want_touched=False, counts_only=True)       # K6
+                scan_result["status"], scan_result["matches"] = st, m
+            elif what == "K":
+                # K1 is independent of everything else in the step (own stream); where it is queued only decides
+                # which kernels it runs beside
+                w.verify_cids_async()                                                   # K1
+            elif what == "V":
+                w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len,
+                                             t_status.data_ptr())                       # exec order + verify
 
     def fence():
         if world > 1:

@@ -46,6 +46,11 @@ struct ipcfp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream_k1 = nullptr;  // K1 (VALU-bound hashing) runs beside the latency-bound walk kernels
     hipStream_t stream_aux = nullptr; // the block-order event parse (k_block_events) runs beside both
+    // the filter of the last scan on this context: a verify call that has to tabulate the events itself counts THIS
+    // filter's matches while it is at it, so that the scan that follows finds its PASS 1 done (a guess about a
+    // parameter, never about data: a different filter simply counts from the records)
+    ipcfp::ScanParams scan_hint{};
+    bool has_scan_hint = false;
     hipEvent_t aux_event = nullptr;   // main stream ← aux stream dependency (host/scan_events.cpp)
     std::string last_error;
     hipDeviceProp_t props{};
@@ -320,6 +325,12 @@ struct EventTableCached {
     DevBuf<ReceiptRec> receipts;  // one per enumerated receipt leaf
     const EventRec* events = nullptr;  // the witness's block table owns the records (ipcfp_witness::bt_events)
     uint64_t n = 0;
+    // match counts per receipt for the filter the block table was built with (has_counts), and the first failing
+    // receipt of the build (packed like an enumeration error; a device word, read back by whoever reports it)
+    DevBuf<uint32_t> counts;
+    bool has_counts = false;
+    ScanParams counts_filter{};
+    DevBuf<unsigned long long> err_word;
     EventTableView view() const { return EventTableView{receipts.p, events}; }
 };
 }  // namespace ipcfp

@@ -28,8 +28,11 @@ struct ExecState {
 // view every block the traversal loads is marked.
 // `host_len` = false leaves exec_len on the device only (ExecState::total) and saves a synchronisation.
 // `prepared` = true: stage 1 (ex.roots / ex.err) was already run by launch_tipset_prepare.
+// `extra` (with `prepared`): one more AMT — the receipts AMT, whose root launch_tipset_prepare left at
+// ex.roots[2 * n_parents] — enumerated in the same launches as the message AMTs (amt_enum.h).
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex, int verify_txmeta = 1, bool host_len = true, bool prepared = false);
+                     ExecState& ex, int verify_txmeta = 1, bool host_len = true, bool prepared = false,
+                     EnumExtra* extra = nullptr);
 // allocate ex.roots / ex.err for a context with n_parents parent blocks and reset the error word
 int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents);
 
@@ -48,12 +51,11 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
                        int has_actor, uint64_t actor, uint32_t* touched_d, ScanResult& out,
                        uint64_t cap_matches = kAllMatches);
 
-// The event table of the receipts AMT `root` (range = the witness's receipt range): the cached one, or a new one.
-// With `filter` the building pass also counts that filter's matches per receipt into counts_d (and reports the
-// first failing receipt through err_d, as PASS 1 does); *built tells whether it did.  `en` = the enumeration.
-int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en,
-                    const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, uint32_t* counts_d,
-                    unsigned long long* err_d, const EventTableCached** out, bool* built);
+// The event table of the receipts AMT `root` (range = the witness's receipt range): the cached one, or a new one
+// (k_receipt_events; the first failing receipt goes to the table's err_word).  `en` = the enumeration.
+int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en, const EventTableCached** out);
+// the table's per-receipt match counts when they were counted for exactly this filter, else null
+const uint32_t* event_table_counts(const EventTableCached* t, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor);
 
 // queue the block-order event parse of the witness on the aux stream unless its block table exists (scan_events.cpp)
 int block_table_prefetch(ipcfp_ctx* ctx, ipcfp_witness* w, const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor);

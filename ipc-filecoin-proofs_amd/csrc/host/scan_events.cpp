@@ -18,6 +18,14 @@ CidKey key_from_slot(const uint8_t* slot40);
 
 namespace ipcfp {
 
+static ScanParams scan_params_of(const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor) {
+    ScanParams p{};  // (zeroed, padding included: compared with memcmp)
+    p.filter = filter;
+    p.actor = has_actor ? actor : 0;
+    p.has_actor = has_actor ? 1u : 0u;
+    return p;
+}
+
 // Queue k_block_events for the witness (aux stream) unless its block table is already there.  `filter` (nullable):
 // the scan filter whose matches the pass counts per block.  Called at the START of a scan / verify call, before the
 // main stream's own work is queued, so that the parse runs beside the receipts enumeration (and K1).
@@ -37,7 +45,7 @@ int block_table_prefetch(ipcfp_ctx* ctx, ipcfp_witness* w, const ipcfp_event_fil
     IPCFP_HIP(ctx, hipMemsetAsync(w->bt_used.p, 0, size_t(kPoolParts) * kPoolCounterStride * 4, s));
     w->bt_has_filter = filter != nullptr;
     w->bt_filter = ScanParams{};
-    if (filter) w->bt_filter = ScanParams{*filter, has_actor ? actor : 0, has_actor ? 1u : 0u, 0};
+    if (filter) w->bt_filter = scan_params_of(*filter, has_actor, actor);
     int rc = launch_block_events(ctx, s, w->arena.p, w->k1_meta.p, uint32_t(n), filter, has_actor, actor, w->bt_blocks.p,
                                  w->bt_events.p, uint32_t(w->bt_events.count), w->bt_used.p);
     if (rc) return rc;
@@ -47,16 +55,19 @@ int block_table_prefetch(ipcfp_ctx* ctx, ipcfp_witness* w, const ipcfp_event_fil
     return IPCFP_OK;
 }
 
-int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en,
-                    const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, uint32_t* counts_d,
-                    unsigned long long* err_d, const EventTableCached** out, bool* built) {
-    *built = false;
+const uint32_t* event_table_counts(const EventTableCached* t, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor) {
+    if (!t || !t->has_counts) return nullptr;
+    const ScanParams want = scan_params_of(filter, has_actor, actor);
+    return std::memcmp(&want, &t->counts_filter, sizeof want) == 0 ? t->counts.p : nullptr;
+}
+
+int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en, const EventTableCached** out) {
     for (auto& t : w->table_cache)
         if (t->lo == w->receipt_lo && t->hi == w->receipt_hi && std::memcmp(t->root, root.w, 40) == 0) {
             *out = t.get();
             return IPCFP_OK;
         }
-    int rc = block_table_prefetch(ctx, w, filter, has_actor, actor);  // (queued long ago by the callers that care)
+    int rc = block_table_prefetch(ctx, w, nullptr, 0, 0);  // (queued long ago by the callers that care)
     if (rc) return rc;
     if (!w->bt_joined) {
         IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
@@ -70,23 +81,22 @@ int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const 
     t->events = w->bt_events.p;
     const uint64_t n = en->n;
     IPCFP_HIP(ctx, t->receipts.alloc(n));
-    DevBuf<unsigned long long> err_own;
-    if (!err_d) IPCFP_HIP(ctx, ctl_words(ctx, err_own, err_d, 1, true));
-    // the per-block match counts are this scan's iff the block pass ran with this very filter
-    bool counted = false;
-    if (filter && counts_d && w->bt_has_filter) {
-        const ScanParams want{*filter, has_actor ? actor : 0, has_actor ? 1u : 0u, 0};
-        counted = std::memcmp(&want, &w->bt_filter, sizeof want) == 0;
+    IPCFP_HIP(ctx, t->err_word.alloc(1));
+    IPCFP_HIP(ctx, hipMemsetAsync(t->err_word.p, 0xff, 8, ctx->stream));  // kNoEnumError
+    // the per-block match counts belong to the filter the block pass ran with: the receipts inherit them
+    t->has_counts = w->bt_has_filter;
+    if (t->has_counts) {
+        t->counts_filter = w->bt_filter;
+        IPCFP_HIP(ctx, t->counts.alloc(n));
     }
     const WitnessView view = witness_view(w);
     rc = launch_receipt_events(ctx, view, reinterpret_cast<const LeafRef*>(en->leaves.p), uint32_t(n),
-                               counted ? filter : nullptr, has_actor, actor, w->bt_blocks.p, t->receipts.p,
-                               counted ? counts_d : nullptr, err_d);
+                               t->has_counts ? &w->bt_filter.filter : nullptr, int(w->bt_filter.has_actor), w->bt_filter.actor,
+                               w->bt_blocks.p, t->receipts.p, t->has_counts ? t->counts.p : nullptr, t->err_word.p);
     if (rc) return rc;
-    *built = counted;
     *out = t.get();
     w->table_cache.push_back(std::move(t));
-    return IPCFP_OK;  // `err_own` returns to the pool; reuse is ordered on the stream
+    return IPCFP_OK;
 }
 
 // PASS 1 + prefix sum + PASS 2 on the device.  `touched_d` (nullable, device, words = ceil(n/32)) is
@@ -97,6 +107,8 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     // the block-order event parse starts now, beside everything below up to the table lookup
     int rc0 = block_table_prefetch(ctx, w, &filter, has_actor, actor);
     if (rc0) return rc0;
+    ctx->scan_hint = scan_params_of(filter, has_actor, actor);
+    ctx->has_scan_hint = true;
     DevBuf<unsigned long long> err_own;
     unsigned long long* err_p = nullptr;  // kNoEnumError
     IPCFP_HIP(ctx, ctl_words(ctx, err_own, err_p, 1, true));
@@ -135,13 +147,17 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     // PASS 1: with the events tabulated once per witness (kernels/event_table.h) — the first scan builds the table
     // and counts in one kernel, a later one (another filter) counts from the records
     EventTableView tview{nullptr, nullptr};
+    const uint32_t* cnt = counts.p;
+    unsigned long long e_table = kNoEnumError;
     if (w->use_event_table && n) {
         const EventTableCached* table = nullptr;
-        bool built = false;
-        rc = event_table_get(ctx, w, root, en, &filter, has_actor, actor, counts.p, err.p, &table, &built);
+        rc = event_table_get(ctx, w, root, en, &table);
         if (rc) return rc;
         tview = table->view();
-        if (!built) {
+        if (const uint32_t* c = event_table_counts(table, filter, has_actor, actor)) {
+            cnt = c;  // counted while the table was built: PASS 1 is done
+            IPCFP_HIP(ctx, d2h_small(ctx, &e_table, table->err_word.p, 8, ctx->stream));  // ... and so is its error report
+        } else {
             rc = launch_count_from_table(ctx, view, leaves, n, filter, has_actor, actor, tview, counts.p, err.p);
             if (rc) return rc;
         }
@@ -149,7 +165,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         rc = launch_scan_pass1(ctx, view, leaves, n, filter, has_actor, actor, counts.p, err.p);
         if (rc) return rc;
     }
-    rc = launch_scan_u32(ctx, counts.p, n, offsets.p, total.p, scratch.p);
+    rc = launch_scan_u32(ctx, cnt, n, offsets.p, total.p, scratch.p);
     if (rc) return rc;
     uint64_t nm = 0;
     unsigned long long e1 = kNoEnumError;
@@ -159,6 +175,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     if (cap_matches > (1ull << 26)) {  // unknown (kAllMatches) or too big to reserve blindly:
         // size the match list to the count — one more synchronisation
         IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+        if (e_table < e1) e1 = e_table;
         if (e1 != kNoEnumError) {
             out.status = enum_error_code(e1);
             return IPCFP_OK;
@@ -168,10 +185,11 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     IPCFP_HIP(ctx, out.matches.alloc(cap));
     WitnessView rec = view;
     rec.touched = touched_d;
-    rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, counts.p, offsets.p,
+    rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, cnt, offsets.p,
                            cap ? out.matches.p : nullptr, cap, out.has.p, n_idx, lo, tview.receipts ? &tview : nullptr);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // delivers nm / e1 when they were not waited for above
+    if (e_table < e1) e1 = e_table;
     if (e1 != kNoEnumError) {  // PASS 2 ran on a tipset PASS 1 rejected: its output is discarded
         out.status = enum_error_code(e1);
         return IPCFP_OK;

@@ -33,7 +33,7 @@ int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents) {
 
 // Reconstruct the execution order of the context stored at ctx_d (device) on the device.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex, int verify_txmeta, bool host_len, bool prepared) {
+                     ExecState& ex, int verify_txmeta, bool host_len, bool prepared, EnumExtra* extra) {
     int rc;
     if (!prepared) {
         rc = exec_state_prepare(ctx, ex, n_parents);
@@ -42,7 +42,8 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
         if (rc) return rc;
     }
     AmtEnumResult en;
-    rc = amt_enumerate(ctx, view, ex.roots.p, 2 * n_parents, VK_CID, ex.err.p, en, 0, ~0ULL, &ex.keys);
+    rc = amt_enumerate(ctx, view, ex.roots.p, 2 * n_parents, VK_CID, ex.err.p, en, 0, ~0ULL, &ex.keys,
+                       prepared ? extra : nullptr);
     if (rc) return rc;
     const unsigned long long e = en.error;  // read back by the enumerator: stage-1 errors and its own, merged
     ex.status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
@@ -83,7 +84,8 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
     const WitnessView view = witness_view(w);
     // when no scan has tabulated the events yet, the block-order parse runs beside the whole tipset prologue
-    int rc_bt = block_table_prefetch(ctx, w, nullptr, 0, 0);
+    int rc_bt = ctx->has_scan_hint ? block_table_prefetch(ctx, w, &ctx->scan_hint.filter, int(ctx->scan_hint.has_actor), ctx->scan_hint.actor)
+                                   : block_table_prefetch(ctx, w, nullptr, 0, 0);
     if (rc_bt) return rc_bt;
     DevBuf<TipsetCtxDev> tcs_d;
     IPCFP_HIP(ctx, tcs_d.alloc(tcs.size()));
@@ -118,10 +120,25 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     // the header facts come back with the first synchronisation below (the enumerator's), not one of their own
     std::vector<TipsetCtxDev> facts(tcs.size());
     IPCFP_HIP(ctx, d2h_small(ctx, facts.data(), tcs_d.p, tcs.size() * sizeof(TipsetCtxDev), ctx->stream));
+    // The receipts AMT of a context rides along with its message AMTs (same per-level launches, same two
+    // synchronisations) unless the witness already holds an enumeration of receipts — a scan that ran before.
+    bool receipts_known = false;
+    for (auto& e : w->enum_cache) receipts_known = receipts_known || (e->vkind == VK_RECEIPT && e->lo == w->receipt_lo && e->hi == w->receipt_hi);
+    std::vector<std::unique_ptr<AmtEnumResult>> rec_en(tcs.size());
+    std::vector<EnumExtra> rec_extra(tcs.size());
     bool synced = false;
     for (size_t k = 0; k < tcs.size(); ++k) {
         if (!execs[k]) continue;
-        rc = build_exec_order(ctx, view, tcs_d.p + k, tcs[k].n_parents, *execs[k], 1, /*host_len=*/false, /*prepared=*/true);
+        EnumExtra* extra = nullptr;
+        if (!receipts_known) {
+            rec_en[k].reset(new AmtEnumResult());
+            rec_extra[k].vkind = VK_RECEIPT;
+            rec_extra[k].lo = w->receipt_lo;
+            rec_extra[k].hi = w->receipt_hi;
+            rec_extra[k].out = rec_en[k].get();
+            extra = &rec_extra[k];
+        }
+        rc = build_exec_order(ctx, view, tcs_d.p + k, tcs[k].n_parents, *execs[k], 1, /*host_len=*/false, /*prepared=*/true, extra);
         if (rc) return rc;
         synced = true;
     }
@@ -153,7 +170,18 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
             tc.exec_inv = execs[k]->inv.p;
         }
         tc.exec_len = 0;  // patched on the device below
-        // receipts AMT of this context: enumerate once (shared with ipcfp_scan_events through the witness cache)
+        // receipts AMT of this context: enumerated once (shared with ipcfp_scan_events through the witness cache) —
+        // along with the message AMTs above when it was, else by itself here
+        if (rec_en[k] && rec_extra[k].done && tc.child_status == IPCFP_ST_TRUE) {
+            bool have = false;
+            for (auto& e : w->enum_cache)
+                have = have || (e->version == 0 && e->vkind == VK_RECEIPT && e->lo == w->receipt_lo && e->hi == w->receipt_hi &&
+                                std::memcmp(e->root, tc.receipts_root.w, 40) == 0);
+            if (!have) {
+                rc = enum_cache_put(ctx, w, tc.receipts_root, 0, VK_RECEIPT, w->receipt_lo, w->receipt_hi, *rec_en[k]);
+                if (rc) return rc;
+            }
+        }
         const EnumCached* rc_enum = nullptr;
         rc = amt_enumerate_cached(ctx, w, tc.receipts_root, 0, VK_RECEIPT, &rc_enum, w->receipt_lo, w->receipt_hi);
         if (rc) return rc;
@@ -164,8 +192,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
             // ... and their events tabulated once (shared with the scan through the witness cache)
             if (w->use_event_table && rc_enum->n) {
                 const EventTableCached* table = nullptr;
-                bool built = false;
-                rc = event_table_get(ctx, w, tc.receipts_root, rc_enum, nullptr, 0, 0, nullptr, nullptr, &table, &built);
+                rc = event_table_get(ctx, w, tc.receipts_root, rc_enum, &table);
                 if (rc) return rc;
                 tc.receipt_recs = table->receipts.p;
                 tc.event_recs = table->events;

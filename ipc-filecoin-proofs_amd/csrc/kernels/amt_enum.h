@@ -26,7 +26,8 @@ struct AmtRootSpec {
     uint32_t version;  // 0 | 3
     uint32_t seq;      // error-ordering sequence number of this AMT (ascending in traversal order)
     uint32_t skip;     // 1 ⇒ do not load (an earlier stage already failed for it)
-    uint32_t pad;
+    uint32_t kind_p1;  // 0: the value type of the call; else value type + 1 — the EXTRA root of amt_enumerate (below),
+                       // whose load failure is not an error of the call (it is then enumerated on its own)
 };
 
 // one frontier entry
@@ -73,13 +74,30 @@ struct AmtEnumResult {
 // subtrees that hold no index of the range are neither resolved nor loaded — their blocks live in another
 // shard's witness — while every node that is visited is validated completely.  Meant for ONE root.
 
+// One more AMT riding along with a call (dense fast path only): its spec is roots_d[n_roots], written by the caller
+// or by a kernel queued before; its values have their own type and index range and go to a result of their own.
+// `done` stays false when the fast path did not take it (not dense, failed to load, anomaly): the caller then
+// enumerates it by itself.  This is how the verify path walks the receipts AMT in the same launches as the
+// message AMTs of the execution order instead of in a second chain of per-level launches.
+struct EnumExtra {
+    int vkind = 0;
+    uint64_t lo = 0, hi = ~0ULL;
+    AmtEnumResult* out = nullptr;
+    bool done = false;
+};
+
 // Enumerate `n_roots` AMTs (device array `roots_d`) whose values have type `vkind`.
 // `err_d` is a device u64 initialised by the caller (kNoEnumError or earlier-stage errors); the
 // enumerator atomicMin's into it.  Synchronises the stream twice on the dense path (root shapes; anomaly flag
 // + error word), once more per level on the general path.
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
                   unsigned long long* err_d, AmtEnumResult& out, uint64_t lo = 0, uint64_t hi = ~0ULL,
-                  DevBuf<CidKey>* keys_out = nullptr);  // VK_CID on the dense path: the links as witness keys, no LeafRefs
+                  DevBuf<CidKey>* keys_out = nullptr,  // VK_CID on the dense path: the links as witness keys, no LeafRefs
+                  EnumExtra* extra = nullptr);
+
+// hand a finished enumeration of one AMT to the witness's cache (what amt_enumerate_cached would have produced)
+int enum_cache_put(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, int version, int vkind, uint64_t lo, uint64_t hi,
+                   AmtEnumResult& en);
 
 // Enumerate one AMT of the witness, or return the cached enumeration (owned by the witness; valid
 // until ipcfp_witness_rebuild_index).

@@ -29,9 +29,9 @@ __global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootS
     root_info[2 * t + 1] = 0;
     if (!spec.skip) {
         AmtRootInfo info;
-        const uint32_t st = amt_load(w, spec.root, int(spec.version), vkind, info);
+        const uint32_t st = amt_load(w, spec.root, int(spec.version), spec.kind_p1 ? int(spec.kind_p1) - 1 : vkind, info);
         if (st != IPCFP_ST_TRUE) {
-            enum_error(err, spec.seq, 0, st);
+            if (!spec.kind_p1) enum_error(err, spec.seq, 0, st);  // (the extra root: left to its own enumeration)
         } else {
             e.block = info.block;
             e.node_off = info.node_off;
@@ -229,6 +229,9 @@ struct DenseRoot {
     uint32_t height, bit_width;
     uint64_t count;
     uint64_t lo, hi;  // the indices to enumerate: [lo, hi) with lo < hi <= count, or (0, 0) for an empty tree
+    uint32_t vkind;   // value type of this tree
+    uint32_t out_sel; // where its values go: 0 = keys_out (links as witness keys), 1 = leaves, 2 = leaves of the extra root
+    uint64_t out_off; // ... from this element on
 };
 
 // nodes of `level` (node height) the whole tree has
@@ -351,20 +354,22 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
 // leaf level: one lane per leaf node validates it in one pass and writes its values' locations
 __global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumNode* __restrict__ cur,
                                                       const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t n_nodes,
-                                                      int vkind, LeafRef* __restrict__ leaves, uint32_t* __restrict__ anomaly,
-                                                      CidKey* __restrict__ keys_out) {
+                                                      LeafRef* __restrict__ leaves_main, uint32_t* __restrict__ anomaly,
+                                                      CidKey* __restrict__ keys_main, LeafRef* __restrict__ leaves_extra) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_nodes) return;
     uint32_t r = 0, node_off0 = 0;
-    uint64_t leaf_off = 0;
     DenseRoot dr = roots[0];
     uint64_t n_here = dense_nodes(dr, 0);
     while (t >= node_off0 + n_here) {
         node_off0 += uint32_t(n_here);
-        leaf_off += dr.hi - dr.lo;
         dr = roots[++r];
         n_here = dense_nodes(dr, 0);
     }
+    const uint64_t leaf_off = dr.out_off;
+    const int vkind = int(dr.vkind);
+    CidKey* const keys_out = dr.out_sel == 0 ? keys_main : nullptr;
+    LeafRef* const leaves = dr.out_sel == 1 ? leaves_main : (dr.out_sel == 2 ? leaves_extra : nullptr);
     const uint64_t p = dense_first(dr, 0) + (t - node_off0);  // absolute leaf-node number
     const EnumNode e = cur[t];
     if (e.block == kNoBlock) return;  // reported where the link failed to resolve
@@ -447,8 +452,14 @@ static uint64_t amt_span_host(uint32_t bw, uint64_t height) {
 }
 
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
-                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo, uint64_t hi, DevBuf<CidKey>* keys_out) {
+                  unsigned long long* err_d, AmtEnumResult& out, uint64_t lo, uint64_t hi, DevBuf<CidKey>* keys_out,
+                  EnumExtra* extra) {
     out.keys_written = false;
+    if (extra) {
+        extra->done = false;
+        if (!extra->out || n_roots == 0) extra = nullptr;
+    }
+    const uint32_t n_all = n_roots + (extra ? 1u : 0u);  // the extra root's spec is roots_d[n_roots]
     const EnumRange rg{lo, hi};
     const bool whole = lo == 0 && hi == ~0ULL;
     out.n_leaves = 0;
@@ -459,16 +470,16 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     DevBuf<EnumNode> cur, nxt;
     DevBuf<uint32_t> counts, offsets, small_own;
     DevBuf<uint64_t> scratch, total_d, root_info_own;
-    IPCFP_HIP(ctx, cur.alloc(n_roots));
+    IPCFP_HIP(ctx, cur.alloc(n_all));
     IPCFP_HIP(ctx, total_d.alloc(2));
     uint32_t* small = nullptr;      // [0] = max height; [2] = anomaly flag of the dense path
     uint64_t* root_info_d = nullptr;
     IPCFP_HIP(ctx, ctl_words(ctx, small_own, small, 4, false));
-    IPCFP_HIP(ctx, ctl_words(ctx, root_info_own, root_info_d, 2 * size_t(n_roots), false));
-    hipLaunchKernelGGL(k_enum_roots, dim3(div_up(n_roots, 64)), dim3(64), 0, ctx->stream, view, roots_d, n_roots, vkind,
+    IPCFP_HIP(ctx, ctl_words(ctx, root_info_own, root_info_d, 2 * size_t(n_all), false));
+    hipLaunchKernelGGL(k_enum_roots, dim3(div_up(n_all, 64)), dim3(64), 0, ctx->stream, view, roots_d, n_all, vkind,
                        cur.p, small, err_d, root_info_d);
     uint32_t max_height = 0;
-    std::vector<uint64_t> root_info(2 * size_t(n_roots));
+    std::vector<uint64_t> root_info(2 * size_t(n_all));
     IPCFP_HIP(ctx, ctl_read(ctx, &max_height, small, 4));
     IPCFP_HIP(ctx, ctl_read(ctx, root_info.data(), root_info_d, root_info.size() * 8));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
@@ -476,52 +487,74 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     // ---- dense fast path: the tree's shape follows from the roots; one kernel per level ----
     out.dense = false;
     {
-        std::vector<DenseRoot> dr(n_roots);
+        const bool want_keys = keys_out && vkind == VK_CID;
+        auto shape = [&](uint32_t i, uint64_t rlo, uint64_t rhi, DenseRoot& d) -> bool {  // false: not a dense candidate
+            if (root_info[2 * size_t(i)] == ~0ULL) return false;  // a dead root: let the general path sort it out
+            d.height = uint32_t(root_info[2 * size_t(i)]);
+            d.bit_width = uint32_t(root_info[2 * size_t(i)] >> 32);
+            d.count = root_info[2 * size_t(i) + 1];
+            if (d.count == 0 && d.height > 0) return false;  // empty tree with a tall root
+            if (d.count > amt_span_host(d.bit_width, d.height + 1)) return false;
+            d.lo = rlo < d.count ? rlo : d.count;
+            d.hi = rhi < d.count ? rhi : d.count;
+            if (d.count && d.lo >= d.hi) return false;  // nothing of this tree in the range
+            if (d.count == 0) d.lo = d.hi = 0;
+            return true;
+        };
+        std::vector<DenseRoot> dr(n_all);
         bool try_dense = true;
         uint64_t n_leaves = 0;
         for (uint32_t i = 0; i < n_roots && try_dense; ++i) {
-            if (root_info[2 * size_t(i)] == ~0ULL) try_dense = false;  // a dead root: let the general path sort it out
-            dr[i].height = uint32_t(root_info[2 * size_t(i)]);
-            dr[i].bit_width = uint32_t(root_info[2 * size_t(i)] >> 32);
-            dr[i].count = root_info[2 * size_t(i) + 1];
-            if (dr[i].count == 0 && dr[i].height > 0) try_dense = false;  // empty tree with a tall root
-            if (dr[i].count > amt_span_host(dr[i].bit_width, dr[i].height + 1)) try_dense = false;
-            dr[i].lo = lo < dr[i].count ? lo : dr[i].count;
-            dr[i].hi = hi < dr[i].count ? hi : dr[i].count;
-            if (dr[i].count && dr[i].lo >= dr[i].hi) try_dense = false;  // nothing of this tree in the range
-            if (dr[i].count == 0) dr[i].lo = dr[i].hi = 0;
+            try_dense = shape(i, lo, hi, dr[i]);
+            dr[i].vkind = uint32_t(vkind);
+            dr[i].out_sel = want_keys ? 0u : 1u;
+            dr[i].out_off = n_leaves;
             n_leaves += dr[i].hi - dr[i].lo;
+        }
+        // the extra root joins when it is a dense candidate itself; otherwise the call goes on without it
+        uint32_t n_use = n_roots;
+        uint64_t n_extra = 0;
+        if (extra && try_dense && shape(n_roots, extra->lo, extra->hi, dr[n_roots])) {
+            dr[n_roots].vkind = uint32_t(extra->vkind);
+            dr[n_roots].out_sel = 2u;
+            dr[n_roots].out_off = 0;
+            n_extra = dr[n_roots].hi - dr[n_roots].lo;
+            n_use = n_all;
+        }
+        if (try_dense) {  // the tallest of the roots in use (the device word also counts an extra root that stays out)
+            max_height = 0;
+            for (uint32_t i = 0; i < n_use; ++i) max_height = dr[i].height > max_height ? dr[i].height : max_height;
         }
         std::vector<uint64_t> n_level(max_height + 1, 0);
         for (uint32_t level = 0; level <= max_height && try_dense; ++level) {
-            for (uint32_t i = 0; i < n_roots; ++i) n_level[level] += dense_nodes(dr[i], level);
+            for (uint32_t i = 0; i < n_use; ++i) n_level[level] += dense_nodes(dr[i], level);
             try_dense = n_level[level] < 0x7fffffffULL;
         }
-        try_dense = try_dense && n_leaves < 0x7fffffffULL && n_level[max_height] == n_roots;
+        try_dense = try_dense && n_leaves < 0x7fffffffULL && n_extra < 0x7fffffffULL && n_level[max_height] == n_use;
         if (try_dense) {
             DevBuf<EnumNode> a, b;
             DevBuf<DenseRoot> dr_d;
             struct { uint32_t* p; } anomaly{small + 2};  // still zero: nothing has written it
-            uint64_t biggest = n_roots;
+            uint64_t biggest = n_use;
             for (auto v : n_level) biggest = v > biggest ? v : biggest;
             IPCFP_HIP(ctx, a.alloc(biggest));
             IPCFP_HIP(ctx, b.alloc(biggest));
-            IPCFP_HIP(ctx, dr_d.alloc(n_roots));
-            const bool want_keys = keys_out && vkind == VK_CID;
+            IPCFP_HIP(ctx, dr_d.alloc(n_use));
             if (want_keys) IPCFP_HIP(ctx, keys_out->alloc(n_leaves));
             else IPCFP_HIP(ctx, out.leaves.alloc(n_leaves));
-            IPCFP_HIP(ctx, h2d_small(ctx, dr_d.p, dr.data(), size_t(n_roots) * sizeof(DenseRoot), ctx->stream));
+            if (n_use > n_roots) IPCFP_HIP(ctx, extra->out->leaves.alloc(n_extra));
+            IPCFP_HIP(ctx, h2d_small(ctx, dr_d.p, dr.data(), size_t(n_use) * sizeof(DenseRoot), ctx->stream));
             const EnumNode* src = cur.p;
             for (uint32_t level = max_height; level >= 1; --level) {
                 const uint32_t nn = uint32_t(n_level[level - 1]);
-                hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p, n_roots,
+                hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p, n_use,
                                    level, nn, vkind, a.p, anomaly.p);
                 src = a.p;
                 a.swap(b);  // `src` now lives in b; the next level writes a
             }
             hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_level[0], 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p,
-                               n_roots, uint32_t(n_level[0]), vkind, want_keys ? nullptr : out.leaves.p, anomaly.p,
-                               want_keys ? keys_out->p : nullptr);
+                               n_use, uint32_t(n_level[0]), want_keys ? nullptr : out.leaves.p, anomaly.p,
+                               want_keys ? keys_out->p : nullptr, n_use > n_roots ? extra->out->leaves.p : nullptr);
             uint32_t bad = 0;
             unsigned long long e = kNoEnumError;  // err_d is untouched here: report what earlier stages left in it
             IPCFP_HIP(ctx, ctl_read(ctx, &bad, anomaly.p, 4));
@@ -533,11 +566,28 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
                 out.error = e;
                 out.dense = true;
                 out.keys_written = want_keys;
+                if (n_use > n_roots) {
+                    extra->out->n_leaves = n_extra;
+                    extra->out->error = kNoEnumError;
+                    extra->out->dense = true;
+                    extra->out->keys_written = false;
+                    extra->done = true;
+                }
                 return IPCFP_OK;
             }
             out.leaves.release();
             if (want_keys) keys_out->release();
+            if (n_use > n_roots) extra->out->leaves.release();
+            // the anomaly may be the extra root's: the general paths below walk the call's own roots only
         }
+        // what follows knows nothing of the extra root
+        max_height = 0;
+        for (uint32_t i = 0; i < n_roots; ++i)
+            if (root_info[2 * size_t(i)] != ~0ULL) {
+                const uint32_t h = uint32_t(root_info[2 * size_t(i)]);
+                max_height = h > max_height ? h : max_height;
+            }
+        root_info.resize(2 * size_t(n_roots));
     }
 
     // ---- speculative pass: every level launched back to back with PREDICTED sizes, one sync at the end ----
@@ -671,6 +721,29 @@ __global__ __launch_bounds__(256) void k_check_dense(const LeafRef* __restrict__
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
+// move an enumeration result into a cache entry (the density check runs only for results of the general paths)
+static int enum_cache_fill(ipcfp_ctx* ctx, EnumCached* e, AmtEnumResult& en, uint64_t lo, uint32_t* flag_p) {
+    e->n = en.n_leaves;
+    e->error = en.error;
+    uint32_t not_dense = 0;
+    if (en.n_leaves && !en.dense) {
+        const uint32_t n = uint32_t(en.n_leaves);
+        hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, lo, flag_p);
+        IPCFP_HIP(ctx, ctl_read(ctx, &not_dense, flag_p, 4));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    }
+    e->dense = !not_dense;
+    // move the leaves into the cache entry (byte-typed buffer)
+    e->leaves.p = reinterpret_cast<uint8_t*>(en.leaves.p);
+    e->leaves.count = en.leaves.count * sizeof(LeafRef);
+    e->leaves.cap = en.leaves.cap;
+    e->leaves.owner = en.leaves.owner;
+    en.leaves.p = nullptr;
+    en.leaves.count = en.leaves.cap = 0;
+    en.leaves.owner = nullptr;
+    return IPCFP_OK;
+}
+
 int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, int version, int vkind,
                          const EnumCached** out, uint64_t lo, uint64_t hi) {
     for (auto& e : w->enum_cache)
@@ -711,25 +784,26 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     AmtEnumResult en;
     int rc = amt_enumerate(ctx, view, roots.p, 1, vkind, err.p, en, lo, hi);
     if (rc) return rc;
-    e->n = en.n_leaves;
-    e->error = en.error;
-    uint32_t not_dense = 0;
-    if (en.n_leaves && !en.dense) {
-        const uint32_t n = uint32_t(en.n_leaves);
-        hipLaunchKernelGGL(k_check_dense, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, en.leaves.p, n, lo, flag.p);
-        IPCFP_HIP(ctx, ctl_read(ctx, &not_dense, flag.p, 4));
-        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    }
-    e->dense = !not_dense;
-    // move the leaves into the cache entry (byte-typed buffer)
-    e->leaves.p = reinterpret_cast<uint8_t*>(en.leaves.p);
-    e->leaves.count = en.leaves.count * sizeof(LeafRef);
-    e->leaves.cap = en.leaves.cap;
-    e->leaves.owner = en.leaves.owner;
-    en.leaves.p = nullptr;
-    en.leaves.count = en.leaves.cap = 0;
-    en.leaves.owner = nullptr;
+    rc = enum_cache_fill(ctx, e.get(), en, lo, flag.p);
+    if (rc) return rc;
     *out = e.get();
+    w->enum_cache.push_back(std::move(e));
+    return IPCFP_OK;
+}
+
+int enum_cache_put(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, int version, int vkind, uint64_t lo, uint64_t hi,
+                   AmtEnumResult& en) {
+    std::unique_ptr<EnumCached> e(new EnumCached());
+    std::memcpy(e->root, root.w, 40);
+    e->version = version;
+    e->vkind = vkind;
+    e->lo = lo;
+    e->hi = hi;
+    DevBuf<uint32_t> flag_own;
+    uint32_t* flag_p = nullptr;
+    IPCFP_HIP(ctx, ctl_words(ctx, flag_own, flag_p, 1, false));
+    int rc = enum_cache_fill(ctx, e.get(), en, lo, flag_p);
+    if (rc) return rc;
     w->enum_cache.push_back(std::move(e));
     return IPCFP_OK;
 }

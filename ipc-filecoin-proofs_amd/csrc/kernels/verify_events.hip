@@ -59,7 +59,10 @@ constexpr uint32_t kHeaderLds = 8192;
 // Two wavefronts per context, side by side: block 2t decodes the child header, block 2t+1 the first
 // parent header (a header decode is ~100 CBOR items parsed by ONE lane — tens of microseconds of pure
 // latency — so the two are not done one after the other).
-__device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtxDev& c, bool child_part, uint8_t* lds) {
+// `receipts_spec` (nullable, child part): where to leave the receipts AMT as an enumeration root, so that the
+// enumerator can take it along with the message AMTs without the host having seen the header (amt_enum.h EnumExtra)
+__device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtxDev& c, bool child_part, uint8_t* lds,
+                                                 AmtRootSpec* receipts_spec = nullptr) {
     const bool lead = threadIdx.x == 0;
     const bool parsed = (c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
     if (child_part) {
@@ -99,6 +102,14 @@ __device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtx
             c.child_status = status;
             c.parents_match = match;
             c.child_height = height;
+            if (receipts_spec) {
+                AmtRootSpec rs{};
+                rs.version = 0;  // Amtv0<Receipt>
+                rs.kind_p1 = uint32_t(VK_RECEIPT) + 1u;
+                rs.skip = status == IPCFP_ST_TRUE ? 0u : 1u;
+                if (!rs.skip) rs.root = c.receipts_root;
+                *receipts_spec = rs;
+            }
         }
     } else {
         uint32_t status = IPCFP_ST_ERR_BAD_CLAIM;
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, const Prep
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
     const PrepareJob jb = jobs[job];
-    if (slot < 2) ctx_headers_body(w, *jb.ctx, slot == 0, lds);
+    if (slot < 2) ctx_headers_body(w, *jb.ctx, slot == 0, lds, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
     else if (jb.roots) exec_roots_body(w, jb.ctx, jb.roots, jb.err, 1, slot - 2, lds);
 }
 

@@ -149,10 +149,12 @@ class TipsetShard:
         w = self.witness
         w.rebuild_index()                                                                    # K4
         w.verify_cids_async()                                                                # K1 (second stream)
-        st, nr, nm = w.scan_events_device(self.receipts_root, topic0, topic1, actor, has_ptr, layout.w_has,
-                                          summary_ptr=header_ptr + 24)                       # K6, range-restricted
+        # verify first: it walks the receipts AMT along with the message AMTs and tabulates the events (counting the
+        # matches of the last scan's filter); the scan that follows finds its enumeration and its PASS 1 done
         if self.n_claims:
             w.verify_event_claims_device(self.tipsets, claims_ptr, self.n_claims, blob_ptr, self.blob_len, status_ptr)
+        st, nr, nm = w.scan_events_device(self.receipts_root, topic0, topic1, actor, has_ptr, layout.w_has,
+                                          summary_ptr=header_ptr + 24)                       # K6, range-restricted
         bits_bytes = (w.n + 31) // 32 * 4
         B.allgather_segments(self.eng, comm, [header_ptr, status_ptr, has_ptr, w.cid_bitmap_ptr],
                              [HEADER_BYTES, layout.w_status, layout.w_has, bits_bytes], staging_ptr, recv_ptr,
