@@ -94,11 +94,6 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     // headers, TxMeta re-hash, message AMT roots) — is one launch.  The execution order is prepared for every
     // context whose claim strings parsed, before the header facts are known on the host; a context that fails
     // steps 1-2 simply never looks at it.
-    struct PrepareJob {
-        TipsetCtxDev* ctx;
-        AmtRootSpec* roots;
-        unsigned long long* err;
-    };
     std::vector<std::unique_ptr<ExecState>> execs(tcs.size());
     std::vector<PrepareJob> jobs(tcs.size());
     int rc;

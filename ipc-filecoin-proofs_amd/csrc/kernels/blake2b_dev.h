@@ -200,4 +200,36 @@ __device__ __forceinline__ void mask_tail(uint64_t m[16], uint32_t rem) {
 }
 
 }  // namespace b2b
+// Blake2b-256 of a short byte buffer on one lane (the TxMeta re-hash, events/utils.rs:65)
+__device__ __forceinline__ void blake2b256_small(const uint8_t* buf, uint32_t len, uint64_t out[4]) {
+    uint64_t h[8];
+    b2b::init256(h);
+    uint32_t done = 0;
+    uint64_t t = 0;
+    for (;;) {
+        const uint32_t left = len - done;
+        const bool last = left <= 128;
+        const uint32_t take = last ? left : 128;
+        uint64_t m[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t idx = 8u * w + b;
+                if (idx < take) v |= uint64_t(buf[done + idx]) << (8 * b);
+            }
+            m[w] = v;
+        }
+        t += take;
+        b2b::compress<0>(h, m, t, last);
+        done += take;
+        if (last) break;
+    }
+    out[0] = h[0];
+    out[1] = h[1];
+    out[2] = h[2];
+    out[3] = h[3];
+}
+
+
 }  // namespace ipcfp

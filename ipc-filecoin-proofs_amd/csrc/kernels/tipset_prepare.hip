@@ -1,0 +1,216 @@
+// csrc/kernels/tipset_prepare.hip — the tipset prologue of the verify path, parsed out of LDS.
+//
+// What `verify_single_proof` derives from (parent_tipset_cids, child_block_cid) before it looks at a proof: the child
+// header and the first parent header (verify_header_consistency, src/proofs/events/verifier.rs:147-181) and, per parent
+// block, its header, its TxMeta and the TxMeta's re-hash (reconstruct_execution_order / collect_exec_list,
+// src/proofs/events/utils.rs:16-30,48-94).  Each is a parse of ≈100 CBOR items by ONE lane — there is no data
+// parallelism inside a header — so the launch is a handful of single-wavefront workgroups whose time is the length
+// of one lane's instruction stream, stretched further by whatever shares the CU (K1, the block-order event parse).
+// Hence this unit: the wavefront stages the block in LDS and the lane parses it with the LDS reader (cbor_dev.h
+// IPCFP_RD_LDS: a byte is a ds_read_u8, a header one aligned ds_read2_b64 — no window to maintain), a third of the
+// instructions of the windowed reader the same parse needs on global memory.
+//
+// A block that does not fit the stage is not parsed here: the slot is flagged in TipsetCtxDev::prologue_general and
+// k_tipset_prepare_general (verify_events.hip), launched right behind, does that slot the general way.
+#define IPCFP_RD_LDS 1
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "blake2b_dev.h"
+#include "claims_dev.h"
+#include "header_dev.h"
+#include "tipset_ctx.h"
+
+namespace ipcfp {
+
+constexpr uint32_t kPrologueStageChunks = 512;  // 8 KB: a block header is 0.6-2 KB, a TxMeta 90 bytes
+
+typedef __attribute__((address_space(3))) const uint8_t* lds_bytes_t;
+
+// every lane of the wavefront: block b → the stage; false when it does not fit
+__device__ __forceinline__ bool stage_block(const WitnessView& w, uint32_t b, rd_chunk_t* stage, uint32_t& len) {
+    len = w.len[b];
+    if (len + 32u > kPrologueStageChunks * 16u) return false;
+    const rd_chunk_t* src = reinterpret_cast<const rd_chunk_t*>(w.arena + w.off[b]);  // line-aligned, padded, + tail slack
+    const uint32_t chunks = ((len + 15u) >> 4) + 2u;
+    for (uint32_t i = threadIdx.x; i < chunks; i += 64u) stage[i] = src[i];
+    __syncthreads();
+    return true;
+}
+
+__device__ __forceinline__ void flag_general(TipsetCtxDev& c, uint32_t slot) {
+    if (threadIdx.x == 0) atomicOr(&c.prologue_general, 1u << slot);
+}
+
+// slots 0 / 1: the child header / the first parent header (ctx_headers_body in verify_events.hip is the general form)
+__device__ __forceinline__ void headers_slot(const WitnessView& w, TipsetCtxDev& c, bool child_part, rd_chunk_t* stage,
+                                             AmtRootSpec* receipts_spec) {
+    const bool lead = threadIdx.x == 0;
+    const bool parsed = (c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
+    uint32_t status = IPCFP_ST_ERR_BAD_CLAIM, match = 0;
+    long long height = 0;
+    const bool wanted = parsed && (child_part || c.n_parents > 0);
+    if (wanted) {
+        const uint32_t hb = witness_find(w, child_part ? c.child : c.parents[0]);  // uniform across the wavefront
+        if (hb == kNoBlock) {
+            status = IPCFP_ST_ERR_MISSING_BLOCK;
+        } else {
+            uint32_t len;
+            if (!stage_block(w, hb, stage, len)) return flag_general(c, child_part ? 0u : 1u);
+            if (lead) {
+                Rd r;
+                r.init((lds_bytes_t)stage, len);
+                HeaderLite h;
+                status = decode_header(r, h);
+                if (status == IPCFP_ST_TRUE) {
+                    height = h.height;
+                    if (child_part) {
+                        c.receipts_root = h.parent_message_receipts;
+                        // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
+                        bool same = h.n_parents == c.n_parents;
+                        if (same) {
+                            Rd q = r;
+                            q.err = 0;
+                            q.pos = h.parents_off;
+                            for (uint32_t i = 0; i < c.n_parents && same; ++i) {
+                                CidKey k;
+                                q.read_link_key(k);
+                                same = q.ok() && cid_equal(k, c.parents[i]);
+                            }
+                        }
+                        match = same ? 1u : 0u;
+                    }
+                }
+            }
+        }
+    }
+    if (!lead) return;
+    if (child_part) {
+        c.child_status = status;
+        c.parents_match = match;
+        c.child_height = height;
+        if (receipts_spec) {  // the receipts AMT as an enumeration root (amt_enum.h EnumExtra)
+            AmtRootSpec rs{};
+            rs.version = 0;  // Amtv0<Receipt>
+            rs.kind_p1 = uint32_t(VK_RECEIPT) + 1u;
+            rs.skip = status == IPCFP_ST_TRUE ? 0u : 1u;
+            if (!rs.skip) rs.root = c.receipts_root;
+            *receipts_spec = rs;
+        }
+    } else {
+        c.parent0_status = status;
+        c.parent0_height = height;
+    }
+}
+
+// slot 2 + b: parent block b → its header, its TxMeta (re-hashed), its two message-AMT roots
+// (exec_roots_body in verify_events.hip is the general form; error sequence numbers as there)
+__device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c, AmtRootSpec* __restrict__ roots,
+                                           unsigned long long* __restrict__ err, uint32_t b, rd_chunk_t* stage) {
+    __shared__ CidKey s_tx;
+    __shared__ uint32_t s_have_tx;
+    const uint32_t P = c.n_parents;
+    if (b >= P) return;
+    const bool lead = threadIdx.x == 0;
+    auto fail = [&](uint32_t seq, uint32_t code) { atomicMin(err, (unsigned long long)pack_enum_error(seq, 0, code)); };
+    // reconstruct_execution_order (utils.rs:20-27): the parent header
+    if (lead) s_have_tx = 0;
+    const uint32_t hb = witness_find(w, c.parents[b]);
+    if (hb == kNoBlock) {
+        if (lead) fail(b, IPCFP_ST_ERR_MISSING_BLOCK);
+    } else {
+        uint32_t len;
+        if (!stage_block(w, hb, stage, len)) return flag_general(c, 2u + b);
+        if (lead) {
+            Rd hr;
+            hr.init((lds_bytes_t)stage, len);
+            HeaderLite h;
+            const uint32_t st = decode_header(hr, h);
+            if (st == IPCFP_ST_TRUE) {
+                s_tx = h.messages;
+                s_have_tx = 1;
+            } else {
+                fail(b, st);
+            }
+        }
+    }
+    __syncthreads();  // s_tx / s_have_tx; and the header's stage is free again
+    // collect_exec_list (utils.rs:56-91)
+    const uint32_t seq = P + 3 * b;
+    AmtRootSpec bls{}, secp{};
+    bls.version = secp.version = 0;
+    bls.seq = seq + 1;
+    secp.seq = seq + 2;
+    bls.skip = secp.skip = 1;
+    if (s_have_tx) {
+        const CidKey tx = s_tx;
+        const uint32_t tb = witness_find(w, tx);  // :58-60
+        if (tb == kNoBlock) {
+            if (lead) fail(seq, IPCFP_ST_ERR_MISSING_BLOCK);
+        } else {
+            uint32_t len;
+            if (!stage_block(w, tb, stage, len)) return flag_general(c, 2u + b);
+            if (lead) {
+                Rd r;
+                r.init((lds_bytes_t)stage, len);
+                uint32_t o0, l0, o1, l1;
+                r.expect_array(2);  // (Cid, Cid)  :61
+                r.read_link(o0, l0);
+                r.read_link(o1, l1);
+                r.finish();
+                if (!r.ok()) {
+                    fail(seq, IPCFP_ST_ERR_DECODE);
+                } else {
+                    // put_cbor(&(bls_root, secp_root), Blake2b256): canonical re-encoding, hashed (:65-72)
+                    uint8_t enc[200];
+                    uint32_t n = 0;
+                    enc[n++] = 0x82;
+                    const uint32_t offs[2] = {o0, o1}, lens[2] = {l0, l1};
+                    for (int k = 0; k < 2; ++k) {
+                        enc[n++] = 0xd8;
+                        enc[n++] = 0x2a;
+                        const uint32_t bl = lens[k] + 1;
+                        if (bl < 24) enc[n++] = uint8_t(0x40 | bl);
+                        else { enc[n++] = 0x58; enc[n++] = uint8_t(bl); }
+                        enc[n++] = 0x00;
+                        for (uint32_t i = 0; i < lens[k]; ++i) enc[n++] = uint8_t(r.at(offs[k] + i));
+                    }
+                    uint64_t d[4];
+                    blake2b256_small(enc, n, d);
+                    CidKey re;
+                    re.w[0] = 0x00002002e4a07101ULL | (d[0] << 48);
+                    re.w[1] = (d[0] >> 16) | (d[1] << 48);
+                    re.w[2] = (d[1] >> 16) | (d[2] << 48);
+                    re.w[3] = (d[2] >> 16) | (d[3] << 48);
+                    re.w[4] = d[3] >> 16;
+                    if (!cid_equal(re, tx)) {  // (the verify path always checks: reconstruct_execution_order)
+                        fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
+                    } else {
+                        bls.root = lens[0] <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        secp.root = lens[1] <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        bls.skip = secp.skip = 0;
+                    }
+                }
+            }
+        }
+    }
+    if (lead) {
+        roots[2 * b] = bls;
+        roots[2 * b + 1] = secp;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, const PrepareJob* __restrict__ jobs, uint32_t n_jobs) {
+    __shared__ rd_chunk_t stage[kPrologueStageChunks];
+    const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
+    if (job >= n_jobs) return;
+    const PrepareJob jb = jobs[job];
+    if (slot < 2) headers_slot(w, *jb.ctx, slot == 0, stage, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
+    else if (jb.roots) roots_slot(w, *jb.ctx, jb.roots, jb.err, slot - 2, stage);
+}
+
+void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJob* jobs_d, uint32_t n_jobs) {
+    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs_d, n_jobs);
+}
+
+}  // namespace ipcfp

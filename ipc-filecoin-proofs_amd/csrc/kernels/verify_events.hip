@@ -17,251 +17,6 @@
 
 namespace ipcfp {
 
-// ---------------------------------------------------------------------------
-// Blake2b-256 of a short byte buffer on one lane (the TxMeta re-hash, events/utils.rs:65)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void blake2b256_small(const uint8_t* buf, uint32_t len, uint64_t out[4]) {
-    uint64_t h[8];
-    b2b::init256(h);
-    uint32_t done = 0;
-    uint64_t t = 0;
-    for (;;) {
-        const uint32_t left = len - done;
-        const bool last = left <= 128;
-        const uint32_t take = last ? left : 128;
-        uint64_t m[16];
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            uint64_t v = 0;
-            for (int b = 0; b < 8; ++b) {
-                const uint32_t idx = 8u * w + b;
-                if (idx < take) v |= uint64_t(buf[done + idx]) << (8 * b);
-            }
-            m[w] = v;
-        }
-        t += take;
-        b2b::compress<0>(h, m, t, last);
-        done += take;
-        if (last) break;
-    }
-    out[0] = h[0];
-    out[1] = h[1];
-    out[2] = h[2];
-    out[3] = h[3];
-}
-
-// ---------------------------------------------------------------------------
-// context headers: one thread per context
-// ---------------------------------------------------------------------------
-// One wavefront (= one 64-thread workgroup) per context: the wave stages each header in LDS, lane 0 parses.
-constexpr uint32_t kHeaderLds = 8192;
-
-// Two wavefronts per context, side by side: block 2t decodes the child header, block 2t+1 the first
-// parent header (a header decode is ~100 CBOR items parsed by ONE lane — tens of microseconds of pure
-// latency — so the two are not done one after the other).
-// `receipts_spec` (nullable, child part): where to leave the receipts AMT as an enumeration root, so that the
-// enumerator can take it along with the message AMTs without the host having seen the header (amt_enum.h EnumExtra)
-__device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtxDev& c, bool child_part, uint8_t* lds,
-                                                 AmtRootSpec* receipts_spec = nullptr) {
-    const bool lead = threadIdx.x == 0;
-    const bool parsed = (c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
-    if (child_part) {
-        uint32_t status = IPCFP_ST_ERR_BAD_CLAIM, match = 0;
-        long long height = 0;
-        if (parsed) {
-            // child header (events/verifier.rs:155-158)
-            const uint32_t hb = witness_find(w, c.child);  // uniform across the wave
-            if (hb == kNoBlock) {
-                status = IPCFP_ST_ERR_MISSING_BLOCK;
-            } else {
-                Rd r = open_block_staged(w, hb, lds, kHeaderLds);
-                if (lead) {
-                    HeaderLite h;
-                    status = decode_header(r, h);
-                    if (status == IPCFP_ST_TRUE) {
-                        height = h.height;
-                        c.receipts_root = h.parent_message_receipts;
-                        // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
-                        bool same = h.n_parents == c.n_parents;
-                        if (same) {
-                            Rd q = r;
-                            q.err = 0;
-                            q.pos = h.parents_off;
-                            for (uint32_t i = 0; i < c.n_parents && same; ++i) {
-                                CidKey k;
-                                q.read_link_key(k);
-                                same = q.ok() && cid_equal(k, c.parents[i]);
-                            }
-                        }
-                        match = same ? 1u : 0u;
-                    }
-                }
-            }
-        }
-        if (lead) {
-            c.child_status = status;
-            c.parents_match = match;
-            c.child_height = height;
-            if (receipts_spec) {
-                AmtRootSpec rs{};
-                rs.version = 0;  // Amtv0<Receipt>
-                rs.kind_p1 = uint32_t(VK_RECEIPT) + 1u;
-                rs.skip = status == IPCFP_ST_TRUE ? 0u : 1u;
-                if (!rs.skip) rs.root = c.receipts_root;
-                *receipts_spec = rs;
-            }
-        }
-    } else {
-        uint32_t status = IPCFP_ST_ERR_BAD_CLAIM;
-        long long height = 0;
-        if (parsed && c.n_parents > 0) {  // parent_cids[0] (:171-174)
-            const uint32_t pb = witness_find(w, c.parents[0]);
-            if (pb == kNoBlock) {
-                status = IPCFP_ST_ERR_MISSING_BLOCK;
-            } else {
-                Rd r = open_block_staged(w, pb, lds, kHeaderLds);
-                if (lead) {
-                    HeaderLite ph;
-                    status = decode_header(r, ph);
-                    if (status == IPCFP_ST_TRUE) height = ph.height;
-                }
-            }
-        }
-        if (lead) {
-            c.parent0_status = status;
-            c.parent0_height = height;
-        }
-    }
-}
-
-__global__ __launch_bounds__(64) void k_ctx_headers(WitnessView w, TipsetCtxDev* __restrict__ ctxs, uint32_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
-    const uint32_t t = blockIdx.x >> 1;
-    if (t >= n) return;
-    ctx_headers_body(w, ctxs[t], (blockIdx.x & 1u) == 0, lds);
-}
-
-// ---------------------------------------------------------------------------
-// execution order, stage 1 (one thread): parent headers → TxMeta → AMT roots
-//   error sequence numbers: parent header b → b;  TxMeta of block b → P + 3b;
-//   its BLS AMT → P + 3b + 1;  its secp AMT → P + 3b + 2   (traversal order of utils.rs)
-// ---------------------------------------------------------------------------
-// One lane per parent block (the per-block work is independent; the error word orders the outcomes).
-// `err` must hold kNoEnumError on entry.
-__device__ __forceinline__ void exec_roots_body(const WitnessView& w, const TipsetCtxDev* __restrict__ ctx,
-                                                AmtRootSpec* __restrict__ roots, unsigned long long* __restrict__ err,
-                                                int verify_txmeta, uint32_t b, uint8_t* lds) {
-    const uint32_t P = ctx->n_parents;  // one wavefront per parent block b; lane 0 parses what the wave staged
-    if (b >= P) return;
-    const bool lead = threadIdx.x == 0;
-    auto fail = [&](uint32_t seq, uint32_t code) { atomicMin(err, (unsigned long long)pack_enum_error(seq, 0, code)); };
-    // reconstruct_execution_order (utils.rs:20-27): every parent header is decoded first
-    CidKey tx[1];
-    bool have_tx[1];
-    {
-        have_tx[0] = false;
-        const uint32_t hb = witness_find(w, ctx->parents[b]);
-        if (hb == kNoBlock) {
-            if (lead) fail(b, IPCFP_ST_ERR_MISSING_BLOCK);
-        } else {
-            Rd hr = open_block_staged(w, hb, lds, kHeaderLds);
-            if (lead) {
-                HeaderLite h;
-                const uint32_t st = decode_header(hr, h);
-                have_tx[0] = st == IPCFP_ST_TRUE;
-                if (have_tx[0]) tx[0] = h.messages;
-                else fail(b, st);
-            }
-        }
-    }
-    if (!lead) return;  // the rest is a short chain on small blocks
-    // collect_exec_list (utils.rs:56-91)
-    {
-        const uint32_t seq = P + 3 * b;
-        AmtRootSpec bls{}, secp{};
-        bls.version = secp.version = 0;
-        bls.seq = seq + 1;
-        secp.seq = seq + 2;
-        bls.skip = secp.skip = 1;
-        if (have_tx[0]) {
-            const uint32_t tb = witness_find(w, tx[0]);  // :58-60
-            if (tb == kNoBlock) {
-                fail(seq, IPCFP_ST_ERR_MISSING_BLOCK);
-            } else {
-                Rd r = open_block(w, tb);
-                uint32_t o0, l0, o1, l1;
-                r.expect_array(2);  // (Cid, Cid)  :61
-                r.read_link(o0, l0);
-                r.read_link(o1, l1);
-                r.finish();
-                if (!r.ok()) {
-                    fail(seq, IPCFP_ST_ERR_DECODE);
-                } else {
-                    // put_cbor(&(bls_root, secp_root), Blake2b256): canonical re-encoding, hashed (:65-72)
-                    uint8_t enc[200];
-                    uint32_t n = 0;
-                    enc[n++] = 0x82;
-                    const uint32_t offs[2] = {o0, o1}, lens[2] = {l0, l1};
-                    for (int k = 0; k < 2; ++k) {
-                        enc[n++] = 0xd8;
-                        enc[n++] = 0x2a;
-                        const uint32_t bl = lens[k] + 1;
-                        if (bl < 24) enc[n++] = uint8_t(0x40 | bl);
-                        else { enc[n++] = 0x58; enc[n++] = uint8_t(bl); }
-                        enc[n++] = 0x00;
-                        for (uint32_t i = 0; i < lens[k]; ++i) enc[n++] = uint8_t(r.at(offs[k] + i));
-                    }
-                    uint64_t d[4];
-                    blake2b256_small(enc, n, d);
-                    CidKey re;
-                    re.w[0] = 0x00002002e4a07101ULL | (d[0] << 48);
-                    re.w[1] = (d[0] >> 16) | (d[1] << 48);
-                    re.w[2] = (d[1] >> 16) | (d[2] << 48);
-                    re.w[3] = (d[2] >> 16) | (d[3] << 48);
-                    re.w[4] = d[3] >> 16;
-                    // verify_txmeta = false on the generation path (build_execution_order, utils.rs:44)
-                    if (verify_txmeta && !cid_equal(re, tx[0])) {
-                        fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
-                    } else {
-                        bls.root = lens[0] <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
-                        secp.root = lens[1] <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
-                        bls.skip = secp.skip = 0;
-                    }
-                }
-            }
-        }
-        roots[2 * b] = bls;
-        roots[2 * b + 1] = secp;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCtxDev* __restrict__ ctx,
-                                                   AmtRootSpec* __restrict__ roots,
-                                                   unsigned long long* __restrict__ err, int verify_txmeta) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
-    exec_roots_body(w, ctx, roots, err, verify_txmeta, blockIdx.x, lds);
-}
-
-// The whole tipset prologue of the verify path in ONE launch: per context, two wavefronts decode the child and
-// the first parent header (ctx_headers_body) and one wavefront per parent block decodes its header, its TxMeta
-// and re-hashes it (exec_roots_body).  They are independent single-lane parses of tens of microseconds each;
-// launched one after the other they were the longest idle stretch of a step.
-struct PrepareJob {
-    TipsetCtxDev* ctx;
-    AmtRootSpec* roots;          // nullptr: no execution order for this context
-    unsigned long long* err;
-};
-constexpr uint32_t kPrepareSlots = 2 + kMaxParents;
-
-__global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, const PrepareJob* __restrict__ jobs, uint32_t n_jobs) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
-    const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
-    if (job >= n_jobs) return;
-    const PrepareJob jb = jobs[job];
-    if (slot < 2) ctx_headers_body(w, *jb.ctx, slot == 0, lds, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
-    else if (jb.roots) exec_roots_body(w, jb.ctx, jb.roots, jb.err, 1, slot - 2, lds);
-}
-
 // stage 2: leaf values (tag-42 links, already validated) → message CID keys
 __global__ __launch_bounds__(256) void k_exec_keys(WitnessView w, const LeafRef* __restrict__ leaves, uint32_t n,
                                                    CidKey* __restrict__ keys) {
@@ -439,36 +194,10 @@ __global__ __launch_bounds__(256) void k_exec_finish(TipsetCtxDev* __restrict__ 
 }
 
 // ------------------------------ launchers -----------------------------------
-int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs_d, uint32_t n_jobs) {
-    if (n_jobs == 0) return IPCFP_OK;
-    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, ctx->stream, w,
-                       static_cast<const PrepareJob*>(jobs_d), n_jobs);
-    IPCFP_HIP(ctx, hipGetLastError());
-    return IPCFP_OK;
-}
-
 int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d, const uint32_t* first_d,
                        const uint32_t* pos_d, uint32_t n, uint32_t* inv_d) {
     hipLaunchKernelGGL(k_exec_finish, dim3(n ? div_up(n, 256) : 1), dim3(256), 0, ctx->stream, ctx_d, total_d, first_d, pos_d,
                        n, inv_d);
-    IPCFP_HIP(ctx, hipGetLastError());
-    return IPCFP_OK;
-}
-
-int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n) {
-    if (n == 0) return IPCFP_OK;
-    hipLaunchKernelGGL(k_ctx_headers, dim3(2 * n), dim3(64), 0, ctx->stream, w, ctxs_d, n);
-    IPCFP_HIP(ctx, hipGetLastError());
-    return IPCFP_OK;
-}
-
-int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
-                      unsigned long long* err_d, int verify_txmeta) {
-    const unsigned long long none = kNoEnumError;
-    IPCFP_HIP(ctx, hipMemsetAsync(err_d, 0xff, 8, ctx->stream));  // kNoEnumError
-    (void)none;
-    hipLaunchKernelGGL(k_exec_roots, dim3(IPCFP_MAX_PARENTS), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d,
-                       verify_txmeta);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
