@@ -257,6 +257,23 @@ def main():
         cnt, ms = eng.profile_read(k)
         kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
     roof = k1_roofline(eng, tip.lens, tip.n_blocks, traffic_file="r01_k1_traffic.json")
+    # In the step K1 shares the chip with the block-order event parse (both on side streams).  The same launch with the
+    # chip to itself, untimed and outside `value`: what the kernel does when nothing runs beside it.
+    eng.sync()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    for _ in range(5):
+        w.verify_cids_async()
+        eng.sync()
+    eng.profile_enable(False)
+    a_cnt, a_ms = eng.profile_read("blake2b_cid")
+    if a_cnt:
+        alone_ms = a_ms / a_cnt
+        roof["alone"] = {"kernel_avg_ms": alone_ms, "launches": a_cnt,
+                         "achieved": roof["algorithmic_bytes_per_launch"] / (alone_ms * 1e-3) / 1e9,
+                         "frac": roof["algorithmic_bytes_per_launch"] / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "the same launch with nothing beside it (5 launches after the timed region); `achieved` / "
+                                 "`frac` above are the in-step figures, K1 sharing the chip with k_block_events"}
 
     if rank == 0:
         out = {

@@ -249,3 +249,60 @@ def test_packed_device_claims_equal_string_claims(tip, both, engine):
     w.rebuild_index()
     w.verify_event_claims_device(ts, d_cl.data_ptr(), len(cl), d_blob.data_ptr(), blob_len, d_st.data_ptr())
     assert np.array_equal(d_st.cpu().numpy(), want)
+
+
+def _cbor_skip(b: bytes, pos: int) -> int:
+    """position after the DAG-CBOR item at pos (any major type)"""
+    ib = b[pos]
+    major, info = ib >> 5, ib & 31
+    pos += 1
+    arg = info
+    if info >= 24:
+        nb = {24: 1, 25: 2, 26: 4, 27: 8}[info]
+        arg = int.from_bytes(b[pos:pos + nb], "big")
+        pos += nb
+    if major in (2, 3):
+        return pos + arg
+    if major == 4:
+        for _ in range(arg):
+            pos = _cbor_skip(b, pos)
+    elif major == 5:
+        for _ in range(2 * arg):
+            pos = _cbor_skip(b, pos)
+    elif major == 6:
+        pos = _cbor_skip(b, pos)
+    return pos
+
+
+def test_headers_larger_than_the_prologue_stage(tip, engine, oracle):
+    """The tipset prologue parses headers out of an 8 KB LDS stage (tipset_prepare.hip); a header that does not fit —
+    legal for serde: HeaderLite ignores the first five fields whatever they hold — takes the general companion kernel.
+    Child header, first parent header and another parent header are padded to 9-20 KB (same CIDs: the verify path
+    never hashes witness blocks, src/proofs/events/verifier.rs:82-86) and every status must stay what it was."""
+    ec = claims.EventClaims(tip, indices=np.arange(0, 200))
+    ec.arr[5].exec_index += 1
+    ec.set_str(9, "child_block_cid", claims.cid_str(tip.parent_cids[0]))
+    data = [tip.data]
+    off, lens = tip.off.copy(), tip.lens.copy()
+    end = int(tip.data.size)
+    for cid, pad in ((tip.child_cid, 9000), (tip.parent_cids[0], 20000), (tip.parent_cids[2], 12000)):
+        i = tip.find_block(cid)
+        old = tip.block(i)
+        assert old[0] == 0x90  # array(16)
+        after0 = _cbor_skip(old, 1)
+        new = bytes([0x90, 0x59, pad >> 8, pad & 0xFF]) + bytes(pad) + old[after0:]
+        data.append(np.frombuffer(new, dtype=np.uint8))
+        off[i], lens[i] = end, len(new)
+        end += len(new)
+    data = np.concatenate(data)
+    with engine.witness(data, off, lens, tip.cids) as w, engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w0:
+        got = w.verify_event_proofs(ec.arr, ec.n)
+        plain = w0.verify_event_proofs(ec.arr, ec.n)
+        gs, gc = w.exec_order(tip.parent_cids)
+    st = oracle.store(data, off, lens, tip.cids)
+    want = st.verify_event_proofs(ec, mode=0)
+    os_, oc = st.exec_order(tip.parent_cids)
+    st.close()
+    assert np.array_equal(got, want) and np.array_equal(got, plain)
+    assert (got == 1).sum() >= 190 and got[5] != 1 and got[9] != 1
+    assert gs == os_ == 1 and np.array_equal(gc, oc)
