@@ -100,9 +100,11 @@ enum {
 };
 
 /* Host-side string forms (no GPU involved; usable without a context).
- * ipcfp_cid_from_string: `Cid::try_from(&str)` (src/proofs/common/witness.rs:60-64): multibase b/B (base32),
- *   f/F (base16), z (base58btc) or a bare CIDv0 "Qm…".  Returns the CID's byte length (written
- *   zero-padded into the 40-byte slot), IPCFP_E_PARSE if the reference's parse would be Err, or
+ * ipcfp_cid_from_string: `Cid::try_from(&str)` (src/proofs/common/witness.rs:60-64) as the cid crate does it: the text
+ *   up to and including the first "/ipfs/" is dropped; a 46-character "Qm…" is a CIDv0 (base58btc); else multibase,
+ *   case-strict — b (base32 lower), B (base32 upper), f / F (base16 lower / upper), z (base58btc).  The other
+ *   multibase alphabets (k, m, u, …) are an ENGINE LIMIT: such a string is reported like an unparsable one.  Returns
+ *   the CID's byte length (written zero-padded into the 40-byte slot), IPCFP_E_PARSE if the parse is Err, or
  *   IPCFP_E_UNSUPPORTED for a valid CID longer than the slot.
  * ipcfp_cid_to_string: `Cid::to_string()` — "b" + base32-lower for CIDv1, base58btc for CIDv0; returns
  *   the string length (excluding NUL) or IPCFP_E_INVALID if cap is too small / the bytes are not a CID. */

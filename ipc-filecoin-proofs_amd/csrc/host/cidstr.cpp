@@ -19,18 +19,20 @@ bool uvarint(const uint8_t* p, size_t n, size_t& pos, uint64_t& v) {
     return false;
 }
 
-int b32val(char c) {
-    if (c >= 'a' && c <= 'z') return c - 'a';
-    if (c >= 'A' && c <= 'Z') return c - 'A';
+// multibase 'b' is the LOWER-case RFC 4648 alphabet and 'B' the upper-case one: the other case is not in the alphabet
+// (multibase decodes through data-encoding specifications without case translation)
+int b32val(char c, bool upper) {
+    if (!upper && c >= 'a' && c <= 'z') return c - 'a';
+    if (upper && c >= 'A' && c <= 'Z') return c - 'A';
     if (c >= '2' && c <= '7') return 26 + (c - '2');
     return -1;
 }
 
-bool base32_decode(const char* s, size_t n, std::vector<uint8_t>& out) {
+bool base32_decode(const char* s, size_t n, bool upper, std::vector<uint8_t>& out) {
     uint32_t acc = 0;
     int bits = 0;
     for (size_t i = 0; i < n; ++i) {
-        const int v = b32val(s[i]);
+        const int v = b32val(s[i], upper);
         if (v < 0) return false;
         acc = (acc << 5) | uint32_t(v);
         bits += 5;
@@ -99,19 +101,35 @@ bool cid_binary_ok(const uint8_t* p, size_t n) {
     return n - pos == size;
 }
 
+// hex digits of ONE case (multibase 'f' / 'F')
+bool hex_decode_cased(const char* s, size_t n, bool upper, std::vector<uint8_t>& out) {
+    for (size_t i = 0; i < n; ++i) {
+        const char c = s[i];
+        if (upper ? (c >= 'a' && c <= 'f') : (c >= 'A' && c <= 'F')) return false;
+    }
+    return hex_decode(s, n, out);
+}
+
+// `Cid::try_from(&str)` of the cid crate: everything up to and including the first "/ipfs/" is dropped, a 46-character
+// "Qm…" string is a CIDv0 in base58btc, anything else a multibase string.  Of the multibase alphabets the ones Lotus
+// and the reference produce or print are decoded — b / B (base32 lower / upper, unpadded), f / F (base16), z
+// (base58btc); the others (k, m, u, …) are an engine limit: such a claim string is reported as unparsable.
 bool cid_from_string(const char* s, std::vector<uint8_t>& out) {
     out.clear();
     if (!s) return false;
+    if (const char* cut = std::strstr(s, "/ipfs/")) s = cut + 6;
     const size_t n = std::strlen(s);
+    if (n < 2) return false;
     if (n == 46 && s[0] == 'Q' && s[1] == 'm') {
         if (!base58_decode(s, n, out)) return false;
     } else {
-        if (n < 2) return false;
         bool ok;
         switch (s[0]) {
-            case 'b': case 'B': ok = base32_decode(s + 1, n - 1, out); break;
+            case 'b': ok = base32_decode(s + 1, n - 1, false, out); break;
+            case 'B': ok = base32_decode(s + 1, n - 1, true, out); break;
             case 'z': ok = base58_decode(s + 1, n - 1, out); break;
-            case 'f': case 'F': ok = hex_decode(s + 1, n - 1, out); break;
+            case 'f': ok = hex_decode_cased(s + 1, n - 1, false, out); break;
+            case 'F': ok = hex_decode_cased(s + 1, n - 1, true, out); break;
             default: ok = false;
         }
         if (!ok) return false;

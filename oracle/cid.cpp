@@ -31,15 +31,17 @@ std::string base32_lower(const uint8_t* p, size_t n) {
     return out;
 }
 
-bool base32_decode(const std::string& s, size_t from, Bytes& out) {
+// `upper`: multibase 'B' (RFC 4648 upper-case alphabet); 'b' is the lower-case one.  multibase decodes through
+// data-encoding specifications that do not translate case ⚠ (recollection, cid 0.10 / multibase 0.9)
+bool base32_decode(const std::string& s, size_t from, Bytes& out, bool upper) {
     out.clear();
     uint32_t acc = 0;
     int bits = 0;
     for (size_t i = from; i < s.size(); ++i) {
         const char c = s[i];
         int v;
-        if (c >= 'a' && c <= 'z') v = c - 'a';
-        else if (c >= 'A' && c <= 'Z') v = c - 'A';
+        if (!upper && c >= 'a' && c <= 'z') v = c - 'a';
+        else if (upper && c >= 'A' && c <= 'Z') v = c - 'A';
         else if (c >= '2' && c <= '7') v = 26 + (c - '2');
         else return false;
         acc = (acc << 5) | uint32_t(v);
@@ -113,15 +115,22 @@ std::string cid_to_string(const Cid& c) {
     return "b" + base32_lower(c.b.data(), c.b.size());
 }
 
-bool cid_from_string(const std::string& s, Cid& out) {
+// `impl TryFrom<&str> for Cid` (cid crate): `cid_str.find("/ipfs/")` → the text after it; shorter than 2 → Err;
+// Version::is_v0_str (46 characters, "Qm") → base58btc; else multibase::decode.
+bool cid_from_string(const std::string& full, Cid& out) {
     Bytes raw;
+    const size_t cut = full.find("/ipfs/");
+    const std::string s = cut == std::string::npos ? full : full.substr(cut + 6);
     if (s.size() == 46 && s[0] == 'Q' && s[1] == 'm') {
         if (!base58btc_decode(s, 0, raw)) return false;
     } else {
         if (s.size() < 2) return false;
         switch (s[0]) {
-            case 'b': case 'B':
-                if (!base32_decode(s, 1, raw)) return false;
+            case 'b':
+                if (!base32_decode(s, 1, raw, false)) return false;
+                break;
+            case 'B':
+                if (!base32_decode(s, 1, raw, true)) return false;
                 break;
             case 'z':
                 if (!base58btc_decode(s, 1, raw)) return false;
@@ -129,10 +138,11 @@ bool cid_from_string(const std::string& s, Cid& out) {
             case 'f': case 'F': {
                 if ((s.size() - 1) % 2) return false;
                 for (size_t i = 1; i < s.size(); i += 2) {
-                    auto hv = [](char c) -> int {
+                    const bool up = s[0] == 'F';  // one case per prefix
+                    auto hv = [up](char c) -> int {
                         if (c >= '0' && c <= '9') return c - '0';
-                        if (c >= 'a' && c <= 'f') return c - 'a' + 10;
-                        if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+                        if (!up && c >= 'a' && c <= 'f') return c - 'a' + 10;
+                        if (up && c >= 'A' && c <= 'F') return c - 'A' + 10;
                         return -1;
                     };
                     const int h = hv(s[i]), l = hv(s[i + 1]);

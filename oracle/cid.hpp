@@ -58,7 +58,7 @@ Cid cid_for_block(const uint8_t* data, size_t len);
 
 // ---- strings ----
 std::string base32_lower(const uint8_t* p, size_t n);
-bool base32_decode(const std::string& s, size_t from, Bytes& out);  // accepts upper or lower, no padding
+bool base32_decode(const std::string& s, size_t from, Bytes& out, bool upper = false);  // one case per call (multibase b / B), no padding
 std::string base58btc(const uint8_t* p, size_t n);
 bool base58btc_decode(const std::string& s, size_t from, Bytes& out);
 

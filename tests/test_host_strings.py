@@ -59,3 +59,34 @@ def test_engine_and_oracle_agree_on_random_and_malformed_strings(oracle):
             assert got is None  # valid but longer than the ABI slot
         else:
             assert got == want, s
+
+
+def test_cid_string_case_and_ipfs_prefix(oracle):
+    """`Cid::try_from(&str)` as the cid crate spells it (ADVICE r1): multibase prefixes are case-strict — 'b' / 'f' take
+    lower-case digits only, 'B' / 'F' upper-case only — and everything up to and including the first "/ipfs/" is dropped.
+    Engine (host/cidstr.cpp) and oracle (oracle/cid.cpp) are written separately and must agree with this table."""
+    import ipc_filecoin_proofs_amd as ipcfp
+
+    cid = bytes.fromhex("0171a0e40220") + bytes(range(32))
+    b = ipcfp.cid_to_string(cid)
+    assert b[0] == "b" and b == b.lower()
+    table = [
+        (b, cid),
+        ("B" + b[1:].upper(), cid),
+        ("b" + b[1:].upper(), None),                 # upper-case digits under the lower-case prefix
+        ("B" + b[1:], None),
+        (b[:10] + b[10].upper() + b[11:], None),     # one letter of the other case
+        ("f" + cid.hex(), cid),
+        ("F" + cid.hex().upper(), cid),
+        ("f" + cid.hex().upper(), None),
+        ("F" + cid.hex(), None),
+        ("/ipfs/" + b, cid),
+        ("https://gateway.example/ipfs/" + b, cid),
+        ("/ipfs/" + "/ipfs/" + b, None),             # only the FIRST delimiter is cut: "/ipfs/bafy…" is no multibase
+        ("/ipfs/", None),
+        ("/ipfs/b", None),
+        ("k" + b[1:], None),                         # base36: an engine limit, reported as unparsable
+    ]
+    for s, want in table:
+        assert ipcfp.cid_from_string(s) == want, s
+        assert oracle.cid_from_string(s) == want, s
