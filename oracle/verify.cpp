@@ -447,7 +447,7 @@ uint8_t verify_storage_proof_one(const Blockstore& bs, const ipcfp_storage_proof
     if (!read_storage_slot(bs, storage_root, slot, raw)) raw.clear();       // :160-162 missing ⇒ zero
     uint8_t padded[32] = {0};                                               // left_pad_32 (common/evm.rs:91-100)
     if (raw.size() >= 32) std::memcpy(padded, raw.data() + raw.size() - 32, 32);
-    else std::memcpy(padded + 32 - raw.size(), raw.data(), raw.size());
+    else if (!raw.empty()) std::memcpy(padded + 32 - raw.size(), raw.data(), raw.size());  // (an empty value has no data())
     return eq_ignore_ascii_case(hex0x(padded, 32), p.value) ? IPCFP_ST_TRUE : IPCFP_ST_FALSE_VALUE;  // :165-169
 }
 
@@ -650,7 +650,7 @@ GeneratedStorageProof generate_storage_proof(const Blockstore& bs, const Cid& ch
         if (!read_storage_slot(rec, out.storage_root, slot, raw)) raw.clear();
         std::memset(out.value, 0, 32);
         if (raw.size() >= 32) std::memcpy(out.value, raw.data() + raw.size() - 32, 32);
-        else std::memcpy(out.value + 32 - raw.size(), raw.data(), raw.size());
+        else if (!raw.empty()) std::memcpy(out.value + 32 - raw.size(), raw.data(), raw.size());  // (an empty value has no data())
         for (const Cid& c : rec.take_seen()) needed.insert(c);
     }
     for (const Cid& c : needed) {

@@ -298,6 +298,10 @@ def build():
 def load() -> Oracle:
     global _cached
     if _cached is None:
+        override = os.environ.get("IPCFP_ORACLE_LIB")  # e.g. oracle/_asan/libipcfp_oracle.so (tests/test_sanitizers.py)
+        if override:
+            _cached = Oracle(C.CDLL(override))
+            return _cached
         if not os.path.exists(LIB):
             build()
         _cached = Oracle(C.CDLL(LIB))
