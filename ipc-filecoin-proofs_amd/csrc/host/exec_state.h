@@ -1,5 +1,7 @@
 // csrc/host/exec_state.h — host-side handles shared by the verifier and the generator entry points.
 #pragma once
+#include <functional>
+
 #include "../common.h"
 #include "../kernels/exec_order.h"
 #include "../kernels/launch.h"
@@ -30,9 +32,11 @@ struct ExecState {
 // `prepared` = true: stage 1 (ex.roots / ex.err) was already run by launch_tipset_prepare.
 // `extra` (with `prepared`): one more AMT — the receipts AMT, whose root launch_tipset_prepare left at
 // ex.roots[2 * n_parents] — enumerated in the same launches as the message AMTs (amt_enum.h).
+// `after_enum` (nullable): called once the enumeration is back (the stream is idle at that moment), before the
+// execution-order hash kernels are queued — the caller's chance to start independent work on another stream.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
                      ExecState& ex, int verify_txmeta = 1, bool host_len = true, bool prepared = false,
-                     EnumExtra* extra = nullptr);
+                     EnumExtra* extra = nullptr, const std::function<int()>* after_enum = nullptr);
 // allocate ex.roots / ex.err for a context with n_parents parent blocks and reset the error word
 int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents);
 
@@ -53,7 +57,12 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
 
 // The event table of the receipts AMT `root` (range = the witness's receipt range): the cached one, or a new one
 // (k_receipt_events; the first failing receipt goes to the table's err_word).  `en` = the enumeration.
-int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en, const EventTableCached** out);
+// `on_aux`: a NEW table's kernels go to the aux stream (behind the block-order parse they depend on) instead of the
+// main stream, which joins them where the table is first read.  Only for a caller whose main stream is idle right now.
+int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en, const EventTableCached** out,
+                    bool on_aux = false);
+// the main stream waits (on the device) for what the aux stream has queued for this witness's tables
+int event_table_join(ipcfp_ctx* ctx, ipcfp_witness* w);
 // the table's per-receipt match counts when they were counted for exactly this filter, else null
 const uint32_t* event_table_counts(const EventTableCached* t, const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor);
 

@@ -61,17 +61,28 @@ const uint32_t* event_table_counts(const EventTableCached* t, const ipcfp_event_
     return std::memcmp(&want, &t->counts_filter, sizeof want) == 0 ? t->counts.p : nullptr;
 }
 
-int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en, const EventTableCached** out) {
+int event_table_join(ipcfp_ctx* ctx, ipcfp_witness* w) {
+    if (w->bt_valid && !w->bt_joined) {
+        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
+        w->bt_joined = true;
+    }
+    return IPCFP_OK;
+}
+
+int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const EnumCached* en, const EventTableCached** out,
+                    bool on_aux) {
     for (auto& t : w->table_cache)
         if (t->lo == w->receipt_lo && t->hi == w->receipt_hi && std::memcmp(t->root, root.w, 40) == 0) {
             *out = t.get();
-            return IPCFP_OK;
+            return on_aux ? IPCFP_OK : event_table_join(ctx, w);  // (its kernels may still be on the aux stream)
         }
     int rc = block_table_prefetch(ctx, w, nullptr, 0, 0);  // (queued long ago by the callers that care)
     if (rc) return rc;
-    if (!w->bt_joined) {
-        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
-        w->bt_joined = true;
+    on_aux = on_aux && ctx->stream_aux != ctx->stream;
+    hipStream_t ks = on_aux ? ctx->stream_aux : ctx->stream;  // behind the block-order parse, or joined with it
+    if (!on_aux) {
+        rc = event_table_join(ctx, w);
+        if (rc) return rc;
     }
     std::unique_ptr<EventTableCached> t(new EventTableCached());
     std::memcpy(t->root, root.w, 40);
@@ -82,7 +93,7 @@ int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const 
     const uint64_t n = en->n;
     IPCFP_HIP(ctx, t->receipts.alloc(n));
     IPCFP_HIP(ctx, t->err_word.alloc(1));
-    IPCFP_HIP(ctx, hipMemsetAsync(t->err_word.p, 0xff, 8, ctx->stream));  // kNoEnumError
+    IPCFP_HIP(ctx, hipMemsetAsync(t->err_word.p, 0xff, 8, ks));  // kNoEnumError
     // the per-block match counts belong to the filter the block pass ran with: the receipts inherit them
     t->has_counts = w->bt_has_filter;
     if (t->has_counts) {
@@ -92,8 +103,12 @@ int event_table_get(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, const 
     const WitnessView view = witness_view(w);
     rc = launch_receipt_events(ctx, view, reinterpret_cast<const LeafRef*>(en->leaves.p), uint32_t(n),
                                t->has_counts ? &w->bt_filter.filter : nullptr, int(w->bt_filter.has_actor), w->bt_filter.actor,
-                               w->bt_blocks.p, t->receipts.p, t->has_counts ? t->counts.p : nullptr, t->err_word.p);
+                               w->bt_blocks.p, t->receipts.p, t->has_counts ? t->counts.p : nullptr, t->err_word.p, ks);
     if (rc) return rc;
+    if (on_aux) {  // the next reader on the main stream joins (event_table_join)
+        IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ks));
+        w->bt_joined = false;
+    }
     *out = t.get();
     w->table_cache.push_back(std::move(t));
     return IPCFP_OK;

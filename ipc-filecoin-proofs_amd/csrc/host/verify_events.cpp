@@ -33,7 +33,8 @@ int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents) {
 
 // Reconstruct the execution order of the context stored at ctx_d (device) on the device.
 int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev* ctx_d, uint32_t n_parents,
-                     ExecState& ex, int verify_txmeta, bool host_len, bool prepared, EnumExtra* extra) {
+                     ExecState& ex, int verify_txmeta, bool host_len, bool prepared, EnumExtra* extra,
+                     const std::function<int()>* after_enum) {
     int rc;
     if (!prepared) {
         rc = exec_state_prepare(ctx, ex, n_parents);
@@ -45,6 +46,10 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     rc = amt_enumerate(ctx, view, ex.roots.p, 2 * n_parents, VK_CID, ex.err.p, en, 0, ~0ULL, &ex.keys,
                        prepared ? extra : nullptr);
     if (rc) return rc;
+    if (after_enum && *after_enum) {
+        rc = (*after_enum)();
+        if (rc) return rc;
+    }
     const unsigned long long e = en.error;  // read back by the enumerator: stage-1 errors and its own, merged
     ex.status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
     ex.raw_len = ex.exec_len = 0;
@@ -133,7 +138,25 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
             rec_extra[k].out = rec_en[k].get();
             extra = &rec_extra[k];
         }
-        rc = build_exec_order(ctx, view, tcs_d.p + k, tcs[k].n_parents, *execs[k], 1, /*host_len=*/false, /*prepared=*/true, extra);
+        // With the receipts on board, their event table (k_receipt_events) does not wait for the execution-order
+        // hash kernels: it is queued on the aux stream — idle once the block-order parse is through — the moment the
+        // enumeration is back, and joined before the verify kernel.
+        const std::function<int()> start_table = [&, k]() -> int {
+            const TipsetCtxDev& f = facts[k];
+            if (!rec_en[k] || !rec_extra[k].done || f.child_status != IPCFP_ST_TRUE) return IPCFP_OK;
+            int r = enum_cache_put(ctx, w, f.receipts_root, 0, VK_RECEIPT, w->receipt_lo, w->receipt_hi, *rec_en[k]);
+            if (r) return r;
+            rec_extra[k].done = false;  // (handed over)
+            if (!w->use_event_table) return IPCFP_OK;
+            const EnumCached* en_r = nullptr;
+            r = amt_enumerate_cached(ctx, w, f.receipts_root, 0, VK_RECEIPT, &en_r, w->receipt_lo, w->receipt_hi);
+            if (r) return r;
+            if (en_r->error != kNoEnumError || !en_r->dense || !en_r->n) return IPCFP_OK;
+            const EventTableCached* table = nullptr;
+            return event_table_get(ctx, w, f.receipts_root, en_r, &table, /*on_aux=*/true);
+        };
+        rc = build_exec_order(ctx, view, tcs_d.p + k, tcs[k].n_parents, *execs[k], 1, /*host_len=*/false, /*prepared=*/true, extra,
+                              extra ? &start_table : nullptr);
         if (rc) return rc;
         synced = true;
     }
@@ -201,6 +224,8 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
                                     uint32_t(execs[k]->raw_len), execs[k]->inv.p);
             if (rc) return rc;
         }
+    rc = event_table_join(ctx, w);
+    if (rc) return rc;
     bool tabulated = false;
     for (auto& tc : tcs) tabulated = tabulated || tc.receipt_recs != nullptr;
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, uint32_t(tcs.size()), blob_d, blob_len,

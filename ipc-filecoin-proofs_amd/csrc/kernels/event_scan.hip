@@ -439,15 +439,16 @@ int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* recei
 
 int launch_receipt_events(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
                           const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, const BlockRec* brecs_d,
-                          ReceiptRec* rrecs_d, uint32_t* counts_d, unsigned long long* err_d) {
+                          ReceiptRec* rrecs_d, uint32_t* counts_d, unsigned long long* err_d, hipStream_t stream) {
     if (n == 0) return IPCFP_OK;
+    if (!stream) stream = ctx->stream;
     ScanParams sp{};
     if (filter) sp = ScanParams{*filter, actor, has_actor ? 1u : 0u, 0};
     {
-        ProfileScope prof(ctx, IPCFP_K_EVENT_SCAN);
-        hipLaunchKernelGGL(k_receipt_events, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n,
+        ProfileScope prof(ctx, IPCFP_K_EVENT_SCAN, stream);
+        hipLaunchKernelGGL(k_receipt_events, dim3(div_up(n, 256)), dim3(256), 0, stream, w, receipts_d, n,
                            filter ? 1 : 0, brecs_d, rrecs_d, counts_d, err_d);
-        hipLaunchKernelGGL(k_receipt_walk, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, receipts_d, n, sp,
+        hipLaunchKernelGGL(k_receipt_walk, dim3(div_up(n, 256)), dim3(256), 0, stream, w, receipts_d, n, sp,
                            filter ? 1 : 0, rrecs_d, counts_d, err_d);
     }
     IPCFP_HIP(ctx, hipGetLastError());

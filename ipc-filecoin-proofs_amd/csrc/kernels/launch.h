@@ -93,7 +93,7 @@ int launch_scan_pass2(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& receip
 struct BlockRec;
 int launch_receipt_events(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
                           const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, const BlockRec* brecs_d,
-                          ReceiptRec* rrecs_d, uint32_t* counts_d, unsigned long long* err_d);
+                          ReceiptRec* rrecs_d, uint32_t* counts_d, unsigned long long* err_d, hipStream_t stream = nullptr);
 // --- block_events.hip --- step 1: every block parsed out of LDS in arena order, on `stream` (meta_d: K1Meta[n])
 int launch_block_events(ipcfp_ctx* ctx, hipStream_t stream, const uint8_t* arena, const void* meta_d, uint32_t n,
                         const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, BlockRec* brecs_d,
