@@ -154,6 +154,7 @@ int ipcfp_witness_put_keyed(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
     w->n = nw->n;
     w->nbytes = nw->nbytes;
     w->arena_bytes = nw->arena_bytes;
+    w->max_block_len = nw->max_block_len;
     w->arena.swap(nw->arena);
     w->off.swap(nw->off);
     w->len.swap(nw->len);

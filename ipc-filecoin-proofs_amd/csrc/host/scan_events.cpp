@@ -251,6 +251,7 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
                                       hipMemcpyDeviceToHost, ctx->stream));
     if (touched_bits) IPCFP_HIP(ctx, hipMemcpyAsync(touched_bits, touched.p, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    ctl_preprime(ctx);
     return IPCFP_OK;
 }
 
@@ -286,6 +287,7 @@ int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t
                                       (res.n_matches < cap_matches ? res.n_matches : cap_matches) * sizeof(ipcfp_event_match_t),
                                       hipMemcpyDeviceToDevice, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // `res` returns its buffers to the pool on exit
+    ctl_preprime(ctx);
     return IPCFP_OK;
 }
 

@@ -112,10 +112,13 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         jobs[k].roots = execs[k]->roots.p;
         jobs[k].err = execs[k]->err.p;
     }
-    DevBuf<PrepareJob> jobs_d;
-    IPCFP_HIP(ctx, jobs_d.alloc(jobs.size()));
-    IPCFP_HIP(ctx, h2d_small(ctx, jobs_d.p, jobs.data(), jobs.size() * sizeof(PrepareJob), ctx->stream));
-    rc = launch_tipset_prepare(ctx, view, jobs_d.p, uint32_t(jobs.size()));
+    DevBuf<PrepareJob> jobs_d;  // (a handful of jobs travel as a kernel argument instead)
+    if (jobs.size() > kInlineJobs) {
+        IPCFP_HIP(ctx, jobs_d.alloc(jobs.size()));
+        IPCFP_HIP(ctx, h2d_small(ctx, jobs_d.p, jobs.data(), jobs.size() * sizeof(PrepareJob), ctx->stream));
+    }
+    rc = launch_tipset_prepare(ctx, view, jobs.data(), jobs_d.p, uint32_t(jobs.size()),
+                               /*need_general=*/uint64_t(w->max_block_len) + 32u > uint64_t(kPrologueStageChunks) * 16u);
     if (rc) return rc;
     // the header facts come back with the first synchronisation below (the enumerator's), not one of their own
     std::vector<TipsetCtxDev> facts(tcs.size());
@@ -327,6 +330,7 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
                            static_cast<const uint8_t*>(blob_d), blob_len, trust, filter, static_cast<uint8_t*>(status_d));
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    ctl_preprime(ctx);
     return IPCFP_OK;
 }
 

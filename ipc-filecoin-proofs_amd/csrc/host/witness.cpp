@@ -59,8 +59,15 @@ int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_b
     rc = launch_gather_cids(ctx, w->order.p, w->cids.p, n, w->k1_cids.p);
     if (rc) return rc;
     uint64_t total = 0;
+    uint64_t meta0[2] = {0, 0};  // K1Meta of the first lane of the schedule = the longest block: {off, len | id << 32}
     IPCFP_HIP(ctx, d2h_small(ctx, &total, total_d, sizeof total, ctx->stream));
+    if (n) IPCFP_HIP(ctx, d2h_small(ctx, meta0, w->k1_meta.p, sizeof meta0, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    {   // the schedule sorts by 128-byte chunk COUNT (classes capped at 255): the first block bounds every length
+        const uint32_t len0 = uint32_t(meta0[1]);
+        const uint32_t chunks0 = len0 ? (len0 + 127u) / 128u : 1u;
+        w->max_block_len = !n ? 0u : (chunks0 >= 255u ? 0xffffffffu : chunks0 * 128u);
+    }
     w->arena_bytes = total + kTailSlack;
     IPCFP_HIP(ctx, w->arena.alloc(w->arena_bytes));
     IPCFP_HIP(ctx, hipMemsetAsync(w->arena.p + total, 0, kTailSlack, ctx->stream));

@@ -62,7 +62,8 @@ int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_
 int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d, const uint32_t* first_d,
                        const uint32_t* pos_d, uint32_t n, uint32_t* inv_d);
 // jobs_d: device array of {TipsetCtxDev* ctx, AmtRootSpec* roots (nullable), unsigned long long* err}
-int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs_d, uint32_t n_jobs);
+int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs, const void* jobs_d, uint32_t n_jobs,
+                          bool need_general);
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
                       unsigned long long* err_d, int verify_txmeta = 1);
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,

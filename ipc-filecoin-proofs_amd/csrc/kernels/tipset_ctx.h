@@ -50,5 +50,16 @@ struct PrepareJob {
     unsigned long long* err;
 };
 constexpr uint32_t kPrepareSlots = 2 + IPCFP_MAX_PARENTS;
+// the jobs travel as a kernel ARGUMENT when there are at most this many (a verification call has one context per
+// distinct tipset pair — usually one): one H2D copy less at the head of the call
+constexpr uint32_t kInlineJobs = 4;
+struct PrepareJobs {
+    PrepareJob inline_jobs[kInlineJobs];
+    const PrepareJob* more;  // non-null: the jobs are in device memory instead
+};
+__device__ __forceinline__ PrepareJob prepare_job(const PrepareJobs& j, uint32_t i) { return j.more ? j.more[i] : j.inline_jobs[i]; }
+// LDS stage of the prologue (tipset_prepare.hip): a block header is 0.6-2 KB, a TxMeta 90 bytes.  A witness whose
+// largest block fits needs no general companion launch.
+constexpr uint32_t kPrologueStageChunks = 512;  // 8 KB
 
 }  // namespace ipcfp

@@ -23,7 +23,6 @@
 
 namespace ipcfp {
 
-constexpr uint32_t kPrologueStageChunks = 512;  // 8 KB: a block header is 0.6-2 KB, a TxMeta 90 bytes
 
 typedef __attribute__((address_space(3))) const uint8_t* lds_bytes_t;
 
@@ -200,17 +199,17 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
     }
 }
 
-__global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, const PrepareJob* __restrict__ jobs, uint32_t n_jobs) {
+__global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, PrepareJobs jobs, uint32_t n_jobs) {
     __shared__ rd_chunk_t stage[kPrologueStageChunks];
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
-    const PrepareJob jb = jobs[job];
+    const PrepareJob jb = prepare_job(jobs, job);
     if (slot < 2) headers_slot(w, *jb.ctx, slot == 0, stage, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
     else if (jb.roots) roots_slot(w, *jb.ctx, jb.roots, jb.err, slot - 2, stage);
 }
 
-void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJob* jobs_d, uint32_t n_jobs) {
-    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs_d, n_jobs);
+void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs) {
+    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs, n_jobs);
 }
 
 }  // namespace ipcfp

@@ -5,6 +5,8 @@
 // parse a 43 KB workgroup waits for a CU to drain.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "../common.h"
 #include "blake2b_dev.h"
 #include "claims_dev.h"
@@ -208,23 +210,29 @@ __global__ __launch_bounds__(64) void k_exec_roots(WitnessView w, const TipsetCt
 // The general companion of the tipset prologue (tipset_prepare.hip): the same jobs and slots, for the slots that
 // kernel left alone because a block did not fit its LDS stage (TipsetCtxDev::prologue_general).  Normally every
 // workgroup leaves at once.
-__global__ __launch_bounds__(64) void k_tipset_prepare_general(WitnessView w, const PrepareJob* __restrict__ jobs, uint32_t n_jobs) {
+__global__ __launch_bounds__(64) void k_tipset_prepare_general(WitnessView w, PrepareJobs jobs, uint32_t n_jobs) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
-    const PrepareJob jb = jobs[job];
+    const PrepareJob jb = prepare_job(jobs, job);
     if (!((jb.ctx->prologue_general >> slot) & 1u)) return;
     if (slot < 2) ctx_headers_body(w, *jb.ctx, slot == 0, lds, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
     else if (jb.roots) exec_roots_body(w, jb.ctx, jb.roots, jb.err, 1, slot - 2, lds);
 }
 
-void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJob* jobs_d, uint32_t n_jobs);  // tipset_prepare.hip
+void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs);  // tipset_prepare.hip
 
-int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs_d, uint32_t n_jobs) {
+// `jobs`: HOST array; `jobs_d`: device copy, needed (and read) only when there are more than kInlineJobs.
+// `need_general`: some block of the witness may exceed the LDS stage, so the general companion has to look.
+int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs, const void* jobs_d, uint32_t n_jobs,
+                          bool need_general) {
     if (n_jobs == 0) return IPCFP_OK;
-    launch_tipset_prepare_lds(ctx->stream, w, static_cast<const PrepareJob*>(jobs_d), n_jobs);
-    hipLaunchKernelGGL(k_tipset_prepare_general, dim3(n_jobs * kPrepareSlots), dim3(64), 0, ctx->stream, w,
-                       static_cast<const PrepareJob*>(jobs_d), n_jobs);
+    PrepareJobs pj{};
+    if (n_jobs <= kInlineJobs) std::memcpy(pj.inline_jobs, jobs, size_t(n_jobs) * sizeof(PrepareJob));
+    else pj.more = static_cast<const PrepareJob*>(jobs_d);
+    launch_tipset_prepare_lds(ctx->stream, w, pj, n_jobs);
+    if (need_general)
+        hipLaunchKernelGGL(k_tipset_prepare_general, dim3(n_jobs * kPrepareSlots), dim3(64), 0, ctx->stream, w, pj, n_jobs);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
