@@ -141,3 +141,48 @@ def test_fast_path_agrees_with_the_general_decode():
         else:
             declined += 1
     assert accepted > 15_000 and declined > 15_000, (accepted, declined)
+
+
+def head_branchless(buf: bytes, pos: int, n: int, err: int):
+    """transcription of Rd::head in its LDS form (cbor_dev.h, IPCFP_RD_LDS): → (major, arg, pos', err')"""
+    inside = pos < n
+    at_pos = pos if inside else 0
+    raw = int.from_bytes(buf[at_pos:at_pos + 8], "little")
+    b = raw & 0xFF
+    m, ai = b >> 5, b & 31
+    imm = ai < 24
+    nb = 0 if imm else (1 << ((ai - 24) & 3))
+    bad = (not inside) or ai > 27
+    bad = bad or (m == 7 and ((not (20 <= ai <= 22)) if imm else ai != 27))
+    bad = bad or (inside and nb > n - at_pos - 1)
+    be = int.from_bytes((raw >> 8).to_bytes(8, "little"), "big")  # bswap64(raw >> 8)
+    if nb == 8:
+        be |= buf[at_pos + 8]
+    v = ai if imm else (be if nb == 8 else (be >> ((64 - 8 * nb) & 63)))
+    good = (not err) and (not bad)
+    err2 = err if err else (66 if bad else 0)
+    return (m if good else 8), (v if good else 0), pos + ((1 + nb) if good else 0), err2
+
+
+def head_reference(buf: bytes, pos: int, n: int, err: int):
+    """the windowed reader's head(): early returns"""
+    if err:
+        return 8, 0, pos, err
+    try:
+        m, a, p2 = head(buf, pos, n)
+    except Bad:
+        return 8, 0, pos, 66
+    return m, a, p2, 0
+
+
+def test_branchless_item_header_equals_the_early_return_form():
+    rng = random.Random(7)
+    for it in range(200_000):
+        n = rng.randrange(0, 24)
+        body = bytearray(rng.randbytes(n))
+        if n and it % 3 == 0:  # bias the initial byte towards every (major, additional-info) pair
+            body[0] = rng.randrange(256)
+        buf = bytes(body) + rng.randbytes(24)
+        pos = rng.randrange(0, n + 2)
+        err = 66 if it % 11 == 0 else 0
+        assert head_branchless(buf, pos, n, err) == head_reference(buf, pos, n, err), (buf[:n].hex(), pos, n, err)
