@@ -412,7 +412,7 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev):
         kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
     # ---- what was timed must be right: every rank merges the gathered messages and checks the WHOLE tipset ----
     gathered = d_recv.cpu().numpy()
-    positions = [shard.route_claims(cl["exec_index"], *ipcfp.shard_range(sh.n_receipts_total, world, r)) for r in range(world)]
+    positions = shard.route_all(cl["exec_index"], sh.n_receipts_total, world)
     merged = shard.merge(gathered, layout, world, positions, len(cl), sh.n_receipts_total)
     if not (merged["status"] == 1).all() or merged["n_bad_cids"] or merged["scan_status"] != 1:
         raise SystemExit("bench self-check failed (rank %d): merged verdicts are not all TRUE" % rank)

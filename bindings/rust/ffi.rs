@@ -46,6 +46,8 @@ pub const IPCFP_CID_SLOT: usize = 40;
 pub const IPCFP_MAX_PARENTS: usize = 16;
 pub const IPCFP_ST_TRUE: u8 = 1;
 pub const IPCFP_ST_FALSE_FILTER: u8 = 17;
+/// `ipcfp_check_event_fn` of the header: the host predicate of ipcfp_verify_event_proofs_with
+pub type ipcfp_check_event_fn = Option<unsafe extern "C" fn(user: *mut std::ffi::c_void, proof_index: u64, stamped_event: *const u8, len: u64) -> c_int>;
 
 #[repr(C)]
 pub struct ipcfp_event_proof_t {
@@ -235,23 +237,24 @@ impl Witness<'_> {
     /// are still true — `Ok(false)` where it declines, exactly where the reference calls it.
     pub fn verify_event_proof_with(&self, bundle: &EventProofBundle, trust: &ipcfp_trust_policy_t,
                                    check_event: &dyn Fn(&fvm_shared::event::ActorEvent) -> bool) -> Result<Vec<bool>> {
+        // the trampoline libipcfp.so calls for every proof that is still true (ipcfp_verify_event_proofs_with does the
+        // "predicate false => FALSE_FILTER" fold behind the ABI): decode the located StampedEvent, hand its ActorEvent on
+        struct Env<'a> { f: &'a dyn Fn(&fvm_shared::event::ActorEvent) -> bool }
+        unsafe extern "C" fn tramp(user: *mut std::ffi::c_void, _proof: u64, ev: *const u8, len: u64) -> c_int {
+            let env = &*(user as *const Env);
+            let raw = std::slice::from_raw_parts(ev, len as usize);
+            match fvm_ipld_encoding::from_slice::<fvm_shared::event::StampedEvent>(raw) {  // validated on the device already
+                Ok(stamped) => (env.f)(&stamped.event) as c_int,
+                Err(_) => 0,
+            }
+        }
         let keep: Vec<_> = bundle.proofs.iter().map(CEventProof::new).collect();
         let raw: Vec<ipcfp_event_proof_t> = keep.iter().map(|k| k.raw()).collect();
-        let n = raw.len();
-        let (mut st, mut loc) = (vec![0u8; n], vec![ipcfp_value_loc_t::default(); n]);
-        let rc = unsafe { ipcfp_verify_event_proofs_located(self.eng.ctx, self.raw(), raw.as_ptr(), n as u64, trust, std::ptr::null(),
-                                                            st.as_mut_ptr(), loc.as_mut_ptr()) };
-        if rc != 0 { return Err(self.eng.err("ipcfp_verify_event_proofs_located", rc)); }
-        let stride = loc.iter().map(|l| l.len as usize).max().unwrap_or(0).max(1);
-        let mut bytes = vec![0u8; n * stride];
-        let rc = unsafe { ipcfp_witness_read_values(self.eng.ctx, self.raw(), loc.as_ptr(), n as u64, bytes.as_mut_ptr(), stride as u64) };
-        if rc != 0 { return Err(self.eng.err("ipcfp_witness_read_values", rc)); }
-        for i in 0..n {
-            if st[i] != IPCFP_ST_TRUE { continue; }
-            let raw_event = &bytes[i * stride..i * stride + loc[i].len as usize];
-            let stamped: fvm_shared::event::StampedEvent = fvm_ipld_encoding::from_slice(raw_event)?;  // already validated on the device
-            if !check_event(&stamped.event) { st[i] = IPCFP_ST_FALSE_FILTER; }
-        }
+        let mut st = vec![0u8; raw.len()];
+        let env = Env { f: check_event };
+        let rc = unsafe { ipcfp_verify_event_proofs_with(self.eng.ctx, self.raw(), raw.as_ptr(), raw.len() as u64, trust, std::ptr::null(),
+                                                         Some(tramp), &env as *const Env as *mut std::ffi::c_void, st.as_mut_ptr()) };
+        if rc != 0 { return Err(self.eng.err("ipcfp_verify_event_proofs_with", rc)); }
         statuses_to_result(&st)
     }
 

@@ -448,6 +448,19 @@ int ipcfp_verify_event_proofs_located(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, cons
                                       const ipcfp_event_filter_t* filter, ipcfp_status_t* status,
                                       ipcfp_value_loc_t* event_loc);
 
+/* `verify_event_proof(bundle, .., Some(check_event))` with an ARBITRARY host closure, end to end behind the ABI
+ * (src/proofs/events/verifier.rs:51-56; the predicate is applied at :247-251, AFTER verify_event_data_matches, and
+ * only to proofs that are still true).  The device verifies the batch and locates each proof's StampedEvent; the
+ * events of the proofs whose status is TRUE are gathered by one kernel and copied back, and `check_event` runs on
+ * the calling thread, in proof order, over the DAG-CBOR bytes of the StampedEvent item `[emitter, ActorEvent]`
+ * (already validated on the device): a zero return turns the status into IPCFP_ST_FALSE_FILTER (`Ok(false)`).
+ * A Rust wrapper passes a trampoline that decodes the item and calls the `&dyn Fn(&ActorEvent) -> bool`.
+ * check_event == NULL: identical to ipcfp_verify_event_proofs.                                                    */
+typedef int (*ipcfp_check_event_fn)(void* user, uint64_t proof_index, const uint8_t* stamped_event, uint64_t len);
+int ipcfp_verify_event_proofs_with(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
+                                   const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                                   ipcfp_check_event_fn check_event, void* user, ipcfp_status_t* status);
+
 /* `verify_storage_proof` (src/proofs/storage/verifier.rs:24-63) over a batch. */
 int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_storage_proof_t* proofs,
                                 uint64_t n, const ipcfp_trust_policy_t* trust, ipcfp_status_t* status);

@@ -212,6 +212,7 @@ def load_library() -> C.CDLL:
         "ipcfp_witness_put_keyed": (i32, [vp, vp, vp, vp, vp, vp, u64]),
         "ipcfp_witness_read_values": (i32, [vp, vp, vp, u64, vp, u64]),
         "ipcfp_verify_event_proofs_located": (i32, [vp, vp, vp, u64, vp, vp, vp, vp]),
+        "ipcfp_verify_event_proofs_with": (i32, [vp, vp, vp, u64, vp, vp, vp, vp, vp]),
         "ipcfp_generate_proof_bundle": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, vp, u64, vp, vp, vp, vp, vp, u64,
                                               C.POINTER(u64), vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
         "ipcfp_shard_range": (None, [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]),
@@ -903,6 +904,31 @@ class Witness:
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st), _p(loc)), "verify_event_proofs_located")
         return st, loc
+
+    def verify_event_proofs_with(self, claims_arr, n, check_event, trust=None, filt=None):
+        """verify_event_proof with an arbitrary host predicate (events/verifier.rs:51-56,247-251), end to end through
+        ipcfp_verify_event_proofs_with: `check_event(proof_index, stamped_event_bytes) -> bool` is called by the
+        library, on this thread, for every proof that is otherwise TRUE; False => FALSE_FILTER."""
+        st = np.zeros(n, dtype=np.uint8)
+        cb_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64)
+        raised = []
+
+        def tramp(_user, idx, ptr, ln):
+            try:
+                return 1 if check_event(int(idx), C.string_at(ptr, int(ln))) else 0
+            except BaseException as e:  # a Python exception cannot cross the C frame: keep it, decline, re-raise below
+                raised.append(e)
+                return 0
+
+        cb = cb_t(tramp)
+        self.eng._check(self.lib.ipcfp_verify_event_proofs_with(
+            self.eng.h, self.h, C.cast(claims_arr, C.c_void_p), n,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, C.cast(cb, C.c_void_p), None, _p(st)),
+            "verify_event_proofs_with")
+        if raised:
+            raise raised[0]
+        return st
 
     def generate_proof_bundle(self, parent_cids, child_cid: bytes, storage_specs, event_specs):
         """generate_proof_bundle.  storage_specs: [(actor_id, slot32)], event_specs: [(signature, topic_1, actor|None)].

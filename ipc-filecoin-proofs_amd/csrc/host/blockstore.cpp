@@ -8,6 +8,7 @@
 // so that unmodified fvm_ipld_amt / fvm_ipld_hamt callers can sit on top of the HBM-resident store (bindings/rust/ffi.rs
 // implements the trait over these three).  The lookups run on the device through the same CID index the walk
 // kernels use; a put re-lays the witness out (blocks are immutable once placed: puts are meant to be batched).
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -81,22 +82,31 @@ int ipcfp_witness_read_values(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     if (!ctx || !w || w->ctx != ctx || (n && (!locs || !out || !stride))) return IPCFP_E_INVALID;
     if (n == 0) return IPCFP_OK;
     IPCFP_ENTER(ctx);
-    // block offsets of the named blocks, then one copy per value (values are few: matches, proofs to re-check)
-    std::vector<uint64_t> offs(n, 0);
-    for (uint64_t i = 0; i < n; ++i)
-        if (locs[i].block != 0xffffffffu) {
-            if (locs[i].block >= w->n) return set_error(ctx, IPCFP_E_INVALID, "value %llu names block %u of %llu",
-                                                        (unsigned long long)i, locs[i].block, (unsigned long long)w->n);
-            IPCFP_HIP(ctx, d2h_small(ctx, &offs[i], w->off.p + locs[i].block, 8, ctx->stream));
-            if ((i & 255) == 255) IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // the pinned page is small
-        }
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    for (uint64_t i = 0; i < n; ++i) {
-        if (locs[i].block == 0xffffffffu) continue;
-        const uint64_t take = locs[i].len < stride ? locs[i].len : stride;
-        if (take) IPCFP_HIP(ctx, hipMemcpyAsync(out + i * stride, w->arena.p + offs[i] + locs[i].off, take, hipMemcpyDeviceToHost, ctx->stream));
+    // ONE gather kernel into a staging buffer and ONE copy back per chunk of values (a 1M-proof bundle used to be 2M tiny
+    // copies); the kernel checks every location against its block before it reads (block < n, off + len <= block len)
+    if (stride > (uint64_t(1) << 30)) return set_error(ctx, IPCFP_E_INVALID, "stride too large");
+    const uint64_t per_chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (uint64_t(256) << 20) / stride));
+    DevBuf<ipcfp_value_loc_t> locs_d;
+    DevBuf<uint8_t> stage;
+    DevBuf<unsigned long long> bad_d;
+    IPCFP_HIP(ctx, locs_d.alloc(per_chunk));
+    IPCFP_HIP(ctx, stage.alloc(per_chunk * stride));
+    IPCFP_HIP(ctx, bad_d.alloc(1));
+    const WitnessView view = witness_view(w);
+    for (uint64_t at = 0; at < n; at += per_chunk) {
+        const uint64_t m = std::min<uint64_t>(per_chunk, n - at);
+        IPCFP_HIP(ctx, hipMemsetAsync(bad_d.p, 0xff, 8, ctx->stream));
+        IPCFP_HIP(ctx, hipMemcpyAsync(locs_d.p, locs + at, m * sizeof(ipcfp_value_loc_t), hipMemcpyHostToDevice, ctx->stream));
+        int rc = launch_gather_values(ctx, view, locs_d.p, uint32_t(m), stage.p, stride, bad_d.p);
+        if (rc) return rc;
+        unsigned long long bad = ~0ull;
+        IPCFP_HIP(ctx, d2h_small(ctx, &bad, bad_d.p, 8, ctx->stream));
+        IPCFP_HIP(ctx, hipMemcpyAsync(out + at * stride, stage.p, m * stride, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+        if (bad != ~0ull)
+            return set_error(ctx, IPCFP_E_INVALID, "value %llu (block %u, off %u, len %u) does not lie inside a block of the witness",
+                             (unsigned long long)(at + bad), locs[at + bad].block, locs[at + bad].off, locs[at + bad].len);
     }
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
 }
 
@@ -107,7 +117,10 @@ int ipcfp_witness_put_keyed(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
     if (w->n + n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
     IPCFP_ENTER(ctx);
     uint64_t nbytes = 0;
-    for (uint64_t i = 0; i < n; ++i) nbytes = std::max<uint64_t>(nbytes, off[i] + len[i]);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (off[i] + len[i] < off[i]) return set_error(ctx, IPCFP_E_INVALID, "block %llu: off + len overflows", (unsigned long long)i);
+        nbytes = std::max<uint64_t>(nbytes, off[i] + len[i]);
+    }
     if (nbytes && !bytes) return IPCFP_E_INVALID;
     const uint64_t total = w->n + n;
     // the source table of the new layout: old blocks where they lie in the old arena, new blocks in an upload buffer —

@@ -1,4 +1,5 @@
 // csrc/host/context.cpp — context lifecycle, error text and HIP-event kernel timing.
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -21,15 +22,16 @@ int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...) {
 thread_local DevPool* g_tls_pool = nullptr;
 
 hipError_t wait_stream(ipcfp_ctx* ctx, hipStream_t s) {
-    if (!ctx->spin_sync) return hipStreamSynchronize(s);
-    if (!ctx->spin_event && hipEventCreateWithFlags(&ctx->spin_event, hipEventDisableTiming) != hipSuccess)
-        return hipStreamSynchronize(s);
+    // (the polling event was created on the context's device by ipcfp_ctx_create; without one: the blocking call)
+    if (!ctx->spin_sync || !ctx->spin_event) return hipStreamSynchronize(s);
     hipError_t e = hipEventRecord(ctx->spin_event, s);
     if (e != hipSuccess) return e;
+    // poll for a bounded WALL-CLOCK time (2 ms: every wait of a verification step is shorter), then give the core back
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
     for (uint32_t spins = 0;; ++spins) {
         e = hipEventQuery(ctx->spin_event);
         if (e != hipErrorNotReady) return e;
-        if (spins > 200000) return hipStreamSynchronize(s);  // a long wait: give the core back
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() > deadline) return hipStreamSynchronize(s);
     }
 }
 
@@ -217,6 +219,8 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
         }
     }
     if (const char* e = std::getenv("IPCFP_SPIN_SYNC")) ctx->spin_sync = std::atoi(e) != 0;
+    // wait_stream's polling event belongs to THIS device (created here, right after hipSetDevice(device))
+    if (hipEventCreateWithFlags(&ctx->spin_event, hipEventDisableTiming) != hipSuccess) ctx->spin_event = nullptr;
     if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = (std::atoi(e) >= 0 && std::atoi(e) <= 3) ? std::atoi(e) : 0;
     if (const char* e = std::getenv("IPCFP_B2B_WG")) {
         const int wg = std::atoi(e);
@@ -274,6 +278,7 @@ void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx) { return ctx ? reinterpret_cast<void*>(
 
 int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
     if (!ctx) return IPCFP_E_INVALID;
+    IPCFP_HIP(ctx, hipSetDevice(ctx->device));  // (a multi-device process: the event record below is per device)
     IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream));
     IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream_k1));
     if (ctx->stream_aux != ctx->stream) IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream_aux));

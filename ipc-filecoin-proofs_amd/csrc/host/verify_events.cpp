@@ -4,6 +4,7 @@
 // proofs by tipset context (parent_tipset_cids, child_block_cid), prepare each context on the
 // device (header facts + execution order — both recomputed PER PROOF by the reference,
 // events/verifier.rs:105,115,190), then verify the whole batch with one kernel.
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -262,6 +263,40 @@ int ipcfp_verify_event_proofs_located(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, cons
                                       ipcfp_status_t* status, ipcfp_value_loc_t* event_loc) {
     if (n && !event_loc) return IPCFP_E_INVALID;
     return verify_event_proofs_impl(ctx, w, proofs, n, trust, filter, status, event_loc);
+}
+
+// verify_event_proof with an arbitrary host predicate (events/verifier.rs:51-56, applied at :247-251): the fold
+// "still true and the predicate declines => Ok(false)" happens here, behind the ABI.
+int ipcfp_verify_event_proofs_with(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,
+                                   const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                                   ipcfp_check_event_fn check_event, void* user, ipcfp_status_t* status) {
+    if (!check_event) return verify_event_proofs_impl(ctx, w, proofs, n, trust, filter, status, nullptr);
+    if (n == 0) return ctx && w && w->ctx == ctx ? IPCFP_OK : IPCFP_E_INVALID;
+    std::vector<ipcfp_value_loc_t> loc(n);
+    int rc = verify_event_proofs_impl(ctx, w, proofs, n, trust, filter, status, loc.data());
+    if (rc) return rc;
+    // the events of the proofs that are still true, compacted (a proof that failed earlier never reaches the predicate)
+    std::vector<uint64_t> who;
+    std::vector<ipcfp_value_loc_t> want;
+    uint64_t stride = 16;
+    for (uint64_t i = 0; i < n; ++i)
+        if (status[i] == IPCFP_ST_TRUE && loc[i].block != 0xffffffffu) {
+            who.push_back(i);
+            want.push_back(loc[i]);
+            stride = std::max<uint64_t>(stride, (uint64_t(loc[i].len) + 15) & ~uint64_t(15));
+        }
+    // chunks bound the host buffer (an event is < 64 KB, usually ~130 B)
+    const uint64_t per = std::max<uint64_t>(1, (uint64_t(128) << 20) / stride);
+    std::vector<uint8_t> bytes;
+    for (uint64_t at = 0; at < who.size(); at += per) {
+        const uint64_t m = std::min<uint64_t>(per, who.size() - at);
+        bytes.resize(m * stride);
+        rc = ipcfp_witness_read_values(ctx, w, want.data() + at, m, bytes.data(), stride);
+        if (rc) return rc;
+        for (uint64_t k = 0; k < m; ++k)
+            if (!check_event(user, who[at + k], bytes.data() + k * stride, want[at + k].len)) status[who[at + k]] = IPCFP_ST_FALSE_FILTER;
+    }
+    return IPCFP_OK;
 }
 
 static int verify_event_proofs_impl(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_event_proof_t* proofs, uint64_t n,

@@ -121,6 +121,8 @@ int launch_gather_block_cids(ipcfp_ctx* ctx, const uint8_t* cids_d, const uint32
 // --- shard.hip ---
 int launch_plan_receipts(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint64_t lo, uint32_t n);
 int launch_find_blocks(ipcfp_ctx* ctx, const WitnessView& w, const CidKey* keys_d, uint32_t n, uint32_t* ids_d);
+int launch_gather_values(ipcfp_ctx* ctx, const WitnessView& w, const void* locs_d /* ipcfp_value_loc_t[n] */, uint32_t n,
+                         uint8_t* out_d, uint64_t stride, unsigned long long* first_bad_d);
 int launch_absolute_offsets(ipcfp_ctx* ctx, const uint64_t* off_d, uint32_t n, uint64_t base, uint64_t* out_d);
 int launch_amt_root_info(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, int version, int vkind, uint64_t* out_d);
 int launch_subset_tables(ipcfp_ctx* ctx, const uint32_t* ids_d, uint32_t n, uint32_t n_src, const uint64_t* src_off,

@@ -133,6 +133,35 @@ __global__ __launch_bounds__(256) void k_absolute_offsets(const uint64_t* __rest
     if (t < n) out[t] = base + off[t];
 }
 
+// ipcfp_witness_read_values: value i (block, off, len) → out[i * stride ..), truncated to stride; one wavefront per
+// value, 16 lanes-bytes at a time.  A location that does not lie inside its block (block >= n, off + len past the
+// block's end) is never dereferenced: the first such index goes to *first_bad.
+__global__ __launch_bounds__(256) void k_gather_values(WitnessView w, const ValueLoc* __restrict__ locs, uint32_t n,
+                                                       uint8_t* __restrict__ out, uint64_t stride,
+                                                       unsigned long long* __restrict__ first_bad) {
+    const uint32_t v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const ValueLoc l = locs[v];
+    if (l.block == kNoBlock) return;
+    if (l.block >= w.n || uint64_t(l.off) + l.len > w.len[l.block]) {
+        if ((threadIdx.x & 63u) == 0) atomicMin(first_bad, (unsigned long long)v);
+        return;
+    }
+    const uint8_t* src = w.arena + w.off[l.block] + l.off;
+    uint8_t* dst = out + uint64_t(v) * stride;
+    const uint64_t take = l.len < stride ? l.len : stride;
+    for (uint64_t i = threadIdx.x & 63u; i < take; i += 64) dst[i] = src[i];
+}
+
+int launch_gather_values(ipcfp_ctx* ctx, const WitnessView& w, const void* locs_d, uint32_t n, uint8_t* out_d, uint64_t stride,
+                         unsigned long long* first_bad_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_gather_values, dim3(div_up(n, 4)), dim3(256), 0, ctx->stream, w, static_cast<const ValueLoc*>(locs_d),
+                       n, out_d, stride, first_bad_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 int launch_find_blocks(ipcfp_ctx* ctx, const WitnessView& w, const CidKey* keys_d, uint32_t n, uint32_t* ids_d) {
     if (n == 0) return IPCFP_OK;
     hipLaunchKernelGGL(k_find_blocks, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, keys_d, n, ids_d);

@@ -44,10 +44,22 @@ class Layout:
         return Layout(*[int(x) for x in allreduce_max(np.asarray(local_counts, dtype=np.int64))])
 
 
-def route_claims(exec_index: np.ndarray, lo: int, hi: int) -> np.ndarray:
-    """Positions of the claims this rank verifies: exec_index in [lo, hi)."""
+def route_claims(exec_index: np.ndarray, lo: int, hi: int, last: bool = False) -> np.ndarray:
+    """Positions of the claims this rank verifies: exec_index in [lo, hi).  The LAST rank (`last`) also takes the claims
+    whose exec_index names no receipt at all (>= hi = the receipt count): every claim has exactly one owner.  Such a
+    claim never reaches a receipt — steps 1-3 of verify_single_proof (events/verifier.rs:92-204: trust anchors, header
+    consistency, the execution order) run on data every rank holds and settle it with the same status the unsharded
+    verifier gives (FALSE_EXEC_INDEX / FALSE_MSG_NOT_IN_EXEC or an earlier one)."""
     e = np.asarray(exec_index, dtype=np.uint64)
-    return np.nonzero((e >= np.uint64(lo)) & (e < np.uint64(hi)))[0]
+    sel = e >= np.uint64(lo)
+    if not last:
+        sel &= e < np.uint64(hi)
+    return np.nonzero(sel)[0]
+
+
+def route_all(exec_index: np.ndarray, n_receipts: int, n_shards: int):
+    """route_claims for every rank of n_shards (what a host needs to merge the gathered status bytes)."""
+    return [route_claims(exec_index, *B.shard_range(n_receipts, n_shards, r), last=(r == n_shards - 1)) for r in range(n_shards)]
 
 
 def merge(gathered: np.ndarray, layout: Layout, n_ranks: int, claim_positions, n_claims_total: int, n_receipts_total: int):
@@ -55,7 +67,7 @@ def merge(gathered: np.ndarray, layout: Layout, n_ranks: int, claim_positions, n
     claim_positions[r]: positions (in the caller's claim order) of the claims rank r verified.
     → dict(status u8[n_claims_total], has u8[n_receipts_total], scan_status, n_matches, n_bad_cids, per_rank)."""
     g = np.asarray(gathered, dtype=np.uint8).reshape(n_ranks, layout.bytes_per_rank)
-    status = np.full(n_claims_total, 255, dtype=np.uint8)
+    status = np.full(n_claims_total, 255, dtype=np.uint8)  # (every claim has an owner: nothing stays 255 — route_claims)
     has = np.zeros(n_receipts_total, dtype=np.uint8)
     scan_status, n_matches, n_bad, per_rank = 1, 0, 0, []
     for r in range(n_ranks):
@@ -126,7 +138,7 @@ class TipsetShard:
     def route(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray):
         """This rank's share of a packed claim batch: claims whose exec_index is one of its receipts."""
         self.tipsets = np.ascontiguousarray(tipsets)
-        self.positions = route_claims(claims["exec_index"], self.lo, self.hi)
+        self.positions = route_claims(claims["exec_index"], self.lo, self.hi, last=(self.shard == self.n_shards - 1))
         self.claims, self.blob, self.blob_len = subset_packed_claims(claims, blob, self.positions)
         self.n_claims = len(self.positions)
         return self.claims, self.blob, self.blob_len

@@ -72,6 +72,21 @@ def test_event_locations_feed_a_host_closure(engine, oracle, tip):
             want[i] = ipcfp.ST.FALSE_FILTER
         checked += 1
     assert checked > 100 and (want == ipcfp.ST.FALSE_FILTER).sum() > 10
+    # ... and the same fold executed END TO END behind the C ABI (ipcfp_verify_event_proofs_with): the library calls the
+    # predicate for exactly the proofs that are otherwise TRUE, in proof order, with the located StampedEvent bytes
+    seen = []
+
+    def emitter_is_even(idx, raw):
+        seen.append(idx)
+        assert raw == events[idx]
+        return claims.extract_evm_log(raw)[0] % 2 == 0
+
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        got = w.verify_event_proofs_with(ec.arr, ec.n, emitter_is_even)
+        none = w.verify_event_proofs_with(ec.arr, ec.n, lambda i, raw: False)
+    assert np.array_equal(got, want)
+    assert seen == np.nonzero(ok)[0].tolist()
+    assert np.array_equal(none, np.where(ok, ipcfp.ST.FALSE_FILTER, st))
 
 
 def test_generate_proof_bundle_is_the_union_in_cid_order(engine, oracle, tip):
