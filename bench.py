@@ -16,12 +16,20 @@ that tipset with every input already resident in HBM:
     K6  two-pass event-filter scan of all receipts (topic0 + topic1 + actor_id_filter)
         exec-order reconstruction (TxMeta re-hash + message AMT walks + first-seen dedupe)
         verify_event_proof for every claim (receipt AMT walk + events AMT walk + event compare)
-`value` = claims verified per second.  Multi-GPU (`--gpus N`, one rank per GPU): the SAME tipset is cut into N
-receipt-range shards (strong scaling): rank r plans and places its shard once (untimed, like the
-single-GPU upload) — its receipts' events AMTs and receipts-AMT paths, plus the replicated headers, TxMeta blocks
-and message AMTs — and a step is CID index + K1 + range-restricted scan + verify of the claims routed to it, closed
-by ONE ncclAllGather (RCCL called directly by libipcfp.so) of [header | status bytes | has-match map | CID bitmap].
-`--workload cid|hamt|storage` run BASELINE.json configs[1], [3], [4] instead (single GPU).
+`value` = claims verified per second.  Multi-GPU (`--gpus N`, one rank per GPU), two partitionings of a proof batch
+(DESIGN.md §6 has the per-rank projection of both):
+  --shard tipsets  (default)  the batch holds one 1M-receipt tipset PER RANK (a chain of epochs: tipsets are independent
+                   objects): rank r runs the single-GPU step on tipset r and ONE ncclAllGather (RCCL called directly
+                   by libipcfp.so) of [header | status bytes | has-match map | CID bitmap] closes the step — no other
+                   data-path collective; per-GPU work is fixed, `scaling: weak`.
+  --shard receipts ONE tipset cut into N receipt-range shards (`scaling: strong`): rank r plans and places its shard
+                   once (untimed) — its receipts' events AMTs and receipts-AMT paths, plus the replicated headers,
+                   TxMeta blocks and message AMTs — and a step is CID index + K1 + range-restricted scan + verify of
+                   the claims routed to it, closed by the same all-gather.
+`--workload cid|hamt|storage` run BASELINE.json configs[1], [3], [4]; with `--gpus N` the block / query / claim index
+range is cut with ipcfp_shard_range (state tree replicated), each rank runs the ordinary entry point on its range and
+ONE ncclAllGather of the status bytes (CID bitmap) closes the step (`scaling: strong`).  The default single-GPU line
+also carries compact records of those three configs (`configs`), each with its own `roofline` and `cpu_baseline`.
 
 torch is plumbing only (HBM residency of inputs, device sync, torch.distributed); every timed
 kernel is launched by libipcfp.so through its C ABI.  DESIGN.md §Measurement has the byte accounting.
@@ -93,6 +101,12 @@ def main():
                     help="order of the three calls of a tipset step after the index rebuild: K = CID check (K1, asynchronous), "
                          "V = verify_event_proof batch (incl. execution order), S = event-filter scan")
     ap.add_argument("--t2-reps", type=int, default=3, help="repetitions of the PCIe-inclusive window (0 = skip)")
+    ap.add_argument("--shard", choices=["tipsets", "receipts"], default="tipsets",
+                    help="--workload tipset with --gpus N > 1: one tipset per rank (weak scaling, default) or ONE tipset "
+                         "cut into N receipt-range shards (strong scaling)")
+    ap.add_argument("--no-sub-records", action="store_true",
+                    help="skip the compact configs[1]/[3]/[4] records the default single-GPU line carries")
+    ap.add_argument("--sub-steps", type=int, default=5, help="timed steps of each compact sub-record")
     args = ap.parse_args()
 
     import torch
@@ -120,16 +134,22 @@ def main():
 
     eng = ipcfp.Engine(local_rank)
     info = eng.device_info()
+    ranks = Ranks(torch, dist, eng, world, rank, dev)
     if args.workload != "tipset":
-        if world > 1:
-            raise SystemExit("--workload %s is a single-GPU line (its shard plan is ipcfp_shard_range + the same "
-                             "entry points; tests/test_gpu_sharding.py)" % args.workload)
-        out = {"cid": run_cid, "hamt": run_hamt, "storage": run_storage}[args.workload](args, eng, info, torch)
-        print(json.dumps(out))
+        out = {"cid": run_cid, "hamt": run_hamt, "storage": run_storage}[args.workload](args, eng, info, torch, ranks)
+        if rank == 0:
+            print(json.dumps(out))
+        ranks.close()
         eng.close()
+        if world > 1:
+            dist.destroy_process_group()
         return
     if world > 1 or args.force_sharded:
-        run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev)
+        if args.shard == "receipts" or args.force_sharded:
+            run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev, ranks)
+        else:
+            run_tipset_batch(args, eng, info, torch, ranks)
+        ranks.close()
         eng.close()
         dist.destroy_process_group()
         return
@@ -275,6 +295,22 @@ def main():
                          "note": "the same launch with nothing beside it (5 launches after the timed region); `achieved` / "
                                  "`frac` above are the in-step figures, K1 sharing the chip with k_block_events"}
 
+    # ---- the other call order, and the step with the multi-GPU message on top (a few extra steps, outside `value`) ----
+    extras = {}
+    if world == 1:
+        other = "S,K,V" if args.order != "S,K,V" else "K,V,S"
+        saved = order[:]
+        order[:] = other.split(",")
+        for _ in range(2):
+            step()
+        fence()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        extras["ms_per_step_by_order"] = {args.order: elapsed / args.steps * 1e3, other: (time.perf_counter() - ta) / args.steps * 1e3}
+        order[:] = saved
+        extras["ms_per_step_with_gather_message"] = tipset_gather_step_ms(args, eng, torch, w, tip, ts, t_claims, t_blob, blob_len, t_status, n_claims)
     if rank == 0:
         out = {
             "metric": METRIC,
@@ -285,7 +321,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
@@ -300,7 +336,7 @@ def main():
                 "witness_blocks_per_gpu": tip.n_blocks,
                 "witness_bytes_per_gpu": tip.stats["payload_bytes"],
                 "scan_matches": int(scan_result["matches"]),
-                "sharding": "single GPU",
+                "sharding": "single GPU (with --gpus N: one such tipset per rank + one ncclAllGather, scaling weak; --shard receipts cuts ONE tipset instead)",
                 "device": info["name"],
                 "setup_seconds_untimed": round(t_gen, 2),
             },
@@ -316,14 +352,264 @@ def main():
             cb = out["cpu_baseline"]
             out["speedup_vs_cpu_all_cores"] = {"T3": out["value"] / cb["value"],
                                                "T2": (t2["value"] / cb["value"]) if t2 else None}
-        print(json.dumps(out))
+        out.update(extras)
     w.close()
+    del t_bytes, t_off, t_len, t_cids, t_claims, t_blob, t_status
+    if rank == 0:
+        if world == 1 and not args.no_sub_records:
+            # BASELINE.json configs[1], [3], [4] in the SAME driver-visible line: compact records, each with its own
+            # `roofline` and `cpu_baseline` (bounded samples)
+            sub_args = argparse.Namespace(**vars(args))
+            sub_args.steps, sub_args.warmup = args.sub_steps, 2
+            state = _state_tipset()
+            out["configs"] = {
+                "configs[1] cid": compact(run_cid(sub_args, eng, info, torch, ranks)),
+                "configs[3] hamt": compact(run_hamt(sub_args, eng, info, torch, ranks, state)),
+                "configs[4] storage": compact(run_storage(sub_args, eng, info, torch, ranks, state)),
+            }
+        print(json.dumps(out))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev):
+class Ranks:
+    """One process per GPU: the host's own channel (torch.distributed: rendezvous, barrier, the max-over-ranks clock,
+    the 128-byte RCCL id) and the engine's communicator of the DATA path (RCCL called directly by libipcfp.so)."""
+
+    def __init__(self, torch, dist, eng, world, rank, dev):
+        self.torch, self.dist, self.eng, self.world, self.rank, self.dev = torch, dist, eng, world, rank, dev
+        self.comm = None
+
+    def make_comm(self):
+        """The engine's RCCL communicator, or a loud failure: there is no torch.distributed fallback on the data path.
+        ncclCommInitRank is a collective, so the ranks first AGREE (over the host channel) that every one of them can
+        resolve librccl — a rank that cannot would otherwise leave the others hanging inside the init."""
+        import ipc_filecoin_proofs_amd as ipcfp
+
+        if self.comm is not None or self.world == 1:
+            return self.comm
+        try:
+            uid_local, ok = ipcfp.comm_unique_id(), 1  # dlopen("librccl.so.1") + ncclGetUniqueId: the probe
+        except ipcfp.EngineError as e:
+            uid_local, ok = None, 0
+            sys.stderr.write("rank %d: librccl cannot be resolved by libipcfp.so: %s\n" % (self.rank, e))
+        flag = self.torch.tensor([ok], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            raise SystemExit("bench.py: the engine's direct RCCL communicator cannot be made on every rank (see stderr); "
+                             "there is no fallback collective")
+        uid = [uid_local if self.rank == 0 else None]
+        self.dist.broadcast_object_list(uid, src=0)
+        self.comm = ipcfp.Comm(self.eng, uid[0], self.world, self.rank)  # raises EngineError (loud) on failure
+        return self.comm
+
+    def fence(self):
+        self.eng.sync()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_seconds(self, seconds: float) -> float:
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
+def timed(ranks, step, steps, warmup):
+    """The contract's clock: W untimed steps, barrier + sync, K steps, barrier + sync, MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    ranks.fence()
+    ranks.eng.profile_reset()
+    ranks.eng.profile_enable(True)
+    ranks.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ranks.fence()
+    elapsed = time.perf_counter() - t0
+    ranks.eng.profile_enable(False)
+    return ranks.max_seconds(elapsed)
+
+
+def compact(rec):
+    """A per-config record cut down to what the default line carries."""
+    keep = ("value", "unit", "ms_per_step", "steps", "roofline", "cpu_baseline", "window")
+    out = {k: rec[k] for k in keep if k in rec}
+    out["workload"] = rec["config"]["workload"]
+    if "roofline" in out:
+        out["roofline"] = {k: v for k, v in out["roofline"].items() if k in
+                           ("bound", "limiter", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_avg_ms", "launches",
+                            "algorithmic_bytes_per_launch")}
+    return out
+
+
+def range_layout(n, world):
+    """[lo, hi) of every rank for n units and the common (16-byte aligned) width of a rank's status segment."""
+    import ipc_filecoin_proofs_amd as ipcfp
+
+    rng = [ipcfp.shard_range(n, world, r) for r in range(world)]
+    width = (max(h - l for l, h in rng) + 15) & ~15
+    return rng, max(width, 16)
+
+
+def tipset_message(torch, dev, n_claims, n_receipts, n_blocks):
+    """Device buffers of one rank's step message [header | status | has map | CID bitmap] (shard.Layout)."""
+    from ipc_filecoin_proofs_amd import shard
+
+    layout = shard.Layout(n_claims, n_receipts, n_blocks)
+    hdr = np.array([n_claims, n_receipts, n_blocks, 0, 0, 0, 0, n_receipts], dtype=np.uint64)
+    d_hdr = torch.from_numpy(hdr.view(np.uint8).copy()).to(dev)
+    d_has = torch.zeros(layout.w_has, dtype=torch.uint8, device=dev)
+    d_stage = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+    return layout, d_hdr, d_has, d_stage
+
+
+def tipset_gather_step_ms(args, eng, torch, w, tip, ts, t_claims, t_blob, blob_len, t_status, n_claims):
+    """N = 1 only: the single-GPU step PLUS what a rank of a multi-GPU run adds to it — the scan's has-match map kept
+    in HBM, the step message packed, the (here degenerate) all-gather — so that the N = 1 point of a scaling curve can
+    be read on the same definition as the N > 1 points."""
+    import ipc_filecoin_proofs_amd as ipcfp
+    from ipc_filecoin_proofs_amd import shard
+
+    dev = t_status.device
+    layout, d_hdr, d_has, d_stage = tipset_message(torch, dev, n_claims, args.receipts, tip.n_blocks)
+    d_recv = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    bits_bytes = (tip.n_blocks + 31) // 32 * 4
+
+    def step():
+        w.rebuild_index()
+        w.verify_cids_async()
+        w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len, t_status.data_ptr())
+        w.scan_events_device(tip.receipts_root, tip.topic0, tip.topic1, tip.filter_actor, d_has.data_ptr(), layout.w_has,
+                             summary_ptr=d_hdr.data_ptr() + 24)
+        ipcfp.allgather_segments(eng, None, [d_hdr.data_ptr(), t_status.data_ptr(), d_has.data_ptr(), w.cid_bitmap_ptr],
+                                 [shard.HEADER_BYTES, n_claims, args.receipts, bits_bytes], d_stage.data_ptr(),
+                                 d_recv.data_ptr(), layout.bytes_per_rank)
+
+    for _ in range(2):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / args.steps * 1e3
+
+
+def run_tipset_batch(args, eng, info, torch, ranks):
+    """--gpus N > 1, --shard tipsets: the proof batch holds one 1M-receipt tipset per rank (rank r generates tipset
+    seed + r: a chain of epochs).  Step = the single-GPU step on the rank's tipset + ONE ncclAllGather of
+    [header | status bytes | has-match map | CID bitmap]; every rank then holds every tipset's verdicts."""
+    import ipc_filecoin_proofs_amd as ipcfp
+    from ipc_filecoin_proofs_amd import shard
+    from tools.synth import SEED_BASE, Tipset
+
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
+    t_gen = time.perf_counter()
+    tip = Tipset(seed=SEED_BASE + 3 + rank, n_receipts=args.receipts, n_parents=5, dup_permille=20,
+                 n_planted=max(1, args.receipts // 1000), max_events=4, no_events_permille=0, variety=0)
+    n_claims = len(tip.claim_exec)
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec, tip.claim_event,
+        tip.claim_emitter, tip.exec_order[tip.claim_exec.astype(np.int64)], tip.claim_ntopics, tip.claim_topics,
+        tip.claim_datalen, tip.claim_data)
+    t_gen = time.perf_counter() - t_gen
+    t_bytes = torch.from_numpy(tip.data).to(dev)
+    t_off = torch.from_numpy(tip.off.view(np.int64)).to(dev)
+    t_len = torch.from_numpy(tip.lens.view(np.int32)).to(dev)
+    t_cids = torch.from_numpy(tip.cids.reshape(-1)).to(dev)
+    t_claims = torch.from_numpy(cl.view(np.uint8).reshape(-1)).to(dev)
+    t_blob = torch.from_numpy(blob).to(dev)
+    torch.cuda.synchronize()
+    w = eng.witness_device(t_bytes.data_ptr(), tip.data.size, t_off.data_ptr(), t_len.data_ptr(), t_cids.data_ptr(), tip.n_blocks)
+    # message widths: the maxima over ranks (tipsets differ a little in their block counts)
+    counts = torch.tensor([n_claims, args.receipts, tip.n_blocks], dtype=torch.int64, device=dev)
+    ranks.dist.all_reduce(counts, op=ranks.dist.ReduceOp.MAX)
+    mc, mr, mb = [int(x) for x in counts.tolist()]
+    layout = shard.Layout(mc, mr, mb)
+    hdr = np.array([n_claims, args.receipts, tip.n_blocks, 0, 0, 0, 0, args.receipts], dtype=np.uint64)
+    d_hdr = torch.from_numpy(hdr.view(np.uint8).copy()).to(dev)
+    d_status = torch.zeros(layout.w_status, dtype=torch.uint8, device=dev)
+    d_has = torch.zeros(layout.w_has, dtype=torch.uint8, device=dev)
+    d_stage = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+    d_recv = torch.zeros(world * layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    comm = ranks.make_comm()
+    bits_bytes = (tip.n_blocks + 31) // 32 * 4
+
+    def step():
+        w.rebuild_index()                                                                    # K4
+        w.verify_cids_async()                                                                # K1 (second stream)
+        w.verify_event_claims_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len, d_status.data_ptr())
+        w.scan_events_device(tip.receipts_root, tip.topic0, tip.topic1, tip.filter_actor, d_has.data_ptr(), layout.w_has,
+                             summary_ptr=d_hdr.data_ptr() + 24)                              # K6
+        ipcfp.allgather_segments(eng, comm, [d_hdr.data_ptr(), d_status.data_ptr(), d_has.data_ptr(), w.cid_bitmap_ptr],
+                                 [shard.HEADER_BYTES, layout.w_status, layout.w_has, bits_bytes], d_stage.data_ptr(),
+                                 d_recv.data_ptr(), layout.bytes_per_rank)                   # the ONE collective
+
+    elapsed = timed(ranks, step, args.steps, args.warmup)
+    kern = {}
+    for k in ("blake2b_cid", "cid_index", "event_scan", "replay", "event_verify", "exec_order", "allgather"):
+        cnt, ms = eng.profile_read(k)
+        kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
+    roof = k1_roofline(eng, tip.lens, tip.n_blocks)
+    # ---- what was timed must be right: EVERY rank checks EVERY tipset's gathered verdicts ----
+    g = d_recv.cpu().numpy().reshape(world, layout.bytes_per_rank)
+    total_claims, matches = 0, []
+    for r in range(world):
+        h = g[r, :shard.HEADER_BYTES].view(np.uint64)
+        nc, nr, nb, sst, nm = int(h[0]), int(h[1]), int(h[2]), int(h[3]), int(h[4])
+        st_r = g[r, layout.off_status: layout.off_status + nc]
+        bits = np.unpackbits(g[r, layout.off_bits: layout.off_bits + (nb + 31) // 32 * 4], bitorder="little")[:nb]
+        if not (st_r == 1).all() or sst != 1 or int(bits.sum()) != nb or nm < max(1, args.receipts // 1000):
+            raise SystemExit("bench self-check failed (rank %d): tipset %d's gathered verdicts are not all TRUE" % (rank, r))
+        total_claims += nc
+        matches.append(nm)
+    has_own = g[rank, layout.off_has: layout.off_has + args.receipts]
+    if not has_own[tip.planted.astype(np.int64)].all():
+        raise SystemExit("bench self-check failed (rank %d): the scan missed planted matches" % rank)
+    per_rank = [None] * world
+    ranks.dist.all_gather_object(per_rank, {"rank": rank, "blocks": tip.n_blocks, "claims": n_claims, "setup_seconds": round(t_gen, 2),
+                                            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kern.items()}})
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": total_claims * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[2] (the 1M-receipt tipset the metric is quoted on), one tipset PER RANK "
+                            "(%d tipsets of %d receipts, seeds base+3+rank; %d claims in all): step = per-rank CID index + "
+                            "Blake2b-256 CID check + exec-order reconstruction + verify_event_proof of every claim + event-filter "
+                            "scan, closed by ONE ncclAllGather of %d bytes per rank [header | status | has map | CID bitmap]"
+                            % (world, args.receipts, total_claims, layout.bytes_per_rank),
+                "receipts_per_gpu": args.receipts, "claims_per_gpu": n_claims, "tipsets": world,
+                "sharding": "--shard tipsets: independent tipsets, one per rank; no data-path collective besides the closing "
+                            "all-gather (SURVEY.md §8e; `--shard receipts` cuts ONE tipset by receipt range instead)",
+                "collective": "ncclAllGather called by libipcfp.so (RCCL resolved at run time)",
+                "allgather_bytes_per_rank": layout.bytes_per_rank, "scan_matches_per_tipset": matches,
+                "per_rank": per_rank, "device": info["name"],
+            },
+            "roofline": roof,
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in kern.items()},
+            "window": "T3 (tipsets resident in HBM; index rebuilt and every cached enumeration dropped each step)",
+        }
+        print(json.dumps(out))
+    w.close()
+
+
+def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev, ranks):
     """--gpus N > 1: ONE tipset, N receipt-range shards (strong scaling).  Setup (untimed, the analogue of the
     single-GPU upload): every rank holds the tipset in host memory, uploads it, plans its shard on its own GPU,
     cuts the shard's witness out and drops the rest.  Timed step: ipc_filecoin_proofs_amd.shard.TipsetShard.step."""
@@ -350,23 +636,9 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev):
         return t.cpu().numpy()
 
     layout = shard.Layout.agree(sh.counts, allreduce_max)
-    # the communicator of the data path: RCCL through libipcfp.so; its id travels over the host's channel
-    uid = [ipcfp.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    collective = "ncclAllGather called by libipcfp.so (RCCL resolved at run time)"
-    try:
-        comm = ipcfp.Comm(eng, uid[0], world, rank)
-        made = 1
-    except ipcfp.EngineError as e:  # e.g. librccl.so.1 cannot be resolved: keep the run alive on the host's channel
-        comm, made = None, 0
-        sys.stderr.write("rank %d: direct RCCL communicator failed (%s); falling back to torch.distributed\n" % (rank, e))
-    flag = torch.tensor([made], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 0:  # every rank takes the same route
-        if comm is not None:
-            comm.close()
-        comm = None
-        collective = "FALLBACK: torch.distributed all_gather_into_tensor (the direct RCCL communicator could not be made)"
+    # the communicator of the data path: RCCL through libipcfp.so (Ranks.make_comm: agreed on beforehand, loud on failure)
+    comm = ranks.make_comm() if world > 1 else None
+    collective = "ncclAllGather called by libipcfp.so (RCCL resolved at run time)" if comm is not None else "single rank: the packed message is the result"
 
     def dev_bytes(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
@@ -382,9 +654,6 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev):
     def step():
         sh.step(layout, comm, filt, d_cl.data_ptr(), d_blob.data_ptr(), d_status.data_ptr(), d_has.data_ptr(),
                 d_hdr.data_ptr(), d_stage.data_ptr(), d_recv.data_ptr())
-        if comm is None and world > 1:  # fallback route only: the packed message sits in d_stage
-            eng.sync()
-            dist.all_gather_into_tensor(d_recv, d_stage)
 
     def fence():
         eng.sync()
@@ -453,8 +722,6 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev):
             "window": "T3 (shards resident in HBM; index rebuilt and every cached enumeration dropped each step)",
         }
         print(json.dumps(out))
-    if comm is not None:
-        comm.close()
     sh.close()
 
 
@@ -493,45 +760,68 @@ def k1_roofline(eng, lens, n_blocks, traffic_file=None, extra_note=""):
     }
 
 
-def run_cid(args, eng, info, torch):
-    """BASELINE.json configs[1]: N x 1 KiB blocks (59 03 FD + 1021 PRNG bytes), digest bit flipped where i % 1024 == 7."""
+def _gather_line(world, width):
+    return ("; with --gpus %d: index ranges cut by ipcfp_shard_range, one ncclAllGather of %d status bytes per rank closes the step"
+            % (world, width)) if world > 1 else ""
+
+
+def run_cid(args, eng, info, torch, ranks):
+    """BASELINE.json configs[1]: N x 1 KiB blocks (59 03 FD + 1021 PRNG bytes), digest bit flipped where i % 1024 == 7.
+    --gpus N: rank r holds ONLY the blocks [lo_r, hi_r) and one ncclAllGather of the per-rank CID bitmaps closes the step."""
     from tools.synth import SEED_BASE
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ipc_filecoin_proofs_amd as ipcfp_mod
     import oracle_lib
 
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
     n = args.blocks
     data, off, lens = make_cfg2(n, SEED_BASE + 2)
-    dig = eng.blake2b256(data, off, lens)
-    cids = np.zeros((n, 40), dtype=np.uint8)
+    rng, _ = range_layout(n, world)
+    lo, hi = rng[rank]
+    m = hi - lo
+    d_lo = data[lo * 1024: hi * 1024]
+    o_lo = off[lo:hi] - np.uint64(lo * 1024)
+    l_lo = lens[lo:hi]
+    dig = eng.blake2b256(d_lo, o_lo, l_lo)
+    cids = np.zeros((m, 40), dtype=np.uint8)
     cids[:, :6] = np.frombuffer(bytes.fromhex("0171a0e40220"), dtype=np.uint8)
     cids[:, 6:38] = dig
-    flipped = np.arange(7, n, 1024)
-    cids[flipped, 6] ^= 1
-    w = eng.witness(data, off, lens, cids)
-    for _ in range(args.warmup):
+    glob = np.arange(lo, hi)
+    flipped_local = np.nonzero(glob % 1024 == 7)[0]
+    cids[flipped_local, 6] ^= 1
+    w = eng.witness(d_lo, o_lo, l_lo, cids)
+    width = ((max(h - l for l, h in rng) + 31) // 32 * 4 + 15) & ~15  # bitmap bytes per rank
+    comm = ranks.make_comm()
+    d_recv = torch.zeros(world * width, dtype=torch.uint8, device=dev) if world > 1 else None
+    d_send = torch.zeros(width, dtype=torch.uint8, device=dev) if world > 1 else None
+    bits_bytes = (m + 31) // 32 * 4
+
+    def step():
         w.verify_cids_async()
-    eng.sync()
-    eng.profile_reset()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        w.verify_cids_async()
-    eng.sync()
-    elapsed = time.perf_counter() - t0
-    eng.profile_enable(False)
+        if comm is not None:  # (the engine joins K1's stream before the collective)
+            ipcfp_mod.allgather_segments(eng, comm, [w.cid_bitmap_ptr], [bits_bytes], d_send.data_ptr(), d_recv.data_ptr(), width)
+
+    elapsed = timed(ranks, step, args.steps, args.warmup)
     st, nbad = w.cid_results()
-    if nbad != len(flipped) or not (st[flipped] == 0).all() or int(st.sum()) != n - len(flipped):
+    if nbad != len(flipped_local) or not (st[flipped_local] == 0).all() or int(st.sum()) != m - len(flipped_local):
         raise SystemExit("bench self-check failed: CID verdicts")
-    roof = k1_roofline(eng, lens, n, extra_note="; %d blocks = %d wavefronts on 1024 SIMDs" % (n, (n + 63) // 64))
-    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
+    if world > 1:  # every rank checks the WHOLE batch's gathered bitmap
+        g = d_recv.cpu().numpy().reshape(world, width)
+        for r, (l, h) in enumerate(rng):
+            bits = np.unpackbits(g[r, : (h - l + 31) // 32 * 4], bitorder="little")[: h - l]
+            want = (np.arange(l, h) % 1024 != 7).astype(np.uint8)
+            if not np.array_equal(bits, want):
+                raise SystemExit("bench self-check failed (rank %d): gathered CID bitmap of rank %d" % (rank, r))
+    roof = k1_roofline(eng, l_lo, m, extra_note="; %d blocks = %d wavefronts on 1024 SIMDs" % (m, (m + 63) // 64))
+    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[1]: %d Blake2b-256 CID verifications over 1 KiB blocks; step = one "
-                                  "K1 launch over the resident batch (1 proof = 1 CID check)" % n, "blocks": n,
-                      "device": info["name"]},
+                                  "K1 launch over the resident batch (1 proof = 1 CID check)%s" % (n, _gather_line(world, width)),
+                      "blocks": n, "blocks_per_gpu": m, "device": info["name"]},
            "roofline": roof, "window": "T3"}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
         orc, march = oracle_lib.load_native()
         exp = np.ascontiguousarray(cids[:, 6:38])
         best = None
@@ -571,104 +861,139 @@ def _idaddr(i: int) -> bytes:
             return bytes(b)
 
 
-def run_hamt(args, eng, info, torch):
-    """BASELINE.json configs[3]: 4M-actor state tree (HAMT v3, bit width 5), 65 536 present ids + 1 % absent."""
+def run_hamt(args, eng, info, torch, ranks, state=None):
+    """BASELINE.json configs[3]: 4M-actor state tree (HAMT v3, bit width 5), 65 536 present ids + 1 % absent.
+    The state tree is replicated; --gpus N cuts the QUERY index range, each rank runs ipcfp_hamt_get_device on its keys
+    (resident in HBM) and one ncclAllGather of the status bytes closes the step."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    T = _state_tipset()
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
+    T = state if state is not None else _state_tipset()
     w = eng.witness(T.data, T.off, T.lens, T.cids)
     keys = [_idaddr(int(i)) for i in T.query_ids]
     n = len(keys)
-    for _ in range(args.warmup):
-        w.hamt_get(T.actors_root, 5, "actor_state", keys)
-    eng.profile_reset()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gs, gl = w.hamt_get(T.actors_root, 5, "actor_state", keys)
-    elapsed = time.perf_counter() - t0
-    eng.profile_enable(False)
+    rng, width = range_layout(n, world)
+    lo, hi = rng[rank]
+    m = hi - lo
+    kl = np.array([len(k) for k in keys[lo:hi]], dtype=np.uint32)
+    ko = np.zeros(m, dtype=np.uint32)
+    ko[1:] = np.cumsum(kl[:-1])
+    kb = np.frombuffer(b"".join(keys[lo:hi]) + bytes(32), dtype=np.uint8).copy()
+    d_kb, d_ko, d_kl = torch.from_numpy(kb).to(dev), torch.from_numpy(ko.view(np.int32)).to(dev), torch.from_numpy(kl.view(np.int32)).to(dev)
+    d_st = torch.zeros(width, dtype=torch.uint8, device=dev)
+    d_loc = torch.zeros(m * 12 + 16, dtype=torch.uint8, device=dev)
+    d_recv = torch.zeros(world * width, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    comm = ranks.make_comm()
+
+    def step():
+        w.hamt_get_device(T.actors_root, 5, "actor_state", d_kb.data_ptr(), d_ko.data_ptr(), d_kl.data_ptr(), m,
+                          d_st.data_ptr(), d_loc.data_ptr())
+        if comm is not None:
+            comm.allgather_device(d_st.data_ptr(), d_recv.data_ptr(), width)
+
+    elapsed = timed(ranks, step, args.steps, args.warmup)
     cnt, ms = eng.profile_read("hamt_get")
     k_avg_ms = ms / max(cnt, 1)
     present = T.query_present.astype(bool)
-    if not ((gs[present] == 1).all() and (gs[~present] == 32).all()):
+    want = np.where(present, 1, 32).astype(np.uint8)
+    gs = d_st.cpu().numpy()[:m]
+    if not np.array_equal(gs, want[lo:hi]):
         raise SystemExit("bench self-check failed: actor gets")
+    if world > 1:
+        g = d_recv.cpu().numpy().reshape(world, width)
+        for r, (l, h) in enumerate(rng):
+            if not np.array_equal(g[r, : h - l], want[l:h]):
+                raise SystemExit("bench self-check failed (rank %d): gathered statuses of rank %d" % (rank, r))
     # walk bytes per get (SURVEY.md §8d cfg 4 (ii)): per level 4 B bitfield + 43 B link, + <= 3 x 105 B bucket = 0.55 KB
-    algo = n * 550.0
-    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
+    algo = m * 550.0
+    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[3]: HAMT state-tree actor lookup, %d actors, %d gets (%d absent), bit "
-                                  "width 5; step = one ipcfp_hamt_get call (keys uploaded, statuses + locations downloaded: "
-                                  "window T2 for the keys, witness resident)" % (4_000_000, n, int((~present).sum())),
-                      "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
+                                  "width 5; step = one ipcfp_hamt_get_device call (keys, statuses and locations resident in HBM, "
+                                  "witness resident)%s" % (4_000_000, n, int((~present).sum()), _gather_line(world, width)),
+                      "gets_per_gpu": m, "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
            "roofline": {"bound": "hbm", "limiter": "latency", "kernel": "k_hamt_get", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel_avg_ms": k_avg_ms, "launches": cnt, "algorithmic_bytes_per_launch": algo,
-                        "value_kernel_only_gets_per_s": n / (k_avg_ms * 1e-3),
-                        "note": "0.55 KB walked per get (§8d cfg 4 (ii)); a chain of ~6 dependent node decodes per lane"},
-           "window": "T3 witness / T2 keys"}
-    if not args.no_cpu_baseline:
+                        "value_kernel_only_gets_per_s": m / (k_avg_ms * 1e-3),
+                        "note": "0.55 KB walked per get (§8d cfg 4 (ii)); a chain of ~6 dependent node decodes per query"},
+           "window": "T3"}
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
         orc, march = oracle_lib.load_native()
         ost = orc.store(T.data, T.off, T.lens, T.cids, threads=0)
         orc.use_threads(0)
-        t0 = time.perf_counter()
-        os_, ov = ost.hamt_get(T.actors_root, 5, "actor_state", keys)
-        dt = time.perf_counter() - t0
+        os_, _ = ost.hamt_get(T.actors_root, 5, "actor_state", keys, want_values=False)
+        os_, _ = ost.hamt_get(T.actors_root, 5, "actor_state", keys, want_values=False)  # (second call: arenas grown)
+        dt = ost.last_call_seconds
         ost.close()
         if not np.array_equal(os_, gs):
             raise SystemExit("cpu_baseline: actor-get statuses differ")
         out["cpu_baseline"] = {"value": n / dt, "unit": "proofs/s", "cores": orc.use_threads(0), "kind": "port",
-                               "sample": "C++ oracle Hamt::get of all %d keys (incl. Python marshalling of the values), "
+                               "sample": "C++ oracle Hamt::get of all %d keys (the C call alone, store built before the clock), "
                                          "-march=%s, OpenMP all processors" % (n, march)}
     w.close()
     return out
 
 
-def run_storage(args, eng, info, torch):
-    """BASELINE.json configs[4]: 10 000 contracts x 256 slots, every StorageProof claim, 0.1 % with a wrong value."""
+def run_storage(args, eng, info, torch, ranks, state=None):
+    """BASELINE.json configs[4]: 10 000 contracts x 256 slots, every StorageProof claim, 0.1 % with a wrong value.
+    The state tree and the contracts are replicated; --gpus N cuts the CLAIM index range (the loop of
+    src/proofs/verifier.rs:19-28) and one ncclAllGather of the status bytes closes the step."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ipc_filecoin_proofs_amd as ipcfp
     import oracle_lib
 
-    T = _state_tipset()
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
+    T = state if state is not None else _state_tipset()
     w = eng.witness(T.data, T.off, T.lens, T.cids)
     n = len(T.sc_actor)
     cl = ipcfp.pack_storage_claims(T.child_cid, T.state_root, T.child_epoch, T.sc_actor, T.sc_actor_state,
                                    T.sc_storage_root, T.sc_slot, T.sc_value)
     wrong = np.arange(500, n, 1000)
     cl["value"][wrong, 31] ^= 1
-    d_cl = torch.from_numpy(cl.view(np.uint8).reshape(-1)).cuda()
-    d_st = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    want = np.ones(n, dtype=np.uint8)
+    want[wrong] = 21
+    rng, width = range_layout(n, world)
+    lo, hi = rng[rank]
+    m = hi - lo
+    d_cl = torch.from_numpy(cl[lo:hi].view(np.uint8).reshape(-1).copy()).to(dev)
+    d_st = torch.zeros(width, dtype=torch.uint8, device=dev)
+    d_recv = torch.zeros(world * width, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        w.verify_storage_claims_device(d_cl.data_ptr(), n, d_st.data_ptr())
-    eng.profile_reset()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        w.verify_storage_claims_device(d_cl.data_ptr(), n, d_st.data_ptr())
-    elapsed = time.perf_counter() - t0
-    eng.profile_enable(False)
+    comm = ranks.make_comm()
+
+    def step():
+        w.verify_storage_claims_device(d_cl.data_ptr(), m, d_st.data_ptr())
+        if comm is not None:
+            comm.allgather_device(d_st.data_ptr(), d_recv.data_ptr(), width)
+
+    elapsed = timed(ranks, step, args.steps, args.warmup)
     cnt, ms = eng.profile_read("storage_verify")
     k_avg_ms = ms / max(cnt, 1)
-    got = d_st.cpu().numpy()
-    if not ((got[wrong] == 21).all() and int((got == 1).sum()) == n - len(wrong)):
+    got = d_st.cpu().numpy()[:m]
+    if not np.array_equal(got, want[lo:hi]):
         raise SystemExit("bench self-check failed: storage verdicts")
-    algo = float(T.stats["payload_bytes"]) + n * 760.0  # §8d cfg 5: unique witness bytes + 0.76 KB walked per proof
-    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps,
+    if world > 1:
+        g = d_recv.cpu().numpy().reshape(world, width)
+        for r, (l, h) in enumerate(rng):
+            if not np.array_equal(g[r, : h - l], want[l:h]):
+                raise SystemExit("bench self-check failed (rank %d): gathered statuses of rank %d" % (rank, r))
+    algo = float(T.stats["payload_bytes"]) + m * 760.0  # §8d cfg 5: unique witness bytes + 0.76 KB walked per proof
+    out = {"metric": METRIC, "value": n * args.steps / elapsed, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[4]: EVM storage proofs, 10 000 contracts x 256 slots = %d claims "
                                   "(0.1 %% wrong), Keccak slot key + state-tree HAMT get + EVM state + storage HAMT get; "
-                                  "step = one ipcfp_verify_storage_claims_device call, claims resident" % n,
-                      "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
+                                  "step = one ipcfp_verify_storage_claims_device call, claims resident%s" % (n, _gather_line(world, width)),
+                      "claims_per_gpu": m, "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
            "roofline": {"bound": "hbm", "limiter": "latency", "kernel": "k_verify_storage", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel_avg_ms": k_avg_ms, "launches": cnt, "algorithmic_bytes_per_launch": algo},
            "window": "T3"}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
         orc, march = oracle_lib.load_native()
         ost = orc.store(T.data, T.off, T.lens, T.cids, threads=0)
         sample = min(n, 400_000)
@@ -679,7 +1004,7 @@ def run_storage(args, eng, info, torch):
             t0 = time.perf_counter()
             g = ost.verify_storage_claims_packed(cl[:k], threads=t)
             dt = time.perf_counter() - t0
-            if not np.array_equal(g, got[:k]):
+            if not np.array_equal(g, want[:k]):
                 raise SystemExit("cpu_baseline: storage verdicts differ")
             if best is None or k / dt > best[0]:
                 best = (k / dt, t)

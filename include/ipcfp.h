@@ -265,6 +265,14 @@ int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid
                    int value_kind, const uint8_t* keys, const uint32_t* key_off, const uint32_t* key_len, uint64_t n,
                    ipcfp_status_t* status, ipcfp_value_loc_t* loc);
 
+/* ipcfp_hamt_get with every buffer already resident in HBM (keys_d readable up to the last key's end + 16 bytes;
+ * key_off_d / key_len_d u32[n]; status_d u8[n]; loc_d ipcfp_value_loc_t[n] or NULL).  Asynchronous on the context's
+ * stream: results are complete after ipcfp_ctx_sync.  A multi-GPU host calls it for its query-index range and
+ * all-gathers the status bytes (ipcfp_allgather_device) — the loop it cuts: src/proofs/common/decode.rs:29-39.     */
+int ipcfp_hamt_get_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid40, uint32_t bit_width,
+                          int value_kind, const void* keys_d, const void* key_off_d, const void* key_len_d, uint64_t n,
+                          void* status_d, void* loc_d);
+
 /* `reconstruct_execution_order(bs, parent_hdr_cids)` (src/proofs/events/utils.rs:16-30 →
  * collect_exec_list(verify_txmeta = true), :48-94): per parent header the TxMeta is loaded and
  * re-hashed (Blake2b-256 of its canonical encoding must reproduce the header's `messages` CID),

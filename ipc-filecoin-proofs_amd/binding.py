@@ -202,6 +202,7 @@ def load_library() -> C.CDLL:
         "ipcfp_sha256_batch": (i32, [vp, vp, u64, vp, vp, u64, vp]),
         "ipcfp_amt_get": (i32, [vp, vp, vp, i32, i32, vp, u64, vp, vp]),
         "ipcfp_hamt_get": (i32, [vp, vp, vp, C.c_uint32, i32, vp, vp, vp, u64, vp, vp]),
+        "ipcfp_hamt_get_device": (i32, [vp, vp, vp, C.c_uint32, i32, vp, vp, vp, u64, vp, vp]),
         "ipcfp_exec_order": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_scan_events": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
         "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
@@ -713,6 +714,14 @@ class Witness:
         self.eng._check(self.lib.ipcfp_hamt_get(self.eng.h, self.h, _p(root), bit_width, VALUE_KINDS[kind], _p(kb),
                                                 _p(ko), _p(kl), n, _p(st), _p(loc)), "hamt_get")
         return st, loc
+
+    def hamt_get_device(self, root_cid: bytes, bit_width: int, kind: str, keys_ptr: int, key_off_ptr: int, key_len_ptr: int,
+                        n: int, status_ptr: int, loc_ptr: int = 0):
+        """K7 with every buffer resident in HBM; asynchronous (eng.sync() completes it)."""
+        root = np.frombuffer(bytes(root_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        self.eng._check(self.lib.ipcfp_hamt_get_device(self.eng.h, self.h, _p(root), bit_width, VALUE_KINDS[kind], keys_ptr,
+                                                       key_off_ptr, key_len_ptr, int(n), status_ptr, loc_ptr or None),
+                        "hamt_get_device")
 
     def exec_order(self, parent_cids, cap=None):
         """reconstruct_execution_order → (status, cids u8[count, 40])."""

@@ -87,4 +87,21 @@ int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid
     return IPCFP_OK;
 }
 
+// ipcfp_hamt_get with every buffer already in HBM (keys_d: the concatenated key bytes, readable up to the last key's
+// end + 16 bytes of slack; key_off_d / key_len_d: u32[n]; status_d: u8[n]; loc_d: ipcfp_value_loc_t[n] or null).  What a
+// multi-GPU host calls for its query-index range before it all-gathers the status bytes.
+// Asynchronous: the results are complete after ipcfp_ctx_sync (or any later synchronising call on this context).
+int ipcfp_hamt_get_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid40, uint32_t bit_width, int value_kind,
+                          const void* keys_d, const void* key_off_d, const void* key_len_d, uint64_t n, void* status_d,
+                          void* loc_d) {
+    if (!ctx || !w || w->ctx != ctx || !root_cid40 || (n && (!keys_d || !key_off_d || !key_len_d || !status_d)))
+        return IPCFP_E_INVALID;
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    if (n == 0) return IPCFP_OK;
+    IPCFP_ENTER(ctx);
+    return launch_hamt_get(ctx, witness_view(w), key_from_slot(root_cid40), bit_width, value_kind,
+                           static_cast<const uint8_t*>(keys_d), static_cast<const uint32_t*>(key_off_d),
+                           static_cast<const uint32_t*>(key_len_d), uint32_t(n), static_cast<uint8_t*>(status_d), loc_d);
+}
+
 }  // extern "C"

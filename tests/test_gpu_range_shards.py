@@ -1,0 +1,153 @@
+"""GPU: configs 2, 4 and 5 cut into G index-range shards (block range / query range / claim range over a
+replicated state tree) — run as G LOGICAL shards on the one GPU here, each through the entry point a rank of a multi-GPU
+host calls (`ipcfp_shard_range` + the ordinary device entry points + the engine's all-gather on a 1-rank communicator).
+The concatenation of the shards' status bytes must equal the unsharded engine's, bit for bit, and the oracle's.
+The loops being cut: src/proofs/verifier.rs:19-28 (storage proofs one by one), src/proofs/common/decode.rs:29-39."""
+import numpy as np
+import pytest
+import torch
+
+import ipc_filecoin_proofs_amd as ipcfp
+from tools.synth import Tipset
+
+pytestmark = pytest.mark.gpu
+
+GS = [1, 2, 3, 8]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+
+
+def idaddr(i):
+    b = bytearray([0])
+    while True:
+        c = i & 0x7F
+        i >>= 7
+        if i:
+            b.append(c | 0x80)
+        else:
+            b.append(c)
+            return bytes(b)
+
+
+@pytest.fixture(scope="module")
+def comm1(engine):
+    c = ipcfp.Comm(engine, ipcfp.comm_unique_id(), 1, 0)
+    yield c
+    c.close()
+
+
+def gather(engine, comm1, d_status, width):
+    """What a rank does with its status bytes: ncclAllGather on the engine's stream (1 rank: recv == send)."""
+    recv = torch.zeros(width, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    comm1.allgather_device(d_status.data_ptr(), recv.data_ptr(), width)
+    engine.sync()
+    return recv.cpu().numpy()
+
+
+@pytest.mark.parametrize("G", GS)
+def test_cfg2_block_range_shards(engine, oracle, comm1, G):
+    rng = np.random.default_rng(22)
+    n = 3001
+    data = rng.integers(0, 256, n * 1024, dtype=np.uint8)
+    data[0::1024], data[1::1024], data[2::1024] = 0x59, 0x03, 0xFD
+    off = np.arange(n, dtype=np.uint64) * np.uint64(1024)
+    lens = np.full(n, 1024, dtype=np.uint32)
+    dig = oracle.hash_batch("blake2b256", data, off, lens)
+    cids = np.zeros((n, 40), dtype=np.uint8)
+    cids[:, :6] = np.frombuffer(bytes.fromhex("0171a0e40220"), dtype=np.uint8)
+    cids[:, 6:38] = dig
+    cids[np.arange(7, n, 1024), 6] ^= 1
+    with engine.witness(data, off, lens, cids) as w:
+        want, nbad = w.verify_cids()
+    assert nbad == len(np.arange(7, n, 1024)) and np.array_equal(want == 1, np.arange(n) % 1024 != 7)
+    parts = []
+    for r in range(G):
+        lo, hi = ipcfp.shard_range(n, G, r)
+        with engine.witness(data[lo * 1024: hi * 1024], off[lo:hi] - np.uint64(lo * 1024), lens[lo:hi], cids[lo:hi]) as ws:
+            ws.verify_cids_async()
+            nbytes = ((hi - lo + 31) // 32 * 4 + 15) & ~15
+            stage = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            recv = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ipcfp.allgather_segments(engine, comm1, [ws.cid_bitmap_ptr], [(hi - lo + 31) // 32 * 4], stage.data_ptr(), recv.data_ptr(), nbytes)
+            engine.sync()
+            parts.append(np.unpackbits(recv.cpu().numpy(), bitorder="little")[: hi - lo])
+    assert np.array_equal(np.concatenate(parts), (want == 1).astype(np.uint8))
+
+
+@pytest.fixture(scope="module")
+def state():
+    return Tipset(n_receipts=8, n_planted=0, n_actors=60_000, n_contracts=40, slots_per_contract=24, storage_layout_mix=1,
+                  keep_full_state=0, n_actor_queries=3030, seed=909)
+
+
+@pytest.mark.parametrize("G", GS)
+def test_cfg4_query_range_shards(engine, oracle, comm1, state, G):
+    T = state
+    keys = [idaddr(int(i)) for i in T.query_ids]
+    keys[5] = b"\x00"  # (an id address no actor has) ... and a key that is no address at all
+    keys[6] = b"\xff" * 9
+    n = len(keys)
+    ost = oracle.store(T.data, T.off, T.lens, T.cids)
+    os_, ovals = ost.hamt_get(T.actors_root, 5, "actor_state", keys)
+    ost.close()
+    with engine.witness(T.data, T.off, T.lens, T.cids) as w:
+        want_st, want_loc = w.hamt_get(T.actors_root, 5, "actor_state", keys)
+        assert np.array_equal(want_st, os_) and (want_st == 1).sum() > n // 2 and (want_st == 32).sum() > 10
+        st_parts, loc_parts = [], []
+        for r in range(G):
+            lo, hi = ipcfp.shard_range(n, G, r)
+            m = hi - lo
+            kl = np.array([len(k) for k in keys[lo:hi]], dtype=np.uint32)
+            ko = np.zeros(max(m, 1), dtype=np.uint32)[:m]
+            if m:
+                ko[1:] = np.cumsum(kl[:-1])
+            kb = np.frombuffer(b"".join(keys[lo:hi]) + bytes(32), dtype=np.uint8)
+            width = (m + 15) & ~15 or 16
+            d_kb, d_ko, d_kl = dev(kb), dev(ko if m else np.zeros(1, np.uint32)), dev(kl if m else np.zeros(1, np.uint32))
+            d_st = torch.zeros(width, dtype=torch.uint8, device="cuda")
+            d_loc = torch.zeros(max(m, 1) * 12, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            w.hamt_get_device(T.actors_root, 5, "actor_state", d_kb.data_ptr(), d_ko.data_ptr(), d_kl.data_ptr(), m,
+                              d_st.data_ptr(), d_loc.data_ptr())
+            st_parts.append(gather(engine, comm1, d_st, width)[:m])
+            loc_parts.append(d_loc.cpu().numpy()[: m * 12].view(ipcfp.LOC_DTYPE))
+        got_st, got_loc = np.concatenate(st_parts), np.concatenate(loc_parts)
+        assert np.array_equal(got_st, want_st) and np.array_equal(got_loc, want_loc)
+        hit = np.nonzero(got_st == 1)[0][:64]
+        vals = w.read_values(got_loc[hit])
+    assert [vals[k] for k in range(len(hit))] == [ovals[i] for i in hit]
+
+
+@pytest.mark.parametrize("G", GS)
+def test_cfg5_claim_range_shards(engine, oracle, comm1, state, G):
+    T = state
+    n = len(T.sc_actor)
+    cl = ipcfp.pack_storage_claims(T.child_cid, T.state_root, T.child_epoch, T.sc_actor, T.sc_actor_state,
+                                   T.sc_storage_root, T.sc_slot, T.sc_value)
+    cl["value"][np.arange(3, n, 41), 31] ^= 1            # wrong values
+    cl["actor_id"][np.arange(11, n, 97)] += 10 ** 9      # actors that do not exist
+    cl["storage_root"][np.arange(17, n, 113), 10] ^= 4   # a storage root nobody has
+    ost = oracle.store(T.data, T.off, T.lens, T.cids)
+    want = ost.verify_storage_claims_packed(cl, threads=0)
+    ost.close()
+    assert n > 500 and len(set(want.tolist())) >= 4
+    with engine.witness(T.data, T.off, T.lens, T.cids) as w:
+        d_all, d_all_st = dev(cl), torch.zeros(n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        w.verify_storage_claims_device(d_all.data_ptr(), n, d_all_st.data_ptr())
+        assert np.array_equal(d_all_st.cpu().numpy(), want)
+        parts = []
+        for r in range(G):
+            lo, hi = ipcfp.shard_range(n, G, r)
+            m = hi - lo
+            width = (m + 15) & ~15 or 16
+            d_cl = dev(cl[lo:hi]) if m else torch.zeros(16, dtype=torch.uint8, device="cuda")
+            d_st = torch.zeros(width, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            w.verify_storage_claims_device(d_cl.data_ptr(), m, d_st.data_ptr())
+            parts.append(gather(engine, comm1, d_st, width)[:m])
+    assert np.array_equal(np.concatenate(parts), want)
