@@ -99,70 +99,95 @@ inline bool cid_parse_binary(const uint8_t* p, size_t n, CidParts& out) {
     return true;
 }
 
-struct Reader {
+// `kThrow` = true: the first violation throws Err (the `?` of the reference) — every decode of the oracle.
+// `kThrow` = false ("try" reader): the first violation sets `bad`, every later call is a no-op returning zero and the
+// caller looks at `bad` where a `?` would return.  Same rules, no C++ exception: read_storage_slot attempts five
+// decodes of one block per proof (storage/decode.rs:46-89), serde's failures there are plain `Err` values — while a
+// C++ throw takes a process-wide lock in the unwinder, which made the all-cores storage baseline run at the speed of
+// ONE thread.
+template <bool kThrow>
+struct ReaderT {
     const uint8_t* p;
     size_t n;
     size_t pos = 0;
-    Reader(const uint8_t* data, size_t len) : p(data), n(len) {}
-    explicit Reader(const Bytes& b) : p(b.data()), n(b.size()) {}
+    bool bad = false;
+    ReaderT(const uint8_t* data, size_t len) : p(data), n(len) {}
+    explicit ReaderT(const Bytes& b) : p(b.data()), n(b.size()) {}
 
+    // returns false so that call sites read `return fail("…")` / `if (…) return fail(…)`
+    bool fail(const char* what) {
+        if constexpr (kThrow) decode_err(what);
+        bad = true;
+        return false;
+    }
     bool eof() const { return pos >= n; }
-    uint8_t peek() const {
-        if (pos >= n) decode_err("unexpected end of input");
+    uint8_t peek() {
+        if (bad) return 0xff;
+        if (pos >= n) {
+            fail("unexpected end of input");
+            return 0xff;
+        }
         return p[pos];
     }
-    int peek_major() const { return peek() >> 5; }
+    int peek_major() { return peek() >> 5; }
 
-    // header: major type + argument
+    // header: major type + argument (major = -1 once the reader has failed)
     void head(int& major, uint64_t& arg) {
+        major = -1;
+        arg = 0;
         uint8_t b = peek();
+        if (bad) return;
         ++pos;
-        major = b >> 5;
+        const int m = b >> 5;
         const int ai = b & 31;
         if (ai < 24) {
-            if (major == 7 && !(ai >= 20 && ai <= 22)) decode_err("unsupported simple value");
+            if (m == 7 && !(ai >= 20 && ai <= 22)) { fail("unsupported simple value"); return; }
+            major = m;
             arg = uint64_t(ai);
             return;
         }
-        if (major == 7 && ai != 27) decode_err("unsupported simple/float width");
+        if (m == 7 && ai != 27) { fail("unsupported simple/float width"); return; }
         int nb;
         if (ai == 24) nb = 1;
         else if (ai == 25) nb = 2;
         else if (ai == 26) nb = 4;
         else if (ai == 27) nb = 8;
-        else { decode_err("indefinite length or reserved additional info"); }
-        if (pos + size_t(nb) > n) decode_err("truncated argument");
+        else { fail("indefinite length or reserved additional info"); return; }
+        if (pos + size_t(nb) > n) { fail("truncated argument"); return; }
         uint64_t v = 0;
         for (int k = 0; k < nb; ++k) v = (v << 8) | p[pos + k];
         pos += size_t(nb);
+        major = m;
         arg = v;
     }
 
     uint64_t read_uint() {
         int m; uint64_t a;
         head(m, a);
-        if (m != 0) decode_err("expected unsigned integer");
+        if (bad) return 0;
+        if (m != 0) { fail("expected unsigned integer"); return 0; }
         return a;
     }
     int64_t read_int() {  // i64
         int m; uint64_t a;
         head(m, a);
-        if (m == 0) {
-            if (a > uint64_t(INT64_MAX)) decode_err("integer out of i64 range");
-            return int64_t(a);
+        if (bad) return 0;
+        if (m == 0 || m == 1) {
+            if (a > uint64_t(INT64_MAX)) { fail("integer out of i64 range"); return 0; }
+            return m == 0 ? int64_t(a) : -1 - int64_t(a);
         }
-        if (m == 1) {
-            if (a > uint64_t(INT64_MAX)) decode_err("integer out of i64 range");
-            return -1 - int64_t(a);
-        }
-        decode_err("expected integer");
+        fail("expected integer");
+        return 0;
     }
     // byte string → [ptr, len)
     void read_bytes(const uint8_t*& out, size_t& len) {
+        out = p;
+        len = 0;
         int m; uint64_t a;
         head(m, a);
-        if (m != 2) decode_err("expected byte string");
-        if (a > n - pos) decode_err("byte string runs past the end");
+        if (bad) return;
+        if (m != 2) { fail("expected byte string"); return; }
+        if (a > n - pos) { fail("byte string runs past the end"); return; }
         out = p + pos;
         len = size_t(a);
         pos += len;
@@ -170,14 +195,15 @@ struct Reader {
     Bytes read_bytes_vec() {
         const uint8_t* q; size_t l;
         read_bytes(q, l);
-        return Bytes(q, q + l);
+        return bad ? Bytes() : Bytes(q, q + l);
     }
     std::string read_text() {
         int m; uint64_t a;
         head(m, a);
-        if (m != 3) decode_err("expected text string");
-        if (a > n - pos) decode_err("text string runs past the end");
-        if (!utf8_valid(p + pos, size_t(a))) decode_err("invalid UTF-8 in text string");
+        if (bad) return std::string();
+        if (m != 3) { fail("expected text string"); return std::string(); }
+        if (a > n - pos) { fail("text string runs past the end"); return std::string(); }
+        if (!utf8_valid(p + pos, size_t(a))) { fail("invalid UTF-8 in text string"); return std::string(); }
         std::string s(reinterpret_cast<const char*>(p + pos), size_t(a));
         pos += size_t(a);
         return s;
@@ -185,69 +211,78 @@ struct Reader {
     uint64_t read_array() {
         int m; uint64_t a;
         head(m, a);
-        if (m != 4) decode_err("expected array");
+        if (bad) return 0;
+        if (m != 4) { fail("expected array"); return 0; }
         return a;
     }
     void expect_array(uint64_t len) {
-        if (read_array() != len) decode_err("tuple arity mismatch");
+        const uint64_t a = read_array();
+        if (!bad && a != len) fail("tuple arity mismatch");
     }
     uint64_t read_map() {
         int m; uint64_t a;
         head(m, a);
-        if (m != 5) decode_err("expected map");
+        if (bad) return 0;
+        if (m != 5) { fail("expected map"); return 0; }
         return a;
     }
-    bool is_null() const { return peek() == 0xf6; }
+    bool is_null() { return peek() == 0xf6 && !bad; }
     void read_null() {
-        if (peek() != 0xf6) decode_err("expected null");
-        ++pos;
+        if (peek() != 0xf6) { fail("expected null"); return; }
+        if (!bad) ++pos;
     }
     // tag 42 link → raw CID bytes (without the 0x00 multibase prefix); structure validated by the caller
     void read_link(const uint8_t*& cid, size_t& len) {
+        cid = p;
+        len = 0;
         int m; uint64_t a;
         head(m, a);
-        if (m != 6 || a != 42) decode_err("expected tag 42");
+        if (bad) return;
+        if (m != 6 || a != 42) { fail("expected tag 42"); return; }
         const uint8_t* q; size_t l;
         read_bytes(q, l);
-        if (l < 1 || q[0] != 0x00) decode_err("CID link must start with the identity multibase prefix");
+        if (bad) return;
+        if (l < 1 || q[0] != 0x00) { fail("CID link must start with the identity multibase prefix"); return; }
         cid = q + 1;
         len = l - 1;
     }
     // IgnoredAny: skip exactly one well-formed item
     void skip() {
         uint64_t todo = 1;
-        while (todo) {
+        while (todo && !bad) {
             --todo;
             int m; uint64_t a;
             head(m, a);
+            if (bad) return;
             switch (m) {
                 case 0: case 1: break;
                 case 2:
-                    if (a > n - pos) decode_err("byte string runs past the end");
+                    if (a > n - pos) { fail("byte string runs past the end"); return; }
                     pos += size_t(a);
                     break;
                 case 3:
-                    if (a > n - pos) decode_err("text string runs past the end");
-                    if (!utf8_valid(p + pos, size_t(a))) decode_err("invalid UTF-8 in text string");
+                    if (a > n - pos) { fail("text string runs past the end"); return; }
+                    if (!utf8_valid(p + pos, size_t(a))) { fail("invalid UTF-8 in text string"); return; }
                     pos += size_t(a);
                     break;
                 case 4:
-                    if (a > n - pos) decode_err("array longer than the input");
+                    if (a > n - pos) { fail("array longer than the input"); return; }
                     todo += a;
                     break;
                 case 5:
                     // IgnoredAny over a map: 2·a items.  (Key typing is not enforced when
                     // skipping ⚠; typed map decodes in storage.cpp do enforce text keys.)
-                    if (a > (n - pos) / 2) decode_err("map longer than the input");
+                    if (a > (n - pos) / 2) { fail("map longer than the input"); return; }
                     todo += 2 * a;
                     break;
                 case 6: {
-                    if (a != 42) decode_err("unsupported tag");
+                    if (a != 42) { fail("unsupported tag"); return; }
                     const uint8_t* q; size_t l;
                     read_bytes(q, l);
-                    if (l < 1 || q[0] != 0x00) decode_err("CID link must start with 0x00");
+                    if (bad) return;
+                    if (l < 1 || q[0] != 0x00) { fail("CID link must start with 0x00"); return; }
                     CidParts parts;  // deserialize_any on tag 42 builds a Cid, so the bytes must parse
-                    if (!cid_parse_binary(q + 1, l - 1, parts)) decode_err("malformed CID in link");
+                    if (!cid_parse_binary(q + 1, l - 1, parts)) { fail("malformed CID in link"); return; }
                     break;
                 }
                 case 7: break;  // false/true/null/f64: validated by head()
@@ -255,8 +290,10 @@ struct Reader {
         }
     }
     void finish() {
-        if (pos != n) decode_err("trailing bytes after the top-level item");
+        if (!bad && pos != n) fail("trailing bytes after the top-level item");
     }
 };
+using Reader = ReaderT<true>;
+using TryReader = ReaderT<false>;
 
 }  // namespace orc

@@ -52,6 +52,14 @@ inline Cid read_cid(Reader& r) {
     r.read_link(p, n);
     return cid_from_link(p, n);
 }
+// the same through a try-reader: a malformed CID marks the reader instead of throwing
+inline Cid read_cid(TryReader& r) {
+    const uint8_t* p; size_t n;
+    r.read_link(p, n);
+    CidParts parts;
+    if (!r.bad && !cid_parse_binary(p, n, parts)) r.fail("malformed CID in link");
+    return r.bad ? Cid{} : Cid{Bytes(p, p + n)};
+}
 
 // Filecoin chain CID for a DAG-CBOR block: CIDv1, 0x71, blake2b-256.
 Cid cid_for_block(const uint8_t* data, size_t len);

@@ -12,6 +12,9 @@ import pytest
 # the parity tests need the oracle's answers, not its peak throughput (bench.py sets its own thread counts)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("IPCFP_ORACLE_MAX_THREADS", "48")
+# the oracle's read_storage_slot runs on a non-throwing reader; under test every call is also answered by the
+# exception-based form it replaced and the two must agree (oracle/verify.cpp)
+os.environ.setdefault("IPCFP_ORACLE_CHECK_TRY", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
