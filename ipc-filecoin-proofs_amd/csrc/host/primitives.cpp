@@ -1,7 +1,9 @@
 // csrc/host/primitives.cpp — C-ABI entry points of the batch path-walk primitives.
+#include <cstdlib>
 #include <cstring>
 
 #include "../common.h"
+#include "../kernels/hamt_table.h"
 #include "../kernels/launch.h"
 
 using namespace ipcfp;
@@ -25,6 +27,28 @@ CidKey key_from_slot(const uint8_t* slot40) {
     CidKey k;
     std::memcpy(k.w, slot40, 40);
     return k;
+}
+
+// K7 for a batch: one query per lane walks the blocks (k_hamt_get).  IPCFP_HAMT_TABLE=1 (A/B measurements): first
+// tabulate every block as a HAMT node (kernels/hamt_table.h; the table lives for this call only) and walk records.
+int hamt_get_batch(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, uint32_t bit_width, int vkind, const uint8_t* keys_d,
+                   const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n, uint8_t* status_d, void* loc_d) {
+    static const int forced = [] {
+        const char* e = std::getenv("IPCFP_HAMT_TABLE");
+        return e ? std::atoi(e) : -1;
+    }();
+    const uint32_t kbit = hamt_kind_bit(vkind);
+    // (default: walk.  On configs 4/5's witness the table pass costs more than 66 k walks: profiles/r03_experiments.md)
+    const bool tabled = kbit && forced == 1;
+    ProfileScope prof(ctx, IPCFP_K_HAMT_GET);
+    const WitnessView view = witness_view(w);
+    if (!tabled) return launch_hamt_get(ctx, view, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d);
+    DevBuf<HamtNodeRec> table;
+    IPCFP_HIP(ctx, table.alloc(w->n));
+    int rc = launch_hamt_node_table(ctx, w->arena.p, w->k1_meta.p, uint32_t(w->n), kbit, table.p);
+    if (rc) return rc;
+    return launch_hamt_get_table(ctx, view, table.p, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d);
+    // (the table goes back to the pool on return; reuse is ordered on the one stream)
 }
 
 }  // namespace ipcfp
@@ -78,8 +102,7 @@ int ipcfp_hamt_get(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* root_cid
     if (kbytes) IPCFP_HIP(ctx, hipMemcpyAsync(kb.p, keys, kbytes, hipMemcpyHostToDevice, ctx->stream));
     IPCFP_HIP(ctx, hipMemcpyAsync(ko.p, key_off, n * 4, hipMemcpyHostToDevice, ctx->stream));
     IPCFP_HIP(ctx, hipMemcpyAsync(kl.p, key_len, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    int rc = launch_hamt_get(ctx, witness_view(w), key_from_slot(root_cid40), bit_width, value_kind, kb.p, ko.p, kl.p,
-                             uint32_t(n), st.p, lc.p);
+    int rc = hamt_get_batch(ctx, w, key_from_slot(root_cid40), bit_width, value_kind, kb.p, ko.p, kl.p, uint32_t(n), st.p, lc.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, st.p, n, hipMemcpyDeviceToHost, ctx->stream));
     if (loc) IPCFP_HIP(ctx, hipMemcpyAsync(loc, lc.p, n * sizeof(ipcfp_value_loc_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -99,9 +122,9 @@ int ipcfp_hamt_get_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* r
     if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
     if (n == 0) return IPCFP_OK;
     IPCFP_ENTER(ctx);
-    return launch_hamt_get(ctx, witness_view(w), key_from_slot(root_cid40), bit_width, value_kind,
-                           static_cast<const uint8_t*>(keys_d), static_cast<const uint32_t*>(key_off_d),
-                           static_cast<const uint32_t*>(key_len_d), uint32_t(n), static_cast<uint8_t*>(status_d), loc_d);
+    return hamt_get_batch(ctx, w, key_from_slot(root_cid40), bit_width, value_kind, static_cast<const uint8_t*>(keys_d),
+                          static_cast<const uint32_t*>(key_off_d), static_cast<const uint32_t*>(key_len_d), uint32_t(n),
+                          static_cast<uint8_t*>(status_d), loc_d);
 }
 
 }  // extern "C"

@@ -3,12 +3,15 @@
 // Host side of src/proofs/storage/verifier.rs:24-63: parse the claim strings once
 // (parse_cid → src/proofs/common/witness.rs:60-64; hex → storage/verifier.rs:155-157), upload the
 // packed claims, run one kernel over the batch, download the status bytes.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../common.h"
 #include "../kernels/claims_dev.h"
 #include "../kernels/launch.h"
+#include "../kernels/hamt_table.h"
+#include "../kernels/storage_runs.h"
 #include "cidstr.h"
 
 using namespace ipcfp;
@@ -35,6 +38,62 @@ void parse_cid_claim(const char* s, CidKey& key, bool& parsed, bool& canonical) 
 }
 
 static const ipcfp_trust_policy_t kAcceptAll = {0, 0, 0, 0};
+
+// `verify_storage_proof` over a batch of packed claims resident in HBM (src/proofs/storage/verifier.rs:24-63, the loop of
+// src/proofs/verifier.rs:19-28).  A batch that is large against the witness
+//   1. cuts the claims into RUNS that agree on (child, state root, actor, actor state, storage root) and decodes what a
+//      run shares once (kernels/storage_runs.h),
+//   2. tabulates every block of the witness as a HAMT node (kernels/hamt_table.h: ONE parse per node instead of one per
+//      proof that passes through it — a contract's storage root is decoded once, not 256 times),
+//   3. settles every claim from its run's record and two or three table records (k_verify_storage_table),
+// and the one-lane kernel takes what that leaves pending (an inline small-map layout, a block the table does not cover).
+// A small batch — and everything, with IPCFP_HAMT_TABLE=0 — goes through the one-lane kernel alone.  The table lives
+// for this call only.  One host synchronisation (the number of runs).
+int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaimPacked* claims_d, uint32_t n,
+                          const ipcfp_trust_policy_t& trust, uint8_t* status_d) {
+    if (n == 0) return IPCFP_OK;
+    ProfileScope prof(ctx, IPCFP_K_STORAGE_VERIFY);
+    const WitnessView w = witness_view(wit);
+    static const int forced = [] {
+        const char* e = std::getenv("IPCFP_HAMT_TABLE");
+        return e ? std::atoi(e) : -1;
+    }();
+    const bool tabled = forced == 1 || (forced != 0 && uint64_t(n) * 16u >= wit->n);
+    if (!tabled) return launch_verify_storage_lanes(ctx, w, claims_d, n, trust, status_d, 0);
+    constexpr uint32_t kUndecided = 0xfdu;
+    DevBuf<HamtNodeRec> table;
+    IPCFP_HIP(ctx, table.alloc(wit->n));
+    int rc = launch_hamt_node_table(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+    if (rc) return rc;
+    DevBuf<uint32_t> flag, pos, run_of;
+    DevBuf<uint64_t> scratch, total_d;
+    IPCFP_HIP(ctx, flag.alloc(n));
+    IPCFP_HIP(ctx, pos.alloc(n));
+    IPCFP_HIP(ctx, run_of.alloc(n));
+    IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
+    IPCFP_HIP(ctx, total_d.alloc(1));
+    rc = launch_storage_run_flags(ctx, claims_d, n, flag.p);
+    if (rc) return rc;
+    rc = launch_scan_u32(ctx, flag.p, n, pos.p, total_d.p, scratch.p);
+    if (rc) return rc;
+    uint64_t n_runs = 0;
+    IPCFP_HIP(ctx, d2h_small(ctx, &n_runs, total_d.p, 8, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    DevBuf<StorageRun> runs;
+    IPCFP_HIP(ctx, runs.alloc(n_runs));
+    rc = launch_storage_run_heads(ctx, flag.p, pos.p, n, run_of.p, runs.p);
+    if (rc) return rc;
+    rc = launch_storage_run_facts(ctx, w, claims_d, runs.p, uint32_t(n_runs));
+    if (rc) return rc;
+    rc = launch_storage_run_actors_table(ctx, w, table.p, claims_d, runs.p, uint32_t(n_runs), kUndecided);
+    if (rc) return rc;
+    rc = launch_storage_run_actors_lane(ctx, w, claims_d, runs.p, uint32_t(n_runs), kUndecided);
+    if (rc) return rc;
+    rc = launch_verify_storage_table(ctx, w, table.p, claims_d, n, run_of.p, runs.p, trust, kUndecided, status_d);
+    if (rc) return rc;
+    return launch_verify_storage_lanes(ctx, w, claims_d, n, trust, status_d, 1);
+    // (the scratch buffers go back to the pool on return; reuse is ordered on the one stream)
+}
 
 }  // namespace ipcfp
 
@@ -86,7 +145,7 @@ int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcf
     IPCFP_HIP(ctx, cd.alloc(n));
     IPCFP_HIP(ctx, sd.alloc(n));
     IPCFP_HIP(ctx, hipMemcpyAsync(cd.p, packed.data(), n * sizeof(StorageClaimPacked), hipMemcpyHostToDevice, ctx->stream));
-    int rc = launch_verify_storage(ctx, witness_view(w), cd.p, uint32_t(n), trust ? *trust : kAcceptAll, sd.p);
+    int rc = launch_verify_storage(ctx, w, cd.p, uint32_t(n), trust ? *trust : kAcceptAll, sd.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
@@ -99,7 +158,7 @@ int ipcfp_verify_storage_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, con
     if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
     if (n == 0) return IPCFP_OK;
     IPCFP_ENTER(ctx);
-    int rc = launch_verify_storage(ctx, witness_view(w), static_cast<const StorageClaimPacked*>(claims_d), uint32_t(n),
+    int rc = launch_verify_storage(ctx, w, static_cast<const StorageClaimPacked*>(claims_d), uint32_t(n),
                                    trust ? *trust : kAcceptAll, static_cast<uint8_t*>(status_d));
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));

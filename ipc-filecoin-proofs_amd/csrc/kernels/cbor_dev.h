@@ -81,6 +81,23 @@ __device__ __noinline__ bool utf8_ok_bytes(const uint8_t* s, uint32_t len) {
 
 typedef unsigned long long rd_chunk_t __attribute__((ext_vector_type(2)));  // one 16-byte window chunk
 
+// IPCFP_RD_RING = G (a mode of the LDS reader, per translation unit; G = 8: hamt_table.hip): a GROUP of G lanes drives ONE
+// reader in lockstep over an item that stays in HBM.  The group streams it through a 1 KB ring in LDS: every step the G
+// lanes fetch the next 2·G chunks (256 bytes for G = 8) with one coalesced load each and hold them in registers while
+// the parser works on what is already in the ring; when the parser runs off the end of the ring the registers are
+// written to LDS and the step after is requested.  So a sequential parse of a block of ANY size costs one memory
+// latency per 256 bytes, most of it hidden behind the parse of the previous 256 — where one lane with a 16-byte window
+// pays a latency per 16 bytes — for 1 KB of LDS per query.  The ring keeps the last ≥ 768 bytes: a reader may look back
+// that far (a bucket's key after its value, a link's bytes after its header); further back is an error of the CALLER,
+// reported as err = kRdRingLost so that it can never pass for a decode result.
+#ifndef IPCFP_RD_RING
+#define IPCFP_RD_RING 0
+#endif
+#if IPCFP_RD_RING && !IPCFP_RD_LDS
+#error "IPCFP_RD_RING is a mode of the LDS reader"
+#endif
+constexpr uint32_t kRdRingLost = 0xfdu;  // not an ipcfp_status_t
+
 struct Rd {
     const IPCFP_RD_AS uint8_t* p;
     uint32_t n;
@@ -206,7 +223,107 @@ struct Rd {
         hi = w.hi;
         ph = w.ph;
     }
-#if IPCFP_RD_LDS
+#if IPCFP_RD_RING
+    // ---- the ring (see IPCFP_RD_RING above).  Coordinates are BIASED: byte i of the item is ring byte i + bias ----
+    static constexpr uint32_t kRingBytes = 1024u, kRingStep = uint32_t(IPCFP_RD_RING) * 32u;
+    static_assert(kRingBytes % kRingStep == 0 && kRingStep >= 128u, "a step must divide the ring");
+    const rd_chunk_t* g16;    // HBM: the 16-byte chunk that holds the item's first byte
+    uint32_t rhi;             // biased bytes committed so far: the ring holds [rhi - kRingBytes, rhi)
+    uint32_t rlo;             // … of which the bytes from rlo on are really there (a forward jump leaves a hole behind it)
+    uint32_t rlim;            // biased bytes worth fetching (the item, the reader's 16 bytes of slack, rounded up to a step)
+    rd_chunk_t pend0, pend1;  // this lane's two chunks of the step [rhi, rhi + kRingStep), in flight
+    struct RingState {
+        uint32_t rhi, rlo;
+        rd_chunk_t pend0, pend1;
+    };
+    // The slow path — commit the step in flight, request the next, until byte e is in — is deliberately NOT inlined
+    // (by value in, by value out): inlined at every at()/peek64() it costs the walk kernels ≈70 VGPRs, i.e. one or two
+    // of the three or four wavefronts per SIMD that hide its own memory latency.
+    __device__ __attribute__((noinline)) static RingState ring_fill(IPCFP_RD_AS uint8_t* ring, const rd_chunk_t* g16, uint32_t rlim,
+                                                                    uint32_t e, RingState st) {
+        const uint32_t sub = threadIdx.x & (uint32_t(IPCFP_RD_RING) - 1u);
+        IPCFP_RD_AS rd_chunk_t* ring16 = (IPCFP_RD_AS rd_chunk_t*)(uintptr_t)(ring);
+        if (e > st.rhi + 4u * kRingStep && st.rhi < rlim) {  // a long jump forward (a skipped byte string): do not stream what nobody reads
+            const uint32_t target = (e - 1u) / kRingStep * kRingStep;
+            st.rhi = target < rlim ? target : rlim - kRingStep;
+            st.rlo = st.rhi;
+            st.pend0 = g16[(st.rhi >> 4) + sub];
+            st.pend1 = g16[(st.rhi >> 4) + uint32_t(IPCFP_RD_RING) + sub];
+        }
+        while (st.rhi < e && st.rhi < rlim) {
+            const uint32_t c = (st.rhi >> 4) & (kRingBytes / 16u - 1u);  // a multiple of 2·G: no wrap inside a step
+            __builtin_amdgcn_wave_barrier();
+            ring16[c + sub] = st.pend0;
+            ring16[c + uint32_t(IPCFP_RD_RING) + sub] = st.pend1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            st.rhi += kRingStep;
+            if (st.rhi > kRingBytes && st.rlo < st.rhi - kRingBytes) st.rlo = st.rhi - kRingBytes;
+            if (st.rhi < rlim) {
+                st.pend0 = g16[(st.rhi >> 4) + sub];
+                st.pend1 = g16[(st.rhi >> 4) + uint32_t(IPCFP_RD_RING) + sub];
+            }
+        }
+        return st;
+    }
+    // eight bytes at BIASED offset j of the ring, any lane its own j (the caller has ring_ensure'd, group-uniformly)
+    __device__ __forceinline__ uint64_t ring_raw64(uint32_t j) const {
+        const IPCFP_RD_AS uint64_t* q = (const IPCFP_RD_AS uint64_t*)(uintptr_t)(p);
+        const uint32_t wi = (j >> 3) & (kRingBytes / 8u - 1u);
+        const uint64_t w0 = q[wi], w1 = q[(wi + 1u) & (kRingBytes / 8u - 1u)];
+        const uint32_t sh = (j & 7u) * 8u;
+        return (w0 >> sh) | ((w1 << 1) << (63u - sh));
+    }
+    // bytes below biased offset e are in the ring (or e lies beyond everything worth fetching)
+    __device__ __forceinline__ void ring_ensure(uint32_t e) {
+        if (rhi < e && rhi < rlim) {
+            const RingState st = ring_fill((IPCFP_RD_AS uint8_t*)(uintptr_t)(p), g16, rlim, e, RingState{rhi, rlo, pend0, pend1});
+            rhi = st.rhi;
+            rlo = st.rlo;
+            pend0 = st.pend0;
+            pend1 = st.pend1;
+        }
+    }
+    // every lane of the group with the same arguments.  `ring`: kRingBytes of LDS, 16-byte aligned, the group's own.
+    __device__ __forceinline__ void init_ring(const uint8_t* item, uint32_t len, IPCFP_RD_AS uint8_t* ring) {
+        p = ring;
+        n = len;
+        pos = 0;
+        err = 0;
+        const uintptr_t a = (uintptr_t)item;
+        g16 = (const rd_chunk_t*)(a & ~uintptr_t(15));
+        bias = uint32_t(a & 15);
+        base16 = nullptr;
+        cwi = phi = 0;
+        lo = hi = ph = 0;
+        stage = false;
+        rlim = (bias + len + 16u + kRingStep - 1u) / kRingStep * kRingStep;
+        rhi = rlo = 0;
+        {
+            const uint32_t sub = threadIdx.x & (uint32_t(IPCFP_RD_RING) - 1u);
+            pend0 = g16[sub];
+            pend1 = g16[uint32_t(IPCFP_RD_RING) + sub];
+        }
+        ring_ensure(1u);
+    }
+    __device__ __forceinline__ uint32_t at(uint32_t i) {
+        const uint32_t j = i + bias;
+        ring_ensure(j + 1u);
+        if (j < rlo) err = err ? err : kRdRingLost;
+        return p[j & (kRingBytes - 1u)];
+    }
+    __device__ __forceinline__ uint64_t peek64(uint32_t i) {
+        const uint32_t j = i + bias;
+        ring_ensure(j + 16u);
+        if ((j & ~7u) < rlo) err = err ? err : kRdRingLost;
+        return ring_raw64(j);
+    }
+    __device__ __forceinline__ void peek128(uint32_t i, uint64_t& w0, uint64_t& w1) {
+        w0 = peek64(i);
+        w1 = peek64(i + 8u);
+    }
+#elif IPCFP_RD_LDS
     // A reader that sits in LDS needs no window: a byte is one ds_read_u8, eight unaligned bytes one ds_read_b64
     // (gfx950 serves unaligned LDS accesses).  The window above exists to cut the NUMBER of global load instructions;
     // what it costs is instructions — ≈10 k VALU per wavefront of 64 receipts in k_scan_pass1 / k_event_table, which
@@ -437,7 +554,12 @@ struct Rd {
             if (hi < 0x80) return true;
 #endif
         }
+#if IPCFP_RD_RING
+        if (!err) err = kRdRingLost;  // (a long or non-ASCII text is not linear in the ring: the caller's one-lane path decides)
+        return false;
+#else
         return utf8_ok_bytes((const uint8_t*)(p + off), len);  // (an LDS reader hands out the generic address)
+#endif
     }
     __device__ __forceinline__ void read_text(uint32_t& off, uint32_t& len) {
         off = len = 0;
@@ -515,6 +637,16 @@ struct Rd {
     // tag-42 link → offset/len of the CID bytes (without the 0x00 prefix)
     __device__ __forceinline__ void read_link(uint32_t& off, uint32_t& len) {
         off = len = 0;
+        // The standard 43-byte link — d8 2a | 58 27 | 00 | 01 71 a0 e4 02 20 | digest[32]: tag 42, a 39-byte string, the
+        // identity multibase byte, CIDv1 dag-cbor blake2b-256 — passes every check below; seeing it is two compares
+        // instead of two item headers and four varints (≈40 instructions instead of ≈250).  Nearly every link of a
+        // Filecoin witness has this form: a 32-link HAMT node is 8 k instructions the long way.
+        if (!err && pos + 43u <= n && peek64(pos) == 0xa071010027582ad8ull && (peek64(pos + 8u) & 0xffffffull) == 0x2002e4ull) {
+            off = pos + 5u;
+            len = 38u;
+            pos += 43u;
+            return;
+        }
         uint32_t m;
         uint64_t a;
         head(m, a);
@@ -662,9 +794,42 @@ __device__ __forceinline__ void check_actor_state(Rd& r) {
     }
 }
 
+// One element of a serde Vec<u8> (a CBOR array of small unsigned integers) out of the 8 bytes `w` fetched at the reader's
+// position, `used` bytes of which are consumed already: 00..17 is the value in one byte, 18 xx the value in two — what
+// every encoder writes.  false: the element is spelled some other way (or may straddle the fetch): take the general path.
+__device__ __forceinline__ bool vec_u8_step(uint64_t w, uint32_t& used, uint32_t& value) {
+    if (used > 6u) return false;
+    const uint32_t b = uint32_t(w >> (8u * used)) & 0xffu;
+    if (b < 0x18u) {
+        value = b;
+        used += 1u;
+        return true;
+    }
+    if (b == 0x18u) {
+        value = uint32_t(w >> (8u * used + 8u)) & 0xffu;
+        used += 2u;
+        return true;
+    }
+    return false;
+}
+
 __device__ __forceinline__ void check_vec_u8(Rd& r) {  // serde Vec<u8> = array of u8
     const uint64_t n = r.read_array();
-    for (uint64_t i = 0; i < n && r.ok(); ++i)
+    uint64_t i = 0;
+    // A storage value is up to 32 such elements and a storage node holds hundreds: one generic item header per element
+    // (≈80 instructions) was 50 instructions per byte of witness (profiles/r03_experiments.md).  Eight bytes per fetch,
+    // a handful of instructions per element; anything unusual falls through to read_uint.
+    while (i < n && r.ok() && r.pos + 8u <= r.n) {
+        const uint64_t w = r.peek64(r.pos);
+        uint32_t used = 0, v;
+        while (i < n && vec_u8_step(w, used, v)) ++i;
+        r.pos += used;
+        if (i < n && used <= 6u) {  // the element at the reader's position is not in the short form
+            if (r.read_uint() > 255) r.fail();
+            ++i;
+        }
+    }
+    for (; i < n && r.ok(); ++i)
         if (r.read_uint() > 255) r.fail();
 }
 

@@ -41,10 +41,30 @@ int launch_hamt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, ui
                     const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
                     uint8_t* status_d, void* loc_d);
 
+// --- hamt_table.hip / walk.hip --- the HAMT node table of a witness (hamt_table.h) and K7 over it
+int launch_hamt_node_table(ipcfp_ctx* ctx, const uint8_t* arena, const void* k1_meta_d, uint32_t n_blocks, uint32_t kinds, void* recs_d);
+uint32_t hamt_kind_bit(int vkind);  // HK_* bit of a value kind, 0: the table does not know that kind
+int launch_hamt_get_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const CidKey& root, uint32_t bit_width,
+                          int vkind, const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
+                          uint8_t* status_d, void* loc_d);
+
 // --- verify_storage.hip ---
 struct StorageClaimPacked;
-int launch_verify_storage(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,
-                          const ipcfp_trust_policy_t& trust, uint8_t* status_d);
+int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* w, const StorageClaimPacked* claims_d, uint32_t n,
+                          const ipcfp_trust_policy_t& trust, uint8_t* status_d);  // host/verify_storage.cpp
+// the pieces of it (verify_storage.hip: runs of claims and their decoded facts; the one-lane kernel)
+int launch_storage_run_flags(ipcfp_ctx* ctx, const void* claims_d, uint32_t n, uint32_t* flag_d);
+int launch_storage_run_heads(ipcfp_ctx* ctx, const uint32_t* flag_d, const uint32_t* pos_d, uint32_t n, uint32_t* run_of_d, void* runs_d);
+int launch_storage_run_facts(ipcfp_ctx* ctx, const WitnessView& w, const void* claims_d, void* runs_d, uint32_t n_runs);
+int launch_storage_run_actors_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, void* runs_d,
+                                    uint32_t n_runs, uint32_t undecided);
+int launch_verify_storage_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, uint32_t n,
+                                const uint32_t* run_of_d, const void* runs_d, const ipcfp_trust_policy_t& trust, uint32_t undecided,
+                                uint8_t* status_d);
+int launch_storage_run_actors_lane(ipcfp_ctx* ctx, const WitnessView& w, const void* claims_d, void* runs_d, uint32_t n_runs,
+                                   uint32_t undecided);
+int launch_verify_storage_lanes(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,
+                                const ipcfp_trust_policy_t& trust, uint8_t* status_d, int pending_only);
 
 // --- scan.hip ---
 int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* out_d, uint64_t* total_d,

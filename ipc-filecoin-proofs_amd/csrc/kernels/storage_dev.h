@@ -80,6 +80,85 @@ __device__ __forceinline__ void left_pad_32_vec(const WitnessView& w, const Valu
     }
 }
 
+// The layout sniff of read_storage_slot alone (storage/decode.rs:46-96): WHICH of the six decodes succeeds is a property
+// of the root block, not of the slot.  → 0 = A1, 1 = A2, 2 = A3 (inline maps), 3 = a HAMT (root, bw: B1 / B2 / C),
+// 4 = the root block is not in the witness.  Same attempts, same order as read_storage_slot_padded below.
+__device__ __forceinline__ uint32_t sniff_storage_root(const WitnessView& w, const CidKey& root, CidKey& hamt_root, uint32_t& bw) {
+    hamt_root = root;
+    bw = 5;
+    const uint32_t b = witness_find(w, root);
+    if (b == kNoBlock) return 4;
+    const uint8_t none[32] = {0};
+    SlotHit hit{false, 0, 0};
+    {
+        Rd r = open_block(w, b);
+        uint32_t o, l;
+        r.expect_array(2);
+        r.read_bytes(o, l);
+        const uint64_t n = r.read_array();
+        for (uint64_t i = 0; i < n && r.ok(); ++i) read_small_map(r, none, false, hit);
+        r.finish();
+        if (r.ok() && n > 0) return 0;
+    }
+    {
+        Rd r = open_block(w, b);
+        uint32_t o, l;
+        r.expect_array(2);
+        r.read_bytes(o, l);
+        read_small_map(r, none, false, hit);
+        r.finish();
+        if (r.ok()) return 1;
+    }
+    {
+        Rd r = open_block(w, b);
+        read_small_map(r, none, false, hit);
+        r.finish();
+        if (r.ok()) return 2;
+    }
+    {
+        Rd r = open_block(w, b);
+        CidKey inner;
+        r.expect_array(2);
+        r.read_link_key(inner);
+        const uint64_t v = r.read_uint();
+        r.finish();
+        if (r.ok()) {
+            hamt_root = inner;
+            bw = uint32_t(v);  // `bw as u32`
+            return 3;
+        }
+    }
+    {
+        Rd r = open_block(w, b);
+        CidKey inner;
+        uint64_t v = 0;
+        bool have_root = false, have_bw = false;
+        const uint64_t n = r.read_map();
+        for (uint64_t i = 0; i < n && r.ok(); ++i) {
+            uint32_t ko, kl;
+            r.read_text(ko, kl);
+            if (!r.ok()) break;
+            if (text_is(r, ko, kl, "root", 4)) {
+                if (have_root) r.fail();
+                have_root = true;
+                r.read_link_key(inner);
+            } else if (text_is(r, ko, kl, "bitwidth", 8)) {
+                if (have_bw) r.fail();
+                have_bw = true;
+                v = r.read_uint();
+            } else {
+                r.skip();
+            }
+        }
+        r.finish();
+        if (r.ok() && have_root && have_bw) {
+            hamt_root = inner;
+            bw = uint32_t(v);
+        }
+    }
+    return 3;
+}
+
 // read_storage_slot + left_pad_32.  TRUE ⇒ padded holds the 32-byte value (zero when absent).
 __device__ __forceinline__ uint32_t read_storage_slot_padded(const WitnessView& w, const CidKey& root,
                                                              const uint8_t slot[32], uint8_t padded[32]) {

@@ -10,7 +10,6 @@
 namespace ipcfp {
 
 // internal status byte: "not settled from the event table — the general walker decides" (never leaves the library)
-constexpr uint32_t kStPending = 0xfeu;
 
 constexpr unsigned long long kEmptySlot64 = ~0ULL;
 

@@ -14,6 +14,7 @@
 #include "claims_dev.h"
 #include "launch.h"
 #include "storage_dev.h"
+#include "storage_runs.h"
 
 namespace ipcfp {
 
@@ -66,27 +67,269 @@ __device__ __forceinline__ uint32_t verify_storage_one(const WitnessView& w, con
 template <int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_verify_storage(WitnessView w, const StorageClaimPacked* __restrict__ claims,
                                                                uint32_t n, ipcfp_trust_policy_t trust,
-                                                               uint8_t* __restrict__ status) {
+                                                               uint8_t* __restrict__ status, int pending_only) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (pending_only && status[t] != kStPending) return;  // settled from the node table (k_verify_storage_table)
     status[t] = uint8_t(verify_storage_one(w, claims[t], trust));
 }
 
-int launch_verify_storage(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,
-                          const ipcfp_trust_policy_t& trust, uint8_t* status_d) {
-    if (n == 0) return IPCFP_OK;
+// ---------------------------------------------------------------------------------------------------------------------
+// Runs of claims (storage_runs.h): the one-lane half — run boundaries and, per run, every fact that is a plain typed
+// decode (child header, StateRoot, EVM state, the storage root's layout).  The HAMT walks go over the node table (hamt_table.h).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool same_run(const StorageClaimPacked& a, const StorageClaimPacked& b) {
+    return a.actor_id == b.actor_id && cid_equal(a.child, b.child) && cid_equal(a.state_root, b.state_root) &&
+           cid_equal(a.actor_state, b.actor_state) && cid_equal(a.storage_root, b.storage_root);
+}
+
+__global__ __launch_bounds__(256) void k_storage_run_flags(const StorageClaimPacked* __restrict__ claims, uint32_t n,
+                                                           uint32_t* __restrict__ flag) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    flag[t] = (t == 0 || !same_run(claims[t], claims[t - 1])) ? 1u : 0u;
+}
+
+// run_of[t] = index of claim t's run; the run's record gets its first claim
+__global__ __launch_bounds__(256) void k_storage_run_heads(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos,
+                                                           uint32_t n, uint32_t* __restrict__ run_of, StorageRun* __restrict__ runs) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t r = pos[t] + flag[t] - 1u;  // pos: exclusive sum of flag
+    run_of[t] = r;
+    if (flag[t]) runs[r].first_claim = t;
+}
+
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_storage_run_facts(WitnessView w, const StorageClaimPacked* __restrict__ claims,
+                                                                             StorageRun* __restrict__ runs, uint32_t n_runs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_runs) return;
+    StorageRun run = runs[i];
+    const StorageClaimPacked& c = claims[run.first_claim];
+    // verify_parent_state_root (storage/verifier.rs:95-111): the child header
+    HeaderLite hdr;
+    uint32_t hb;
+    run.hdr_status = load_header(w, c.child, hdr, hb);
+    run.parent_state_root = hdr.parent_state_root;
+    // get_actor_state, first half (common/decode.rs:23-26): StateRoot [version, actors, info] behind the CLAIMED state root
     {
-        ProfileScope prof(ctx, IPCFP_K_STORAGE_VERIFY);
-        static const int waves = [] {
-            const char* e = std::getenv("IPCFP_STORAGE_WAVES");
-            const int v = e ? std::atoi(e) : 4;
-            return v >= 2 && v <= 4 ? v : 4;
-        }();
-        const dim3 g(div_up(n, 256)), blk(256);
-        if (waves == 2) hipLaunchKernelGGL(k_verify_storage<2>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d);
-        else if (waves == 3) hipLaunchKernelGGL(k_verify_storage<3>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d);
-        else hipLaunchKernelGGL(k_verify_storage<4>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d);
+        run.sr_status = IPCFP_ST_TRUE;
+        const uint32_t b = witness_find(w, c.state_root);
+        if (b == kNoBlock) {
+            run.sr_status = IPCFP_ST_ERR_MISSING_BLOCK;
+        } else {
+            Rd r = open_block(w, b);
+            CidKey info;
+            r.expect_array(3);
+            if (r.read_uint() > 5) r.fail();
+            r.read_link_key(run.actors);
+            r.read_link_key(info);
+            r.finish();
+            if (!r.ok()) run.sr_status = IPCFP_ST_ERR_DECODE;
+        }
     }
+    run.actor_status = IPCFP_ST_ERR;  // (k_storage_run_actors_table / _lane)
+    // verify_storage_root (storage/verifier.rs:130-145): the EVM state behind the CLAIMED actor-state CID
+    {
+        const uint32_t eb = witness_find(w, c.actor_state);
+        run.evm_status = eb == kNoBlock ? uint32_t(IPCFP_ST_ERR_MISSING_BLOCK) : parse_evm_state(w, eb, run.contract_state);
+    }
+    // read_storage_slot's layout sniff of the CLAIMED storage root (storage/decode.rs:46-96)
+    run.root_kind = sniff_storage_root(w, c.storage_root, run.hamt_root, run.hamt_bw);
+    runs[i] = run;
+}
+
+// get_actor_state's HAMT half for the runs k_storage_run_actors_table left undecided (a block the table does not cover)
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_storage_run_actors_lane(WitnessView w, const StorageClaimPacked* __restrict__ claims,
+                                                                                   StorageRun* __restrict__ runs, uint32_t n_runs,
+                                                                                   uint32_t undecided) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_runs) return;
+    if (runs[i].sr_status != IPCFP_ST_TRUE || runs[i].actor_status != undecided) return;
+    uint8_t key[12];
+    const uint32_t kl = id_address_bytes(claims[runs[i].first_claim].actor_id, key);  // common/decode.rs:34
+    ValueLoc loc;
+    uint32_t st = hamt_get(w, runs[i].actors, 5, VK_ACTOR_STATE, key, kl, loc);         // decode.rs:29-37
+    CidKey actor_state{};
+    if (st == IPCFP_ST_NOT_FOUND) st = IPCFP_ST_ERR_ACTOR_NOT_FOUND;                    // decode.rs:39
+    if (st == IPCFP_ST_TRUE) {
+        Rd v;
+        v.init(w.arena + w.off[loc.block] + loc.off, loc.len);
+        CidKey code;
+        v.expect_array(5);
+        v.read_link_key(code);
+        v.read_link_key(actor_state);
+        if (!v.ok()) st = IPCFP_ST_ERR_DECODE;
+    }
+    runs[i].actor_status = st;
+    runs[i].actor_state = actor_state;
+}
+
+int launch_storage_run_actors_lane(ipcfp_ctx* ctx, const WitnessView& w, const void* claims_d, void* runs_d, uint32_t n_runs,
+                                   uint32_t undecided) {
+    if (n_runs == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_storage_run_actors_lane, dim3(div_up(n_runs, 256)), dim3(256), 0, ctx->stream, w,
+                       static_cast<const StorageClaimPacked*>(claims_d), static_cast<StorageRun*>(runs_d), n_runs, undecided);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+// get_actor_state's HAMT half over the node table (hamt_table.h), one run per lane; what the table does not cover stays
+// `undecided` for k_storage_run_actors_lane
+__global__ __launch_bounds__(256) void k_storage_run_actors_table(WitnessView w, const HamtNodeRec* __restrict__ table,
+                                                                  const StorageClaimPacked* __restrict__ claims,
+                                                                  StorageRun* __restrict__ runs, uint32_t n_runs, uint32_t undecided) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_runs) return;
+    if (runs[i].sr_status != IPCFP_ST_TRUE) return;
+    uint8_t key[12];
+    const uint32_t kl = id_address_bytes(claims[runs[i].first_claim].actor_id, key);  // common/decode.rs:34
+    ValueLoc loc;
+    uint32_t st = table_hamt_get(w, table, runs[i].actors, 5, HK_ACTOR_STATE, key, kl, loc);  // decode.rs:29-37
+    CidKey actor_state{};
+    if (st == kTablePunt) st = undecided;
+    if (st == IPCFP_ST_NOT_FOUND) st = IPCFP_ST_ERR_ACTOR_NOT_FOUND;                          // decode.rs:39
+    if (st == IPCFP_ST_TRUE) {
+        Rd v;
+        v.init(w.arena + w.off[loc.block] + loc.off, loc.len);
+        CidKey code;
+        v.expect_array(5);
+        v.read_link_key(code);
+        v.read_link_key(actor_state);
+        if (!v.ok()) st = IPCFP_ST_ERR_DECODE;
+    }
+    runs[i].actor_status = st;
+    runs[i].actor_state = actor_state;
+}
+
+// left_pad_32 (src/proofs/common/evm.rs:91-100) of a serde Vec<u8> (a CBOR array of u8, type-checked by the table) as four
+// little-endian words: byte i of the padded value = word i/8, bits 8·(i%8)…
+__device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    const uint64_t n = v.read_array();
+    auto put = [&](uint64_t i, uint32_t x) {
+        if (n >= 32 && i < n - 32) return;
+        const uint32_t j = n >= 32 ? uint32_t(i - (n - 32)) : uint32_t(32 - n + i);
+        const uint64_t b = uint64_t(x & 0xffu) << (8u * (j & 7u));
+        const uint32_t k = j >> 3;
+        out[0] |= k == 0 ? b : 0ull;
+        out[1] |= k == 1 ? b : 0ull;
+        out[2] |= k == 2 ? b : 0ull;
+        out[3] |= k == 3 ? b : 0ull;
+    };
+    uint64_t i = 0;
+    while (i < n && v.ok() && v.pos + 8u <= v.n) {  // eight bytes per fetch (cbor_dev.h vec_u8_step)
+        const uint64_t w = v.peek64(v.pos);
+        uint32_t used = 0, x;
+        while (i < n && vec_u8_step(w, used, x)) put(i++, x);
+        v.pos += used;
+        if (i < n && used <= 6u) put(i++, uint32_t(v.read_uint()));
+    }
+    for (; i < n && v.ok(); ++i) put(i, uint32_t(v.read_uint()));
+}
+
+// verify_storage_proof, steps 2-6 in the reference's order of checks (src/proofs/storage/verifier.rs:24-63), one claim per
+// lane: everything its run shares comes from the run's record, `read_storage_slot`'s HAMT get (storage/decode.rs:79-96)
+// walks the node table.  A claim it cannot settle (an inline small-map layout, a block the table does not cover) is left
+// kStPending for k_verify_storage.
+__global__ __launch_bounds__(256) void k_verify_storage_table(WitnessView w, const HamtNodeRec* __restrict__ table,
+                                                              const StorageClaimPacked* __restrict__ claims, uint32_t n,
+                                                              const uint32_t* __restrict__ run_of, const StorageRun* __restrict__ runs,
+                                                              ipcfp_trust_policy_t trust, uint32_t undecided, uint8_t* __restrict__ status) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const StorageClaimPacked& c = claims[t];
+    const StorageRun& run = runs[run_of[t]];
+    const uint32_t flags = c.flags;
+    uint32_t st = kStPending;
+    do {
+        // Step 2: verify_trust_anchor (storage/verifier.rs:81-92)
+        if (!(flags & SC_CHILD_PARSED)) { st = IPCFP_ST_ERR_BAD_CLAIM; break; }                           // :85
+        if (!trusted(trust, c.child_epoch)) { st = IPCFP_ST_FALSE_UNTRUSTED_CHILD; break; }               // :87
+        // Step 3: verify_parent_state_root (:95-111)
+        if (run.hdr_status != IPCFP_ST_TRUE) { st = run.hdr_status; break; }                              // :101-107
+        if (!((flags & SC_STATE_ROOT_CANON) && cid_equal(run.parent_state_root, c.state_root))) { st = IPCFP_ST_FALSE_STATE_ROOT; break; }  // :110
+        // Step 4: verify_actor_state (:114-127)
+        if (run.sr_status != IPCFP_ST_TRUE) { st = run.sr_status; break; }                                // decode.rs:23-26
+        if (run.actor_status == undecided) break;                                                         // (pending)
+        if (run.actor_status != IPCFP_ST_TRUE) { st = run.actor_status; break; }                          // :122
+        if (!((flags & SC_ACTOR_STATE_CANON) && cid_equal(run.actor_state, c.actor_state))) { st = IPCFP_ST_FALSE_ACTOR_STATE; break; }  // :126
+        // Step 5: verify_storage_root (:130-145)
+        if (run.evm_status != IPCFP_ST_TRUE) { st = run.evm_status; break; }                              // :136-141
+        if (!((flags & SC_STORAGE_ROOT_CANON) && cid_equal(run.contract_state, c.storage_root))) { st = IPCFP_ST_FALSE_STORAGE_ROOT; break; }  // :144
+        // Step 6: verify_storage_value (:148-170)
+        if (!(flags & SC_SLOT_PARSED)) { st = IPCFP_ST_ERR_BAD_CLAIM; break; }                            // :155-157
+        if (run.root_kind == 4) { st = IPCFP_ST_ERR_MISSING_BLOCK; break; }                               // decode.rs:41-43
+        if (run.root_kind != 3) break;  // an inline small map (A1-A3): the one-lane kernel searches it
+        uint64_t padded[4] = {0, 0, 0, 0};
+        ValueLoc loc;
+        const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, c.slot, 32, loc);  // decode.rs:79-96
+        if (hs == kTablePunt) break;
+        if (hs != IPCFP_ST_NOT_FOUND) {  // unwrap_or_default(): a missing key means zero
+            if (hs != IPCFP_ST_TRUE) { st = hs; break; }
+            Rd v;
+            v.init(w.arena + w.off[loc.block] + loc.off, loc.len);
+            left_pad_32_words(v, padded);
+        }
+        if (!(flags & SC_VALUE_MATCHABLE)) { st = IPCFP_ST_FALSE_VALUE; break; }  // can never equal "0x" + 64 hex digits
+        const uint64_t* cv = reinterpret_cast<const uint64_t*>(c.value);
+        const uint64_t diff = (padded[0] ^ cv[0]) | (padded[1] ^ cv[1]) | (padded[2] ^ cv[2]) | (padded[3] ^ cv[3]);
+        st = diff == 0 ? IPCFP_ST_TRUE : IPCFP_ST_FALSE_VALUE;                                            // :169
+    } while (false);
+    status[t] = uint8_t(st);
+}
+
+int launch_storage_run_actors_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, void* runs_d,
+                                    uint32_t n_runs, uint32_t undecided) {
+    if (n_runs == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_storage_run_actors_table, dim3(div_up(n_runs, 256)), dim3(256), 0, ctx->stream, w,
+                       static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageClaimPacked*>(claims_d),
+                       static_cast<StorageRun*>(runs_d), n_runs, undecided);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+int launch_verify_storage_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, uint32_t n,
+                                const uint32_t* run_of_d, const void* runs_d, const ipcfp_trust_policy_t& trust, uint32_t undecided,
+                                uint8_t* status_d) {
+    hipLaunchKernelGGL(k_verify_storage_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w,
+                       static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageClaimPacked*>(claims_d), n, run_of_d,
+                       static_cast<const StorageRun*>(runs_d), trust, undecided, status_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_storage_run_flags(ipcfp_ctx* ctx, const void* claims_d, uint32_t n, uint32_t* flag_d) {
+    hipLaunchKernelGGL(k_storage_run_flags, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const StorageClaimPacked*>(claims_d), n, flag_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+int launch_storage_run_heads(ipcfp_ctx* ctx, const uint32_t* flag_d, const uint32_t* pos_d, uint32_t n, uint32_t* run_of_d, void* runs_d) {
+    hipLaunchKernelGGL(k_storage_run_heads, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, flag_d, pos_d, n, run_of_d,
+                       static_cast<StorageRun*>(runs_d));
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+int launch_storage_run_facts(ipcfp_ctx* ctx, const WitnessView& w, const void* claims_d, void* runs_d, uint32_t n_runs) {
+    if (n_runs == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_storage_run_facts, dim3(div_up(n_runs, 256)), dim3(256), 0, ctx->stream, w,
+                       static_cast<const StorageClaimPacked*>(claims_d), static_cast<StorageRun*>(runs_d), n_runs);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+// the one-lane kernel over the whole batch (pending_only = 0) or over what the run / group kernels left kStPending
+int launch_verify_storage_lanes(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,
+                                const ipcfp_trust_policy_t& trust, uint8_t* status_d, int pending_only) {
+    static const int waves = [] {
+        const char* e = std::getenv("IPCFP_STORAGE_WAVES");
+        const int v = e ? std::atoi(e) : 4;
+        return v >= 2 && v <= 4 ? v : 4;
+    }();
+    const dim3 g(div_up(n, 256)), blk(256);
+    if (waves == 2) hipLaunchKernelGGL(k_verify_storage<2>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d, pending_only);
+    else if (waves == 3) hipLaunchKernelGGL(k_verify_storage<3>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d, pending_only);
+    else hipLaunchKernelGGL(k_verify_storage<4>, g, blk, 0, ctx->stream, w, claims_d, n, trust, status_d, pending_only);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -6,6 +6,8 @@
 // src/proofs/storage/decode.rs:81,88,96).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../common.h"
 #include "launch.h"
 #include "walk_dev.h"
@@ -29,13 +31,45 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_get(WitnessView 
                                                   const uint8_t* __restrict__ keys,
                                                   const uint32_t* __restrict__ key_off,
                                                   const uint32_t* __restrict__ key_len, uint32_t n,
-                                                  uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+                                                  uint8_t* __restrict__ status, ValueLoc* __restrict__ loc, int pending_only) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (pending_only && status[t] != kStPending) return;  // settled from the node table (k_hamt_get_table)
     ValueLoc l{kNoBlock, 0, 0};
     const uint32_t st = hamt_get(w, root, bit_width, vkind, keys + key_off[t], key_len[t], l);
     status[t] = uint8_t(st);
     if (loc) loc[t] = (st == IPCFP_ST_TRUE) ? l : ValueLoc{kNoBlock, 0, 0};
+}
+
+// K7 over the node table (hamt_table.h): one query per lane, one record per level.  What the table does not cover is left
+// kStPending for k_hamt_get (pending_only).
+__global__ __launch_bounds__(256) void k_hamt_get_table(WitnessView w, const HamtNodeRec* __restrict__ table, CidKey root,
+                                                        uint32_t bit_width, uint32_t kbit, const uint8_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ key_off, const uint32_t* __restrict__ key_len,
+                                                        uint32_t n, uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    ValueLoc l{kNoBlock, 0, 0};
+    uint32_t st = table_hamt_get(w, table, root, bit_width, kbit, keys + key_off[t], key_len[t], l);
+    if (st == kTablePunt) st = kStPending;
+    status[t] = uint8_t(st);
+    if (loc) loc[t] = (st == IPCFP_ST_TRUE) ? l : ValueLoc{kNoBlock, 0, 0};
+}
+
+uint32_t hamt_kind_bit(int vkind) {
+    return vkind == VK_ACTOR_STATE ? uint32_t(HK_ACTOR_STATE) : vkind == VK_VEC_U8 ? uint32_t(HK_VEC_U8) : vkind == VK_ANY ? uint32_t(HK_ANY) : 0u;
+}
+
+int launch_hamt_get_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const CidKey& root, uint32_t bit_width,
+                          int vkind, const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
+                          uint8_t* status_d, void* loc_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_hamt_get_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, static_cast<const HamtNodeRec*>(table_d),
+                       root, bit_width, hamt_kind_bit(vkind), keys_d, key_off_d, key_len_d, n, status_d, static_cast<ValueLoc*>(loc_d));
+    hipLaunchKernelGGL(k_hamt_get, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, root, bit_width, vkind, keys_d, key_off_d,
+                       key_len_d, n, status_d, static_cast<ValueLoc*>(loc_d), 1);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
 }
 
 int launch_amt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, int version, int vkind,
@@ -54,11 +88,9 @@ int launch_hamt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, ui
                     const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
                     uint8_t* status_d, void* loc_d) {
     if (n == 0) return IPCFP_OK;
-    {
-        ProfileScope prof(ctx, IPCFP_K_HAMT_GET);
-        hipLaunchKernelGGL(k_hamt_get, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, root, bit_width, vkind,
-                           keys_d, key_off_d, key_len_d, n, status_d, static_cast<ValueLoc*>(loc_d));
-    }
+    // (timed by the caller: host/primitives.cpp hamt_get_batch)
+    hipLaunchKernelGGL(k_hamt_get, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, root, bit_width, vkind, keys_d, key_off_d,
+                       key_len_d, n, status_d, static_cast<ValueLoc*>(loc_d), 0);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -14,6 +14,7 @@
 // child select is a mask + popcount in registers.
 #pragma once
 #include "cbor_dev.h"
+#include "hamt_table.h"
 #include "sha256_dev.h"
 
 // The walk / scan / verify kernels are chains of dependent loads (one parser per lane): what hides
@@ -25,12 +26,6 @@
 #endif
 
 namespace ipcfp {
-
-struct ValueLoc {
-    uint32_t block;  // witness block id
-    uint32_t off;    // byte offset of the value's CBOR item inside the block
-    uint32_t len;    // its encoded length
-};
 
 __device__ __forceinline__ Rd open_block(const WitnessView& w, uint32_t b) {
     Rd r;
@@ -348,6 +343,78 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
         const CidKey ck = link_len <= 40 ? r.key_at(link_off, link_len)
                                          : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
         block = witness_find(w, ck);
+        if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// HAMT get over the node table (hamt_table.h): same outcomes as hamt_get above, or kTablePunt when the walk meets a block
+// the table does not cover (the caller then walks).  `kbit`: the HK_* bit of the HAMT's value kind.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kTablePunt = 0xfdu;  // not an ipcfp_status_t
+
+__device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const HamtNodeRec* __restrict__ table, const CidKey& root,
+                                                   uint32_t bit_width, uint32_t kbit, const uint8_t* key, uint32_t key_len,
+                                                   ValueLoc& loc) {
+    if (bit_width < 1 || bit_width > 8) return IPCFP_ST_ERR_DECODE;
+    uint32_t h[8];
+    sha256::hash_bytes(key, key_len, h);
+    uint32_t consumed = 0;
+    uint32_t block = witness_find(w, root);
+    if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+    for (;;) {
+        const HamtNodeRec* rec = table + block;
+        const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);  // status | kinds_ok << 8 | np << 16
+        if ((head & 0xffu) != 1u) return kTablePunt;
+        if (!((head >> 8) & kbit)) return IPCFP_ST_ERR_DECODE;  // a value of another type in one of the node's buckets
+        const uint32_t np = (head >> 16) & 0xffu;
+        // HashBits::next happens after the node is decoded
+        if (consumed + bit_width > 256) return IPCFP_ST_ERR_MAX_DEPTH;
+        const uint32_t idx = sha256::take_bits(h, consumed, bit_width);
+        consumed += bit_width;
+        const uint64_t bf = rec->bitfield;
+        if (idx >= 64u || !((bf >> idx) & 1ull)) return IPCFP_ST_NOT_FOUND;
+        const uint32_t rank = uint32_t(__popcll(bf & ((1ull << idx) - 1ull)));
+        if (rank >= np) return IPCFP_ST_ERR_DECODE;
+        const uint32_t off = rec->ptr_off[rank];
+        const uint8_t* g = w.arena + w.off[block];
+        CidKey link;
+        if ((rec->std_links >> rank) & 1u) {
+            // the standard 43-byte link: its 38 CID bytes lie at off + 5
+#pragma unroll
+            for (int j = 0; j < 5; ++j) __builtin_memcpy(&link.w[j], g + off + 5 + 8 * j, 8);  // unaligned 8-byte loads
+            link.w[4] &= (1ull << 48) - 1ull;
+        } else {
+            Rd r;
+            r.init(g, w.len[block]);
+            r.pos = off;
+            if ((r.peek() >> 5) == 6) {
+                uint32_t o, l;
+                r.read_link(o, l);
+                if (!r.ok()) return kTablePunt;  // (cannot happen: the table validated it)
+                link = l <= 40 ? r.key_at(o, l) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+            } else {
+                // a bucket: `[[key, value]…]`, validated; find the key, skip the values
+                const uint64_t nkv = r.read_array();
+                for (uint64_t k = 0; k < nkv && r.ok(); ++k) {
+                    r.expect_array(2);
+                    uint32_t ko, kl;
+                    r.read_bytes(ko, kl);
+                    const uint32_t vstart = r.pos;
+                    bool eq = r.ok() && kl == key_len;
+                    for (uint32_t c = 0; eq && c < kl; ++c) eq = r.at(ko + c) == key[c];
+                    r.skip();
+                    if (eq && r.ok()) {
+                        loc.block = block;
+                        loc.off = vstart;
+                        loc.len = r.pos - vstart;
+                        return IPCFP_ST_TRUE;
+                    }
+                }
+                return r.ok() ? uint32_t(IPCFP_ST_NOT_FOUND) : kTablePunt;
+            }
+        }
+        block = witness_find(w, link);
         if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
     }
 }

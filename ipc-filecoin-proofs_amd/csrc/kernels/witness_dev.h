@@ -10,6 +10,15 @@
 namespace ipcfp {
 
 constexpr uint32_t kNoBlock = 0xffffffffu;
+// not an ipcfp_status_t: "not settled by the fast kernel — the general walker launched right behind takes it"
+constexpr uint32_t kStPending = 0xfeu;
+
+// a located value: the CBOR item of witness block `block` at [off, off + len)
+struct ValueLoc {
+    uint32_t block;  // witness block id
+    uint32_t off;    // byte offset of the value's CBOR item inside the block
+    uint32_t len;    // its encoded length
+};
 
 // (Raising the issue priority of the main-stream kernels with s_setprio, so that K1 and the block-order event parse
 // beside them would not stretch their dependent steps, was measured and made every one of them SLOWER — AMT levels
