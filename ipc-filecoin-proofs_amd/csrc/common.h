@@ -95,6 +95,12 @@ struct ipcfp_ctx {
     hipEvent_t spin_event = nullptr;           // wait_stream's polling event
     bool spin_sync = true;                     // env IPCFP_SPIN_SYNC=0: always block in hipStreamSynchronize
     ipcfp::UploadRing* upload_ring = nullptr;  // pinned staging ring of ipcfp::upload (created on first use)
+    // --- the mailbox: a page of COHERENT pinned host memory a kernel writes while the stream keeps going (device →
+    // host without a synchronisation; kernels/amt_enum.hip k_enum_roots, host/verify_fast.cpp) ---
+    unsigned long long* mailbox = nullptr;      // host address
+    unsigned long long* mailbox_dev = nullptr;  // the same page as the device addresses it
+    unsigned long long mailbox_seq = 0;
+    hipEvent_t main_event = nullptr;            // aux stream ← main stream dependency (host/verify_fast.cpp)
 };
 
 namespace ipcfp {

@@ -230,6 +230,23 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
         ctx->pinned_cap = 64 * 1024;
     else
         ctx->pinned = nullptr;  // read-backs fall back to pageable copies
+    // the mailbox page (IPCFP_MAILBOX=0: none — every caller then takes its synchronising route)
+    {
+        const char* e = std::getenv("IPCFP_MAILBOX");
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (!(e && std::atoi(e) == 0) &&
+            hipHostMalloc(&hp, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess &&
+                hipEventCreateWithFlags(&ctx->main_event, hipEventDisableTiming) == hipSuccess) {
+                std::memset(hp, 0, 4096);
+                ctx->mailbox = static_cast<unsigned long long*>(hp);
+                ctx->mailbox_dev = static_cast<unsigned long long*>(dp);
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+    }
     // the control block and its pinned template / mirror (IPCFP_CTL_BLOCK=0: individual memsets and copies)
     const char* ctl_env = std::getenv("IPCFP_CTL_BLOCK");
     if (!(ctl_env && std::atoi(ctl_env) == 0) &&
@@ -263,6 +280,8 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
     if (ctx->ctl_dev) (void)hipFree(ctx->ctl_dev);
     if (ctx->upload_ring) upload_ring_destroy(ctx->upload_ring);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+    if (ctx->main_event) (void)hipEventDestroy(ctx->main_event);
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->spin_event) (void)hipEventDestroy(ctx->spin_event);
     if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);

@@ -84,10 +84,23 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
 
 // Shared device path of the string and the packed entry points: prepare every tipset context
 // (header facts, execution order) and verify the batch.  `claims_d`, `blob_d`, `status_d` are device.
+int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
+                       uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
+                       const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done);  // verify_fast.cpp
+
 int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
                   uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                   const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d = nullptr) {
     static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
+    {   // one tipset pair, receipts not enumerated yet: the route without a mid-call synchronisation (verify_fast.cpp);
+        // whenever its dense walk does not hold, everything is done again below
+        const std::vector<TipsetCtxDev> saved = tcs;
+        bool done = false;
+        int rc_fast = verify_packed_fast(ctx, w, tcs, claims_d, n, blob_d, blob_len, trust, filter, status_d, where_d, &done);
+        if (rc_fast) return rc_fast;
+        if (done) return IPCFP_OK;
+        tcs = saved;
+    }
     const WitnessView view = witness_view(w);
     // when no scan has tabulated the events yet, the block-order parse runs beside the whole tipset prologue
     int rc_bt = ctx->has_scan_hint ? block_table_prefetch(ctx, w, &ctx->scan_hint.filter, int(ctx->scan_hint.has_actor), ctx->scan_hint.actor)

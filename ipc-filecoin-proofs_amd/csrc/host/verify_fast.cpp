@@ -1,0 +1,215 @@
+// csrc/host/verify_fast.cpp — `verify_event_proof` for a batch of ONE tipset pair without a mid-call synchronisation.
+//
+// host/verify_events.cpp::verify_packed waits for the device twice before the verify kernel runs — for the AMT roots'
+// shapes (to size the walk) and for the walk's anomaly flag — and each wait drains the stream, wakes the host and
+// leaves the GPU idle until the next launch arrives (≈40 + ≈80 µs of a 1.3 ms step).  Here
+//   * the root shapes reach the host through the MAILBOX — a page of coherent pinned host memory that k_enum_roots
+//     writes while the stream keeps going — so the host sizes and queues everything else without draining anything;
+//   * the anomaly flag is read at the END of the call, with the status bytes: every kernel behind the walk is queued
+//     before the host knows whether the dense walk held.  They are safe on whatever it left (k_dense_leaves writes every
+//     LeafRef it owes, kNoBlock when there is no value; readers skip those), and when the flag is set — a sparse AMT, a
+//     lying count, a missing block, a decode error — the call's results are thrown away and verify_packed does the
+//     whole batch again its own way (the general level-synchronous walk orders errors as the reference does);
+//   * what the host did between the second wait and the verify kernel (is the execution order reachable, where are the
+//     tables, exec_len, the inverse permutation) happens on the device (k_ctx_finish).
+// The call synchronises once.  Same kernels otherwise, same results: tests/test_gpu_events.py, test_gpu_baseline_sizes.py,
+// test_gpu_enum_shapes.py (every shape that leaves the dense path) run through this file first.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../common.h"
+#include "../kernels/claims_dev.h"
+#include "../kernels/exec_order.h"
+#include "../kernels/launch.h"
+#include "exec_state.h"
+
+using namespace ipcfp;
+
+namespace ipcfp {
+
+int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents);
+
+// → IPCFP_OK with *done = true: status_d (and where_d) hold the batch's results;
+//   IPCFP_OK with *done = false: not this route's case, or the dense walk did not hold — nothing the caller may use;
+//   anything else: an ABI error.
+int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
+                       uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
+                       const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done) {
+    static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
+    static const bool enabled = [] {
+        const char* e = std::getenv("IPCFP_FAST_VERIFY");
+        return !(e && std::atoi(e) == 0);
+    }();
+    *done = false;
+    if (!enabled || !ctx->mailbox || tcs.size() != 1 || !w->use_event_table || ctx->stream_aux == ctx->stream) return IPCFP_OK;
+    const TipsetCtxDev& in = tcs[0];
+    if (!(in.flags & TC_PARENTS_PARSED) || !(in.flags & TC_CHILD_PARSED) || in.n_parents == 0 || in.n_parents > kMaxParents) return IPCFP_OK;
+    for (auto& e : w->enum_cache)  // a scan enumerated the receipts already: verify_packed shares that enumeration
+        if (e->vkind == VK_RECEIPT && e->lo == w->receipt_lo && e->hi == w->receipt_hi) return IPCFP_OK;
+    const WitnessView view = witness_view(w);
+    const uint32_t P = in.n_parents, n_roots = 2 * P, n_all = n_roots + 1;
+    // the block-order event parse runs beside everything below (aux stream), counting the last scan's filter
+    int rc = ctx->has_scan_hint ? block_table_prefetch(ctx, w, &ctx->scan_hint.filter, int(ctx->scan_hint.has_actor), ctx->scan_hint.actor)
+                                : block_table_prefetch(ctx, w, nullptr, 0, 0);
+    if (rc) return rc;
+    DevBuf<TipsetCtxDev> tcs_d;
+    IPCFP_HIP(ctx, tcs_d.alloc(1));
+    IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, tcs.data(), sizeof(TipsetCtxDev), ctx->stream));
+    ExecState ex;
+    rc = exec_state_prepare(ctx, ex, P);
+    if (rc) return rc;
+    PrepareJob job{tcs_d.p, ex.roots.p, ex.err.p};
+    rc = launch_tipset_prepare(ctx, view, &job, nullptr, 1,
+                               /*need_general=*/uint64_t(w->max_block_len) + 32u > uint64_t(kPrologueStageChunks) * 16u);
+    if (rc) return rc;
+    // ---- the roots; their shapes come back through the mailbox ----
+    DevBuf<EnumNode> frontier;
+    DevBuf<DenseNode> dense_frontier;
+    DevBuf<uint32_t> small_own;
+    DevBuf<uint64_t> info_own;
+    uint32_t* small = nullptr;  // [0] = max height (unused here), [2] = anomaly flag of the dense walk
+    uint64_t* info_d = nullptr;
+    IPCFP_HIP(ctx, frontier.alloc(n_all));
+    IPCFP_HIP(ctx, dense_frontier.alloc(n_all));
+    IPCFP_HIP(ctx, ctl_words(ctx, small_own, small, 4, false));
+    IPCFP_HIP(ctx, ctl_words(ctx, info_own, info_d, 2 * size_t(n_all), false));
+    const unsigned long long seq = ++ctx->mailbox_seq;
+    rc = launch_enum_roots(ctx, view, ex.roots.p, n_all, VK_CID, frontier.p, small, ex.err.p, info_d, ctx->mailbox_dev, seq,
+                           dense_frontier.p);
+    if (rc) return rc;
+    {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(5);
+        uint32_t spins = 0;
+        while (__atomic_load_n(ctx->mailbox, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() > deadline) {
+                IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // (a failed launch surfaces here)
+                if (__atomic_load_n(ctx->mailbox, __ATOMIC_ACQUIRE) != seq)
+                    return set_error(ctx, IPCFP_E_HIP, "the AMT roots' shapes never reached the mailbox");
+            }
+        }
+    }
+    std::vector<uint64_t> root_info(2 * size_t(n_all));
+    for (size_t i = 0; i < root_info.size(); ++i) root_info[i] = __atomic_load_n(ctx->mailbox + 1 + i, __ATOMIC_RELAXED);
+    DensePlan plan;
+    dense_plan(root_info, n_roots, VK_CID, /*want_keys=*/true, 0, ~0ULL, 1, VK_RECEIPT, w->receipt_lo, w->receipt_hi, plan);
+    if (!plan.ok || plan.n_use != n_all || plan.n_leaves == 0 || plan.n_extra == 0) {
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // (the kernels above still use this call's scratch)
+        return IPCFP_OK;
+    }
+    // ---- everything else, queued in one go ----
+    const uint32_t n_msgs = uint32_t(plan.n_leaves), n_rcpt = uint32_t(plan.n_extra);
+    DevBuf<DenseNode> a, b;
+    DevBuf<LeafRef> rleaves;
+    IPCFP_HIP(ctx, a.alloc(plan.biggest));
+    IPCFP_HIP(ctx, b.alloc(plan.biggest));
+    IPCFP_HIP(ctx, ex.keys.alloc(n_msgs));
+    IPCFP_HIP(ctx, rleaves.alloc(n_rcpt));
+    rc = launch_dense_walk(ctx, view, dense_frontier.p, plan, a.p, b.p, nullptr, ex.keys.p, rleaves.p, small + 2);
+    if (rc) return rc;
+    // the receipts' event records: aux stream, behind the block-order parse and behind the leaves just queued
+    std::unique_ptr<EventTableCached> table(new EventTableCached());
+    table->lo = w->receipt_lo;
+    table->hi = w->receipt_hi;
+    table->n = n_rcpt;
+    table->events = w->bt_events.p;
+    IPCFP_HIP(ctx, table->receipts.alloc(n_rcpt));
+    IPCFP_HIP(ctx, table->err_word.alloc(1));
+    table->has_counts = w->bt_has_filter;
+    if (table->has_counts) {
+        table->counts_filter = w->bt_filter;
+        IPCFP_HIP(ctx, table->counts.alloc(n_rcpt));
+    }
+    IPCFP_HIP(ctx, hipEventRecord(ctx->main_event, ctx->stream));
+    IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->main_event, 0));
+    IPCFP_HIP(ctx, hipMemsetAsync(table->err_word.p, 0xff, 8, ctx->stream_aux));  // kNoEnumError
+    rc = launch_receipt_events(ctx, view, rleaves.p, n_rcpt, table->has_counts ? &w->bt_filter.filter : nullptr,
+                               int(w->bt_filter.has_actor), w->bt_filter.actor, w->bt_blocks.p, table->receipts.p,
+                               table->has_counts ? table->counts.p : nullptr, table->err_word.p, ctx->stream_aux);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream_aux));
+    w->bt_joined = false;
+    // the execution order: first-seen dedupe of the message CIDs, positions, inverse — main stream, beside the above
+    uint32_t size = 64;
+    while (size < 2ull * n_msgs) size <<= 1;
+    ex.mask = size - 1;
+    ex.raw_len = n_msgs;
+    IPCFP_HIP(ctx, ex.slots.alloc(size));
+    IPCFP_HIP(ctx, ex.first.alloc(n_msgs));
+    IPCFP_HIP(ctx, ex.pos.alloc(n_msgs));
+    IPCFP_HIP(ctx, ex.inv.alloc(n_msgs));
+    IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 8, ctx->stream));
+    rc = launch_exec_dedup(ctx, view, nullptr, n_msgs, ex.keys.p, ex.slots.p, ex.mask, ex.first.p);
+    if (rc) return rc;
+    DevBuf<uint64_t> scratch;
+    IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n_msgs, 1024)) + 2));
+    IPCFP_HIP(ctx, ctl_words(ctx, ex.total_own, ex.total.p, 1, false));
+    rc = launch_scan_u32(ctx, ex.first.p, n_msgs, ex.pos.p, ex.total.p, scratch.p);
+    if (rc) return rc;
+    CtxFinish fin{};
+    fin.err = ex.err.p;
+    fin.total = ex.total.p;
+    fin.first = ex.first.p;
+    fin.pos = ex.pos.p;
+    fin.inv = ex.inv.p;
+    fin.slots = ex.slots.p;
+    fin.keys = ex.keys.p;
+    fin.mask = ex.mask;
+    fin.raw_len = n_msgs;
+    fin.receipt_leaves = rleaves.p;
+    fin.n_receipt_leaves = n_rcpt;
+    fin.receipt_first = w->receipt_lo;
+    fin.receipt_recs = table->receipts.p;
+    fin.event_recs = table->events;
+    rc = launch_ctx_finish(ctx, tcs_d.p, fin);
+    if (rc) return rc;
+    rc = event_table_join(ctx, w);
+    if (rc) return rc;
+    rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, 1, blob_d, blob_len, trust ? *trust : accept_all, filter, status_d,
+                              where_d, /*tabulated=*/true);
+    if (rc) return rc;
+    // ---- the one synchronisation: did the dense walk hold? ----
+    uint32_t bad = 0;
+    unsigned long long e = kNoEnumError;
+    TipsetCtxDev facts;
+    IPCFP_HIP(ctx, ctl_read(ctx, &bad, small + 2, 4));
+    IPCFP_HIP(ctx, ctl_read(ctx, &e, ex.err.p, 8));
+    IPCFP_HIP(ctx, d2h_small(ctx, &facts, tcs_d.p, sizeof facts, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    IPCFP_HIP(ctx, hipGetLastError());
+    if (bad || e != kNoEnumError || facts.child_status != IPCFP_ST_TRUE) {
+        // (the aux stream may still be writing this call's buffers)
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+        w->bt_joined = true;
+        return IPCFP_OK;  // *done == false: verify_packed decides, in the reference's order of errors
+    }
+    tcs[0] = facts;
+    // the enumeration of the receipts and their event table now belong to the witness: the scan that follows finds them
+    {
+        std::unique_ptr<EnumCached> en(new EnumCached());
+        std::memcpy(en->root, facts.receipts_root.w, 40);
+        en->version = 0;
+        en->vkind = VK_RECEIPT;
+        en->lo = w->receipt_lo;
+        en->hi = w->receipt_hi;
+        en->n = n_rcpt;
+        en->error = kNoEnumError;
+        en->dense = true;
+        en->leaves.p = reinterpret_cast<uint8_t*>(rleaves.p);
+        en->leaves.count = rleaves.count * sizeof(LeafRef);
+        en->leaves.cap = rleaves.cap;
+        en->leaves.owner = rleaves.owner;
+        rleaves.p = nullptr;
+        rleaves.count = rleaves.cap = 0;
+        rleaves.owner = nullptr;
+        w->enum_cache.push_back(std::move(en));
+        std::memcpy(table->root, facts.receipts_root.w, 40);
+        w->table_cache.push_back(std::move(table));
+    }
+    *done = true;
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

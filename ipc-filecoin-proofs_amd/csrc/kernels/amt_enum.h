@@ -15,6 +15,7 @@
 // failing node has no descendants and every node with a smaller base index is visited earlier.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "../common.h"
 #include "amt_types.h"
@@ -53,6 +54,38 @@ struct EnumExtra {
     AmtEnumResult* out = nullptr;
     bool done = false;
 };
+
+// ---- the dense fast path (amt_enum.hip): the tree's shape follows from the roots' (height, bit width, count) ----
+struct DenseRoot {
+    uint32_t height, bit_width;
+    uint64_t count;
+    uint64_t lo, hi;  // the indices to enumerate: [lo, hi) with lo < hi <= count, or (0, 0) for an empty tree
+    uint32_t vkind;   // value type of this tree
+    uint32_t out_sel; // where its values go: 0 = keys_out (links as witness keys), 1 = leaves, 2 = leaves of the extra root
+    uint64_t out_off; // ... from this element on
+};
+constexpr uint32_t kMaxDenseRoots = 2 * IPCFP_MAX_PARENTS + 1;  // BLS + secp per parent block, + the receipts AMT
+constexpr uint32_t kMaxDenseLevels = 24;
+struct DenseRoots {  // travels as a kernel ARGUMENT (1.6 KB): no copy at the head of the walk
+    DenseRoot r[kMaxDenseRoots];
+    uint32_t n;
+};
+struct DensePlan {
+    bool ok = false;          // every root is a dense candidate: the walk below may be launched
+    uint32_t n_use = 0;       // roots in the walk (the call's own + the extra one when it joined)
+    uint32_t max_height = 0;
+    uint64_t n_level[kMaxDenseLevels] = {};  // nodes per level (node height)
+    uint64_t n_leaves = 0, n_extra = 0, biggest = 0;
+    DenseRoots roots{};
+};
+void dense_plan(const std::vector<uint64_t>& root_info, uint32_t n_roots, int vkind, bool want_keys, uint64_t lo, uint64_t hi,
+                uint32_t has_extra, int extra_vkind, uint64_t extra_lo, uint64_t extra_hi, DensePlan& plan);
+int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* frontier, const DensePlan& plan,
+                      DenseNode* a, DenseNode* b, LeafRef* leaves_main, CidKey* keys_main, LeafRef* leaves_extra, uint32_t* anomaly_d);
+
+int launch_enum_roots(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_all, int vkind,
+                      EnumNode* frontier_d, uint32_t* max_height_d, unsigned long long* err_d, uint64_t* root_info_d,
+                      unsigned long long* mailbox, unsigned long long mailbox_seq, DenseNode* dense_frontier_d);
 
 // Enumerate `n_roots` AMTs (device array `roots_d`) whose values have type `vkind`.
 // `err_d` is a device u64 initialised by the caller (kNoEnumError or earlier-stage errors); the

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -15,18 +16,14 @@ __device__ __forceinline__ void enum_error(unsigned long long* err, uint32_t seq
     atomicMin(err, (unsigned long long)pack_enum_error(seq, base, code));
 }
 
-// roots → frontier (one entry per root, in root order)
-__global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootSpec* __restrict__ roots, uint32_t n,
-                                                   int vkind, EnumNode* __restrict__ frontier,
-                                                   uint32_t* __restrict__ max_height,
-                                                   unsigned long long* __restrict__ err,
-                                                   uint64_t* __restrict__ root_info /* n × {height|bw<<32, count} */) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const AmtRootSpec spec = roots[t];
+// one root → its frontier entry and its shape {height | bw << 32, count} (~0: the root did not load)
+__device__ __forceinline__ void enum_root_one(const WitnessView& w, const AmtRootSpec& spec, int vkind, EnumNode* __restrict__ slot,
+                                              uint32_t* __restrict__ max_height, unsigned long long* __restrict__ err,
+                                              uint64_t& info0, uint64_t& info1, DenseNode* __restrict__ dense_slot) {
     EnumNode e{kNoBlock, 0, 0, spec.seq, 0, 0, 0};
-    root_info[2 * t] = ~0ULL;  // dead
-    root_info[2 * t + 1] = 0;
+    DenseNode d{0, 0, kNoBlock, 0, spec.seq, 0};
+    info0 = ~0ULL;  // dead
+    info1 = 0;
     if (!spec.skip) {
         AmtRootInfo info;
         const uint32_t st = amt_load(w, spec.root, int(spec.version), spec.kind_p1 ? int(spec.kind_p1) - 1 : vkind, info);
@@ -38,11 +35,45 @@ __global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootS
             e.height = uint16_t(info.height);
             e.bit_width = uint8_t(info.bit_width);
             atomicMax(max_height, uint32_t(info.height));
-            root_info[2 * t] = uint64_t(uint32_t(info.height)) | (uint64_t(info.bit_width) << 32);
-            root_info[2 * t + 1] = info.count;
+            info0 = uint64_t(uint32_t(info.height)) | (uint64_t(info.bit_width) << 32);
+            info1 = info.count;
+            d.block = info.block;
+            d.goff = w.off[info.block] + info.node_off;
+            d.rem = w.len[info.block] - info.node_off;
         }
     }
-    frontier[t] = e;
+    *slot = e;
+    if (dense_slot) *dense_slot = d;
+}
+
+// roots → frontier (one entry per root, in root order)
+__global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootSpec* __restrict__ roots, uint32_t n,
+                                                   int vkind, EnumNode* __restrict__ frontier,
+                                                   uint32_t* __restrict__ max_height,
+                                                   unsigned long long* __restrict__ err,
+                                                   uint64_t* __restrict__ root_info /* n × {height|bw<<32, count} */,
+                                                   unsigned long long* __restrict__ mailbox, unsigned long long mailbox_seq,
+                                                   DenseNode* __restrict__ dense_frontier) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t info0 = ~0ULL, info1 = 0;
+    if (t < n) {
+        enum_root_one(w, roots[t], vkind, frontier + t, max_height, err, info0, info1, dense_frontier ? dense_frontier + t : nullptr);
+        root_info[2 * t] = info0;
+        root_info[2 * t + 1] = info1;
+    }
+    // The mailbox (host/verify_fast.cpp): PINNED HOST memory the device writes while the stream keeps going.  The root
+    // shapes are all the host needs to size and queue the rest of the walk, so it polls these words instead of draining
+    // the stream with a synchronisation: [0] = sequence number (written last), [1 + 2t ..] = the shapes.  Single-block
+    // launches only (n ≤ 64 roots), so that "every root is through" is a __syncthreads.
+    if (mailbox && gridDim.x == 1) {
+        if (t < n) {
+            __hip_atomic_store(mailbox + 1 + 2 * t, (unsigned long long)info0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mailbox + 2 + 2 * t, (unsigned long long)info1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(mailbox, mailbox_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // decode the node of entry e (validating it completely); false ⇒ decode error
@@ -225,15 +256,6 @@ __global__ __launch_bounds__(256) void k_enum_emit(WitnessView w, const EnumNode
 // lying count, a missing block, a decode error — raises `anomaly` and the caller redoes the walk with
 // the general level-synchronous path, which also knows how to order errors.
 // ---------------------------------------------------------------------------------------------
-struct DenseRoot {
-    uint32_t height, bit_width;
-    uint64_t count;
-    uint64_t lo, hi;  // the indices to enumerate: [lo, hi) with lo < hi <= count, or (0, 0) for an empty tree
-    uint32_t vkind;   // value type of this tree
-    uint32_t out_sel; // where its values go: 0 = keys_out (links as witness keys), 1 = leaves, 2 = leaves of the extra root
-    uint64_t out_off; // ... from this element on
-};
-
 // nodes of `level` (node height) the whole tree has
 __host__ __device__ inline uint64_t dense_total(const DenseRoot& r, uint32_t level) {
     if (r.height < level) return 1;  // rides along until its own level
@@ -253,33 +275,106 @@ __host__ __device__ inline uint64_t dense_nodes(const DenseRoot& r, uint32_t lev
     return ((r.hi - 1) >> shift) - (r.lo >> shift) + 1;
 }
 
-// frontier entering `level` (≥ 1) → frontier entering level-1; one lane per child
-__global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNode* __restrict__ cur,
-                                                     const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t level,
-                                                     uint32_t n_next, int vkind, EnumNode* __restrict__ next,
-                                                     uint32_t* __restrict__ anomaly) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_next) return;
-    // which root, and where its entries start on both levels
-    uint32_t r = 0, cur_off = 0, next_off = 0;
-    DenseRoot dr = roots[0];
-    uint64_t n_here = dense_nodes(dr, level - 1);
-    while (j >= next_off + n_here) {
-        next_off += uint32_t(n_here);
-        cur_off += uint32_t(dense_nodes(dr, level));
-        dr = roots[++r];
-        n_here = dense_nodes(dr, level - 1);
+// ---- the dense walk's kernels ------------------------------------------------------------------------------------
+// Every lane's work is a short chain of DEPENDENT memory latencies — the levels are a few thousand lanes at most — so
+// what these kernels are made for is the number of hops, not bytes or instructions:
+//   * a frontier entry (DenseNode) carries the arena offset and length of its node, so a child's lane starts reading its
+//     parent without asking the off / len tables first;
+//   * the node header is not parsed to find out where things are: with the shape known (m entries, the low m bitmap
+//     bits) the canonical spelling of the header is COMPUTED, the 16 bytes at the node's start are compared with it, and
+//     the lane's own link sits at `header + 43·k` — header and link are fetched side by side, one latency;
+//   * after the hash slot, the candidate block's CID, offset and length are fetched side by side as well.
+// Three hops per level (node bytes → hash slot → block facts) instead of six.  Anything that is not spelled
+// canonically — a non-minimal length, a bit width above 6, a link that is not the standard 43 bytes — is an anomaly and
+// the walk is redone by the general level-synchronous path, like every other shape that leaves the dense route.
+
+__device__ __forceinline__ uint64_t load_u64_any(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);  // one unaligned 8-byte load (gfx950 runs in unaligned-access mode)
+    return v;
+}
+
+// The canonical header of an AMT node whose bitmap is the low m bits of a W-bit map: `83 | 4x bitmap | 8m (links) …` for a
+// link node, `83 | 4x bitmap | 80 | 8m (values) …` for a leaf.  → its length (0: this route does not spell such a node)
+// and its bytes as two little-endian words.
+__device__ __forceinline__ uint32_t dense_header(uint32_t W, uint32_t m, bool leaf, uint64_t& h0, uint64_t& h1) {
+    const uint32_t bl = (W + 7u) / 8u;
+    h0 = h1 = 0;
+    if (bl > 8u || m > 64u || m == 0u) return 0;
+    uint32_t n = 0;
+    auto put = [&](uint32_t byte) {  // (no byte array: a dynamically indexed one would live in scratch)
+        if (n < 8u) h0 |= uint64_t(byte & 0xffu) << (8u * n);
+        else h1 |= uint64_t(byte & 0xffu) << (8u * (n - 8u));
+        ++n;
+    };
+    put(0x83);
+    put(0x40u | bl);
+    for (uint32_t i = 0; i < bl; ++i) {
+        const uint32_t lo = i * 8u;
+        put(m >= lo + 8u ? 0xffu : (m > lo ? (1u << (m - lo)) - 1u : 0u));
     }
+    if (leaf) put(0x80);  // a leaf holds no links
+    if (m < 24u) put(0x80u | m);
+    else {
+        put(0x98);
+        put(m);
+    }
+    return n;
+}
+__device__ __forceinline__ bool header_matches(const uint8_t* node, uint32_t hdr, uint64_t h0, uint64_t h1) {
+    const uint64_t g0 = load_u64_any(node), g1 = load_u64_any(node + 8);
+    const uint64_t m0 = hdr >= 8 ? ~0ull : ((1ull << (8u * hdr)) - 1ull);
+    const uint64_t m1 = hdr <= 8 ? 0ull : (hdr >= 16 ? ~0ull : ((1ull << (8u * (hdr - 8u))) - 1ull));
+    return ((g0 ^ h0) & m0) == 0 && ((g1 ^ h1) & m1) == 0;
+}
+// the standard 43-byte link at p:   d8 2a | 58 27 | 00 | 01 71 a0 e4 02 20 | digest[32]
+__device__ __forceinline__ bool std_link_at(const uint8_t* p) {
+    return load_u64_any(p) == 0xa071010027582ad8ull && (load_u64_any(p + 8) & 0xffffffull) == 0x2002e4ull;
+}
+__device__ __forceinline__ CidKey std_link_key(const uint8_t* p) {
+    CidKey k;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) k.w[j] = load_u64_any(p + 5 + 8 * j);
+    k.w[4] &= (1ull << 48) - 1ull;  // 38 = 4·8 + 6 bytes
+    return k;
+}
+
+// which root does frontier entry j of `level` belong to (dense trees side by side), and where do its entries start?
+struct DenseWhere {
+    DenseRoot dr;
+    uint32_t upper_off, here_off;
+};
+__device__ __forceinline__ DenseWhere dense_where(const DenseRoot* roots, uint32_t j, uint32_t level_here) {
+    DenseWhere o;
+    uint32_t r = 0;
+    o.upper_off = o.here_off = 0;
+    o.dr = roots[0];
+    uint64_t n_here = dense_nodes(o.dr, level_here);
+    while (j >= o.here_off + n_here) {
+        o.here_off += uint32_t(n_here);
+        o.upper_off += uint32_t(dense_nodes(o.dr, level_here + 1));
+        o.dr = roots[++r];
+        n_here = dense_nodes(o.dr, level_here);
+    }
+    return o;
+}
+
+// frontier entering `level` (≥ 1) → frontier entering level-1; one lane per child
+__device__ __forceinline__ void dense_level_one(const WitnessView& w, const DenseNode* __restrict__ cur, const DenseRoot* roots,
+                                                uint32_t level, uint32_t j, DenseNode* __restrict__ next,
+                                                uint32_t* __restrict__ anomaly) {
+    const DenseWhere wh = dense_where(roots, j, level - 1);
+    const DenseRoot& dr = wh.dr;
     if (dr.height < level) {  // rides along
-        next[j] = cur[cur_off];
+        next[j] = cur[wh.upper_off];
         return;
     }
-    const uint64_t q = dense_first(dr, level - 1) + (j - next_off);  // absolute node number on the child level
+    const uint64_t q = dense_first(dr, level - 1) + (j - wh.here_off);  // absolute node number on the child level
     const uint32_t W = 1u << dr.bit_width;
     const uint64_t p = q >> dr.bit_width;
     const uint32_t k = uint32_t(q) & (W - 1u);
-    const EnumNode e = cur[cur_off + uint32_t(p - dense_first(dr, level))];
-    EnumNode c{kNoBlock, 0, 0, e.seq, uint16_t(level - 1), e.bit_width, 0};
+    const DenseNode e = cur[wh.upper_off + uint32_t(p - dense_first(dr, level))];
+    DenseNode c{0, e.base + uint64_t(k) * amt_span(dr.bit_width, level), kNoBlock, 0, e.seq, 1};
     if (e.block == kNoBlock) {
         next[j] = c;
         return;
@@ -287,97 +382,139 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const EnumNo
     const uint64_t remaining = dense_total(dr, level - 1) - p * W;
     const uint32_t m = remaining < W ? uint32_t(remaining) : W;  // links this parent must hold
     // a parent on the edge of the range has children without a lane: the first / last lane it does have stands in
-    const bool edge_first = j == next_off && k > 0;
-    const bool edge_last = j + 1 == next_off + n_here && k + 1 < m;
-    // The parent is validated BY ITS CHILDREN, each lane a share, instead of by one lane parsing all of it (a
-    // node of eight links is 350 bytes = 22 dependent chunk loads for that one lane — the latency of a level):
-    //   every lane   the node header: array(3), bitmap = exactly the low m bits, links array of m entries;
-    //   lane k       link k, assumed to start 43·k bytes after the first one — true iff links 0..k-1 are the
-    //                standard 43-byte form (tag 42, 39-byte string, identity multibase byte, 38-byte CID), which
-    //                lanes 0..k-1 check on theirs: by induction every start is right or some lane objects;
-    //   lane m-1     what follows the last link: an empty values array and, in a child block, the end of the block.
-    // Together that is everything CollapsedNode::expand checks; any other shape is an anomaly (general path).
-    Rd r2 = open_block(w, e.block);
-    r2.pos = e.node_off;
-    r2.expect_array(3);
-    uint32_t bo, bl;
-    r2.read_bytes(bo, bl);
-    bool ok = r2.ok() && bl == (W + 7) / 8;
-    if (ok) {
-        for (uint32_t i = 0; i < bl; ++i) {
-            const uint32_t lo = i * 8u;
-            const uint32_t want = m >= lo + 8 ? 0xffu : (m > lo ? (1u << (m - lo)) - 1u : 0u);
-            uint32_t have = r2.at(bo + i);
-            if (W < 8) have &= (1u << W) - 1u;
-            ok = ok && have == want;
-        }
+    const uint64_t n_here = dense_nodes(dr, level - 1);
+    const bool edge_first = j == wh.here_off && k > 0;
+    const bool edge_last = j + 1 == wh.here_off + n_here && k + 1 < m;
+    // The parent is validated BY ITS CHILDREN, each lane a share: every lane the header, lane k link k (at header +
+    // 43·k: right iff links 0..k-1 are standard 43-byte links, which lanes 0..k-1 say of theirs), lane m-1 what follows
+    // the last link (an empty values array and, in a child block, the end of the block).  Together: everything
+    // CollapsedNode::expand checks.
+    uint64_t h0, h1;
+    const uint32_t hdr = dense_header(W, m, false, h0, h1);
+    const uint8_t* node = w.arena + e.goff;
+    const uint32_t mine = hdr + 43u * k;
+    bool ok = hdr != 0 && mine + 43u <= e.rem && header_matches(node, hdr, h0, h1) && std_link_at(node + mine);
+    if (ok && edge_first)
+        for (uint32_t i = 0; i < k && ok; ++i) ok = std_link_at(node + hdr + 43u * i);
+    if (ok && edge_last)
+        for (uint32_t i = k + 1; i < m && ok; ++i) ok = hdr + 43u * (i + 1u) <= e.rem && std_link_at(node + hdr + 43u * i);
+    if (ok && (k == m - 1 || edge_last)) {
+        const uint32_t tail = hdr + 43u * m;  // the values array: empty
+        ok = tail + 1u <= e.rem && node[tail] == 0x80u && (!e.whole || tail + 1u == e.rem);
     }
-    const uint64_t nl = r2.read_array();
-    ok = ok && r2.ok() && nl == m;
     if (!ok) {
         atomicOr(anomaly, 1u);
         next[j] = c;
         return;
     }
-    const uint32_t mine = r2.pos + 43u * k;
-    CidKey key;
-    if (edge_first) {  // links 0..k-1 have no lane of their own here: walk them (each must be the 43-byte form)
-        uint32_t o, l;
-        for (uint32_t i = 0; i < k && r2.ok(); ++i) r2.read_link(o, l);
-        ok = r2.ok() && r2.pos == mine;
-    }
-    ok = ok && mine + 43u <= r2.n;  // never read outside the block on the strength of an unverified assumption
-    if (ok) {
-        r2.pos = mine;
-        r2.read_link_key(key);
-        ok = r2.ok() && r2.pos - mine == 43u;
-    }
-    if (ok && edge_last) {  // links k+1..m-1 likewise
-        uint32_t o, l;
-        for (uint32_t i = k + 1; i < m && r2.ok(); ++i) r2.read_link(o, l);
-        ok = r2.ok();
-    }
-    if (ok && (k == m - 1 || edge_last)) {
-        ok = r2.read_array() == 0 && r2.ok();
-        if (ok && e.node_off == 0) {  // a child block holds exactly this node (the root's tail was checked by amt_load)
-            r2.finish();
-            ok = r2.ok();
+    const CidKey key = std_link_key(node + mine);
+    // Blockstore::get: hash slot, then the candidate's CID, offset and length side by side
+    uint32_t s = cid_hash(key) & w.mask;
+    for (;;) {
+        const uint32_t b = w.slots[s];
+        if (b == kNoBlock) {
+            atomicOr(anomaly, 1u);  // a missing block: the general path names it
+            break;
         }
+        const CidKey have = load_cid_slot(w.cids, b);
+        const uint64_t off = w.off[b];
+        const uint32_t len = w.len[b];
+        if (cid_equal(have, key)) {
+            if (w.touched) atomicOr(&w.touched[b >> 5], 1u << (b & 31));
+            c.block = b;
+            c.goff = off;
+            c.rem = len;
+            break;
+        }
+        s = (s + 1) & w.mask;
     }
-    c.base = e.base + uint64_t(k) * amt_span(e.bit_width, level);
-    const uint32_t b = ok ? witness_find(w, key) : kNoBlock;
-    if (b == kNoBlock) atomicOr(anomaly, 1u);
-    c.block = b;
     next[j] = c;
 }
 
-// leaf level: one lane per leaf node validates it in one pass and writes its values' locations
-__global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumNode* __restrict__ cur,
-                                                      const DenseRoot* __restrict__ roots, uint32_t n_roots, uint32_t n_nodes,
-                                                      LeafRef* __restrict__ leaves_main, uint32_t* __restrict__ anomaly,
-                                                      CidKey* __restrict__ keys_main, LeafRef* __restrict__ leaves_extra) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_nodes) return;
+__global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const DenseNode* __restrict__ cur, const DenseRoots roots_arg,
+                                                     uint32_t level, uint32_t n_next, DenseNode* __restrict__ next,
+                                                     uint32_t* __restrict__ anomaly) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_next) dense_level_one(w, cur, roots_arg.r, level, j, next, anomaly);
+}
+
+// leaf level of the trees whose values are LINKS taken as witness keys (Amtv0<Cid>: the message lists) — one lane per
+// VALUE.  The leaf is validated by its values' lanes exactly as an interior node by its children's.
+__global__ __launch_bounds__(256) void k_dense_link_leaves(WitnessView w, const DenseNode* __restrict__ cur, const DenseRoots roots_arg,
+                                                           uint32_t n_key_roots, uint64_t n_values, uint32_t* __restrict__ anomaly,
+                                                           CidKey* __restrict__ keys_main) {
+    const uint64_t v = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v >= n_values) return;
+    // which root (the key trees come first among the roots), which value
+    const DenseRoot* roots = roots_arg.r;
     uint32_t r = 0, node_off0 = 0;
+    uint64_t voff = 0;
     DenseRoot dr = roots[0];
-    uint64_t n_here = dense_nodes(dr, 0);
-    while (t >= node_off0 + n_here) {
-        node_off0 += uint32_t(n_here);
+    while (r + 1 < n_key_roots && v >= voff + (dr.hi - dr.lo)) {
+        voff += dr.hi - dr.lo;
+        node_off0 += uint32_t(dense_nodes(dr, 0));
         dr = roots[++r];
-        n_here = dense_nodes(dr, 0);
     }
+    const uint64_t idx = dr.lo + (v - voff);
+    const uint32_t W = 1u << dr.bit_width;
+    const uint64_t pnode = idx >> dr.bit_width;
+    const uint32_t k = uint32_t(idx) & (W - 1u);
+    const DenseNode e = cur[node_off0 + uint32_t(pnode - dense_first(dr, 0))];
+    if (e.block == kNoBlock) return;  // reported where the link failed to resolve
+    const uint64_t remaining = dr.count - pnode * W;
+    const uint32_t m = remaining < W ? uint32_t(remaining) : W;
+    const bool edge_first = idx == dr.lo && k > 0;
+    const bool edge_last = idx + 1 == dr.hi && k + 1 < m;
+    uint64_t h0, h1;
+    const uint32_t hdr = dense_header(W, m, true, h0, h1);
+    const uint8_t* node = w.arena + e.goff;
+    const uint32_t mine = hdr + 43u * k;
+    bool ok = hdr != 0 && mine + 43u <= e.rem && header_matches(node, hdr, h0, h1) && std_link_at(node + mine);
+    if (ok && edge_first)
+        for (uint32_t i = 0; i < k && ok; ++i) ok = std_link_at(node + hdr + 43u * i);
+    if (ok && edge_last)
+        for (uint32_t i = k + 1; i < m && ok; ++i) ok = hdr + 43u * (i + 1u) <= e.rem && std_link_at(node + hdr + 43u * i);
+    if (ok && (k == m - 1 || edge_last)) ok = !e.whole || hdr + 43u * m == e.rem;  // nothing after the last value
+    if (!ok) {
+        atomicOr(anomaly, 1u);
+        return;
+    }
+    keys_main[dr.out_off + (idx - dr.lo)] = std_link_key(node + mine);
+}
+
+// leaf level of every other tree: one lane per leaf node validates it in one pass and writes its values' locations
+__global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const DenseNode* __restrict__ cur, const DenseRoots roots_arg,
+                                                      uint32_t n_nodes, uint32_t first_node, LeafRef* __restrict__ leaves_main,
+                                                      uint32_t* __restrict__ anomaly, LeafRef* __restrict__ leaves_extra) {
+    const uint32_t t = first_node + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_nodes) return;
+    const DenseWhere wh = dense_where(roots_arg.r, t, 0);
+    const DenseRoot& dr = wh.dr;
+    if (dr.out_sel == 0 && dr.count != 0) return;  // (a key tree with values: k_dense_link_leaves validates its leaves)
     const uint64_t leaf_off = dr.out_off;
     const int vkind = int(dr.vkind);
-    CidKey* const keys_out = dr.out_sel == 0 ? keys_main : nullptr;
     LeafRef* const leaves = dr.out_sel == 1 ? leaves_main : (dr.out_sel == 2 ? leaves_extra : nullptr);
-    const uint64_t p = dense_first(dr, 0) + (t - node_off0);  // absolute leaf-node number
-    const EnumNode e = cur[t];
-    if (e.block == kNoBlock) return;  // reported where the link failed to resolve
+    const uint64_t p = dense_first(dr, 0) + (t - wh.here_off);  // absolute leaf-node number
+    const DenseNode e = cur[t];
     const uint32_t W = 1u << dr.bit_width;
     const uint64_t remaining = dr.count - p * W;
     const uint32_t m = remaining < W ? uint32_t(remaining) : W;
-    Rd rd = open_block(w, e.block);
-    rd.pos = e.node_off;
+    // Whatever happens to this node, every LeafRef it is responsible for is WRITTEN (kNoBlock when there is no value): the
+    // kernels queued behind — before the host has seen the anomaly flag — read them (host/verify_fast.cpp).
+    auto blank = [&]() {
+        if (!leaves) return;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint64_t idx = p * W + i;
+            if (idx >= dr.lo && idx < dr.hi) leaves[leaf_off + (idx - dr.lo)] = LeafRef{kNoBlock, 0, 0, e.seq, idx};
+        }
+    };
+    if (e.block == kNoBlock) {  // reported where the link failed to resolve
+        blank();
+        return;
+    }
+    const uint32_t node_off = uint32_t(e.goff - w.off[e.block]);  // (LeafRefs are relative to the block)
+    Rd rd;
+    rd.init(w.arena + e.goff, e.rem);
     rd.expect_array(3);
     uint32_t bo, bl;
     rd.read_bytes(bo, bl);
@@ -398,24 +535,19 @@ __global__ __launch_bounds__(256) void k_dense_leaves(WitnessView w, const EnumN
     for (uint32_t i = 0; ok && i < m; ++i) {
         const uint32_t start = rd.pos;
         const uint64_t idx = p * W + i;
-        if (keys_out) {
-            // Amtv0<Cid>: the value IS a link — validate it and hand its CID out as a witness key in the same pass
-            // (the execution-order reconstruction needs the keys, not the locations)
-            CidKey key;
-            rd.read_link_key(key);
-            ok = rd.ok();
-            if (ok && idx >= dr.lo && idx < dr.hi) keys_out[leaf_off + (idx - dr.lo)] = key;
-        } else {
-            check_value(rd, vkind);
-            ok = rd.ok();
-        }
-        if (ok && leaves && idx >= dr.lo && idx < dr.hi) leaves[leaf_off + (idx - dr.lo)] = LeafRef{e.block, start, rd.pos - start, e.seq, e.base + i};
+        check_value(rd, vkind);
+        ok = rd.ok();
+        if (ok && leaves && idx >= dr.lo && idx < dr.hi)
+            leaves[leaf_off + (idx - dr.lo)] = LeafRef{e.block, node_off + start, rd.pos - start, e.seq, e.base + i};
     }
-    if (ok && e.node_off == 0) {
+    if (ok && e.whole) {
         rd.finish();
         ok = rd.ok();
     }
-    if (!ok) atomicOr(anomaly, 1u);
+    if (!ok) {
+        atomicOr(anomaly, 1u);
+        blank();
+    }
 }
 
 __global__ void k_enum_check(const uint64_t* __restrict__ actual, uint64_t expected, uint32_t* __restrict__ mismatch) {
@@ -451,6 +583,109 @@ static uint64_t amt_span_host(uint32_t bw, uint64_t height) {
     return shift >= 64 ? ~0ULL : (1ULL << shift);
 }
 
+// The dense plan: what the roots' (height, bit width, count) say about every level (host side; amt_enum.h DensePlan).
+// root_info: 2 words per root as k_enum_roots writes them ({height | bw << 32, count}; ~0 = a root that failed to load);
+// the optional extra root is entry n_roots.
+void dense_plan(const std::vector<uint64_t>& root_info, uint32_t n_roots, int vkind, bool want_keys, uint64_t lo, uint64_t hi,
+                uint32_t has_extra, int extra_vkind, uint64_t extra_lo, uint64_t extra_hi, DensePlan& plan) {
+    plan = DensePlan{};
+    const uint32_t n_all = n_roots + (has_extra ? 1u : 0u);
+    if (n_roots == 0 || n_all > kMaxDenseRoots || root_info.size() < 2 * size_t(n_all)) return;
+    auto shape = [&](uint32_t i, uint64_t rlo, uint64_t rhi, DenseRoot& d) -> bool {  // false: not a dense candidate
+        if (root_info[2 * size_t(i)] == ~0ULL) return false;  // a dead root: let the general path sort it out
+        d.height = uint32_t(root_info[2 * size_t(i)]);
+        d.bit_width = uint32_t(root_info[2 * size_t(i)] >> 32);
+        d.count = root_info[2 * size_t(i) + 1];
+        if (d.count == 0 && d.height > 0) return false;  // empty tree with a tall root
+        if (d.count > amt_span_host(d.bit_width, d.height + 1)) return false;
+        d.lo = rlo < d.count ? rlo : d.count;
+        d.hi = rhi < d.count ? rhi : d.count;
+        if (d.count && d.lo >= d.hi) return false;  // nothing of this tree in the range
+        if (d.count == 0) d.lo = d.hi = 0;
+        return true;
+    };
+    bool try_dense = true;
+    uint64_t n_leaves = 0;
+    for (uint32_t i = 0; i < n_roots && try_dense; ++i) {
+        try_dense = shape(i, lo, hi, plan.roots.r[i]);
+        plan.roots.r[i].vkind = uint32_t(vkind);
+        plan.roots.r[i].out_sel = want_keys ? 0u : 1u;
+        plan.roots.r[i].out_off = n_leaves;
+        n_leaves += plan.roots.r[i].hi - plan.roots.r[i].lo;
+    }
+    // the extra root joins when it is a dense candidate itself; otherwise the call goes on without it
+    uint32_t n_use = n_roots;
+    uint64_t n_extra = 0;
+    if (has_extra && try_dense && shape(n_roots, extra_lo, extra_hi, plan.roots.r[n_roots])) {
+        plan.roots.r[n_roots].vkind = uint32_t(extra_vkind);
+        plan.roots.r[n_roots].out_sel = 2u;
+        plan.roots.r[n_roots].out_off = 0;
+        n_extra = plan.roots.r[n_roots].hi - plan.roots.r[n_roots].lo;
+        n_use = n_all;
+    }
+    if (!try_dense) return;
+    uint32_t max_height = 0;  // the tallest of the roots in use
+    for (uint32_t i = 0; i < n_use; ++i) max_height = plan.roots.r[i].height > max_height ? plan.roots.r[i].height : max_height;
+    if (max_height >= kMaxDenseLevels) return;
+    uint64_t biggest = n_use;
+    for (uint32_t level = 0; level <= max_height; ++level) {
+        uint64_t nl = 0;
+        for (uint32_t i = 0; i < n_use; ++i) nl += dense_nodes(plan.roots.r[i], level);
+        if (nl >= 0x7fffffffULL) return;
+        plan.n_level[level] = nl;
+        biggest = nl > biggest ? nl : biggest;
+    }
+    if (n_leaves >= 0x7fffffffULL || n_extra >= 0x7fffffffULL || plan.n_level[max_height] != n_use) return;
+    plan.ok = true;
+    plan.n_use = n_use;
+    plan.roots.n = n_use;
+    plan.max_height = max_height;
+    plan.n_leaves = n_leaves;
+    plan.n_extra = n_extra;
+    plan.biggest = biggest;
+}
+
+// The launches of the dense walk: one kernel per interior level, one leaf kernel.  `frontier`: the roots' entries
+// (k_enum_roots); a / b: two frontier buffers of plan.biggest entries.  The root shapes travel as a kernel argument.
+int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* frontier, const DensePlan& plan,
+                      DenseNode* a, DenseNode* b, LeafRef* leaves_main, CidKey* keys_main, LeafRef* leaves_extra, uint32_t* anomaly_d) {
+    const DenseNode* src = frontier;
+    // (All interior levels as ONE persistent launch — a workgroup per CU, a grid barrier per level — was built and is
+    // slower: 382 µs against 238 µs for the six launches.  What stretches a level beside K1 and the event parse is the
+    // latency of its three dependent loads under their memory traffic, not the dispatch; a barrier adds an L2
+    // write-back and an L1 invalidate per level on top.  profiles/r03_experiments.md)
+    for (uint32_t level = plan.max_height; level >= 1; --level) {
+        const uint32_t nn = uint32_t(plan.n_level[level - 1]);
+        hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots, level, nn, a, anomaly_d);
+        src = a;
+        DenseNode* t = a;
+        a = b;
+        b = t;  // `src` now lives in b; the next level writes a
+    }
+    // the key trees (links taken as witness keys) come first among the roots: one lane per value; every other tree: one
+    // lane per leaf node
+    uint32_t n_key_roots = 0, key_nodes = 0;
+    uint64_t n_key_values = 0;
+    while (n_key_roots < plan.n_use && plan.roots.r[n_key_roots].out_sel == 0) {
+        n_key_values += plan.roots.r[n_key_roots].hi - plan.roots.r[n_key_roots].lo;
+        key_nodes += uint32_t(dense_nodes(plan.roots.r[n_key_roots], 0));
+        ++n_key_roots;
+    }
+    for (uint32_t i = n_key_roots; i < plan.n_use; ++i)
+        if (plan.roots.r[i].out_sel == 0) return set_error(ctx, IPCFP_E_INVALID, "dense walk: the key trees must come first");
+    if (n_key_values)
+        hipLaunchKernelGGL(k_dense_link_leaves, dim3(div_up(n_key_values, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots,
+                           n_key_roots, n_key_values, anomaly_d, keys_main);
+    // (every leaf node gets a lane here: those of key trees that have values leave at once, an EMPTY key tree's root is
+    // validated here — no value lane looks at it)
+    const uint32_t n_nodes = uint32_t(plan.n_level[0]);
+    (void)key_nodes;
+    hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_nodes, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots, n_nodes, 0u,
+                       leaves_main, anomaly_d, leaves_extra);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_roots, int vkind,
                   unsigned long long* err_d, AmtEnumResult& out, uint64_t lo, uint64_t hi, DevBuf<CidKey>* keys_out,
                   EnumExtra* extra) {
@@ -470,14 +705,16 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     DevBuf<EnumNode> cur, nxt;
     DevBuf<uint32_t> counts, offsets, small_own;
     DevBuf<uint64_t> scratch, total_d, root_info_own;
+    DevBuf<DenseNode> dense_cur;  // the roots again, as the dense walk wants them
     IPCFP_HIP(ctx, cur.alloc(n_all));
+    IPCFP_HIP(ctx, dense_cur.alloc(n_all));
     IPCFP_HIP(ctx, total_d.alloc(2));
     uint32_t* small = nullptr;      // [0] = max height; [2] = anomaly flag of the dense path
     uint64_t* root_info_d = nullptr;
     IPCFP_HIP(ctx, ctl_words(ctx, small_own, small, 4, false));
     IPCFP_HIP(ctx, ctl_words(ctx, root_info_own, root_info_d, 2 * size_t(n_all), false));
     hipLaunchKernelGGL(k_enum_roots, dim3(div_up(n_all, 64)), dim3(64), 0, ctx->stream, view, roots_d, n_all, vkind,
-                       cur.p, small, err_d, root_info_d);
+                       cur.p, small, err_d, root_info_d, static_cast<unsigned long long*>(nullptr), 0ull, dense_cur.p);
     uint32_t max_height = 0;
     std::vector<uint64_t> root_info(2 * size_t(n_all));
     IPCFP_HIP(ctx, ctl_read(ctx, &max_height, small, 4));
@@ -488,73 +725,21 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
     out.dense = false;
     {
         const bool want_keys = keys_out && vkind == VK_CID;
-        auto shape = [&](uint32_t i, uint64_t rlo, uint64_t rhi, DenseRoot& d) -> bool {  // false: not a dense candidate
-            if (root_info[2 * size_t(i)] == ~0ULL) return false;  // a dead root: let the general path sort it out
-            d.height = uint32_t(root_info[2 * size_t(i)]);
-            d.bit_width = uint32_t(root_info[2 * size_t(i)] >> 32);
-            d.count = root_info[2 * size_t(i) + 1];
-            if (d.count == 0 && d.height > 0) return false;  // empty tree with a tall root
-            if (d.count > amt_span_host(d.bit_width, d.height + 1)) return false;
-            d.lo = rlo < d.count ? rlo : d.count;
-            d.hi = rhi < d.count ? rhi : d.count;
-            if (d.count && d.lo >= d.hi) return false;  // nothing of this tree in the range
-            if (d.count == 0) d.lo = d.hi = 0;
-            return true;
-        };
-        std::vector<DenseRoot> dr(n_all);
-        bool try_dense = true;
-        uint64_t n_leaves = 0;
-        for (uint32_t i = 0; i < n_roots && try_dense; ++i) {
-            try_dense = shape(i, lo, hi, dr[i]);
-            dr[i].vkind = uint32_t(vkind);
-            dr[i].out_sel = want_keys ? 0u : 1u;
-            dr[i].out_off = n_leaves;
-            n_leaves += dr[i].hi - dr[i].lo;
-        }
-        // the extra root joins when it is a dense candidate itself; otherwise the call goes on without it
-        uint32_t n_use = n_roots;
-        uint64_t n_extra = 0;
-        if (extra && try_dense && shape(n_roots, extra->lo, extra->hi, dr[n_roots])) {
-            dr[n_roots].vkind = uint32_t(extra->vkind);
-            dr[n_roots].out_sel = 2u;
-            dr[n_roots].out_off = 0;
-            n_extra = dr[n_roots].hi - dr[n_roots].lo;
-            n_use = n_all;
-        }
-        if (try_dense) {  // the tallest of the roots in use (the device word also counts an extra root that stays out)
-            max_height = 0;
-            for (uint32_t i = 0; i < n_use; ++i) max_height = dr[i].height > max_height ? dr[i].height : max_height;
-        }
-        std::vector<uint64_t> n_level(max_height + 1, 0);
-        for (uint32_t level = 0; level <= max_height && try_dense; ++level) {
-            for (uint32_t i = 0; i < n_use; ++i) n_level[level] += dense_nodes(dr[i], level);
-            try_dense = n_level[level] < 0x7fffffffULL;
-        }
-        try_dense = try_dense && n_leaves < 0x7fffffffULL && n_extra < 0x7fffffffULL && n_level[max_height] == n_use;
-        if (try_dense) {
-            DevBuf<EnumNode> a, b;
-            DevBuf<DenseRoot> dr_d;
+        DensePlan plan;
+        dense_plan(root_info, n_roots, vkind, want_keys, lo, hi, extra ? 1u : 0u, extra ? extra->vkind : 0, extra ? extra->lo : 0,
+                   extra ? extra->hi : 0, plan);
+        if (plan.ok) {
+            const uint32_t n_use = plan.n_use;
+            DevBuf<DenseNode> a, b;
             struct { uint32_t* p; } anomaly{small + 2};  // still zero: nothing has written it
-            uint64_t biggest = n_use;
-            for (auto v : n_level) biggest = v > biggest ? v : biggest;
-            IPCFP_HIP(ctx, a.alloc(biggest));
-            IPCFP_HIP(ctx, b.alloc(biggest));
-            IPCFP_HIP(ctx, dr_d.alloc(n_use));
-            if (want_keys) IPCFP_HIP(ctx, keys_out->alloc(n_leaves));
-            else IPCFP_HIP(ctx, out.leaves.alloc(n_leaves));
-            if (n_use > n_roots) IPCFP_HIP(ctx, extra->out->leaves.alloc(n_extra));
-            IPCFP_HIP(ctx, h2d_small(ctx, dr_d.p, dr.data(), size_t(n_use) * sizeof(DenseRoot), ctx->stream));
-            const EnumNode* src = cur.p;
-            for (uint32_t level = max_height; level >= 1; --level) {
-                const uint32_t nn = uint32_t(n_level[level - 1]);
-                hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p, n_use,
-                                   level, nn, vkind, a.p, anomaly.p);
-                src = a.p;
-                a.swap(b);  // `src` now lives in b; the next level writes a
-            }
-            hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_level[0], 256)), dim3(256), 0, ctx->stream, view, src, dr_d.p,
-                               n_use, uint32_t(n_level[0]), want_keys ? nullptr : out.leaves.p, anomaly.p,
-                               want_keys ? keys_out->p : nullptr, n_use > n_roots ? extra->out->leaves.p : nullptr);
+            IPCFP_HIP(ctx, a.alloc(plan.biggest));
+            IPCFP_HIP(ctx, b.alloc(plan.biggest));
+            if (want_keys) IPCFP_HIP(ctx, keys_out->alloc(plan.n_leaves));
+            else IPCFP_HIP(ctx, out.leaves.alloc(plan.n_leaves));
+            if (n_use > n_roots) IPCFP_HIP(ctx, extra->out->leaves.alloc(plan.n_extra));
+            int rc = launch_dense_walk(ctx, view, dense_cur.p, plan, a.p, b.p, want_keys ? nullptr : out.leaves.p,
+                                       want_keys ? keys_out->p : nullptr, n_use > n_roots ? extra->out->leaves.p : nullptr, anomaly.p);
+            if (rc) return rc;
             uint32_t bad = 0;
             unsigned long long e = kNoEnumError;  // err_d is untouched here: report what earlier stages left in it
             IPCFP_HIP(ctx, ctl_read(ctx, &bad, anomaly.p, 4));
@@ -562,12 +747,12 @@ int amt_enumerate(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* ro
             IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
             IPCFP_HIP(ctx, hipGetLastError());
             if (!bad) {
-                out.n_leaves = n_leaves;
+                out.n_leaves = plan.n_leaves;
                 out.error = e;
                 out.dense = true;
                 out.keys_written = want_keys;
                 if (n_use > n_roots) {
-                    extra->out->n_leaves = n_extra;
+                    extra->out->n_leaves = plan.n_extra;
                     extra->out->error = kNoEnumError;
                     extra->out->dense = true;
                     extra->out->keys_written = false;
@@ -741,6 +926,17 @@ static int enum_cache_fill(ipcfp_ctx* ctx, EnumCached* e, AmtEnumResult& en, uin
     en.leaves.p = nullptr;
     en.leaves.count = en.leaves.cap = 0;
     en.leaves.owner = nullptr;
+    return IPCFP_OK;
+}
+
+// k_enum_roots for a caller that queues the walk itself (host/verify_fast.cpp): the shapes also go to `mailbox` (pinned host)
+int launch_enum_roots(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_all, int vkind,
+                      EnumNode* frontier_d, uint32_t* max_height_d, unsigned long long* err_d, uint64_t* root_info_d,
+                      unsigned long long* mailbox, unsigned long long mailbox_seq, DenseNode* dense_frontier_d) {
+    if (n_all == 0 || n_all > 64) return IPCFP_E_INVALID;
+    hipLaunchKernelGGL(k_enum_roots, dim3(1), dim3(64), 0, ctx->stream, view, roots_d, n_all, vkind, frontier_d, max_height_d, err_d,
+                       root_info_d, mailbox, mailbox_seq, dense_frontier_d);
+    IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
 

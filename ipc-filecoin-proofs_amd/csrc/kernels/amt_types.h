@@ -29,6 +29,17 @@ struct EnumNode {
     uint8_t leaf_ready; // a Leaf node met above height 0: carried down unchanged
 };
 
+// one frontier entry of the DENSE walk (amt_enum.hip): where the node's bytes lie, so that the level below starts
+// reading them without first asking the off / len tables
+struct DenseNode {
+    uint64_t goff;    // arena offset of the node's first byte
+    uint64_t base;    // index of the node's first slot
+    uint32_t block;   // kNoBlock ⇒ dead entry
+    uint32_t rem;     // bytes from the node's first byte to the end of its block
+    uint32_t seq;
+    uint32_t whole;   // 1: the node is the whole block (a child block); 0: the root node inside `[height, count, node]`
+};
+
 // one enumerated value, in for_each order
 struct LeafRef {
     uint32_t block, off, len;

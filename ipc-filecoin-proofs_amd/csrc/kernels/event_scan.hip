@@ -294,7 +294,11 @@ __global__ __launch_bounds__(256) void k_receipt_events(WitnessView w, const Lea
     ReceiptRec rr{RK_NO_EVENTS, 0, 0, kNoBlock, 0};
     uint32_t c = 0;
     CidKey ev_root;
-    if (receipt_events_root(w, receipts[t], ev_root)) {
+    if (receipts[t].block == kNoBlock) {
+        // a leaf the enumeration could not produce (its anomaly flag is on its way to the host, which then redoes the
+        // whole walk the general way — host/verify_fast.cpp): nothing to read, nothing decided
+        rr.kind = RK_WALK;
+    } else if (receipt_events_root(w, receipts[t], ev_root)) {
         const uint32_t b = witness_find(w, ev_root);
         rr.block = b;
         if (b == kNoBlock) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_receipt_walk(WitnessV
     if (counts ? counts[t] != kWalkPending : rrecs[t].kind != RK_WALK) return;
     uint32_t c = 0;
     CidKey ev_root;
-    if (receipt_events_root(w, receipts[t], ev_root)) {
+    if (receipts[t].block != kNoBlock && receipt_events_root(w, receipts[t], ev_root)) {
         auto visit = [&](uint64_t, uint32_t, Rd& er) {
             uint64_t emitter;
             EvmLogLoc log;

@@ -79,6 +79,8 @@ struct EventTableView;
 struct LeafRef;
 struct EventClaimPacked;
 int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_d, uint32_t n);
+struct CtxFinish;
+int launch_ctx_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const CtxFinish& a);
 int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d, const uint32_t* first_d,
                        const uint32_t* pos_d, uint32_t n, uint32_t* inv_d);
 // jobs_d: device array of {TipsetCtxDev* ctx, AmtRootSpec* roots (nullable), unsigned long long* err}

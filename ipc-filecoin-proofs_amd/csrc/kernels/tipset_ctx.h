@@ -42,6 +42,22 @@ struct TipsetCtxDev {
     const EventRec* event_recs;
 };
 
+// what k_ctx_finish (verify_events.hip) writes into a context on the device
+struct CtxFinish {
+    const unsigned long long* err;   // packed first error of the execution-order reconstruction (kNoEnumError: none)
+    const uint64_t* total;           // number of distinct messages
+    const uint32_t* first;           // raw position → 1 iff first occurrence
+    const uint32_t* pos;             // raw position → execution index
+    uint32_t* inv;                   // execution index → raw position (filled here)
+    const unsigned long long* slots;
+    const CidKey* keys;
+    uint32_t mask, raw_len;
+    const LeafRef* receipt_leaves;
+    uint64_t n_receipt_leaves, receipt_first;
+    const ReceiptRec* receipt_recs;
+    const EventRec* event_recs;
+};
+
 // One context's share of the tipset prologue (launch_tipset_prepare): two wavefronts decode the child and the first
 // parent header, one wavefront per parent block decodes its header and TxMeta and re-hashes it.
 struct PrepareJob {

@@ -117,6 +117,7 @@ __device__ __forceinline__ uint32_t verify_event_one(const WitnessView& w, const
             if (settled) return ts;
         }
         const LeafRef l = tc.receipt_leaves[slot];
+        if (l.block == kNoBlock) return IPCFP_ST_ERR;  // (a leaf the enumeration could not produce: the host redoes the call)
         rloc = ValueLoc{l.block, l.off, l.len};
     } else {
         AmtRootInfo receipts;
@@ -191,6 +192,48 @@ __global__ __launch_bounds__(256) void k_exec_finish(TipsetCtxDev* __restrict__ 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) c->exec_len = *total;
     if (i < n && first[i]) inv[pos[i]] = i;
+}
+
+// The tail of a tipset context ON THE DEVICE (host/verify_fast.cpp): what host/verify_events.cpp::verify_packed does between
+// its second synchronisation and the verify kernel — decide whether the execution order is reachable, point the context
+// at the tables, copy exec_len, invert exec_pos — without the host having seen the header facts.  Same rules, same order.
+__global__ __launch_bounds__(256) void k_ctx_finish(TipsetCtxDev* __restrict__ c, CtxFinish a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.raw_len && a.first[i]) a.inv[a.pos[i]] = i;
+    if (i != 0) return;
+    c->exec_status = IPCFP_ST_ERR_BAD_CLAIM;
+    c->exec_slots = nullptr;
+    c->exec_inv = nullptr;
+    c->receipt_leaves = nullptr;
+    c->n_receipt_leaves = 0;
+    c->receipt_first = 0;
+    c->receipt_recs = nullptr;
+    c->event_recs = nullptr;
+    // the execution order is only reached when steps 1-2 can pass for some proof of this context
+    const bool reachable = (c->flags & TC_PARENTS_PARSED) && (c->flags & TC_CHILD_PARSED) && c->child_status == IPCFP_ST_TRUE &&
+                           c->parents_match && c->n_parents > 0 && c->parent0_status == IPCFP_ST_TRUE;
+    if (!reachable) return;
+    const unsigned long long e = *a.err;
+    const uint32_t status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
+    c->exec_status = status;
+    c->exec_mask = a.mask;
+    c->exec_slots = a.slots;
+    c->exec_keys = a.keys;
+    c->exec_pos = a.pos;
+    c->exec_inv = status == IPCFP_ST_TRUE ? a.inv : nullptr;
+    c->exec_len = status == IPCFP_ST_TRUE ? *a.total : 0;
+    // the receipts AMT rode along with the message AMTs: a table lookup per claim
+    c->receipt_leaves = a.receipt_leaves;
+    c->n_receipt_leaves = a.n_receipt_leaves;
+    c->receipt_first = a.n_receipt_leaves ? a.receipt_first : 0;
+    c->receipt_recs = a.receipt_recs;
+    c->event_recs = a.event_recs;
+}
+
+int launch_ctx_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const CtxFinish& a) {
+    hipLaunchKernelGGL(k_ctx_finish, dim3(a.raw_len ? div_up(a.raw_len, 256) : 1), dim3(256), 0, ctx->stream, ctx_d, a);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
 }
 
 // ------------------------------ launchers -----------------------------------
