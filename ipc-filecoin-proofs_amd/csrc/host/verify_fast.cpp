@@ -141,13 +141,11 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, ex.pos.alloc(n_msgs));
     IPCFP_HIP(ctx, ex.inv.alloc(n_msgs));
     IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 8, ctx->stream));
-    rc = launch_exec_dedup(ctx, view, nullptr, n_msgs, ex.keys.p, ex.slots.p, ex.mask, ex.first.p);
+    rc = launch_exec_insert(ctx, ex.keys.p, n_msgs, ex.slots.p, ex.mask);
     if (rc) return rc;
-    DevBuf<uint64_t> scratch;
-    IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n_msgs, 1024)) + 2));
+    DevBuf<uint64_t> tiles;
+    IPCFP_HIP(ctx, tiles.alloc(size_t(div_up(n_msgs, 256)) + 2));
     IPCFP_HIP(ctx, ctl_words(ctx, ex.total_own, ex.total.p, 1, false));
-    rc = launch_scan_u32(ctx, ex.first.p, n_msgs, ex.pos.p, ex.total.p, scratch.p);
-    if (rc) return rc;
     CtxFinish fin{};
     fin.err = ex.err.p;
     fin.total = ex.total.p;
@@ -163,7 +161,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     fin.receipt_first = w->receipt_lo;
     fin.receipt_recs = table->receipts.p;
     fin.event_recs = table->events;
-    rc = launch_ctx_finish(ctx, tcs_d.p, fin);
+    rc = launch_exec_finish_fused(ctx, tcs_d.p, fin, ex.first.p, ex.pos.p, tiles.p, ex.total.p);
     if (rc) return rc;
     rc = event_table_join(ctx, w);
     if (rc) return rc;

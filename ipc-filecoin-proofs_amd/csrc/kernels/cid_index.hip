@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256) void k_index_insert(const uint8_t* __restrict_
     }
 }
 
+// (The same table in two passes — every key first STORES its id on its home slot, then only the keys that find another
+// id there resolve the collision with CAS / atomicMax — was built to spare 70 % of the atomics and is slower: 0.29 ms
+// against 0.15 ms.  Random 4-byte stores and a second random read of the table cost more than the atomics they
+// replace.  profiles/r03_experiments.md)
 int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
     const uint32_t n = uint32_t(w->n);
     uint32_t size = 64;
@@ -46,8 +50,8 @@ int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
     if (n == 0) return IPCFP_OK;
     {
         ProfileScope prof(ctx, IPCFP_K_CID_INDEX);
-        hipLaunchKernelGGL(k_index_insert, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n,
-                           w->index_slots.p, w->index_mask);
+        hipLaunchKernelGGL(k_index_insert, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n, w->index_slots.p,
+                           w->index_mask);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

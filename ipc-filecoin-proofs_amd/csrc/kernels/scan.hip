@@ -80,6 +80,13 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict_
     if (threadIdx.x == 0) *total_out = total;
 }
 
+// exclusive scan IN PLACE of ntiles u64 tile sums; *total_d = their sum (one workgroup)
+int launch_scan_tiles_u64(ipcfp_ctx* ctx, uint64_t* tile_sums_d, uint32_t ntiles, uint64_t* total_d) {
+    hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(1024), 0, ctx->stream, tile_sums_d, ntiles, total_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 // out[i] = sum of in[0..i); *total_d = sum of all.  scratch_d must hold div_up(n,1024)+1 u64.
 int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* out_d, uint64_t* total_d,
                     uint64_t* scratch_d) {

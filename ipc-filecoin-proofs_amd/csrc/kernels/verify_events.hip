@@ -13,6 +13,7 @@
 #include "events_dev.h"
 #include "exec_order.h"
 #include "launch.h"
+#include "scan_dev.h"
 #include "verify_dev.h"
 
 namespace ipcfp {
@@ -80,6 +81,83 @@ __global__ __launch_bounds__(256) void k_exec_first(const CidKey* __restrict__ k
         s = (s + 1) & mask;
     }
     first[i] = f;
+}
+
+__device__ __forceinline__ void ctx_finish_fields(TipsetCtxDev* __restrict__ c, const CtxFinish& a) {
+    c->exec_status = IPCFP_ST_ERR_BAD_CLAIM;
+    c->exec_slots = nullptr;
+    c->exec_inv = nullptr;
+    c->receipt_leaves = nullptr;
+    c->n_receipt_leaves = 0;
+    c->receipt_first = 0;
+    c->receipt_recs = nullptr;
+    c->event_recs = nullptr;
+    // the execution order is only reached when steps 1-2 can pass for some proof of this context
+    const bool reachable = (c->flags & TC_PARENTS_PARSED) && (c->flags & TC_CHILD_PARSED) && c->child_status == IPCFP_ST_TRUE &&
+                           c->parents_match && c->n_parents > 0 && c->parent0_status == IPCFP_ST_TRUE;
+    if (!reachable) return;
+    const unsigned long long e = *a.err;
+    const uint32_t status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
+    c->exec_status = status;
+    c->exec_mask = a.mask;
+    c->exec_slots = a.slots;
+    c->exec_keys = a.keys;
+    c->exec_pos = a.pos;
+    c->exec_inv = status == IPCFP_ST_TRUE ? a.inv : nullptr;
+    c->exec_len = status == IPCFP_ST_TRUE ? *a.total : 0;
+    // the receipts AMT rode along with the message AMTs: a table lookup per claim
+    c->receipt_leaves = a.receipt_leaves;
+    c->n_receipt_leaves = a.n_receipt_leaves;
+    c->receipt_first = a.n_receipt_leaves ? a.receipt_first : 0;
+    c->receipt_recs = a.receipt_recs;
+    c->event_recs = a.event_recs;
+}
+
+// stages 4-6 in two kernels instead of five (host/verify_fast.cpp): first-occurrence flags with their tile sums, then —
+// behind the scan of the 256-item tiles' sums (scan.hip k_scan_tiles_u64) — positions, the inverse permutation and the
+// context's tail (k_ctx_finish's part) in one pass
+__global__ __launch_bounds__(256) void k_exec_first_sums(const CidKey* __restrict__ keys, uint32_t n,
+                                                         const unsigned long long* __restrict__ slots, uint32_t mask,
+                                                         uint32_t* __restrict__ first, uint64_t* __restrict__ tile_sums) {
+    __shared__ uint64_t smem[17];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t f = 0;
+    if (i < n) {
+        const CidKey key = keys[i];
+        const uint64_t h = cid_hash64(key);
+        uint32_t s = uint32_t(h >> 32) & mask;
+        for (;;) {
+            const unsigned long long cur = slots[s];
+            if (cur == kEmptySlot64) break;  // cannot happen after stage 3; kept as a stop
+            if (uint32_t(cur >> 32) == uint32_t(h)) {
+                if (uint32_t(cur) == i) {  // the slot is this position's own: no key to read
+                    f = 1;
+                    break;
+                }
+                if (cid_equal(keys[uint32_t(cur)], key)) break;  // an earlier position holds the same CID
+            }
+            s = (s + 1) & mask;
+        }
+        first[i] = f;
+    }
+    uint64_t total;
+    (void)block_exclusive_scan(uint64_t(f), smem, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_exec_apply_finish(const uint32_t* __restrict__ first, uint32_t n,
+                                                           const uint64_t* __restrict__ tile_base, uint32_t* __restrict__ pos,
+                                                           TipsetCtxDev* __restrict__ c, CtxFinish a) {
+    __shared__ uint64_t smem[17];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = i < n ? first[i] : 0u;
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan(uint64_t(f), smem, &total) + tile_base[blockIdx.x];
+    if (i < n) {
+        pos[i] = uint32_t(ex);
+        if (f) a.inv[uint32_t(ex)] = i;
+    }
+    if (i == 0) ctx_finish_fields(c, a);
 }
 
 // the distinct CIDs in execution order (ipcfp_exec_order)
@@ -200,34 +278,19 @@ __global__ __launch_bounds__(256) void k_exec_finish(TipsetCtxDev* __restrict__ 
 __global__ __launch_bounds__(256) void k_ctx_finish(TipsetCtxDev* __restrict__ c, CtxFinish a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.raw_len && a.first[i]) a.inv[a.pos[i]] = i;
-    if (i != 0) return;
-    c->exec_status = IPCFP_ST_ERR_BAD_CLAIM;
-    c->exec_slots = nullptr;
-    c->exec_inv = nullptr;
-    c->receipt_leaves = nullptr;
-    c->n_receipt_leaves = 0;
-    c->receipt_first = 0;
-    c->receipt_recs = nullptr;
-    c->event_recs = nullptr;
-    // the execution order is only reached when steps 1-2 can pass for some proof of this context
-    const bool reachable = (c->flags & TC_PARENTS_PARSED) && (c->flags & TC_CHILD_PARSED) && c->child_status == IPCFP_ST_TRUE &&
-                           c->parents_match && c->n_parents > 0 && c->parent0_status == IPCFP_ST_TRUE;
-    if (!reachable) return;
-    const unsigned long long e = *a.err;
-    const uint32_t status = e == kNoEnumError ? uint32_t(IPCFP_ST_TRUE) : enum_error_code(e);
-    c->exec_status = status;
-    c->exec_mask = a.mask;
-    c->exec_slots = a.slots;
-    c->exec_keys = a.keys;
-    c->exec_pos = a.pos;
-    c->exec_inv = status == IPCFP_ST_TRUE ? a.inv : nullptr;
-    c->exec_len = status == IPCFP_ST_TRUE ? *a.total : 0;
-    // the receipts AMT rode along with the message AMTs: a table lookup per claim
-    c->receipt_leaves = a.receipt_leaves;
-    c->n_receipt_leaves = a.n_receipt_leaves;
-    c->receipt_first = a.n_receipt_leaves ? a.receipt_first : 0;
-    c->receipt_recs = a.receipt_recs;
-    c->event_recs = a.event_recs;
+    if (i == 0) ctx_finish_fields(c, a);
+}
+
+// first flags + tile sums, scan of the tile sums, positions + inverse + the context's tail.  tile_d: div_up(n, 256) + 1 words.
+int launch_exec_finish_fused(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const CtxFinish& a, uint32_t* first_d, uint32_t* pos_d,
+                             uint64_t* tile_d, uint64_t* total_d) {
+    const uint32_t n = a.raw_len, ntiles = div_up(n ? n : 1, 256);
+    hipLaunchKernelGGL(k_exec_first_sums, dim3(ntiles), dim3(256), 0, ctx->stream, a.keys, n, a.slots, a.mask, first_d, tile_d);
+    int rc = launch_scan_tiles_u64(ctx, tile_d, ntiles, total_d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_exec_apply_finish, dim3(ntiles), dim3(256), 0, ctx->stream, first_d, n, tile_d, pos_d, ctx_d, a);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
 }
 
 int launch_ctx_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const CtxFinish& a) {
@@ -252,6 +315,13 @@ int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leave
     if (leaves_d) hipLaunchKernelGGL(k_exec_keys, g, b, 0, ctx->stream, w, leaves_d, n, keys_d);  // else: keys came with the enumeration
     hipLaunchKernelGGL(k_exec_insert, g, b, 0, ctx->stream, keys_d, n, slots_d, mask);
     hipLaunchKernelGGL(k_exec_first, g, b, 0, ctx->stream, keys_d, n, slots_d, mask, first_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_exec_insert(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, unsigned long long* slots_d, uint32_t mask) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_exec_insert, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, keys_d, n, slots_d, mask);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
