@@ -132,7 +132,10 @@ int ipcfp_ctx_device_info(ipcfp_ctx_t* ctx, char name[64], int* cu_count, uint64
 /* Per-kernel timing with HIP events on the context's stream.  While enabled,
  * every launch of a profiled kernel is bracketed by an event pair;
  * ipcfp_profile_read() synchronises and returns the launch count and the summed
- * duration for one kernel id since the last reset. */
+ * duration for one kernel id since the last reset.  ipcfp_profile_enable: on = 0
+ * off, 1 every profiled kernel, 2 + id that kernel id alone (an event pair is a
+ * barrier packet on the stream; a timed region that wants ONE kernel's duration
+ * keeps the others' launches back to back). */
 enum {
     IPCFP_K_BLAKE2B_CID = 0,
     IPCFP_K_KECCAK256 = 1,
@@ -148,6 +151,8 @@ enum {
     IPCFP_K_BLAKE2B_RAW = 11,
     IPCFP_K_BASE64 = 12,
     IPCFP_K_ALLGATHER = 13, /* ipcfp_allgather_segments: message packing + ncclAllGather */
+    IPCFP_K_TIPSET_PROLOGUE = 14, /* header decodes, TxMeta re-hash, AMT roots (events/verifier.rs:147-181, utils.rs:48-72) */
+    IPCFP_K_AMT_WALK = 15,        /* the dense Amt::for_each of message lists + receipts (levels and leaves) */
     IPCFP_K_COUNT = 16
 };
 int ipcfp_profile_enable(ipcfp_ctx_t* ctx, int on);

@@ -65,6 +65,8 @@ KERNEL_IDS = {
     "blake2b_raw": 11,
     "base64": 12,
     "allgather": 13,
+    "tipset_prologue": 14,
+    "amt_walk": 15,
 }
 
 
@@ -325,8 +327,9 @@ class Engine:
         return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": mem.value}
 
     # -- profiling ---------------------------------------------------------------
-    def profile_enable(self, on: bool = True):
-        self._check(self.lib.ipcfp_profile_enable(self.h, 1 if on else 0), "profile_enable")
+    def profile_enable(self, on: bool = True, only: str | None = None):
+        """`only`: bracket the launches of that kernel id alone (the others stay back to back on the stream)."""
+        self._check(self.lib.ipcfp_profile_enable(self.h, (2 + KERNEL_IDS[only]) if (on and only) else (1 if on else 0)), "profile_enable")
 
     def profile_reset(self):
         self._check(self.lib.ipcfp_profile_reset(self.h), "profile_reset")

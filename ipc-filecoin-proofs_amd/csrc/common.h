@@ -60,6 +60,7 @@ struct ipcfp_ctx {
     uint32_t b2b_wg = 64;    // K1 workgroup size (multiple of 64, <= 256)
     // --- per-kernel HIP-event timing (ipcfp_profile_*) ---
     bool profiling = false;
+    int profile_only = -1;  // >= 0: bracket launches of this kernel id alone (the timed region of bench.py: K1)
     std::vector<ipcfp::ProfiledLaunch> launches;   // recorded, not yet read
     std::vector<hipEvent_t> free_events;           // recycled events
     uint64_t prof_count[IPCFP_K_COUNT] = {};

@@ -88,7 +88,7 @@ static hipEvent_t take_event(ipcfp_ctx* ctx) {
 }
 
 ProfileScope::ProfileScope(ipcfp_ctx* c, int id, hipStream_t s) : ctx(c), kernel_id(id), stream(s ? s : c->stream) {
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || (ctx->profile_only >= 0 && ctx->profile_only != id)) return;
     start = take_event(ctx);
     stop = take_event(ctx);
     if (start && stop) (void)hipEventRecord(start, stream);
@@ -323,6 +323,7 @@ int ipcfp_profile_enable(ipcfp_ctx_t* ctx, int on) {
         if (rc) return rc;
     }
     ctx->profiling = on != 0;
+    ctx->profile_only = on >= 2 ? on - 2 : -1;
     return IPCFP_OK;
 }
 

@@ -62,6 +62,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     rc = exec_state_prepare(ctx, ex, P);
     if (rc) return rc;
     PrepareJob job{tcs_d.p, ex.roots.p, ex.err.p};
+    std::unique_ptr<ProfileScope> prof(new ProfileScope(ctx, IPCFP_K_TIPSET_PROLOGUE));
     rc = launch_tipset_prepare(ctx, view, &job, nullptr, 1,
                                /*need_general=*/uint64_t(w->max_block_len) + 32u > uint64_t(kPrologueStageChunks) * 16u);
     if (rc) return rc;
@@ -80,6 +81,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     rc = launch_enum_roots(ctx, view, ex.roots.p, n_all, VK_CID, frontier.p, small, ex.err.p, info_d, ctx->mailbox_dev, seq,
                            dense_frontier.p);
     if (rc) return rc;
+    prof.reset();
     {
         const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(5);
         uint32_t spins = 0;
@@ -107,8 +109,10 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, b.alloc(plan.biggest));
     IPCFP_HIP(ctx, ex.keys.alloc(n_msgs));
     IPCFP_HIP(ctx, rleaves.alloc(n_rcpt));
+    prof.reset(new ProfileScope(ctx, IPCFP_K_AMT_WALK));
     rc = launch_dense_walk(ctx, view, dense_frontier.p, plan, a.p, b.p, nullptr, ex.keys.p, rleaves.p, small + 2);
     if (rc) return rc;
+    prof.reset();
     // the receipts' event records: aux stream, behind the block-order parse and behind the leaves just queued
     std::unique_ptr<EventTableCached> table(new EventTableCached());
     table->lo = w->receipt_lo;
@@ -140,6 +144,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, ex.first.alloc(n_msgs));
     IPCFP_HIP(ctx, ex.pos.alloc(n_msgs));
     IPCFP_HIP(ctx, ex.inv.alloc(n_msgs));
+    prof.reset(new ProfileScope(ctx, IPCFP_K_EXEC_ORDER));
     IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 8, ctx->stream));
     rc = launch_exec_insert(ctx, ex.keys.p, n_msgs, ex.slots.p, ex.mask);
     if (rc) return rc;
@@ -163,6 +168,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     fin.event_recs = table->events;
     rc = launch_exec_finish_fused(ctx, tcs_d.p, fin, ex.first.p, ex.pos.p, tiles.p, ex.total.p);
     if (rc) return rc;
+    prof.reset();
     rc = event_table_join(ctx, w);
     if (rc) return rc;
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, 1, blob_d, blob_len, trust ? *trust : accept_all, filter, status_d,

@@ -3,7 +3,7 @@
 out=${1:-gpurun_out/prof}
 mkdir -p "$out"
 export TMPDIR=/tmp
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$$ -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub-records --t2-reps 0 ) > "$out/prof_run.log" 2>&1
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$$ -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub-records --plain --t2-reps 0 ) > "$out/prof_run.log" 2>&1
 db=$(find /tmp/prof_$$ -name '*.db' | head -1)
 python tools/rocpd_summary.py "$db" > "$out/stats.txt" 2>&1
 python tools/rocpd_summary.py "$db" --timeline > "$out/timeline.txt" 2>&1
