@@ -146,7 +146,8 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, ex.inv.alloc(n_msgs));
     prof.reset(new ProfileScope(ctx, IPCFP_K_EXEC_ORDER));
     IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 8, ctx->stream));
-    rc = launch_exec_insert(ctx, ex.keys.p, n_msgs, ex.slots.p, ex.mask);
+    IPCFP_HIP(ctx, hipMemsetAsync(ex.first.p, 0, size_t(n_msgs) * 4, ctx->stream));
+    rc = launch_exec_insert_flags(ctx, ex.keys.p, n_msgs, ex.slots.p, ex.mask, ex.first.p);
     if (rc) return rc;
     DevBuf<uint64_t> tiles;
     IPCFP_HIP(ctx, tiles.alloc(size_t(div_up(n_msgs, 256)) + 2));
@@ -166,7 +167,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     fin.receipt_first = w->receipt_lo;
     fin.receipt_recs = table->receipts.p;
     fin.event_recs = table->events;
-    rc = launch_exec_finish_fused(ctx, tcs_d.p, fin, ex.first.p, ex.pos.p, tiles.p, ex.total.p);
+    rc = launch_exec_finish_fused(ctx, tcs_d.p, fin, ex.first.p, ex.pos.p, tiles.p, ex.total.p, /*flags_ready=*/true);
     if (rc) return rc;
     prof.reset();
     rc = event_table_join(ctx, w);

@@ -82,8 +82,10 @@ int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_
 struct CtxFinish;
 int launch_ctx_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const CtxFinish& a);
 int launch_exec_finish_fused(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const CtxFinish& a, uint32_t* first_d, uint32_t* pos_d,
-                             uint64_t* tile_d, uint64_t* total_d);
+                             uint64_t* tile_d, uint64_t* total_d, bool flags_ready = false);
 int launch_exec_insert(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, unsigned long long* slots_d, uint32_t mask);
+int launch_exec_insert_flags(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, unsigned long long* slots_d, uint32_t mask,
+                             uint32_t* first_d);
 int launch_scan_tiles_u64(ipcfp_ctx* ctx, uint64_t* tile_sums_d, uint32_t ntiles, uint64_t* total_d);
 int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d, const uint32_t* first_d,
                        const uint32_t* pos_d, uint32_t n, uint32_t* inv_d);

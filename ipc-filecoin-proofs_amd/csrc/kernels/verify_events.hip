@@ -58,6 +58,41 @@ __global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ 
     }
 }
 
+// stages 3+4 in ONE probe per position (host/verify_fast.cpp): `first` (zeroed by the caller) is kept right while the
+// table fills.  A position that takes an empty slot counts itself; one that lowers a slot's minimum counts itself and
+// un-counts the position it displaced.  Additions commute, so whatever order the wavefronts run in, the holder of each
+// slot's final minimum ends at 1 and every other position of that CID at 0 — the second random probe of every position
+// (k_exec_first: another 128-byte line apiece) becomes a streaming read of the flags.
+__global__ __launch_bounds__(256) void k_exec_insert_flags(const CidKey* __restrict__ keys, uint32_t n,
+                                                           unsigned long long* __restrict__ slots, uint32_t mask,
+                                                           uint32_t* __restrict__ first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CidKey key = keys[i];
+    const uint64_t h = cid_hash64(key);
+    const unsigned long long mine = ((unsigned long long)uint32_t(h) << 32) | i;
+    uint32_t s = uint32_t(h >> 32) & mask;
+    for (;;) {
+        unsigned long long cur = slots[s];
+        if (cur == kEmptySlot64) {
+            cur = atomicCAS(&slots[s], kEmptySlot64, mine);
+            if (cur == kEmptySlot64) {
+                atomicAdd(&first[i], 1u);
+                return;
+            }
+        }
+        if (uint32_t(cur >> 32) == uint32_t(h) && cid_equal(keys[uint32_t(cur)], key)) {
+            const unsigned long long old = atomicMin(&slots[s], mine);  // (only positions of THIS CID ever lower this slot)
+            if (old > mine) {
+                atomicAdd(&first[i], 1u);
+                atomicAdd(&first[uint32_t(old)], 0xffffffffu);
+            }
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
 // stage 4: first[i] = 1 iff position i is the first occurrence of its CID (`if seen.insert(*c) { out.push(*c) }`)
 __global__ __launch_bounds__(256) void k_exec_first(const CidKey* __restrict__ keys, uint32_t n,
                                                     const unsigned long long* __restrict__ slots, uint32_t mask,
@@ -142,6 +177,16 @@ __global__ __launch_bounds__(256) void k_exec_first_sums(const CidKey* __restric
     }
     uint64_t total;
     (void)block_exclusive_scan(uint64_t(f), smem, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// the tile sums of flags that are already there (k_exec_insert_flags)
+__global__ __launch_bounds__(256) void k_exec_flag_sums(const uint32_t* __restrict__ first, uint32_t n,
+                                                        uint64_t* __restrict__ tile_sums) {
+    __shared__ uint64_t smem[17];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total;
+    (void)block_exclusive_scan(uint64_t(i < n ? first[i] : 0u), smem, &total);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
@@ -283,9 +328,10 @@ __global__ __launch_bounds__(256) void k_ctx_finish(TipsetCtxDev* __restrict__ c
 
 // first flags + tile sums, scan of the tile sums, positions + inverse + the context's tail.  tile_d: div_up(n, 256) + 1 words.
 int launch_exec_finish_fused(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const CtxFinish& a, uint32_t* first_d, uint32_t* pos_d,
-                             uint64_t* tile_d, uint64_t* total_d) {
+                             uint64_t* tile_d, uint64_t* total_d, bool flags_ready) {
     const uint32_t n = a.raw_len, ntiles = div_up(n ? n : 1, 256);
-    hipLaunchKernelGGL(k_exec_first_sums, dim3(ntiles), dim3(256), 0, ctx->stream, a.keys, n, a.slots, a.mask, first_d, tile_d);
+    if (flags_ready) hipLaunchKernelGGL(k_exec_flag_sums, dim3(ntiles), dim3(256), 0, ctx->stream, first_d, n, tile_d);
+    else hipLaunchKernelGGL(k_exec_first_sums, dim3(ntiles), dim3(256), 0, ctx->stream, a.keys, n, a.slots, a.mask, first_d, tile_d);
     int rc = launch_scan_tiles_u64(ctx, tile_d, ntiles, total_d);
     if (rc) return rc;
     hipLaunchKernelGGL(k_exec_apply_finish, dim3(ntiles), dim3(256), 0, ctx->stream, first_d, n, tile_d, pos_d, ctx_d, a);
@@ -322,6 +368,15 @@ int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leave
 int launch_exec_insert(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, unsigned long long* slots_d, uint32_t mask) {
     if (n == 0) return IPCFP_OK;
     hipLaunchKernelGGL(k_exec_insert, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, keys_d, n, slots_d, mask);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+// first_d must be zero (hipMemsetAsync on the same stream) when this is queued
+int launch_exec_insert_flags(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, unsigned long long* slots_d, uint32_t mask,
+                             uint32_t* first_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_exec_insert_flags, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, keys_d, n, slots_d, mask, first_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

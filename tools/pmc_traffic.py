@@ -58,6 +58,16 @@ def main():
                 factors[pattern] = touched[cname] / (mean * 1024.0)
                 calib_rows[pattern] = {"kernel": kname, "fetch_size_kb_per_launch": mean, "bytes_of_lines_touched": touched[cname],
                                        "factor": round(factors[pattern], 4)}
+    # k_lane_seq (one parser per lane, 16 bytes at a time, EVERY wave slot of the chip occupied) is not a counter
+    # calibration but a measurement of re-fetching: 64 lanes x 32 waves x 256 CUs x one 128-byte line each = 67 MB of lines
+    # in flight against 32 MB of L2, so a line is evicted between two of its eight 16-byte reads.  Its row is kept as
+    # `refetch_ratio`; kernels of that pattern take the streaming factor (K1, the same pattern at 3 waves/SIMD, was
+    # calibrated at exactly 2.0 with tools/calib_fetch.py in round 1)
+    if "lane_seq" in factors and "stream" in factors:
+        calib_rows["lane_seq"]["refetch_ratio"] = round(factors["stream"] / factors["lane_seq"], 3)
+        calib_rows["lane_seq"]["factor"] = round(factors["stream"], 4)
+        calib_rows["lane_seq"]["factor_basis"] = "k_stream's; FETCH_SIZE x factor / bytes touched = refetch_ratio"
+        factors["lane_seq"] = factors["stream"]
     # a lane that reads 16 or 64 bytes of a line does not necessarily move the whole line: the TRUE byte count of those two
     # launches is not known a priori, so they take the factor of the whole-line random read and what they imply per access
     # is recorded (the fetch granularity of a partial-line read)
