@@ -102,11 +102,28 @@ struct ipcfp_ctx {
     unsigned long long* mailbox_dev = nullptr;  // the same page as the device addresses it
     unsigned long long mailbox_seq = 0;
     hipEvent_t main_event = nullptr;            // aux stream ← main stream dependency (host/verify_fast.cpp)
+    // --- reserved CUs (env IPCFP_RESERVE_CUS = CUs per XCD, 0 = off; host/context.cpp): the latency-bound head of a
+    // verify call — tipset prologue, AMT roots, the narrow interior levels — runs on a stream confined to the reserved
+    // CUs while the two side streams (K1, the block-order event parse) are confined to all the others, so those few
+    // wavefronts never share a SIMD's issue slots with the hash or the parse ---
+    hipStream_t stream_narrow = nullptr;        // null: no reservation (the head runs on `stream`)
+    hipEvent_t narrow_event = nullptr;          // main stream ↔ narrow stream hand-overs
+    uint32_t narrow_max_wg = 64;                // a level of at most this many workgroups counts as narrow
+    bool k1_after_be = false;                   // env IPCFP_K1_AFTER_BE: K1 is queued behind the block-order event parse
+    // --- K1 queued late (env IPCFP_K1_DEFER, host/witness.cpp k1_flush): ipcfp_witness_verify_cids_async only notes the
+    // request; the event-verify call that follows queues the launch at the point of ITS kernel sequence where the hash
+    // kernel costs the critical path least (1: behind the AMT walk, 2: before the verify kernel, 3: behind it).  Every
+    // entry point that reads K1's results, synchronises the context or rebuilds the index queues a noted launch first.
+    int k1_defer = 0;
+    bool k1_gate = false;                       // env IPCFP_K1_GATE: … and K1's stream WAITS for the main stream to get there
+    hipEvent_t k1_gate_event = nullptr;
+    struct ipcfp_witness* k1_deferred_w = nullptr;
 };
 
 namespace ipcfp {
 
 int set_error(ipcfp_ctx* ctx, int rc, const char* fmt, ...);
+int k1_flush(ipcfp_ctx* ctx, bool gated = false);  // queue the noted K1 launch, if any (host/witness.cpp)
 
 #define IPCFP_HIP(ctx, call)                                                                    \
     do {                                                                                        \

@@ -1,4 +1,5 @@
 // csrc/host/context.cpp — context lifecycle, error text and HIP-event kernel timing.
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdlib>
@@ -218,6 +219,38 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
             ctx->aux_event = nullptr;
         }
     }
+    // IPCFP_RESERVE_CUS=r: r CUs of every XCD are kept for the narrow stream; K1's stream and the aux stream are re-made
+    // with the complementary mask.  (KFD hands the mask's bits out XCD by XCD — bit i belongs to XCD i % 8 — and inside
+    // an XCD shader engine by shader engine, so bits [0, 8r) are r CUs per XCD spread over its engines.  Whatever the
+    // mapping, the two masks are disjoint.)
+    if (const char* e = std::getenv("IPCFP_RESERVE_CUS")) {
+        const int cus = ctx->props.multiProcessorCount > 0 ? ctx->props.multiProcessorCount : 256;
+        const int r = std::atoi(e);
+        const int n_res = r * 8;
+        if (r > 0 && n_res < cus && ctx->stream_aux != ctx->stream && ctx->stream_k1 != ctx->stream) {
+            std::vector<uint32_t> keep(size_t((cus + 31) / 32), 0u), rest(size_t((cus + 31) / 32), 0u);
+            for (int i = 0; i < cus; ++i) (i < n_res ? keep : rest)[size_t(i) >> 5] |= 1u << (i & 31);
+            hipStream_t nar = nullptr, k1 = nullptr, aux = nullptr;
+            if (hipExtStreamCreateWithCUMask(&nar, uint32_t(keep.size()), keep.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&k1, uint32_t(rest.size()), rest.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&aux, uint32_t(rest.size()), rest.data()) == hipSuccess &&
+                hipEventCreateWithFlags(&ctx->narrow_event, hipEventDisableTiming) == hipSuccess) {
+                (void)hipStreamDestroy(ctx->stream_k1);
+                (void)hipStreamDestroy(ctx->stream_aux);
+                ctx->stream_k1 = k1;
+                ctx->stream_aux = aux;
+                ctx->stream_narrow = nar;
+            } else {
+                if (nar) (void)hipStreamDestroy(nar);
+                if (k1) (void)hipStreamDestroy(k1);
+                if (aux) (void)hipStreamDestroy(aux);
+            }
+        }
+    }
+    if (const char* e = std::getenv("IPCFP_NARROW_MAX_WG")) ctx->narrow_max_wg = uint32_t(std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("IPCFP_K1_AFTER_BE")) ctx->k1_after_be = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IPCFP_K1_DEFER")) ctx->k1_defer = std::atoi(e);
+    if (const char* e = std::getenv("IPCFP_K1_GATE")) ctx->k1_gate = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCFP_SPIN_SYNC")) ctx->spin_sync = std::atoi(e) != 0;
     // wait_stream's polling event belongs to THIS device (created here, right after hipSetDevice(device))
     if (hipEventCreateWithFlags(&ctx->spin_event, hipEventDisableTiming) != hipSuccess) ctx->spin_event = nullptr;
@@ -287,6 +320,9 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
     if (ctx->stream_aux != ctx->stream) (void)hipStreamDestroy(ctx->stream_aux);
     if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
+    if (ctx->stream_narrow) (void)hipStreamDestroy(ctx->stream_narrow);
+    if (ctx->narrow_event) (void)hipEventDestroy(ctx->narrow_event);
+    if (ctx->k1_gate_event) (void)hipEventDestroy(ctx->k1_gate_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -298,6 +334,7 @@ void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx) { return ctx ? reinterpret_cast<void*>(
 int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
     if (!ctx) return IPCFP_E_INVALID;
     IPCFP_HIP(ctx, hipSetDevice(ctx->device));  // (a multi-device process: the event record below is per device)
+    if (int rc = ipcfp::k1_flush(ctx)) return rc;
     IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream));
     IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream_k1));
     if (ctx->stream_aux != ctx->stream) IPCFP_HIP(ctx, wait_stream(ctx, ctx->stream_aux));

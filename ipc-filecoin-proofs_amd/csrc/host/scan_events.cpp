@@ -158,7 +158,8 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     IPCFP_HIP(ctx, ctl_words(ctx, total_own, total_p, 1, false));
     struct { uint64_t* p; } total{total_p};
     IPCFP_HIP(ctx, out.has.alloc(n_idx));
-    if (n_idx) IPCFP_HIP(ctx, hipMemsetAsync(out.has.p, 0, n_idx, ctx->stream));
+    // (a dense enumeration has a leaf for every index of the map and PASS 2 writes the byte of every leaf: nothing to clear)
+    if (n_idx && !en->dense) IPCFP_HIP(ctx, hipMemsetAsync(out.has.p, 0, n_idx, ctx->stream));
     // PASS 1: with the events tabulated once per witness (kernels/event_table.h) — the first scan builds the table
     // and counts in one kernel, a later one (another filter) counts from the records
     EventTableView tview{nullptr, nullptr};
@@ -242,15 +243,23 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
     if (res.status != IPCFP_ST_TRUE) return IPCFP_OK;
     *n_receipts = res.n_idx;
     *n_matches = res.n_matches;
-    if (receipt_has_match && res.n_idx)
+    bool queued = false;  // (a sizing call copies nothing back: the scan's own synchronisation was the last one it needs)
+    if (receipt_has_match && res.n_idx && cap_receipts) {
         IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match, res.has.p, res.n_idx < cap_receipts ? res.n_idx : cap_receipts,
                                       hipMemcpyDeviceToHost, ctx->stream));
-    if (matches && res.n_matches)
+        queued = true;
+    }
+    if (matches && res.n_matches && cap_matches) {
         IPCFP_HIP(ctx, hipMemcpyAsync(matches, res.matches.p,
                                       (res.n_matches < cap_matches ? res.n_matches : cap_matches) * sizeof(ipcfp_event_match_t),
                                       hipMemcpyDeviceToHost, ctx->stream));
-    if (touched_bits) IPCFP_HIP(ctx, hipMemcpyAsync(touched_bits, touched.p, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+        queued = true;
+    }
+    if (touched_bits) {
+        IPCFP_HIP(ctx, hipMemcpyAsync(touched_bits, touched.p, size_t(words) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        queued = true;
+    }
+    if (queued) IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     ctl_preprime(ctx);
     return IPCFP_OK;
 }

@@ -99,6 +99,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         int rc_fast = verify_packed_fast(ctx, w, tcs, claims_d, n, blob_d, blob_len, trust, filter, status_d, where_d, &done);
         if (rc_fast) return rc_fast;
         if (done) return IPCFP_OK;
+        if (int rc_k1 = k1_flush(ctx)) return rc_k1;  // (a noted K1 launch the fast route did not get to queue)
         tcs = saved;
     }
     const WitnessView view = witness_view(w);

@@ -55,6 +55,23 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     int rc = ctx->has_scan_hint ? block_table_prefetch(ctx, w, &ctx->scan_hint.filter, int(ctx->scan_hint.has_actor), ctx->scan_hint.actor)
                                 : block_table_prefetch(ctx, w, nullptr, 0, 0);
     if (rc) return rc;
+    // The head of the call — prologue, AMT roots, the narrow interior levels: a few wavefronts each, bound by their
+    // dependent loads and instruction chains — goes to the narrow stream when CUs are reserved for it (common.h
+    // stream_narrow).  Until launch_dense_walk hands back to the main stream, `ctx->stream` IS the narrow stream, so every
+    // helper that queues "on the call's stream" (control words, small copies, the launchers) follows without knowing.
+    struct StreamSwap {
+        ipcfp_ctx* c;
+        hipStream_t saved;
+        ~StreamSwap() {
+            if (c->stream != saved) (void)hipStreamSynchronize(c->stream);  // (left early: nothing handed the work over)
+            c->stream = saved;
+        }
+    } swap{ctx, ctx->stream};
+    if (ctx->stream_narrow) {
+        IPCFP_HIP(ctx, hipEventRecord(ctx->narrow_event, ctx->stream));  // behind the index build (and the preprimed control block)
+        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_narrow, ctx->narrow_event, 0));
+        ctx->stream = ctx->stream_narrow;
+    }
     DevBuf<TipsetCtxDev> tcs_d;
     IPCFP_HIP(ctx, tcs_d.alloc(1));
     IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, tcs.data(), sizeof(TipsetCtxDev), ctx->stream));
@@ -110,9 +127,22 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, ex.keys.alloc(n_msgs));
     IPCFP_HIP(ctx, rleaves.alloc(n_rcpt));
     prof.reset(new ProfileScope(ctx, IPCFP_K_AMT_WALK));
-    rc = launch_dense_walk(ctx, view, dense_frontier.p, plan, a.p, b.p, nullptr, ex.keys.p, rleaves.p, small + 2);
+    // the receipt leaves are consumed on the aux stream (k_receipt_events), the message keys on the main stream: the two
+    // leaf kernels fork accordingly and run side by side (IPCFP_LEAVES_AUX=0: both on the main stream, one after the other)
+    static const bool leaves_aux = [] {
+        const char* e = std::getenv("IPCFP_LEAVES_AUX");
+        return !(e && std::atoi(e) == 0);
+    }();
+    rc = launch_dense_walk(ctx, view, dense_frontier.p, plan, a.p, b.p, nullptr, ex.keys.p, rleaves.p, small + 2,
+                           leaves_aux ? ctx->stream_aux : nullptr, leaves_aux ? ctx->main_event : nullptr,
+                           ctx->stream != swap.saved ? swap.saved : nullptr, ctx->narrow_event, ctx->narrow_max_wg);
     if (rc) return rc;
+    // (the main stream now waits for everything the narrow stream was given: its small copies are the main stream's)
+    for (auto& r : ctx->pending)
+        if (ctx->stream_narrow && r.stream == ctx->stream_narrow) r.stream = ctx->stream;
+    if (prof) prof->stream = ctx->stream;  // (started on the narrow stream, ends on the main one)
     prof.reset();
+    if (ctx->k1_defer == 1 && (rc = k1_flush(ctx, true))) return rc;
     // the receipts' event records: aux stream, behind the block-order parse and behind the leaves just queued
     std::unique_ptr<EventTableCached> table(new EventTableCached());
     table->lo = w->receipt_lo;
@@ -126,8 +156,10 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
         table->counts_filter = w->bt_filter;
         IPCFP_HIP(ctx, table->counts.alloc(n_rcpt));
     }
-    IPCFP_HIP(ctx, hipEventRecord(ctx->main_event, ctx->stream));
-    IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->main_event, 0));
+    if (!leaves_aux) {  // (forked: the leaves are already on the aux stream, in order before what follows)
+        IPCFP_HIP(ctx, hipEventRecord(ctx->main_event, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->main_event, 0));
+    }
     IPCFP_HIP(ctx, hipMemsetAsync(table->err_word.p, 0xff, 8, ctx->stream_aux));  // kNoEnumError
     rc = launch_receipt_events(ctx, view, rleaves.p, n_rcpt, table->has_counts ? &w->bt_filter.filter : nullptr,
                                int(w->bt_filter.has_actor), w->bt_filter.actor, w->bt_blocks.p, table->receipts.p,
@@ -172,9 +204,11 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     prof.reset();
     rc = event_table_join(ctx, w);
     if (rc) return rc;
+    if (ctx->k1_defer == 2 && (rc = k1_flush(ctx, true))) return rc;
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, 1, blob_d, blob_len, trust ? *trust : accept_all, filter, status_d,
                               where_d, /*tabulated=*/true);
     if (rc) return rc;
+    if ((rc = k1_flush(ctx, true))) return rc;  // (mode 3, and whatever is still noted)
     // ---- the one synchronisation: did the dense walk hold? ----
     uint32_t bad = 0;
     unsigned long long e = kNoEnumError;

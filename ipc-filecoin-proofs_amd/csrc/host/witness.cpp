@@ -11,6 +11,7 @@
 
 #include "../common.h"
 #include "../kernels/launch.h"
+#include "exec_state.h"
 
 using namespace ipcfp;
 
@@ -82,6 +83,21 @@ int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_b
 
 }  // namespace ipcfp
 
+namespace ipcfp {
+int k1_flush(ipcfp_ctx* ctx, bool gated) {
+    ipcfp_witness* w = ctx->k1_deferred_w;
+    if (!w) return IPCFP_OK;
+    ctx->k1_deferred_w = nullptr;
+    if (gated && ctx->k1_gate && ctx->stream_k1 != ctx->stream) {
+        if (!ctx->k1_gate_event) IPCFP_HIP(ctx, hipEventCreateWithFlags(&ctx->k1_gate_event, hipEventDisableTiming));
+        IPCFP_HIP(ctx, hipEventRecord(ctx->k1_gate_event, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_k1, ctx->k1_gate_event, 0));
+    }
+    return launch_blake2b256_cid(ctx, w->arena.p, w->k1_meta.p, w->k1_cids.p, uint32_t(w->n), w->ok_bits.p, w->cid_status.p,
+                                 w->counters.p);
+}
+}  // namespace ipcfp
+
 extern "C" {
 
 int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint64_t* off,
@@ -148,6 +164,7 @@ int ipcfp_witness_create_device(ipcfp_ctx_t* ctx, const void* bytes_d, uint64_t 
 void ipcfp_witness_destroy(ipcfp_witness_t* w) {
     if (!w) return;
     if (w->ctx) {
+        if (w->ctx->k1_deferred_w == w) w->ctx->k1_deferred_w = nullptr;  // (nobody can ask for its results any more)
         (void)hipSetDevice(w->ctx->device);
         (void)hipStreamSynchronize(w->ctx->stream);
         (void)hipStreamSynchronize(w->ctx->stream_k1);
@@ -159,9 +176,32 @@ void ipcfp_witness_destroy(ipcfp_witness_t* w) {
 uint64_t ipcfp_witness_block_count(const ipcfp_witness_t* w) { return w ? w->n : 0; }
 uint64_t ipcfp_witness_byte_count(const ipcfp_witness_t* w) { return w ? w->nbytes : 0; }
 
+static int k1_launch_now(ipcfp_ctx_t* ctx, ipcfp_witness_t* w);
+
 int ipcfp_witness_verify_cids_async(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
     IPCFP_ENTER(ctx);
+    if (ctx->k1_defer) {  // noted; queued by the next event-verify call, or by whoever needs it first (k1_flush)
+        if (ctx->k1_deferred_w && ctx->k1_deferred_w != w) {
+            int rc = ipcfp::k1_flush(ctx);
+            if (rc) return rc;
+        }
+        ctx->k1_deferred_w = w;
+        return IPCFP_OK;
+    }
+    return k1_launch_now(ctx, w);
+}
+
+static int k1_launch_now(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
+    if (ctx->k1_after_be && w->use_event_table && ctx->stream_aux != ctx->stream && ctx->stream_k1 != ctx->stream) {
+        // K1 and the block-order event parse are both bound by instruction issue: side by side each takes about as long
+        // as the two in a row.  Only the parse has consumers waiting for it (the receipts' event records, then the verify
+        // kernel), so it goes first with the chip's side share to itself and K1 fills in behind it.
+        int rc = ctx->has_scan_hint ? block_table_prefetch(ctx, w, &ctx->scan_hint.filter, int(ctx->scan_hint.has_actor), ctx->scan_hint.actor)
+                                    : block_table_prefetch(ctx, w, nullptr, 0, 0);
+        if (rc) return rc;
+        if (w->bt_valid && !w->bt_joined) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_k1, ctx->aux_event, 0));
+    }
     return launch_blake2b256_cid(ctx, w->arena.p, w->k1_meta.p, w->k1_cids.p, uint32_t(w->n), w->ok_bits.p,
                                  w->cid_status.p, w->counters.p);
 }
@@ -171,6 +211,7 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
     IPCFP_ENTER(ctx);
     int rc = ipcfp_witness_verify_cids_async(ctx, w);
     if (rc) return rc;
+    if ((rc = ipcfp::k1_flush(ctx))) return rc;
     unsigned long long bad = 0;
     if (status && w->n)
         IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream_k1));
@@ -184,6 +225,7 @@ int ipcfp_witness_verify_cids(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
 int ipcfp_witness_cid_results(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* status, uint64_t* n_bad) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
     IPCFP_ENTER(ctx);
+    if (int rc = ipcfp::k1_flush(ctx)) return rc;
     unsigned long long bad = 0;
     if (status && w->n)
         IPCFP_HIP(ctx, hipMemcpyAsync(status, w->cid_status.p, w->n, hipMemcpyDeviceToHost, ctx->stream_k1));
@@ -196,6 +238,7 @@ int ipcfp_witness_cid_results(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, uint8_t* sta
 int ipcfp_witness_rebuild_index(ipcfp_ctx_t* ctx, ipcfp_witness_t* w) {
     if (!ctx || !w || w->ctx != ctx) return IPCFP_E_INVALID;
     IPCFP_ENTER(ctx);
+    if (int rc = ipcfp::k1_flush(ctx)) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     w->enum_cache.clear();  // enumerations and event tables are derived from the index
     w->table_cache.clear();

@@ -81,7 +81,13 @@ struct DensePlan {
 void dense_plan(const std::vector<uint64_t>& root_info, uint32_t n_roots, int vkind, bool want_keys, uint64_t lo, uint64_t hi,
                 uint32_t has_extra, int extra_vkind, uint64_t extra_lo, uint64_t extra_hi, DensePlan& plan);
 int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* frontier, const DensePlan& plan,
-                      DenseNode* a, DenseNode* b, LeafRef* leaves_main, CidKey* keys_main, LeafRef* leaves_extra, uint32_t* anomaly_d);
+                      DenseNode* a, DenseNode* b, LeafRef* leaves_main, CidKey* keys_main, LeafRef* leaves_extra, uint32_t* anomaly_d,
+                      hipStream_t leaves_stream = nullptr,  // non-null (with fork_event): k_dense_leaves runs there, beside
+                      hipEvent_t fork_event = nullptr,      // k_dense_link_leaves on the main stream
+                      // non-null: the caller runs on the narrow stream (ctx->stream is that stream); the first level of more
+                      // than `narrow_max_wg` workgroups — the leaves at the latest — hands over to `wide_stream` through
+                      // `wide_event`, and ctx->stream is `wide_stream` on return
+                      hipStream_t wide_stream = nullptr, hipEvent_t wide_event = nullptr, uint32_t narrow_max_wg = 0);
 
 int launch_enum_roots(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_all, int vkind,
                       EnumNode* frontier_d, uint32_t* max_height_d, unsigned long long* err_d, uint64_t* root_info_d,

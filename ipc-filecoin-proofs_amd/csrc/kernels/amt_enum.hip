@@ -648,14 +648,24 @@ void dense_plan(const std::vector<uint64_t>& root_info, uint32_t n_roots, int vk
 // The launches of the dense walk: one kernel per interior level, one leaf kernel.  `frontier`: the roots' entries
 // (k_enum_roots); a / b: two frontier buffers of plan.biggest entries.  The root shapes travel as a kernel argument.
 int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* frontier, const DensePlan& plan,
-                      DenseNode* a, DenseNode* b, LeafRef* leaves_main, CidKey* keys_main, LeafRef* leaves_extra, uint32_t* anomaly_d) {
+                      DenseNode* a, DenseNode* b, LeafRef* leaves_main, CidKey* keys_main, LeafRef* leaves_extra, uint32_t* anomaly_d,
+                      hipStream_t leaves_stream, hipEvent_t fork_event, hipStream_t wide_stream, hipEvent_t wide_event,
+                      uint32_t narrow_max_wg) {
     const DenseNode* src = frontier;
+    auto widen = [&]() -> hipError_t {  // the narrow stream's part ends here
+        if (!wide_stream || ctx->stream == wide_stream) return hipSuccess;
+        hipError_t e = hipEventRecord(wide_event, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(wide_stream, wide_event, 0);
+        ctx->stream = wide_stream;
+        return e;
+    };
     // (All interior levels as ONE persistent launch — a workgroup per CU, a grid barrier per level — was built and is
     // slower: 382 µs against 238 µs for the six launches.  What stretches a level beside K1 and the event parse is the
     // latency of its three dependent loads under their memory traffic, not the dispatch; a barrier adds an L2
     // write-back and an L1 invalidate per level on top.  profiles/r03_experiments.md)
     for (uint32_t level = plan.max_height; level >= 1; --level) {
         const uint32_t nn = uint32_t(plan.n_level[level - 1]);
+        if (div_up(nn, 256) > narrow_max_wg) IPCFP_HIP(ctx, widen());
         hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots, level, nn, a, anomaly_d);
         src = a;
         DenseNode* t = a;
@@ -673,15 +683,26 @@ int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* 
     }
     for (uint32_t i = n_key_roots; i < plan.n_use; ++i)
         if (plan.roots.r[i].out_sel == 0) return set_error(ctx, IPCFP_E_INVALID, "dense walk: the key trees must come first");
-    if (n_key_values)
-        hipLaunchKernelGGL(k_dense_link_leaves, dim3(div_up(n_key_values, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots,
-                           n_key_roots, n_key_values, anomaly_d, keys_main);
+    // The two leaf kernels read the same frontier and write different outputs.  A caller whose consumers sit on two
+    // streams (host/verify_fast.cpp: the message keys feed the execution-order kernels on the main stream, the receipt
+    // leaves feed k_receipt_events on the aux stream) forks here: k_dense_leaves goes to `leaves_stream`, ordered behind
+    // the last interior level by `fork_event`, and runs beside k_dense_link_leaves instead of after it.
+    IPCFP_HIP(ctx, widen());
+    hipStream_t ls = ctx->stream;
+    if (leaves_stream && leaves_stream != ctx->stream && fork_event) {
+        IPCFP_HIP(ctx, hipEventRecord(fork_event, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamWaitEvent(leaves_stream, fork_event, 0));
+        ls = leaves_stream;
+    }
     // (every leaf node gets a lane here: those of key trees that have values leave at once, an EMPTY key tree's root is
     // validated here — no value lane looks at it)
     const uint32_t n_nodes = uint32_t(plan.n_level[0]);
     (void)key_nodes;
-    hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_nodes, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots, n_nodes, 0u,
+    hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_nodes, 256)), dim3(256), 0, ls, view, src, plan.roots, n_nodes, 0u,
                        leaves_main, anomaly_d, leaves_extra);
+    if (n_key_values)
+        hipLaunchKernelGGL(k_dense_link_leaves, dim3(div_up(n_key_values, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots,
+                           n_key_roots, n_key_values, anomaly_d, keys_main);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

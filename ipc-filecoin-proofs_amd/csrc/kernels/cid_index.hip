@@ -9,12 +9,17 @@
 // linear probing; keys are compared against the cids[] array (5 × u64 per CID).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../common.h"
 #include "launch.h"
 #include "witness_dev.h"
 
 namespace ipcfp {
 
+// CAS_FIRST: the probe IS the compare-and-swap (at load ≤ 0.5 most home slots are empty: one round trip to the table
+// instead of a read followed by the CAS); otherwise the slot is read first and the CAS only tried on an empty one.
+template <bool CAS_FIRST>
 __global__ __launch_bounds__(256) void k_index_insert(const uint8_t* __restrict__ cids, uint32_t n,
                                                       uint32_t* __restrict__ slots, uint32_t mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -22,7 +27,7 @@ __global__ __launch_bounds__(256) void k_index_insert(const uint8_t* __restrict_
     const CidKey key = load_cid_slot(cids, i);
     uint32_t s = cid_hash(key) & mask;
     for (;;) {
-        uint32_t cur = slots[s];
+        uint32_t cur = CAS_FIRST ? kNoBlock : slots[s];
         if (cur == kNoBlock) {
             cur = atomicCAS(&slots[s], kNoBlock, i);
             if (cur == kNoBlock) return;  // claimed an empty slot
@@ -50,8 +55,16 @@ int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
     if (n == 0) return IPCFP_OK;
     {
         ProfileScope prof(ctx, IPCFP_K_CID_INDEX);
-        hipLaunchKernelGGL(k_index_insert, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n, w->index_slots.p,
-                           w->index_mask);
+        static const bool cas_first = [] {
+            const char* e = std::getenv("IPCFP_INDEX_CAS_FIRST");
+            return !(e && std::atoi(e) == 0);
+        }();
+        if (cas_first)
+            hipLaunchKernelGGL(k_index_insert<true>, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n,
+                               w->index_slots.p, w->index_mask);
+        else
+            hipLaunchKernelGGL(k_index_insert<false>, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n,
+                               w->index_slots.p, w->index_mask);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

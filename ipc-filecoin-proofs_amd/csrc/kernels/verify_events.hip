@@ -7,6 +7,8 @@
 #define IPCFP_LINE_STAGE 1  // k_verify_events parses whole blocks front to back: see cbor_dev.h
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../common.h"
 #include "blake2b_dev.h"
 #include "claims_dev.h"
@@ -63,6 +65,8 @@ __global__ __launch_bounds__(256) void k_exec_insert(const CidKey* __restrict__ 
 // un-counts the position it displaced.  Additions commute, so whatever order the wavefronts run in, the holder of each
 // slot's final minimum ends at 1 and every other position of that CID at 0 — the second random probe of every position
 // (k_exec_first: another 128-byte line apiece) becomes a streaming read of the flags.
+// (CAS_FIRST as in k_index_insert: the probe is the compare-and-swap itself)
+template <bool CAS_FIRST>
 __global__ __launch_bounds__(256) void k_exec_insert_flags(const CidKey* __restrict__ keys, uint32_t n,
                                                            unsigned long long* __restrict__ slots, uint32_t mask,
                                                            uint32_t* __restrict__ first) {
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void k_exec_insert_flags(const CidKey* __restr
     const unsigned long long mine = ((unsigned long long)uint32_t(h) << 32) | i;
     uint32_t s = uint32_t(h >> 32) & mask;
     for (;;) {
-        unsigned long long cur = slots[s];
+        unsigned long long cur = CAS_FIRST ? kEmptySlot64 : slots[s];
         if (cur == kEmptySlot64) {
             cur = atomicCAS(&slots[s], kEmptySlot64, mine);
             if (cur == kEmptySlot64) {
@@ -376,7 +380,14 @@ int launch_exec_insert(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, unsigne
 int launch_exec_insert_flags(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, unsigned long long* slots_d, uint32_t mask,
                              uint32_t* first_d) {
     if (n == 0) return IPCFP_OK;
-    hipLaunchKernelGGL(k_exec_insert_flags, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, keys_d, n, slots_d, mask, first_d);
+    static const bool cas_first = [] {
+        const char* e = std::getenv("IPCFP_INDEX_CAS_FIRST");
+        return !(e && std::atoi(e) == 0);
+    }();
+    if (cas_first)
+        hipLaunchKernelGGL(k_exec_insert_flags<true>, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, keys_d, n, slots_d, mask, first_d);
+    else
+        hipLaunchKernelGGL(k_exec_insert_flags<false>, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, keys_d, n, slots_d, mask, first_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
