@@ -251,19 +251,21 @@ def main():
             ta = time.perf_counter()
             w2 = eng.witness(tip.data, tip.off, tip.lens, tip.cids)
             tb = time.perf_counter()
-            st2, _, nm2, _ = w2.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
-                                            want_touched=False, counts_only=True)
+            # the calls in the order of the resident step (K, V, S): K1 is queued, the claims cross PCIe beside the
+            # verify call's own AMT walk, the scan finds the receipts enumerated and the events tabulated
             w2.verify_cids_async()
             tc_ = time.perf_counter()
             status2 = w2.verify_event_claims(ts, cl, blob, blob_len)
             td = time.perf_counter()
+            st2, _, nm2, _ = w2.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                            want_touched=False, counts_only=True)
             cs2, nbad2 = w2.cid_results()
             te = time.perf_counter()
             w2.close()
             if st2 != 1 or nbad2 or not np.array_equal(status2, status) or nm2 != scan_result["matches"]:
                 raise SystemExit("bench self-check failed: the from-host pass differs from the resident one")
-            reps.append({"total": te - ta, "witness_create_h2d_repack_index": tb - ta, "k1_launch_scan": tc_ - tb,
-                         "claims_h2d_verify_status_d2h": td - tc_, "cid_verdicts_d2h": te - td})
+            reps.append({"total": te - ta, "witness_create_h2d_repack_index": tb - ta, "k1_launch": tc_ - tb,
+                         "claims_h2d_verify_status_d2h": td - tc_, "scan_cid_verdicts_d2h": te - td})
         reps = reps[1:]
         best = min(reps, key=lambda r: r["total"])
         h2d_bytes = int(tip.data.size + tip.off.nbytes + tip.lens.nbytes + tip.cids.nbytes + cl.nbytes + blob_len)

@@ -747,18 +747,26 @@ class Witness:
                     counts_only=False):
         """K6/K8.  Returns (status, has_match u8[n_receipts], matches structured[n], touched block ids);
         with counts_only: (status, n_receipts, n_matches, None) and nothing is copied back."""
-        root = np.frombuffer(bytes(receipts_root).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
-        filt = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
-        st = np.zeros(1, dtype=np.uint8)
-        nr, nm = C.c_uint64(), C.c_uint64()
-        words = (self.n + 31) // 32
-        touched = np.zeros(max(words, 1), dtype=np.uint32) if want_touched else None
+        # (the marshalled arguments of the last call are kept: a scan repeated with the same filter — a service polling
+        # one subnet's events, the benchmark's step — pays for the numpy / ctypes conversions once)
+        key = (bytes(receipts_root), bytes(topic0), bytes(topic1))
+        cached = getattr(self, "_scan_args", None)
+        if cached is None or cached[0] != key:
+            root = np.frombuffer(key[0].ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+            filt = np.frombuffer(key[1] + key[2], dtype=np.uint8).copy()
+            st = np.zeros(1, dtype=np.uint8)
+            nr, nm = C.c_uint64(), C.c_uint64()
+            cached = (key, root, filt, st, nr, nm, _p(root), _p(filt), _p(st), C.byref(nr), C.byref(nm))
+            self._scan_args = cached
+        _, root, filt, st, nr, nm, p_root, p_filt, p_st, r_nr, r_nm = cached
         a = (0, 0) if actor is None else (1, int(actor))
         # sizing call, then the real one
-        self.eng._check(self.lib.ipcfp_scan_events(self.eng.h, self.h, _p(root), _p(filt), a[0], a[1], _p(st), None, 0,
-                                                   C.byref(nr), None, 0, C.byref(nm), None), "scan_events")
+        self.eng._check(self.lib.ipcfp_scan_events(self.eng.h, self.h, p_root, p_filt, a[0], a[1], p_st, None, 0,
+                                                   r_nr, None, 0, r_nm, None), "scan_events")
         if counts_only:
             return int(st[0]), int(nr.value), int(nm.value), None
+        words = (self.n + 31) // 32
+        touched = np.zeros(max(words, 1), dtype=np.uint32) if want_touched else None
         has = np.zeros(int(nr.value), dtype=np.uint8)
         m = np.zeros(int(nm.value), dtype=MATCH_DTYPE)
         if st[0] == 1:
@@ -989,9 +997,13 @@ class Witness:
     def verify_event_claims_device(self, tipsets: np.ndarray, claims_ptr: int, n: int, blob_ptr: int, blob_len: int,
                                    status_ptr: int, trust=None, filt=None):
         """Packed claims resident in HBM (ipcfp_event_claim_t[n]); status bytes are written to status_ptr."""
-        tipsets = np.ascontiguousarray(tipsets, dtype=TIPSET_DTYPE)
+        cached = getattr(self, "_tipset_args", None)
+        if cached is None or cached[0] is not tipsets:  # (same array object as last time: its pointer is kept)
+            ts = np.ascontiguousarray(tipsets, dtype=TIPSET_DTYPE)
+            cached = (tipsets, ts, _p(ts), len(ts))
+            self._tipset_args = cached if ts is tipsets else None  # (a converted copy would go stale)
         self.eng._check(self.lib.ipcfp_verify_event_claims_device(
-            self.eng.h, self.h, _p(tipsets), len(tipsets), claims_ptr, n, blob_ptr, blob_len,
+            self.eng.h, self.h, cached[2], cached[3], claims_ptr, n, blob_ptr, blob_len,
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, status_ptr), "verify_event_claims_device")
 

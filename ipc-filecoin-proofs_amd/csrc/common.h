@@ -31,6 +31,7 @@ struct DevPool {
 extern thread_local DevPool* g_tls_pool;
 
 struct UploadRing;  // host/upload.cpp
+struct UploadTask;  // host/upload.cpp
 void upload_ring_destroy(UploadRing* r);
 
 struct ProfiledLaunch {
@@ -96,6 +97,9 @@ struct ipcfp_ctx {
     hipEvent_t spin_event = nullptr;           // wait_stream's polling event
     bool spin_sync = true;                     // env IPCFP_SPIN_SYNC=0: always block in hipStreamSynchronize
     ipcfp::UploadRing* upload_ring = nullptr;  // pinned staging ring of ipcfp::upload (created on first use)
+    hipStream_t stream_copy = nullptr;         // the stream of UploadTask's blocking copies (created on first use)
+    ipcfp::UploadTask* upload_task = nullptr;  // claims crossing PCIe on a thread of their own (host/upload.cpp); whoever
+                                               // queues a kernel that reads them calls upload_task_wait first
     // --- the mailbox: a page of COHERENT pinned host memory a kernel writes while the stream keeps going (device →
     // host without a synchronisation; kernels/amt_enum.hip k_enum_roots, host/verify_fast.cpp) ---
     unsigned long long* mailbox = nullptr;      // host address
@@ -107,6 +111,12 @@ struct ipcfp_ctx {
     // CUs while the two side streams (K1, the block-order event parse) are confined to all the others, so those few
     // wavefronts never share a SIMD's issue slots with the hash or the parse ---
     hipStream_t stream_narrow = nullptr;        // null: no reservation (the head runs on `stream`)
+    // --- the head stream (env IPCFP_HEAD_STREAM=1; measured and off by default): a verify call's tipset prologue runs here, beside the CID
+    // index's inserts on the main stream instead of behind them (its lookups wait for their keys: tipset_prepare.hip
+    // LiveIndex).  `ctl_event`: the main stream's last re-initialisation of the control block, which the head waits for ---
+    hipStream_t stream_head = nullptr;
+    hipEvent_t ctl_event = nullptr;
+    hipEvent_t head_event = nullptr;            // head stream → main stream hand-back
     hipEvent_t narrow_event = nullptr;          // main stream ↔ narrow stream hand-overs
     uint32_t narrow_max_wg = 64;                // a level of at most this many workgroups counts as narrow
     bool k1_after_be = false;                   // env IPCFP_K1_AFTER_BE: K1 is queued behind the block-order event parse
@@ -157,8 +167,10 @@ inline void* ctl_take(ipcfp_ctx* ctx, uint32_t bytes, bool ff) {
 // the side streams' grids (13-37 us measured).
 inline void ctl_preprime(ipcfp_ctx* ctx) {
     if (!ctx->ctl_dev || ctx->ctl_preprimed || ctx->call_depth != 1) return;
-    if (hipMemcpyAsync(ctx->ctl_dev, ctx->ctl_host, 2 * kCtlHalf, hipMemcpyHostToDevice, ctx->stream) == hipSuccess)
+    if (hipMemcpyAsync(ctx->ctl_dev, ctx->ctl_host, 2 * kCtlHalf, hipMemcpyHostToDevice, ctx->stream) == hipSuccess) {
         ctx->ctl_preprimed = true;
+        if (ctx->ctl_event) (void)hipEventRecord(ctx->ctl_event, ctx->stream);
+    }
 }
 // Queue ONE read-back of the whole block on the main stream; after sync_stream every word is available through ctl_value.
 inline hipError_t ctl_fetch(ipcfp_ctx* ctx) {
@@ -232,6 +244,8 @@ inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
 // Pageable (or pinned) host memory → HBM, stream-ordered on `s`; large transfers are staged by several threads
 // through the context's pinned ring (host/upload.cpp).
 int upload(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t bytes, hipStream_t s);
+UploadTask* upload_task_start(ipcfp_ctx* ctx, void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1);
+int upload_task_wait(ipcfp_ctx* ctx);
 
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfileScope {
@@ -390,6 +404,15 @@ struct ipcfp_witness {
     // CID → block-id index (K4)
     ipcfp::DevBuf<uint32_t> index_slots;  // table of block ids, 0xffffffff = empty
     uint32_t index_mask = 0;
+    // the fill in progress (kernels/cid_index.hip): workgroups of k_index_insert that have finished / that there are, and
+    // the point of the main stream where the table was cleared (a lookup on another stream may start from there: the
+    // tipset prologue on the head stream, host/verify_fast.cpp)
+    ipcfp::DevBuf<uint32_t> index_done;
+    uint32_t index_wgs = 0;
+    hipEvent_t index_event = nullptr;
+    ~ipcfp_witness() {
+        if (index_event) (void)hipEventDestroy(index_event);
+    }
     bool uniform_chunks = false;  // every block has the same chunk count → identity order
     // a shard of one tipset (host/shard.cpp): enumerations of a receipts AMT are restricted to [receipt_lo, receipt_hi)
     uint64_t receipt_lo = 0, receipt_hi = ~0ULL;

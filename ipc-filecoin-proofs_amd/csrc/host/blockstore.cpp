@@ -14,6 +14,8 @@
 #include <new>
 #include <vector>
 
+#include <utility>
+
 #include "../common.h"
 #include "../kernels/launch.h"
 #include "exec_state.h"
@@ -180,6 +182,9 @@ int ipcfp_witness_put_keyed(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
     w->counters.swap(nw->counters);
     w->index_slots.swap(nw->index_slots);
     w->index_mask = nw->index_mask;
+    w->index_done.swap(nw->index_done);
+    std::swap(w->index_wgs, nw->index_wgs);
+    std::swap(w->index_event, nw->index_event);
     w->uniform_chunks = nw->uniform_chunks;
     return IPCFP_OK;  // nw (the old buffers) is released here
 }

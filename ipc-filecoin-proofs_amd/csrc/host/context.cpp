@@ -247,6 +247,19 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
             }
         }
     }
+    // the head stream (common.h stream_head); it needs the mailbox route's single-context verify call to be of any use
+    {
+        const char* e = std::getenv("IPCFP_HEAD_STREAM");
+        if (e && std::atoi(e) != 0 && !ctx->stream_narrow && ctx->stream_aux != ctx->stream) {  // measured: off (r03_experiments.md)
+            if (hipStreamCreateWithFlags(&ctx->stream_head, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->ctl_event, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->head_event, hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(ctx->ctl_event, ctx->stream) != hipSuccess) {
+                if (ctx->stream_head) (void)hipStreamDestroy(ctx->stream_head);
+                ctx->stream_head = nullptr;
+            }
+        }
+    }
     if (const char* e = std::getenv("IPCFP_NARROW_MAX_WG")) ctx->narrow_max_wg = uint32_t(std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("IPCFP_K1_AFTER_BE")) ctx->k1_after_be = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCFP_K1_DEFER")) ctx->k1_defer = std::atoi(e);
@@ -321,6 +334,10 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (ctx->stream_aux != ctx->stream) (void)hipStreamDestroy(ctx->stream_aux);
     if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
     if (ctx->stream_narrow) (void)hipStreamDestroy(ctx->stream_narrow);
+    if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
+    if (ctx->stream_head) (void)hipStreamDestroy(ctx->stream_head);
+    if (ctx->ctl_event) (void)hipEventDestroy(ctx->ctl_event);
+    if (ctx->head_event) (void)hipEventDestroy(ctx->head_event);
     if (ctx->narrow_event) (void)hipEventDestroy(ctx->narrow_event);
     if (ctx->k1_gate_event) (void)hipEventDestroy(ctx->k1_gate_event);
     (void)hipStreamDestroy(ctx->stream);

@@ -1,15 +1,20 @@
 // csrc/host/upload.cpp — pageable host memory → HBM at PCIe speed.
 //
 // The witness bytes and the claim tables the C ABI borrows are ordinary process memory (the reference's
-// `Vec<u8>` blocks, src/proofs/common/bundle.rs:10-16).  hipMemcpyAsync from pageable memory is staged by the
-// runtime through its own pinned buffer on the calling thread, which is the bottleneck of the PCIe-inclusive
-// window (T2) for a 0.44 GB witness.  Here a few threads copy chunks into a ring of pinned buffers owned by
-// the context and every chunk's DMA is queued on the caller's stream the moment it is staged, so the host
-// copy of chunk k+1 overlaps the DMA of chunk k.  Ordering: all DMAs are on `s`; the call returns when the
-// last chunk has been QUEUED (stream-ordered like a plain hipMemcpyAsync from pinned memory).
+// `Vec<u8>` blocks, src/proofs/common/bundle.rs:10-16).  Measured on the MI355X boxes (tools/ubench/h2d_paths,
+// 512 MB, profiles/r03_h2d_paths.txt): a pinned source 57.6 GB/s (the DMA engine's ceiling), the runtime's BLOCKING
+// hipMemcpy from pageable memory 56.5 GB/s, a ring of pinned chunks filled by 4-24 threads with each chunk's DMA queued
+// at once 39-50 GB/s (2-16 MB chunks; 45 GB/s at the 4 MB this file used until round 3).  So a large transfer is the
+// blocking copy (IPCFP_UPLOAD_MODE=1: the ring); it is not stream-ordered — the stream is drained first, which costs
+// nothing where uploads happen (the head of a call) — and a caller that wants it beside other work runs it on a
+// thread of its own (UploadTask below: the claims of a verify call cross PCIe while the tipset's AMTs are walked).
+// The ring: a few threads copy chunks into pinned buffers owned by the context and every chunk's DMA is queued on
+// the caller's stream the moment it is staged, so the host copy of chunk k+1 overlaps the DMA of chunk k.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -58,6 +63,15 @@ static UploadRing* ring_of(ipcfp_ctx* ctx) {
 
 int upload(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return IPCFP_OK;
+    static const int mode = [] {
+        const char* e = std::getenv("IPCFP_UPLOAD_MODE");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (bytes >= 2 * kChunk && mode == 0) {  // the runtime's blocking copy: nothing queued on `s` may still use dst
+        IPCFP_HIP(ctx, hipStreamSynchronize(s));
+        IPCFP_HIP(ctx, hipMemcpy(dst_d, src, bytes, hipMemcpyHostToDevice));
+        return IPCFP_OK;
+    }
     UploadRing* r = bytes >= 2 * kChunk ? ring_of(ctx) : nullptr;
     if (!r) {  // small transfer (or no pinned memory to be had): the runtime's own staging
         IPCFP_HIP(ctx, hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, s));
@@ -88,6 +102,43 @@ int upload(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t bytes, hipStream
     work(0);
     for (auto& th : pool) th.join();
     if (failed) return set_error(ctx, IPCFP_E_HIP, "staged upload of %zu bytes failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+    return IPCFP_OK;
+}
+
+// ---- an upload beside the caller's own work: blocking copies on a thread of their own --------------------------------
+struct UploadTask {
+    std::thread th;
+    std::atomic<int> err{0};  // hipError_t of the first failed copy
+};
+
+UploadTask* upload_task_start(ipcfp_ctx* ctx, void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1) {
+    UploadTask* t = new (std::nothrow) UploadTask();
+    if (!t) return nullptr;
+    const int device = ctx->device;
+    // (a stream of its own: blocking copies on the NULL stream from two threads would queue up behind each other)
+    if (!ctx->stream_copy && hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess) ctx->stream_copy = nullptr;
+    hipStream_t cs = ctx->stream_copy;
+    t->th = std::thread([=] {
+        hipError_t e = hipSetDevice(device);
+        auto copy = [&](void* d, const void* s, size_t n) {
+            return cs ? hipMemcpyWithStream(d, s, n, hipMemcpyHostToDevice, cs) : hipMemcpy(d, s, n, hipMemcpyHostToDevice);
+        };
+        if (e == hipSuccess && bytes0) e = copy(dst0, src0, bytes0);
+        if (e == hipSuccess && bytes1) e = copy(dst1, src1, bytes1);
+        t->err = int(e);
+    });
+    return t;
+}
+
+// the data is in HBM when this returns IPCFP_OK (idempotent: a finished task is gone)
+int upload_task_wait(ipcfp_ctx* ctx) {
+    UploadTask* t = ctx->upload_task;
+    if (!t) return IPCFP_OK;
+    ctx->upload_task = nullptr;
+    t->th.join();
+    const int e = t->err;
+    delete t;
+    if (e) return set_error(ctx, IPCFP_E_HIP, "upload beside the walk failed: %s", hipGetErrorString(hipError_t(e)));
     return IPCFP_OK;
 }
 

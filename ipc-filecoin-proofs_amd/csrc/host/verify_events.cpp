@@ -5,6 +5,7 @@
 // device (header facts + execution order — both recomputed PER PROOF by the reference,
 // events/verifier.rs:105,115,190), then verify the whole batch with one kernel.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -246,6 +247,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     if (rc) return rc;
     bool tabulated = false;
     for (auto& tc : tcs) tabulated = tabulated || tc.receipt_recs != nullptr;
+    if ((rc = upload_task_wait(ctx))) return rc;  // the claims are in HBM
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, uint32_t(tcs.size()), blob_d, blob_len,
                               trust ? *trust : accept_all, filter, status_d, where_d, tabulated);
     if (rc) return rc;
@@ -406,13 +408,31 @@ int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     IPCFP_HIP(ctx, cd.alloc(n));
     IPCFP_HIP(ctx, bd.alloc(blob_len + 64));
     IPCFP_HIP(ctx, sd.alloc(n));
-    int rc = upload(ctx, cd.p, claims, n * sizeof(EventClaimPacked), ctx->stream);
-    if (rc) return rc;
-    if (blob_len) {
-        rc = upload(ctx, bd.p, blob, blob_len, ctx->stream);
+    // The claims cross PCIe on a thread of their own while this one queues the tipset prologue, the AMT walk and the
+    // execution order, none of which reads a claim; launch_verify_events' callers wait for the copy (upload_task_wait).
+    // (IPCFP_UPLOAD_MODE=1, or a batch too small to matter: uploaded here, first)
+    int rc = IPCFP_OK;
+    static const bool beside = [] {
+        const char* e = std::getenv("IPCFP_UPLOAD_MODE");
+        return !(e && std::atoi(e) != 0);
+    }();
+    if (beside && n * sizeof(EventClaimPacked) >= (size_t(8) << 20)) {
+        IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (nothing queued earlier may still use the buffers just taken)
+        ctx->upload_task = upload_task_start(ctx, cd.p, claims, n * sizeof(EventClaimPacked), bd.p, blob, blob_len);
+        if (!ctx->upload_task) return IPCFP_E_NOMEM;
+    } else {
+        rc = upload(ctx, cd.p, claims, n * sizeof(EventClaimPacked), ctx->stream);
         if (rc) return rc;
+        if (blob_len) {
+            rc = upload(ctx, bd.p, blob, blob_len, ctx->stream);
+            if (rc) return rc;
+        }
     }
     rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(n), bd.p, blob_len, trust, filter, sd.p);
+    {
+        const int rc_up = upload_task_wait(ctx);  // (whatever happened: the copy must be over before cd / bd go back to the pool)
+        if (rc == IPCFP_OK) rc = rc_up;
+    }
     if (rc) return rc;
     IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, n, hipMemcpyDeviceToHost, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));

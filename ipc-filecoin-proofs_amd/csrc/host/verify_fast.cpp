@@ -55,10 +55,14 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     int rc = ctx->has_scan_hint ? block_table_prefetch(ctx, w, &ctx->scan_hint.filter, int(ctx->scan_hint.has_actor), ctx->scan_hint.actor)
                                 : block_table_prefetch(ctx, w, nullptr, 0, 0);
     if (rc) return rc;
-    // The head of the call — prologue, AMT roots, the narrow interior levels: a few wavefronts each, bound by their
-    // dependent loads and instruction chains — goes to the narrow stream when CUs are reserved for it (common.h
-    // stream_narrow).  Until launch_dense_walk hands back to the main stream, `ctx->stream` IS the narrow stream, so every
-    // helper that queues "on the call's stream" (control words, small copies, the launchers) follows without knowing.
+    // Where the head of the call is queued.  `ctx->stream` IS that stream until the hand-back, so every helper that queues
+    // "on the call's stream" (control words, small copies, the launchers) follows without knowing.
+    //   * head stream (IPCFP_HEAD_STREAM=1, measured and off): the tipset prologue runs BESIDE the CID index's inserts — it waits for the point where
+    //     the table was cleared, not for the inserts behind it, and its lookups wait for their keys (tipset_prepare.hip
+    //     LiveIndex); the main stream takes over with k_enum_roots.  Not when a block may exceed the prologue's LDS stage
+    //     (the general companion wants the finished index).
+    //   * narrow stream (IPCFP_RESERVE_CUS, measured and off): prologue, roots and the narrow interior levels on reserved
+    //     CUs, behind the inserts; launch_dense_walk hands back.
     struct StreamSwap {
         ipcfp_ctx* c;
         hipStream_t saved;
@@ -67,7 +71,13 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
             c->stream = saved;
         }
     } swap{ctx, ctx->stream};
-    if (ctx->stream_narrow) {
+    const bool need_general = uint64_t(w->max_block_len) + 32u > uint64_t(kPrologueStageChunks) * 16u;
+    const bool head = ctx->stream_head && w->index_event && w->index_done.p && !need_general;
+    if (head) {
+        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_head, w->index_event, 0));  // the witness is in place, the table cleared
+        IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_head, ctx->ctl_event, 0));  // the control block re-initialised
+        ctx->stream = ctx->stream_head;
+    } else if (ctx->stream_narrow) {
         IPCFP_HIP(ctx, hipEventRecord(ctx->narrow_event, ctx->stream));  // behind the index build (and the preprimed control block)
         IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_narrow, ctx->narrow_event, 0));
         ctx->stream = ctx->stream_narrow;
@@ -79,21 +89,29 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     rc = exec_state_prepare(ctx, ex, P);
     if (rc) return rc;
     PrepareJob job{tcs_d.p, ex.roots.p, ex.err.p};
-    std::unique_ptr<ProfileScope> prof(new ProfileScope(ctx, IPCFP_K_TIPSET_PROLOGUE));
-    rc = launch_tipset_prepare(ctx, view, &job, nullptr, 1,
-                               /*need_general=*/uint64_t(w->max_block_len) + 32u > uint64_t(kPrologueStageChunks) * 16u);
-    if (rc) return rc;
-    // ---- the roots; their shapes come back through the mailbox ----
     DevBuf<EnumNode> frontier;
     DevBuf<DenseNode> dense_frontier;
     DevBuf<uint32_t> small_own;
     DevBuf<uint64_t> info_own;
-    uint32_t* small = nullptr;  // [0] = max height (unused here), [2] = anomaly flag of the dense walk
+    uint32_t* small = nullptr;  // [0] = max height (unused here), [2] = anomaly flag (the dense walk, the live lookups)
     uint64_t* info_d = nullptr;
     IPCFP_HIP(ctx, frontier.alloc(n_all));
     IPCFP_HIP(ctx, dense_frontier.alloc(n_all));
     IPCFP_HIP(ctx, ctl_words(ctx, small_own, small, 4, false));
     IPCFP_HIP(ctx, ctl_words(ctx, info_own, info_d, 2 * size_t(n_all), false));
+    std::unique_ptr<ProfileScope> prof(new ProfileScope(ctx, IPCFP_K_TIPSET_PROLOGUE));
+    rc = head ? launch_tipset_prepare(ctx, view, &job, nullptr, 1, false, w->index_done.p, w->index_wgs, small + 2)
+              : launch_tipset_prepare(ctx, view, &job, nullptr, 1, need_general);
+    if (rc) return rc;
+    if (head) {  // hand back: the main stream (behind the inserts by its own order) waits for the prologue
+        IPCFP_HIP(ctx, hipEventRecord(ctx->head_event, ctx->stream));
+        IPCFP_HIP(ctx, hipStreamWaitEvent(swap.saved, ctx->head_event, 0));
+        ctx->stream = swap.saved;
+        for (auto& r : ctx->pending)
+            if (r.stream == ctx->stream_head) r.stream = ctx->stream;
+        if (prof) prof->stream = ctx->stream;
+    }
+    // ---- the roots; their shapes come back through the mailbox ----
     const unsigned long long seq = ++ctx->mailbox_seq;
     rc = launch_enum_roots(ctx, view, ex.roots.p, n_all, VK_CID, frontier.p, small, ex.err.p, info_d, ctx->mailbox_dev, seq,
                            dense_frontier.p);
@@ -205,6 +223,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     rc = event_table_join(ctx, w);
     if (rc) return rc;
     if (ctx->k1_defer == 2 && (rc = k1_flush(ctx, true))) return rc;
+    if ((rc = upload_task_wait(ctx))) return rc;  // claims that were crossing PCIe beside all of the above are in HBM
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, 1, blob_d, blob_len, trust ? *trust : accept_all, filter, status_d,
                               where_d, /*tabulated=*/true);
     if (rc) return rc;

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../common.h"
 #include "../kernels/launch.h"
@@ -26,8 +28,11 @@ constexpr uint64_t kTailSlack = 256;  // K1 may read one 128-byte chunk past a b
 // Shared tail of the constructors: `raw_bytes_d/raw_off_d` hold the caller's layout on
 // the device; build the aligned arena (adopting nothing: the witness owns its copy),
 // the lane schedule and the CID index.
-int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
-                          const uint32_t* len_d_src, const uint8_t* cids_d_src) {
+// `host_bytes` (nullable): the payload is still in HOST memory and crosses PCIe here, into raw_bytes_d, once everything
+// that needs only the tables has been queued (the K1 schedule, the arena layout, the CID index run beside the copy).
+int witness_finish_create_from(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
+                               const uint32_t* len_d_src, const uint8_t* cids_d_src, const uint8_t* host_bytes,
+                               uint64_t host_nbytes) {
     const uint32_t n = uint32_t(w->n);
     if (const char* e = std::getenv("IPCFP_EVENT_TABLE")) w->use_event_table = std::atoi(e) != 0;
     IPCFP_HIP(ctx, w->off.alloc(n));
@@ -72,13 +77,30 @@ int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_b
     w->arena_bytes = total + kTailSlack;
     IPCFP_HIP(ctx, w->arena.alloc(w->arena_bytes));
     IPCFP_HIP(ctx, hipMemsetAsync(w->arena.p + total, 0, kTailSlack, ctx->stream));
-    rc = launch_repack(ctx, raw_bytes_d, raw_off_d, w->len.p, w->off.p, n, w->arena.p);
-    if (rc) return rc;
-
+    // the CID index needs the CIDs only: its inserts run while the payload crosses PCIe (ipcfp_witness_create)
     rc = witness_build_index(ctx, w);
+    if (rc) return rc;
+    if (host_bytes && host_nbytes) {
+        static const bool ring = [] {
+            const char* e = std::getenv("IPCFP_UPLOAD_MODE");
+            return e && std::atoi(e) != 0;
+        }();
+        if (ring) {
+            rc = upload(ctx, const_cast<uint8_t*>(raw_bytes_d), host_bytes, host_nbytes, ctx->stream);
+            if (rc) return rc;
+        } else {  // the runtime's blocking copy (host/upload.cpp), WITHOUT draining the stream: nothing queued reads or writes raw_bytes_d
+            IPCFP_HIP(ctx, hipMemcpy(const_cast<uint8_t*>(raw_bytes_d), host_bytes, host_nbytes, hipMemcpyHostToDevice));
+        }
+    }
+    rc = launch_repack(ctx, raw_bytes_d, raw_off_d, w->len.p, w->off.p, n, w->arena.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     return IPCFP_OK;
+}
+
+int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
+                          const uint32_t* len_d_src, const uint8_t* cids_d_src) {
+    return witness_finish_create_from(ctx, w, raw_bytes_d, raw_off_d, len_d_src, cids_d_src, nullptr, 0);
 }
 
 }  // namespace ipcfp
@@ -107,12 +129,36 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
     if (n && (!off || !len || !cids40)) return set_error(ctx, IPCFP_E_INVALID, "null table pointer");
     if (nbytes && !bytes) return set_error(ctx, IPCFP_E_INVALID, "null bytes pointer");
     if (n >= 0xffffffffull) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
+    // every block inside the buffer (nothing is uploaded before this is known); a million-block table is checked by a
+    // few threads — on one it is ≈ 1.5 ms of a 15 ms upload
     uint64_t payload = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        if (off[i] > nbytes || uint64_t(len[i]) > nbytes - off[i])
-            return set_error(ctx, IPCFP_E_INVALID, "block %llu [%llu,+%u) lies outside the %llu-byte buffer",
-                             (unsigned long long)i, (unsigned long long)off[i], len[i], (unsigned long long)nbytes);
-        payload += len[i];
+    {
+        const unsigned T = n >= (1u << 18) ? 4u : 1u;
+        std::vector<uint64_t> sum(T, 0), bad(T, ~0ull);
+        auto part = [&](unsigned t) {
+            const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
+            uint64_t acc = 0;
+            for (uint64_t i = lo; i < hi; ++i) {
+                if (off[i] > nbytes || uint64_t(len[i]) > nbytes - off[i]) {
+                    bad[t] = i;
+                    break;
+                }
+                acc += len[i];
+            }
+            sum[t] = acc;
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(part, t);
+        part(0);
+        for (auto& th : pool) th.join();
+        for (unsigned t = 0; t < T; ++t) {
+            if (bad[t] != ~0ull) {
+                const uint64_t i = bad[t];  // (the first offender: the parts are in index order)
+                return set_error(ctx, IPCFP_E_INVALID, "block %llu [%llu,+%u) lies outside the %llu-byte buffer",
+                                 (unsigned long long)i, (unsigned long long)off[i], len[i], (unsigned long long)nbytes);
+            }
+            payload += sum[t];
+        }
     }
     IPCFP_ENTER(ctx);
     std::unique_ptr<ipcfp_witness> w(new (std::nothrow) ipcfp_witness());
@@ -129,14 +175,15 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
     IPCFP_HIP(ctx, raw_len.alloc(n));
     IPCFP_HIP(ctx, raw_cids.alloc(n * IPCFP_CID_SLOT));
     int rc = IPCFP_OK;
-    // tables first: the layout kernels only need len[] and can run while the payload is still crossing PCIe
+    // tables first; the payload crosses PCIe inside witness_finish_create, beside the kernels that need only the tables.
+    // (Two blocking copies at once — the payload on a thread of its own — deliver 38 GB/s together where one delivers 56:
+    // tools/ubench/h2d_paths.)
     if (n) {
-        if ((rc = upload(ctx, raw_len.p, len, n * 4, ctx->stream))) return rc;
-        if ((rc = upload(ctx, raw_off.p, off, n * 8, ctx->stream))) return rc;
-        if ((rc = upload(ctx, raw_cids.p, cids40, n * IPCFP_CID_SLOT, ctx->stream))) return rc;
+        rc = upload(ctx, raw_len.p, len, n * 4, ctx->stream);
+        if (!rc) rc = upload(ctx, raw_off.p, off, n * 8, ctx->stream);
+        if (!rc) rc = upload(ctx, raw_cids.p, cids40, n * IPCFP_CID_SLOT, ctx->stream);
     }
-    if (nbytes && (rc = upload(ctx, raw_bytes.p, bytes, nbytes, ctx->stream))) return rc;
-    rc = witness_finish_create(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p);
+    if (!rc) rc = witness_finish_create_from(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p, bytes, nbytes);
     if (rc) return rc;
     *out = w.release();
     return IPCFP_OK;

@@ -975,15 +975,7 @@ int amt_enumerate_cached(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, i
     e->vkind = vkind;
     e->lo = lo;
     e->hi = hi;
-    WitnessView view;
-    view.arena = w->arena.p;
-    view.off = w->off.p;
-    view.len = w->len.p;
-    view.cids = w->cids.p;
-    view.slots = w->index_slots.p;
-    view.mask = w->index_mask;
-    view.n = uint32_t(w->n);
-    view.touched = nullptr;
+    const WitnessView view = witness_view(w);
     DevBuf<AmtRootSpec> roots;
     DevBuf<unsigned long long> err_own;
     DevBuf<uint32_t> flag_own;

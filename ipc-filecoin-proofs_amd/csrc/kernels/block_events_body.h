@@ -9,6 +9,47 @@ namespace ipcfp {
 
 // EVERY lane of the wavefront calls this (the record reservation is a wave-level prefix sum); the lanes with `mine`
 // parse the block their reader sits on.  On success br becomes RK_TABLE; it is left alone otherwise (RK_WALK).
+// The root of an events AMT in the shape FVM writes it — `84 bw 00 count 83 4x bitmap 80 8n`: bit width and height as
+// immediate uints, the count immediate or one byte, a leaf node whose bitmap has the length the width asks for, no
+// links, up to 255 values — settled from the 16 bytes at the head of the block without a branch.  Exactly what the item-
+// by-item decode below accepts for these bytes (same bitmap, same value count, same position afterwards); any other
+// spelling returns false with the reader untouched and the item-by-item decode takes the block.  Eight item headers
+// are ≈ 550 instructions, and every lane of every wavefront of k_block_events pays them.
+__device__ __forceinline__ bool amt_leaf_root_fast(Rd& r, uint32_t& nv, uint64_t& bits) {
+    if (r.err || r.pos != 0u || r.n < 8u) return false;
+    uint64_t w0, w1;
+    r.peek128(0u, w0, w1);
+    const uint32_t b0 = uint32_t(w0) & 0xffu, bw = uint32_t(w0 >> 8) & 0xffu, b2 = uint32_t(w0 >> 16) & 0xffu,
+                   b3 = uint32_t(w0 >> 24) & 0xffu;
+    bool ok = b0 == 0x84u && bw >= 1u && bw <= 6u && b2 == 0u;
+    const bool c_imm = b3 < 0x18u, c_1 = b3 == 0x18u;
+    ok = ok && (c_imm || c_1);
+    const uint32_t o = c_imm ? 4u : 5u;                    // the node: 83, the bitmap's header, the bitmap
+    const uint32_t bwq = (bw >= 1u && bw <= 6u) ? bw : 1u;
+    const uint32_t width = 1u << bwq, bl = (width + 7u) / 8u;  // 1, 1, 1, 2, 4, 8 bytes
+    const uint64_t nw = bytes_from(w0, w1, o);
+    ok = ok && (uint32_t(nw) & 0xffffu) == (0x83u | ((0x40u + bl) << 8));
+    const uint32_t bo = o + 2u;                            // 6 or 7
+    uint64_t bm = bytes_from(w0, w1, bo);                  // the bitmap's bytes (byte 0 = indices 0..7) and what follows
+    const uint32_t to = bo + bl;                           // links header, values header: byte 7..16
+    ok = ok && to + 2u <= 16u;
+    const uint32_t tq = to + 2u <= 16u ? to : 8u;
+    const uint64_t tw = bytes_from(w0, w1, tq > 8u ? 8u : tq) >> (tq > 8u ? 8u * (tq - 8u) : 0u);
+    const uint32_t l = uint32_t(tw) & 0xffu, v = uint32_t(tw >> 8) & 0xffu, v2 = uint32_t(tw >> 16) & 0xffu;
+    const bool v_imm = (v >> 5) == 4u && (v & 31u) < 24u, v_1 = v == 0x98u && tq + 3u <= 16u;
+    ok = ok && l == 0x80u && (v_imm || v_1);
+    if (bl < 8u) bm &= (1ull << (8u * bl)) - 1ull;
+    if (width < 64u) bm &= (1ull << width) - 1ull;
+    const uint32_t nvals = v_imm ? (v & 31u) : v2;
+    const uint32_t total = to + (v_imm ? 2u : 3u);
+    ok = ok && total <= r.n && nvals == uint32_t(__popcll(bm));
+    if (!ok) return false;
+    nv = nvals;
+    bits = bm;
+    r.pos = total;
+    return true;
+}
+
 __device__ __forceinline__ void block_events_parse(Rd& r, bool mine, uint64_t arena_off, const ScanParams& sp, int count_matches,
                                                    EventRec* __restrict__ erecs, uint32_t cap_events, uint32_t n_parts,
                                                    uint32_t* __restrict__ pool_used, uint32_t wave_no, uint32_t lane,
@@ -17,7 +58,9 @@ __device__ __forceinline__ void block_events_parse(Rd& r, bool mine, uint64_t ar
     uint32_t nv = 0;
     uint64_t bits = 0;
     bool table = false;
-    if (mine) {
+    if (mine && amt_leaf_root_fast(r, nv, bits)) {
+        table = true;
+    } else if (mine) {
         r.expect_array(4);
         const uint64_t bw = r.read_uint();
         if (r.ok() && (bw < 1 || bw > 6)) r.fail();

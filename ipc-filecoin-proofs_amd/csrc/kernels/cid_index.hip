@@ -17,28 +17,20 @@
 
 namespace ipcfp {
 
-// CAS_FIRST: the probe IS the compare-and-swap (at load ≤ 0.5 most home slots are empty: one round trip to the table
-// instead of a read followed by the CAS); otherwise the slot is read first and the CAS only tried on an empty one.
+// `done`: every workgroup counts itself when its keys are in (all its atomics have returned by then), so that a reader on
+// another stream can tell a key that is not in the table YET from one that never will be (tipset_prepare.hip LiveIndex).
 template <bool CAS_FIRST>
 __global__ __launch_bounds__(256) void k_index_insert(const uint8_t* __restrict__ cids, uint32_t n,
-                                                      uint32_t* __restrict__ slots, uint32_t mask) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const CidKey key = load_cid_slot(cids, i);
-    uint32_t s = cid_hash(key) & mask;
-    for (;;) {
-        uint32_t cur = CAS_FIRST ? kNoBlock : slots[s];
-        if (cur == kNoBlock) {
-            cur = atomicCAS(&slots[s], kNoBlock, i);
-            if (cur == kNoBlock) return;  // claimed an empty slot
-        }
-        // slot owned by block `cur` (its CID identity never changes once claimed)
-        if (cid_equal(load_cid_slot(cids, cur), key)) {
-            atomicMax(&slots[s], i);  // duplicate CID: last block wins
-            return;
-        }
-        s = (s + 1) & mask;
-    }
+                                                      uint32_t* __restrict__ slots, uint32_t mask, uint32_t* __restrict__ done) {
+    // workgroups are handed out in blockIdx order: the even ones take the table of CIDs from the front, the odd ones from
+    // the back, so that BOTH ends of the witness are in within the first microseconds — a recorded witness holds the
+    // headers and roots first (they are read first), one built bottom-up holds them last, and the tipset prologue on the
+    // head stream is waiting for exactly those keys
+    const uint32_t wg = (blockIdx.x & 1u) ? gridDim.x - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    const uint32_t i = wg * blockDim.x + threadIdx.x;
+    if (i < n) index_insert_key<CAS_FIRST>(cids, slots, mask, i);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(done, 1u);
 }
 
 // (The same table in two passes — every key first STORES its id on its home slot, then only the keys that find another
@@ -52,6 +44,13 @@ int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
     if (w->index_slots.count != size) IPCFP_HIP(ctx, w->index_slots.alloc(size));  // rebuilds reuse the table
     w->index_mask = size - 1;
     IPCFP_HIP(ctx, hipMemsetAsync(w->index_slots.p, 0xff, size_t(size) * 4, ctx->stream));
+    if (!w->index_done.p) IPCFP_HIP(ctx, w->index_done.alloc_unpooled(1));
+    IPCFP_HIP(ctx, hipMemsetAsync(w->index_done.p, 0, 4, ctx->stream));
+    w->index_wgs = div_up(n, 256);
+    if (ctx->stream_head) {  // "the table is cleared": where a lookup on the head stream may start
+        if (!w->index_event) IPCFP_HIP(ctx, hipEventCreateWithFlags(&w->index_event, hipEventDisableTiming));
+        IPCFP_HIP(ctx, hipEventRecord(w->index_event, ctx->stream));
+    }
     if (n == 0) return IPCFP_OK;
     {
         ProfileScope prof(ctx, IPCFP_K_CID_INDEX);
@@ -61,10 +60,10 @@ int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
         }();
         if (cas_first)
             hipLaunchKernelGGL(k_index_insert<true>, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n,
-                               w->index_slots.p, w->index_mask);
+                               w->index_slots.p, w->index_mask, w->index_done.p);
         else
             hipLaunchKernelGGL(k_index_insert<false>, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w->cids.p, n,
-                               w->index_slots.p, w->index_mask);
+                               w->index_slots.p, w->index_mask, w->index_done.p);
     }
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

@@ -75,14 +75,54 @@ __device__ __forceinline__ bool decode_entry_fast(Rd& r, uint32_t& ko, uint32_t&
     return true;
 }
 
+// 16 bytes as two little-endian words → the 8 bytes that start at byte o (o ≤ 8; beyond byte 15: zeros)
+__device__ __forceinline__ uint64_t bytes_from(uint64_t w0, uint64_t w1, uint32_t o) {
+    const uint32_t sh = 8u * (o & 7u);
+    const uint64_t lo = o < 8u ? w0 : w1, hi = o < 8u ? w1 : 0ull;
+    return (lo >> sh) | ((hi << 1) << (63u - sh));
+}
+
+// The head of a StampedEvent — `82`, the emitter (a uint in any of its five widths), the header of the entries array
+// (up to 255 entries) — from the 16 bytes at the reader's position, without a branch: what expect_array(2) / read_uint /
+// read_array accept for these very bytes, with the same values and the same position afterwards.  Any other spelling
+// (an array header with a 2-8 byte count, an item that runs off the block, a reader that has failed) returns false
+// with the reader untouched and the three general decodes take it — three item headers are ≈ 200 instructions.
+__device__ __forceinline__ bool decode_event_head_fast(Rd& r, uint64_t& emitter, uint64_t& n_entries) {
+    const uint32_t p0 = r.pos;
+    if (r.err || p0 > r.n || r.n - p0 < 3u) return false;
+    uint64_t w0, w1;
+    r.peek128(p0, w0, w1);
+    const uint32_t b0 = uint32_t(w0) & 0xffu, b1 = uint32_t(w0 >> 8) & 0xffu;
+    const uint32_t ai = b1 & 31u;
+    bool ok = b0 == 0x82u && (b1 >> 5) == 0u && ai <= 27u;
+    const uint32_t nb = ai < 24u ? 0u : (1u << ((ai - 24u) & 3u));            // 0, 1, 2, 4, 8 argument bytes
+    const uint64_t arg = __builtin_bswap64(bytes_from(w0, w1, 2u));            // bytes 2..9, big-endian
+    const uint64_t em = ai < 24u ? uint64_t(ai) : (nb == 8u ? arg : (arg >> ((64u - 8u * nb) & 63u)));
+    const uint32_t ho = 2u + nb;                                               // the entries array's header: byte 2..10
+    const uint64_t hw = bytes_from(w0, w1, ho > 8u ? 8u : ho) >> (ho > 8u ? 8u * (ho - 8u) : 0u);
+    const uint32_t h = uint32_t(hw) & 0xffu;
+    const bool h_imm = (h >> 5) == 4u && (h & 31u) < 24u, h_1 = h == 0x98u;
+    ok = ok && (h_imm || h_1);
+    const uint32_t total = ho + (h_imm ? 1u : 2u);
+    ok = ok && total <= r.n - p0;
+    if (!ok) return false;
+    emitter = em;
+    n_entries = h_imm ? uint64_t(h & 31u) : uint64_t(uint32_t(hw >> 8) & 0xffu);
+    r.pos = p0 + total;
+    return true;
+}
+
 // Decode one StampedEvent `[emitter, [[flags, key, codec, value]…]]` located at r (already
 // type-checked by the AMT walk) and extract the EVM log view.  Offsets are relative to r.p.
 __device__ __forceinline__ void decode_event_log(Rd& r, uint64_t& emitter, EvmLogLoc& log) {
     ByteRange topics{0, 0, false}, data{0, 0, false}, d{0, 0, false};
     ByteRange t[4] = {{0, 0, false}, {0, 0, false}, {0, 0, false}, {0, 0, false}};
-    r.expect_array(2);
-    emitter = r.read_uint();
-    const uint64_t ne = r.read_array();
+    uint64_t ne;
+    if (!decode_event_head_fast(r, emitter, ne)) {
+        r.expect_array(2);
+        emitter = r.read_uint();
+        ne = r.read_array();
+    }
     for (uint64_t i = 0; i < ne && r.ok(); ++i) {
         uint32_t ko, kl, vo, vl;
         if (!decode_entry_fast(r, ko, kl, vo, vl)) {

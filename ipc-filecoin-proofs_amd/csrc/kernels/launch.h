@@ -90,8 +90,10 @@ int launch_scan_tiles_u64(ipcfp_ctx* ctx, uint64_t* tile_sums_d, uint32_t ntiles
 int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* total_d, const uint32_t* first_d,
                        const uint32_t* pos_d, uint32_t n, uint32_t* inv_d);
 // jobs_d: device array of {TipsetCtxDev* ctx, AmtRootSpec* roots (nullable), unsigned long long* err}
+// live_done / live_total / anomaly: the CID index is still being filled on another stream (tipset_prepare.hip LiveIndex)
 int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs, const void* jobs_d, uint32_t n_jobs,
-                          bool need_general);
+                          bool need_general, const uint32_t* live_done = nullptr, uint32_t live_total = 0,
+                          uint32_t* anomaly = nullptr);
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
                       unsigned long long* err_d, int verify_txmeta = 1);
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,

@@ -26,6 +26,77 @@ namespace ipcfp {
 
 typedef __attribute__((address_space(3))) const uint8_t* lds_bytes_t;
 
+// ---- lookups in an index that is still being filled ---------------------------------------------------------------------
+// k_index_insert (main stream) fills the table while the prologue's wavefronts (head stream, host/verify_fast.cpp) look
+// their few CIDs up: the prologue is a chain of dependent steps per slot — look the header up, stage it, decode ≈ 100
+// CBOR items on one lane, look the TxMeta up, decode it, re-hash it — ≈ 130 µs that used to start when the ≈ 120 µs of
+// inserts had finished.  Such a lookup
+// can only err one way: a key that is not in the table YET (an entry never moves and the slots in front of it never
+// empty, so a key that is in is found), or — a CID that occurs twice — an id that a later insert still raises.  So a
+// miss is retried until the key shows up or every insert workgroup has counted itself done, whatever was found is
+// taken as provisional, and at the end of its slot the wavefront waits for the count and looks every key up once more:
+// a different answer (or a wait that ran out) raises the call's anomaly flag, and the caller does the batch again the
+// general way.  Reads of the table are device-scope atomic loads (other XCDs' L2s are filling it).
+constexpr uint32_t kLiveSpinMax = 1u << 21;  // ≈ 2 s of 1 µs naps: a launch that cannot finish must not hang the device
+struct LiveIndex {
+    const uint32_t* done;  // workgroups of the insert part that have finished; null: the index is complete (plain lookups)
+    uint32_t total;
+    uint32_t n_used;
+    bool failed;
+    CidKey k0, k1;  // (two named slots, not an array: a dynamically indexed member would live in scratch)
+    uint32_t b0, b1;
+};
+__device__ __forceinline__ uint32_t live_probe(const WitnessView& w, const CidKey& key) {
+    uint32_t s = cid_hash(key) & w.mask;
+    for (;;) {
+        const uint32_t b = __hip_atomic_load(&w.slots[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b == kNoBlock) return kNoBlock;
+        if (cid_equal(load_cid_slot(w.cids, b), key)) return b;
+        s = (s + 1) & w.mask;
+    }
+}
+__device__ __forceinline__ bool live_complete(const LiveIndex& li) {
+    return __hip_atomic_load(li.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= li.total;
+}
+// every lane of the wavefront, same key
+__device__ __forceinline__ uint32_t find_block(const WitnessView& w, LiveIndex& li, const CidKey& key) {
+    if (!li.done) return witness_find(w, key);
+    uint32_t b = kNoBlock;
+    for (uint32_t spin = 0;; ++spin) {
+        const bool complete = live_complete(li);  // read BEFORE the probe: a miss after `complete` is final
+        b = live_probe(w, key);
+        if (b != kNoBlock || complete) break;
+        if (spin >= kLiveSpinMax) {
+            li.failed = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (li.n_used == 0) {
+        li.k0 = key;
+        li.b0 = b;
+    } else if (li.n_used == 1) {
+        li.k1 = key;
+        li.b1 = b;
+    } else {
+        li.failed = true;
+    }
+    ++li.n_used;
+    return b;
+}
+// end of a slot: the provisional answers against the finished index
+__device__ __forceinline__ void live_validate(const WitnessView& w, LiveIndex& li, uint32_t* anomaly) {
+    if (!li.done) return;
+    bool bad = li.failed;
+    for (uint32_t spin = 0; !bad && !live_complete(li); ++spin) {
+        if (spin >= kLiveSpinMax) bad = true;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (!bad && li.n_used > 0) bad = live_probe(w, li.k0) != li.b0;
+    if (!bad && li.n_used > 1) bad = live_probe(w, li.k1) != li.b1;
+    if (bad && threadIdx.x == 0) atomicOr(anomaly, 1u);
+}
+
 // every lane of the wavefront: block b → the stage; false when it does not fit
 __device__ __forceinline__ bool stage_block(const WitnessView& w, uint32_t b, rd_chunk_t* stage, uint32_t& len) {
     len = w.len[b];
@@ -43,14 +114,14 @@ __device__ __forceinline__ void flag_general(TipsetCtxDev& c, uint32_t slot) {
 
 // slots 0 / 1: the child header / the first parent header (ctx_headers_body in verify_events.hip is the general form)
 __device__ __forceinline__ void headers_slot(const WitnessView& w, TipsetCtxDev& c, bool child_part, rd_chunk_t* stage,
-                                             AmtRootSpec* receipts_spec) {
+                                             AmtRootSpec* receipts_spec, LiveIndex& li) {
     const bool lead = threadIdx.x == 0;
     const bool parsed = (c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
     uint32_t status = IPCFP_ST_ERR_BAD_CLAIM, match = 0;
     long long height = 0;
     const bool wanted = parsed && (child_part || c.n_parents > 0);
     if (wanted) {
-        const uint32_t hb = witness_find(w, child_part ? c.child : c.parents[0]);  // uniform across the wavefront
+        const uint32_t hb = find_block(w, li, child_part ? c.child : c.parents[0]);  // uniform across the wavefront
         if (hb == kNoBlock) {
             status = IPCFP_ST_ERR_MISSING_BLOCK;
         } else {
@@ -105,7 +176,7 @@ __device__ __forceinline__ void headers_slot(const WitnessView& w, TipsetCtxDev&
 // slot 2 + b: parent block b → its header, its TxMeta (re-hashed), its two message-AMT roots
 // (exec_roots_body in verify_events.hip is the general form; error sequence numbers as there)
 __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c, AmtRootSpec* __restrict__ roots,
-                                           unsigned long long* __restrict__ err, uint32_t b, rd_chunk_t* stage) {
+                                           unsigned long long* __restrict__ err, uint32_t b, rd_chunk_t* stage, LiveIndex& li) {
     __shared__ CidKey s_tx;
     __shared__ uint32_t s_have_tx;
     const uint32_t P = c.n_parents;
@@ -114,7 +185,7 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
     auto fail = [&](uint32_t seq, uint32_t code) { atomicMin(err, (unsigned long long)pack_enum_error(seq, 0, code)); };
     // reconstruct_execution_order (utils.rs:20-27): the parent header
     if (lead) s_have_tx = 0;
-    const uint32_t hb = witness_find(w, c.parents[b]);
+    const uint32_t hb = find_block(w, li, c.parents[b]);
     if (hb == kNoBlock) {
         if (lead) fail(b, IPCFP_ST_ERR_MISSING_BLOCK);
     } else {
@@ -143,7 +214,7 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
     bls.skip = secp.skip = 1;
     if (s_have_tx) {
         const CidKey tx = s_tx;
-        const uint32_t tb = witness_find(w, tx);  // :58-60
+        const uint32_t tb = find_block(w, li, tx);  // :58-60
         if (tb == kNoBlock) {
             if (lead) fail(seq, IPCFP_ST_ERR_MISSING_BLOCK);
         } else {
@@ -199,17 +270,25 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
     }
 }
 
-__global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, PrepareJobs jobs, uint32_t n_jobs) {
+// `live_done` non-null: the CID index is being filled beside this launch (LiveIndex above); `anomaly`: the call's flag.
+__global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, PrepareJobs jobs, uint32_t n_jobs, const uint32_t* live_done,
+                                                       uint32_t live_total, uint32_t* anomaly) {
     __shared__ rd_chunk_t stage[kPrologueStageChunks];
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
     const PrepareJob jb = prepare_job(jobs, job);
-    if (slot < 2) headers_slot(w, *jb.ctx, slot == 0, stage, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
-    else if (jb.roots) roots_slot(w, *jb.ctx, jb.roots, jb.err, slot - 2, stage);
+    LiveIndex li{};
+    li.done = live_done;
+    li.total = live_total;
+    if (slot < 2) headers_slot(w, *jb.ctx, slot == 0, stage, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr, li);
+    else if (jb.roots) roots_slot(w, *jb.ctx, jb.roots, jb.err, slot - 2, stage, li);
+    live_validate(w, li, anomaly);
 }
 
-void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs) {
-    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs, n_jobs);
+void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs,
+                               const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly) {
+    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs, n_jobs, live_done, live_total,
+                       anomaly);
 }
 
 }  // namespace ipcfp

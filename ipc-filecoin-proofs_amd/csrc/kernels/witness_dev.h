@@ -92,6 +92,32 @@ __device__ __forceinline__ CidKey cid_key_from_bytes(const uint8_t* p, uint32_t 
     return k;
 }
 
+// One key into the CID → block-id table (K4; kernels/cid_index.hip, and the fused index + prologue launch of
+// tipset_prepare.hip).  Open addressing, linear probing; the probe IS the compare-and-swap (at load ≤ 0.5 most home
+// slots are empty: one round trip to the table instead of a read followed by the CAS).  An entry never moves once
+// placed; a duplicate CID raises the slot to the larger block id (last block wins).  Every atomic's result is
+// consumed, so the lane has seen it performed before it goes on (the completion count of the fused launch relies on it).
+template <bool CAS_FIRST>
+__device__ __forceinline__ void index_insert_key(const uint8_t* __restrict__ cids, uint32_t* __restrict__ slots, uint32_t mask,
+                                                 uint32_t i) {
+    const CidKey key = load_cid_slot(cids, i);
+    uint32_t s = cid_hash(key) & mask;
+    for (;;) {
+        uint32_t cur = CAS_FIRST ? kNoBlock : slots[s];
+        if (cur == kNoBlock) {
+            cur = atomicCAS(&slots[s], kNoBlock, i);
+            if (cur == kNoBlock) return;  // claimed an empty slot
+        }
+        // slot owned by block `cur` (its CID identity never changes once claimed)
+        if (cid_equal(load_cid_slot(cids, cur), key)) {
+            const uint32_t old = atomicMax(&slots[s], i);  // duplicate CID: last block wins
+            asm volatile("" ::"v"(old));
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
 // Blockstore::get → block id, or kNoBlock when the CID is not in the witness.
 __device__ __forceinline__ uint32_t witness_find(const WitnessView& w, const CidKey& key) {
     uint32_t s = cid_hash(key) & w.mask;

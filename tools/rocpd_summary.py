@@ -16,7 +16,7 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--timeline", action="store_true")
     ap.add_argument("--pmc", action="store_true")
-    ap.add_argument("--step-marker", default="k_index_insert", help="kernel that starts a bench step")
+    ap.add_argument("--step-marker", default="k_index_", help="kernel that starts a bench step")
     args = ap.parse_args()
     c = sqlite3.connect(args.db)
     if args.pmc:
