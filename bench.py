@@ -273,7 +273,7 @@ def main():
               "ms_phases": {k: round(v * 1e3, 3) for k, v in best.items() if k != "total"},
               "h2d_bytes": h2d_bytes, "h2d_GBps_if_all_transfer": h2d_bytes / best["total"] / 1e9, "reps": len(reps),
               "ms_all_reps": [round(r["total"] * 1e3, 3) for r in reps],
-              "note": "pageable host numpy buffers in, host status bytes out; claims in packed binary form"}
+              "note": "pageable host numpy buffers in, host status bytes out; claims in packed binary form; calls in the order of the resident step (K, V, S); uploads are the runtime's blocking copies (56 GB/s measured, tools/ubench/h2d_paths), the claims cross beside the verify call's AMT walk"}
 
     # ---- the full scan result, untimed, for the oracle cross-check of the cpu_baseline leg ----
     gpu_scan = None
@@ -839,7 +839,7 @@ def tipset_kernels(tip, kern, steps, n_claims, claim_bytes, bracketed_ms):
                      "latency (3 dependent levels, then leaves)", "k_dense_level, k_dense_link_leaves, k_dense_leaves",
                      "message AMTs + receipts AMT read once; 8 B per message key and 16 B per receipt leaf written"),
         "exec_order": (28.0 * n_msgs, "hbm", "latency (hash-table insert, scan, scatter)",
-                       "k_exec_insert, k_exec_first_sums, k_exec_apply_finish",
+                       "k_exec_insert_flags, k_exec_flag_sums, k_scan_tiles_u64, k_exec_apply_finish",
                        "per message: 8-byte key, 8-byte slot, first/pos/inv words"),
         "event_scan": (float(st["events_amt_bytes"]) + 24.0 * n_receipts, "hbm", "valu+latency (one CBOR parser per lane)",
                        "k_block_events_linestage, k_receipt_events, k_count_from_table (aux stream)",

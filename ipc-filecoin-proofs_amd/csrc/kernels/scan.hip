@@ -22,16 +22,29 @@ __global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* __restri
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_tiles_u64(uint64_t* __restrict__ tile_sums, uint32_t ntiles,
-                                                         uint64_t* __restrict__ total_out) {
+// One workgroup of FOUR wavefronts (four items per lane), not sixteen: a 1024-thread workgroup needs sixteen free
+// wavefront slots on ONE compute unit at the same moment, and beside K1's grid it waited 143 µs for them
+// (profiles/r03_experiments.md); four find room anywhere.
+__global__ __launch_bounds__(256) void k_scan_tiles_u64(uint64_t* __restrict__ tile_sums, uint32_t ntiles,
+                                                        uint64_t* __restrict__ total_out) {
     __shared__ uint64_t smem[17];
     uint64_t carry = 0;
     for (uint32_t base = 0; base < ntiles; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint64_t v = i < ntiles ? tile_sums[i] : 0;
+        const uint32_t i0 = base + threadIdx.x * 4u;
+        uint64_t v[4];
+        uint64_t s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = i0 + k < ntiles ? tile_sums[i0 + k] : 0;
+            s += v[k];
+        }
         uint64_t total;
-        const uint64_t ex = block_exclusive_scan(v, smem, &total);
-        if (i < ntiles) tile_sums[i] = carry + ex;
+        uint64_t ex = carry + block_exclusive_scan(s, smem, &total);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < ntiles) tile_sums[i0 + k] = ex;
+            ex += v[k];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) *total_out = carry;
@@ -58,22 +71,23 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     }
 }
 
-// n ≤ 4096: the whole scan in one workgroup, one launch (most tree levels are this small)
-__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict__ in, uint32_t n,
-                                                     uint32_t* __restrict__ out, uint64_t* __restrict__ total_out) {
+// n ≤ 4096: the whole scan in one workgroup (four wavefronts, sixteen items per lane), one launch (most tree levels are
+// this small)
+__global__ __launch_bounds__(256) void k_scan_small(const uint32_t* __restrict__ in, uint32_t n,
+                                                    uint32_t* __restrict__ out, uint64_t* __restrict__ total_out) {
     __shared__ uint64_t smem[17];
-    const uint32_t base = threadIdx.x * 4u;
-    uint32_t r[4];
+    const uint32_t base = threadIdx.x * 16u;
+    uint32_t r[16];
     uint64_t s = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 16; ++k) {
         r[k] = (base + k < n) ? in[base + k] : 0;
         s += r[k];
     }
     uint64_t total;
     uint64_t ex = block_exclusive_scan(s, smem, &total);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 16; ++k) {
         if (base + k < n) out[base + k] = uint32_t(ex);
         ex += r[k];
     }
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict_
 
 // exclusive scan IN PLACE of ntiles u64 tile sums; *total_d = their sum (one workgroup)
 int launch_scan_tiles_u64(ipcfp_ctx* ctx, uint64_t* tile_sums_d, uint32_t ntiles, uint64_t* total_d) {
-    hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(1024), 0, ctx->stream, tile_sums_d, ntiles, total_d);
+    hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(256), 0, ctx->stream, tile_sums_d, ntiles, total_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
@@ -95,13 +109,13 @@ int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* 
         return IPCFP_OK;
     }
     if (n <= 4096) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, in_d, n, out_d, total_d);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(256), 0, ctx->stream, in_d, n, out_d, total_d);
         IPCFP_HIP(ctx, hipGetLastError());
         return IPCFP_OK;
     }
     const uint32_t ntiles = div_up(n, 1024);
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, ctx->stream, in_d, n, scratch_d);
-    hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(1024), 0, ctx->stream, scratch_d, ntiles, total_d);
+    hipLaunchKernelGGL(k_scan_tiles_u64, dim3(1), dim3(256), 0, ctx->stream, scratch_d, ntiles, total_d);
     hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(256), 0, ctx->stream, in_d, n, scratch_d, out_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
