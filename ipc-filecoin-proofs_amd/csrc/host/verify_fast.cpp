@@ -144,6 +144,16 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, b.alloc(plan.biggest));
     IPCFP_HIP(ctx, ex.keys.alloc(n_msgs));
     IPCFP_HIP(ctx, rleaves.alloc(n_rcpt));
+    // the execution order's hash table and first-occurrence flags: sized now, cleared by the walk's last kernel on the way
+    uint32_t size = 64;
+    while (size < 2ull * n_msgs) size <<= 1;
+    ex.mask = size - 1;
+    ex.raw_len = n_msgs;
+    IPCFP_HIP(ctx, ex.slots.alloc(size));
+    IPCFP_HIP(ctx, ex.first.alloc(n_msgs));
+    IPCFP_HIP(ctx, ex.pos.alloc(n_msgs));
+    IPCFP_HIP(ctx, ex.inv.alloc(n_msgs));
+    const DenseClear clear{ex.slots.p, size, ex.first.p, n_msgs};
     prof.reset(new ProfileScope(ctx, IPCFP_K_AMT_WALK));
     // the receipt leaves are consumed on the aux stream (k_receipt_events), the message keys on the main stream: the two
     // leaf kernels fork accordingly and run side by side (IPCFP_LEAVES_AUX=0: both on the main stream, one after the other)
@@ -153,7 +163,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     }();
     rc = launch_dense_walk(ctx, view, dense_frontier.p, plan, a.p, b.p, nullptr, ex.keys.p, rleaves.p, small + 2,
                            leaves_aux ? ctx->stream_aux : nullptr, leaves_aux ? ctx->main_event : nullptr,
-                           ctx->stream != swap.saved ? swap.saved : nullptr, ctx->narrow_event, ctx->narrow_max_wg);
+                           ctx->stream != swap.saved ? swap.saved : nullptr, ctx->narrow_event, ctx->narrow_max_wg, &clear);
     if (rc) return rc;
     // (the main stream now waits for everything the narrow stream was given: its small copies are the main stream's)
     for (auto& r : ctx->pending)
@@ -186,17 +196,8 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream_aux));
     w->bt_joined = false;
     // the execution order: first-seen dedupe of the message CIDs, positions, inverse — main stream, beside the above
-    uint32_t size = 64;
-    while (size < 2ull * n_msgs) size <<= 1;
-    ex.mask = size - 1;
-    ex.raw_len = n_msgs;
-    IPCFP_HIP(ctx, ex.slots.alloc(size));
-    IPCFP_HIP(ctx, ex.first.alloc(n_msgs));
-    IPCFP_HIP(ctx, ex.pos.alloc(n_msgs));
-    IPCFP_HIP(ctx, ex.inv.alloc(n_msgs));
     prof.reset(new ProfileScope(ctx, IPCFP_K_EXEC_ORDER));
-    IPCFP_HIP(ctx, hipMemsetAsync(ex.slots.p, 0xff, size_t(size) * 8, ctx->stream));
-    IPCFP_HIP(ctx, hipMemsetAsync(ex.first.p, 0, size_t(n_msgs) * 4, ctx->stream));
+    // (table and flags were cleared by the walk's k_dense_link_leaves: launch_dense_walk `clear`)
     rc = launch_exec_insert_flags(ctx, ex.keys.p, n_msgs, ex.slots.p, ex.mask, ex.first.p);
     if (rc) return rc;
     DevBuf<uint64_t> tiles;

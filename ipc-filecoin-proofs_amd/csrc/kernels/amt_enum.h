@@ -78,6 +78,13 @@ struct DensePlan {
     uint64_t n_leaves = 0, n_extra = 0, biggest = 0;
     DenseRoots roots{};
 };
+// what k_dense_link_leaves clears on the side (launch_dense_walk `clear`; only when the plan has key values)
+struct DenseClear {
+    unsigned long long* slots;  // n_slots × ~0
+    uint64_t n_slots;
+    uint32_t* words;            // n_words × 0
+    uint64_t n_words;
+};
 void dense_plan(const std::vector<uint64_t>& root_info, uint32_t n_roots, int vkind, bool want_keys, uint64_t lo, uint64_t hi,
                 uint32_t has_extra, int extra_vkind, uint64_t extra_lo, uint64_t extra_hi, DensePlan& plan);
 int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* frontier, const DensePlan& plan,
@@ -87,7 +94,8 @@ int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* 
                       // non-null: the caller runs on the narrow stream (ctx->stream is that stream); the first level of more
                       // than `narrow_max_wg` workgroups — the leaves at the latest — hands over to `wide_stream` through
                       // `wide_event`, and ctx->stream is `wide_stream` on return
-                      hipStream_t wide_stream = nullptr, hipEvent_t wide_event = nullptr, uint32_t narrow_max_wg = 0);
+                      hipStream_t wide_stream = nullptr, hipEvent_t wide_event = nullptr, uint32_t narrow_max_wg = 0,
+                      const DenseClear* clear = nullptr);
 
 int launch_enum_roots(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_all, int vkind,
                       EnumNode* frontier_d, uint32_t* max_height_d, unsigned long long* err_d, uint64_t* root_info_d,

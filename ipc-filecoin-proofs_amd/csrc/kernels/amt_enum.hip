@@ -442,8 +442,15 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const DenseN
 // VALUE.  The leaf is validated by its values' lanes exactly as an interior node by its children's.
 __global__ __launch_bounds__(256) void k_dense_link_leaves(WitnessView w, const DenseNode* __restrict__ cur, const DenseRoots roots_arg,
                                                            uint32_t n_key_roots, uint64_t n_values, uint32_t* __restrict__ anomaly,
-                                                           CidKey* __restrict__ keys_main) {
+                                                           CidKey* __restrict__ keys_main, DenseClear clear) {
     const uint64_t v = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    // (a passenger: the execution order's hash table and first-occurrence flags, which the kernels right behind this one
+    // fill, are cleared by this grid instead of by two fill kernels of their own in front of them)
+    {
+        const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+        for (uint64_t j = v; j < clear.n_slots; j += stride) clear.slots[j] = ~0ull;
+        for (uint64_t j = v; j < clear.n_words; j += stride) clear.words[j] = 0u;
+    }
     if (v >= n_values) return;
     // which root (the key trees come first among the roots), which value
     const DenseRoot* roots = roots_arg.r;
@@ -650,7 +657,7 @@ void dense_plan(const std::vector<uint64_t>& root_info, uint32_t n_roots, int vk
 int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* frontier, const DensePlan& plan,
                       DenseNode* a, DenseNode* b, LeafRef* leaves_main, CidKey* keys_main, LeafRef* leaves_extra, uint32_t* anomaly_d,
                       hipStream_t leaves_stream, hipEvent_t fork_event, hipStream_t wide_stream, hipEvent_t wide_event,
-                      uint32_t narrow_max_wg) {
+                      uint32_t narrow_max_wg, const DenseClear* clear) {
     const DenseNode* src = frontier;
     auto widen = [&]() -> hipError_t {  // the narrow stream's part ends here
         if (!wide_stream || ctx->stream == wide_stream) return hipSuccess;
@@ -700,9 +707,13 @@ int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* 
     (void)key_nodes;
     hipLaunchKernelGGL(k_dense_leaves, dim3(div_up(n_nodes, 256)), dim3(256), 0, ls, view, src, plan.roots, n_nodes, 0u,
                        leaves_main, anomaly_d, leaves_extra);
+    if (clear && !n_key_values) {  // (no lane to take the passenger)
+        if (clear->n_slots) IPCFP_HIP(ctx, hipMemsetAsync(clear->slots, 0xff, clear->n_slots * 8, ctx->stream));
+        if (clear->n_words) IPCFP_HIP(ctx, hipMemsetAsync(clear->words, 0, clear->n_words * 4, ctx->stream));
+    }
     if (n_key_values)
         hipLaunchKernelGGL(k_dense_link_leaves, dim3(div_up(n_key_values, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots,
-                           n_key_roots, n_key_values, anomaly_d, keys_main);
+                           n_key_roots, n_key_values, anomaly_d, keys_main, clear ? *clear : DenseClear{nullptr, 0, nullptr, 0});
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
