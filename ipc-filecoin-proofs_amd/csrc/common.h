@@ -106,6 +106,7 @@ struct ipcfp_ctx {
     unsigned long long* mailbox_dev = nullptr;  // the same page as the device addresses it
     unsigned long long mailbox_seq = 0;
     hipEvent_t main_event = nullptr;            // aux stream ← main stream dependency (host/verify_fast.cpp)
+    hipEvent_t rehash_event = nullptr;          // main stream ← the deferred TxMeta re-hashes on the aux stream (verify_fast.cpp)
     // --- reserved CUs (env IPCFP_RESERVE_CUS = CUs per XCD, 0 = off; host/context.cpp): the latency-bound head of a
     // verify call — tipset prologue, AMT roots, the narrow interior levels — runs on a stream confined to the reserved
     // CUs while the two side streams (K1, the block-order event parse) are confined to all the others, so those few

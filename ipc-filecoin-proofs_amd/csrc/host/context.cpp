@@ -285,6 +285,7 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
             hipHostMalloc(&hp, 4096, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
             if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess &&
                 hipEventCreateWithFlags(&ctx->main_event, hipEventDisableTiming) == hipSuccess) {
+                if (hipEventCreateWithFlags(&ctx->rehash_event, hipEventDisableTiming) != hipSuccess) ctx->rehash_event = nullptr;
                 std::memset(hp, 0, 4096);
                 ctx->mailbox = static_cast<unsigned long long*>(hp);
                 ctx->mailbox_dev = static_cast<unsigned long long*>(dp);
@@ -333,6 +334,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
     if (ctx->stream_aux != ctx->stream) (void)hipStreamDestroy(ctx->stream_aux);
     if (ctx->stream_k1 != ctx->stream) (void)hipStreamDestroy(ctx->stream_k1);
+    if (ctx->rehash_event) (void)hipEventDestroy(ctx->rehash_event);
     if (ctx->stream_narrow) (void)hipStreamDestroy(ctx->stream_narrow);
     if (ctx->stream_copy) (void)hipStreamDestroy(ctx->stream_copy);
     if (ctx->stream_head) (void)hipStreamDestroy(ctx->stream_head);

@@ -84,7 +84,11 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     }
     DevBuf<TipsetCtxDev> tcs_d;
     IPCFP_HIP(ctx, tcs_d.alloc(1));
-    IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, tcs.data(), sizeof(TipsetCtxDev), ctx->stream));
+    {
+        TipsetCtxDev init = tcs[0];
+        for (uint32_t b = 0; b < IPCFP_MAX_PARENTS; ++b) init.txmeta_block[b] = kNoBlock;  // (nothing left to re-hash yet)
+        IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, &init, sizeof(TipsetCtxDev), ctx->stream));
+    }
     ExecState ex;
     rc = exec_state_prepare(ctx, ex, P);
     if (rc) return rc;
@@ -100,8 +104,12 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     IPCFP_HIP(ctx, ctl_words(ctx, small_own, small, 4, false));
     IPCFP_HIP(ctx, ctl_words(ctx, info_own, info_d, 2 * size_t(n_all), false));
     std::unique_ptr<ProfileScope> prof(new ProfileScope(ctx, IPCFP_K_TIPSET_PROLOGUE));
-    rc = head ? launch_tipset_prepare(ctx, view, &job, nullptr, 1, false, w->index_done.p, w->index_wgs, small + 2)
-              : launch_tipset_prepare(ctx, view, &job, nullptr, 1, need_general);
+    // (the TxMeta re-hashes — ≈ 3 k one-lane instructions per parent that gate nothing, they only ever add an error — are
+    // left to a launch of their own on the aux stream, joined at the end of the call; not when a block may need the
+    // general companion, which hashes inline)
+    const bool defer_rehash = !need_general && ctx->rehash_event != nullptr;
+    rc = head ? launch_tipset_prepare(ctx, view, &job, nullptr, 1, false, w->index_done.p, w->index_wgs, small + 2, defer_rehash)
+              : launch_tipset_prepare(ctx, view, &job, nullptr, 1, need_general, nullptr, 0, nullptr, defer_rehash);
     if (rc) return rc;
     if (head) {  // hand back: the main stream (behind the inserts by its own order) waits for the prologue
         IPCFP_HIP(ctx, hipEventRecord(ctx->head_event, ctx->stream));
@@ -195,6 +203,11 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
     if (rc) return rc;
     IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream_aux));
     w->bt_joined = false;
+    if (defer_rehash) {  // behind the receipts' event records, which the verify kernel waits for — this it does not wait for
+        rc = launch_txmeta_rehash(ctx, ctx->stream_aux, view, tcs_d.p, ex.err.p);
+        if (rc) return rc;
+        IPCFP_HIP(ctx, hipEventRecord(ctx->rehash_event, ctx->stream_aux));
+    }
     // the execution order: first-seen dedupe of the message CIDs, positions, inverse — main stream, beside the above
     prof.reset(new ProfileScope(ctx, IPCFP_K_EXEC_ORDER));
     // (table and flags were cleared by the walk's k_dense_link_leaves: launch_dense_walk `clear`)
@@ -229,6 +242,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
                               where_d, /*tabulated=*/true);
     if (rc) return rc;
     if ((rc = k1_flush(ctx, true))) return rc;  // (mode 3, and whatever is still noted)
+    if (defer_rehash) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->rehash_event, 0));  // its errors are in before the flags are read
     // ---- the one synchronisation: did the dense walk hold? ----
     uint32_t bad = 0;
     unsigned long long e = kNoEnumError;

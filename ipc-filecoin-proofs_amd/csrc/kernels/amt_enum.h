@@ -100,6 +100,8 @@ int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* 
 int launch_enum_roots(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_all, int vkind,
                       EnumNode* frontier_d, uint32_t* max_height_d, unsigned long long* err_d, uint64_t* root_info_d,
                       unsigned long long* mailbox, unsigned long long mailbox_seq, DenseNode* dense_frontier_d);
+struct TipsetCtxDev;
+int launch_txmeta_rehash(ipcfp_ctx* ctx, hipStream_t stream, const WitnessView& view, const TipsetCtxDev* ctx_d, unsigned long long* err_d);
 
 // Enumerate `n_roots` AMTs (device array `roots_d`) whose values have type `vkind`.
 // `err_d` is a device u64 initialised by the caller (kNoEnumError or earlier-stage errors); the

@@ -8,7 +8,9 @@
 #include <vector>
 
 #include "../common.h"
+#include "blake2b_dev.h"
 #include "launch.h"
+#include "tipset_ctx.h"
 
 namespace ipcfp {
 
@@ -44,6 +46,76 @@ __device__ __forceinline__ void enum_root_one(const WitnessView& w, const AmtRoo
     }
     *slot = e;
     if (dense_slot) *dense_slot = d;
+}
+
+// The TxMeta re-hash of parent block b, left here by the tipset prologue (tipset_ctx.h txmeta_block): put_cbor(&(bls_root,
+// secp_root), Blake2b256) must give the CID the header named (src/proofs/events/utils.rs:65-72; the verify path always
+// checks).  The block was decoded by the prologue already; its CID is the key it was found under.
+__device__ __forceinline__ void txmeta_rehash_lane(const WitnessView& w, const TipsetCtxDev& c, uint32_t b, unsigned long long* __restrict__ err) {
+    if (b >= c.n_parents || b >= IPCFP_MAX_PARENTS) return;
+    const uint32_t tb = c.txmeta_block[b];
+    if (tb == kNoBlock) return;
+    const uint32_t seq = c.n_parents + 3 * b;
+    Rd r;
+    r.init(w.arena + w.off[tb], w.len[tb]);
+    uint32_t o[2], l[2];
+    r.expect_array(2);
+    r.read_link(o[0], l[0]);
+    r.read_link(o[1], l[1]);
+    r.finish();
+    if (!r.ok() || l[0] > 64u || l[1] > 64u) {  // (the prologue took this very block: not reachable)
+        enum_error(err, seq, 0, IPCFP_ST_ERR_DECODE);
+        return;
+    }
+    uint64_t d[4];
+    if (w.len[tb] == 87u && o[0] == 6u && l[0] == 38u && o[1] == 49u && l[1] == 38u) {
+        // `82 | d8 2a 58 27 00 ‖ 38 | d8 2a 58 27 00 ‖ 38`: the canonical re-encoding IS the block — one compression
+        // straight from its bytes (blocks sit on 128-byte lines with tail slack), no byte buffer in scratch
+        uint64_t m[16];
+        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(w.arena + w.off[tb]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const ulonglong2 v = k < 6 ? q[k] : ulonglong2{0ull, 0ull};
+            m[2 * k] = v.x;
+            m[2 * k + 1] = v.y;
+        }
+        b2b::mask_tail(m, 87u);
+        uint64_t h[8];
+        b2b::init256(h);
+        b2b::compress<0>(h, m, 87ull, true);
+        d[0] = h[0];
+        d[1] = h[1];
+        d[2] = h[2];
+        d[3] = h[3];
+    } else {
+    uint8_t enc[200];
+    uint32_t n = 0;
+    enc[n++] = 0x82;
+    for (int k = 0; k < 2; ++k) {
+        enc[n++] = 0xd8;
+        enc[n++] = 0x2a;
+        const uint32_t bl = l[k] + 1;
+        if (bl < 24) enc[n++] = uint8_t(0x40 | bl);
+        else { enc[n++] = 0x58; enc[n++] = uint8_t(bl); }
+        enc[n++] = 0x00;
+        for (uint32_t i = 0; i < l[k]; ++i) enc[n++] = uint8_t(r.at(o[k] + i));
+    }
+    blake2b256_small(enc, n, d);
+    }
+    CidKey re;
+    re.w[0] = 0x00002002e4a07101ULL | (d[0] << 48);
+    re.w[1] = (d[0] >> 16) | (d[1] << 48);
+    re.w[2] = (d[1] >> 16) | (d[2] << 48);
+    re.w[3] = (d[2] >> 16) | (d[3] << 48);
+    re.w[4] = d[3] >> 16;
+    if (!cid_equal(re, load_cid_slot(w.cids, tb))) enum_error(err, seq, 0, IPCFP_ST_ERR_TXMETA_MISMATCH);
+}
+
+// one lane per parent block.  Nothing waits for this launch but the end of the call (host/verify_fast.cpp queues it on
+// the aux stream behind the receipts' event records): as a second workgroup of k_enum_roots it took 123 µs and held
+// the first level of the walk back for as long.
+__global__ __launch_bounds__(64) void k_txmeta_rehash(WitnessView w, const TipsetCtxDev* __restrict__ c, unsigned long long* __restrict__ err) {
+    txmeta_rehash_lane(w, *c, threadIdx.x, err);
 }
 
 // roots → frontier (one entry per root, in root order)
@@ -968,6 +1040,13 @@ int launch_enum_roots(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec
     if (n_all == 0 || n_all > 64) return IPCFP_E_INVALID;
     hipLaunchKernelGGL(k_enum_roots, dim3(1), dim3(64), 0, ctx->stream, view, roots_d, n_all, vkind, frontier_d, max_height_d, err_d,
                        root_info_d, mailbox, mailbox_seq, dense_frontier_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+// the TxMeta re-hashes the tipset prologue left behind (tipset_ctx.h txmeta_block), on `stream`
+int launch_txmeta_rehash(ipcfp_ctx* ctx, hipStream_t stream, const WitnessView& view, const TipsetCtxDev* ctx_d, unsigned long long* err_d) {
+    hipLaunchKernelGGL(k_txmeta_rehash, dim3(1), dim3(64), 0, stream, view, ctx_d, err_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

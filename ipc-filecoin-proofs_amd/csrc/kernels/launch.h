@@ -93,7 +93,7 @@ int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* tota
 // live_done / live_total / anomaly: the CID index is still being filled on another stream (tipset_prepare.hip LiveIndex)
 int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs, const void* jobs_d, uint32_t n_jobs,
                           bool need_general, const uint32_t* live_done = nullptr, uint32_t live_total = 0,
-                          uint32_t* anomaly = nullptr);
+                          uint32_t* anomaly = nullptr, bool defer_rehash = false);  // defer_rehash: see tipset_ctx.h txmeta_block
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
                       unsigned long long* err_d, int verify_txmeta = 1);
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,

@@ -24,6 +24,10 @@ struct TipsetCtxDev {
     uint32_t parent0_status;   // TRUE or ERR_* for parent_cids[0]
     uint32_t prologue_general;  // bit s: slot s of the tipset prologue is left to the general kernel (a block larger than the LDS stage)
     long long parent0_height;
+    // the TxMeta block of parent b when its re-hash was LEFT to k_txmeta_rehash (amt_enum.hip; tipset_prepare.hip
+    // roots_slot with `defer_rehash`); kNoBlock: nothing to re-hash (checked inline, or never reached).  The host
+    // initialises every entry to kNoBlock.
+    uint32_t txmeta_block[IPCFP_MAX_PARENTS];
     // execution order (filled by the host after the enumeration)
     uint32_t exec_status;      // TRUE or the first ERR_* of reconstruct_execution_order
     uint32_t exec_mask;        // hash-table size - 1

@@ -176,7 +176,8 @@ __device__ __forceinline__ void headers_slot(const WitnessView& w, TipsetCtxDev&
 // slot 2 + b: parent block b → its header, its TxMeta (re-hashed), its two message-AMT roots
 // (exec_roots_body in verify_events.hip is the general form; error sequence numbers as there)
 __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c, AmtRootSpec* __restrict__ roots,
-                                           unsigned long long* __restrict__ err, uint32_t b, rd_chunk_t* stage, LiveIndex& li) {
+                                           unsigned long long* __restrict__ err, uint32_t b, rd_chunk_t* stage, LiveIndex& li,
+                                           bool defer_rehash) {
     __shared__ CidKey s_tx;
     __shared__ uint32_t s_have_tx;
     const uint32_t P = c.n_parents;
@@ -230,6 +231,14 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
                 r.finish();
                 if (!r.ok()) {
                     fail(seq, IPCFP_ST_ERR_DECODE);
+                } else if (defer_rehash) {
+                    // The re-hash — re-encode, one Blake2b compression on ONE lane, ≈ 3 k instructions — gates nothing: it
+                    // only ever adds an error.  A launch of its own on the aux stream does it (amt_enum.hip k_txmeta_rehash), joined
+                    // at the end of the call; a mismatch reaches the same error word with the same sequence number.
+                    c.txmeta_block[b] = tb;
+                    bls.root = l0 <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                    secp.root = l1 <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                    bls.skip = secp.skip = 0;
                 } else {
                     // put_cbor(&(bls_root, secp_root), Blake2b256): canonical re-encoding, hashed (:65-72)
                     uint8_t enc[200];
@@ -272,7 +281,7 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
 
 // `live_done` non-null: the CID index is being filled beside this launch (LiveIndex above); `anomaly`: the call's flag.
 __global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, PrepareJobs jobs, uint32_t n_jobs, const uint32_t* live_done,
-                                                       uint32_t live_total, uint32_t* anomaly) {
+                                                       uint32_t live_total, uint32_t* anomaly, int defer_rehash) {
     __shared__ rd_chunk_t stage[kPrologueStageChunks];
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
@@ -281,14 +290,14 @@ __global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, PrepareJob
     li.done = live_done;
     li.total = live_total;
     if (slot < 2) headers_slot(w, *jb.ctx, slot == 0, stage, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr, li);
-    else if (jb.roots) roots_slot(w, *jb.ctx, jb.roots, jb.err, slot - 2, stage, li);
+    else if (jb.roots) roots_slot(w, *jb.ctx, jb.roots, jb.err, slot - 2, stage, li, defer_rehash != 0);
     live_validate(w, li, anomaly);
 }
 
 void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs,
-                               const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly) {
+                               const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly, bool defer_rehash) {
     hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs, n_jobs, live_done, live_total,
-                       anomaly);
+                       anomaly, defer_rehash ? 1 : 0);
 }
 
 }  // namespace ipcfp
