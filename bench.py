@@ -445,13 +445,15 @@ class Ranks:
             self.comm = None
 
 
-def timed(ranks, step, steps, warmup):
-    """The contract's clock: W untimed steps, barrier + sync, K steps, barrier + sync, MAX over ranks."""
+def timed(ranks, step, steps, warmup, only=None):
+    """The contract's clock: W untimed steps, barrier + sync, K steps, barrier + sync, MAX over ranks.
+    `only`: bracket that kernel group alone over the timed region (as the single-GPU tipset run does: an event pair
+    around EVERY group costs a multi-kernel step about 5 %); None: every group."""
     for _ in range(warmup):
         step()
     ranks.fence()
     ranks.eng.profile_reset()
-    ranks.eng.profile_enable(True)
+    ranks.eng.profile_enable(True, only=only)
     ranks.fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -581,12 +583,21 @@ def run_tipset_batch(args, eng, info, torch, ranks):
                                  [shard.HEADER_BYTES, layout.w_status, layout.w_has, bits_bytes], d_stage.data_ptr(),
                                  d_recv.data_ptr(), layout.bytes_per_rank)                   # the ONE collective
 
-    elapsed = timed(ranks, step, args.steps, args.warmup)
+    # the timed region brackets K1 alone — the N = 1 point of a scaling curve is measured the same way — and the per-kernel
+    # table comes from a second, untimed pass of the same steps (every rank runs it: the step ends in a collective)
+    elapsed = timed(ranks, step, args.steps, args.warmup, only="blake2b_cid")
+    roof = k1_roofline(eng, tip.lens, tip.n_blocks)
+    eng.profile_reset()
+    eng.profile_enable(True)
+    ranks.fence()
+    for _ in range(args.steps):
+        step()
+    ranks.fence()
+    eng.profile_enable(False)
     kern = {}
     for k in STEP_KERNEL_GROUPS + ("allgather",):
         cnt, ms = eng.profile_read(k)
         kern[k] = {"launches": cnt, "ms_per_step": ms / args.steps}
-    roof = k1_roofline(eng, tip.lens, tip.n_blocks)
     # ---- what was timed must be right: EVERY rank checks EVERY tipset's gathered verdicts ----
     g = d_recv.cpu().numpy().reshape(world, layout.bytes_per_rank)
     total_claims, matches = 0, []
