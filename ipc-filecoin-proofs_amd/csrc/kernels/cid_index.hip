@@ -29,8 +29,10 @@ __global__ __launch_bounds__(256) void k_index_insert(const uint8_t* __restrict_
     const uint32_t wg = (blockIdx.x & 1u) ? gridDim.x - 1u - (blockIdx.x >> 1) : (blockIdx.x >> 1);
     const uint32_t i = wg * blockDim.x + threadIdx.x;
     if (i < n) index_insert_key<CAS_FIRST>(cids, slots, mask, i);
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(done, 1u);
+    if (done) {  // (only a context with a head stream has a reader for the count)
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(done, 1u);
+    }
 }
 
 // (The same table in two passes — every key first STORES its id on its home slot, then only the keys that find another
@@ -44,10 +46,10 @@ int witness_build_index(ipcfp_ctx* ctx, ipcfp_witness* w) {
     if (w->index_slots.count != size) IPCFP_HIP(ctx, w->index_slots.alloc(size));  // rebuilds reuse the table
     w->index_mask = size - 1;
     IPCFP_HIP(ctx, hipMemsetAsync(w->index_slots.p, 0xff, size_t(size) * 4, ctx->stream));
-    if (!w->index_done.p) IPCFP_HIP(ctx, w->index_done.alloc_unpooled(1));
-    IPCFP_HIP(ctx, hipMemsetAsync(w->index_done.p, 0, 4, ctx->stream));
     w->index_wgs = div_up(n, 256);
-    if (ctx->stream_head) {  // "the table is cleared": where a lookup on the head stream may start
+    if (ctx->stream_head) {  // the insert workgroups count themselves done; "the table is cleared": where a lookup on the head stream may start
+        if (!w->index_done.p) IPCFP_HIP(ctx, w->index_done.alloc_unpooled(1));
+        IPCFP_HIP(ctx, hipMemsetAsync(w->index_done.p, 0, 4, ctx->stream));
         if (!w->index_event) IPCFP_HIP(ctx, hipEventCreateWithFlags(&w->index_event, hipEventDisableTiming));
         IPCFP_HIP(ctx, hipEventRecord(w->index_event, ctx->stream));
     }
