@@ -591,6 +591,29 @@ int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
                             uint64_t* receipt_lo, uint64_t* receipt_hi, uint64_t* n_receipts, uint32_t* block_ids,
                             uint64_t cap_blocks, uint64_t* n_blocks);
 
+/* PLAN ONCE, SCATTER.  Every shard's plan in ONE call (one pass over the receipts instead of n_shards): run it where
+ * the whole witness is resident — the bundle's producer, or one rank — and hand rank r the list
+ * block_ids[shard_off[r] .. shard_off[r+1]) (ascending ids; the replicated blocks are in every list) and its receipts
+ * [receipt_bounds[r], receipt_bounds[r+1]).  Rank r then uploads ONLY its blocks (ipcfp_witness_cut_host +
+ * ipcfp_witness_create + ipcfp_witness_set_receipt_range) and its claims (ipcfp_route_event_claims): the G PCIe links
+ * of a node carry G different shards instead of G copies of the bundle.  Cuts the same loops as above.
+ *   receipt_bounds, shard_off   u64[n_shards + 1] each;  block_ids truncated to cap_ids, *n_ids = shard_off[n_shards]
+ *   *status_out                 IPCFP_ST_TRUE, or the ERR_* the traversal met first (the lists are then empty)       */
+#define IPCFP_MAX_SHARDS 64
+int ipcfp_shard_plan_tipset_all(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                                const uint8_t* child_cid40, uint32_t n_shards, ipcfp_status_t* status_out,
+                                uint64_t* n_receipts, uint64_t* receipt_bounds, uint64_t* shard_off, uint32_t* block_ids,
+                                uint64_t cap_ids, uint64_t* n_ids);
+
+/* Host only (no context, no device): blocks block_ids[0..n) of a witness that lies in HOST memory, packed back to back
+ * as a witness of their own — out_off[i] / out_len[i] / out_cids40[i] describe block block_ids[i], its bytes at
+ * out_bytes + out_off[i].  *nbytes_out = the payload size; call with every out pointer NULL to size the buffers.
+ * IPCFP_E_INVALID (nothing written) when an id is >= n_src or a block lies outside [0, nbytes).                    */
+int ipcfp_witness_cut_host(const uint8_t* bytes, uint64_t nbytes, const uint64_t* off, const uint32_t* len,
+                           const uint8_t* cids40, uint64_t n_src, const uint32_t* block_ids, uint64_t n,
+                           uint8_t* out_bytes, uint64_t cap_bytes, uint64_t* out_off, uint32_t* out_len,
+                           uint8_t* out_cids40, uint64_t* nbytes_out);
+
 /* A new witness made of blocks block_ids[0..n) of `src` (device-side copy; block i of the new witness is block
  * block_ids[i] of src), tagged as the receipt-range shard [receipt_lo, receipt_hi): ipcfp_scan_events walks only
  * those receipts (receipt_has_match[i - receipt_lo] is receipt i) and ipcfp_verify_event_* resolves them by table.
@@ -600,6 +623,17 @@ int ipcfp_witness_create_subset(ipcfp_ctx_t* ctx, ipcfp_witness_t* src, const ui
 /* Tag / read the receipt range of a witness created by other means (drops its cached enumerations).             */
 int ipcfp_witness_set_receipt_range(ipcfp_witness_t* w, uint64_t lo, uint64_t hi);
 void ipcfp_witness_receipt_range(const ipcfp_witness_t* w, uint64_t* lo, uint64_t* hi);
+
+/* Host only: the packed claims a receipt-range shard verifies — exec_index in [receipt_lo, receipt_hi); the LAST shard
+ * (last_shard != 0) also owns every claim whose exec_index is >= receipt_hi, so that each claim has exactly one owner
+ * (such a claim names no receipt: steps 1-3 of verify_single_proof, src/proofs/events/verifier.rs:92-204, settle it on
+ * data every rank holds).  The shard's claims keep their order and get a blob of their own (topics_off / data_off
+ * rewritten); positions[k] (nullable) = index of out_claims[k] in `claims`, which is where its status byte belongs
+ * when the shards' verdicts are merged.  Call with every out pointer NULL to size (*n_out claims, *blob_out bytes).  */
+int ipcfp_route_event_claims(const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob, uint64_t blob_len,
+                             uint64_t receipt_lo, uint64_t receipt_hi, int last_shard, uint64_t* positions,
+                             ipcfp_event_claim_t* out_claims, uint64_t cap_claims, uint8_t* out_blob, uint64_t cap_blob,
+                             uint64_t* n_out, uint64_t* blob_out);
 
 /* The collective: RCCL's ncclAllGather over xGMI, called directly (librccl.so.1 is resolved when the first
  * communicator is made; single-GPU hosts never need it).  One process per GPU; rank 0 makes the id

@@ -35,4 +35,6 @@ from .binding import (  # noqa: F401
     TIPSET_DTYPE,
     LOC_DTYPE,
     MATCH_DTYPE,
+    witness_cut_host,
+    route_event_claims,
 )

@@ -17,6 +17,8 @@ __all__ = [
     "STORAGE_SPEC_DTYPE",
     "Comm",
     "shard_range",
+    "witness_cut_host",
+    "route_event_claims",
     "comm_unique_id",
     "allgather_segments",
     "EngineError",
@@ -221,6 +223,11 @@ def load_library() -> C.CDLL:
         "ipcfp_shard_range": (None, [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]),
         "ipcfp_shard_plan_tipset": (i32, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(u64),
                                           C.POINTER(u64), C.POINTER(u64), vp, u64, C.POINTER(u64)]),
+        "ipcfp_shard_plan_tipset_all": (i32, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(u64), vp, vp, vp, u64,
+                                              C.POINTER(u64)]),
+        "ipcfp_witness_cut_host": (i32, [vp, u64, vp, vp, vp, u64, vp, u64, vp, u64, vp, vp, vp, C.POINTER(u64)]),
+        "ipcfp_route_event_claims": (i32, [vp, u64, vp, u64, u64, u64, i32, vp, vp, u64, vp, u64, C.POINTER(u64),
+                                           C.POINTER(u64)]),
         "ipcfp_witness_create_subset": (i32, [vp, vp, vp, u64, u64, u64, C.POINTER(vp)]),
         "ipcfp_witness_set_receipt_range": (i32, [vp, u64, u64]),
         "ipcfp_witness_receipt_range": (None, [vp, C.POINTER(u64), C.POINTER(u64)]),
@@ -397,6 +404,52 @@ def shard_range(n: int, n_shards: int, shard: int):
     lo, hi = C.c_uint64(), C.c_uint64()
     load_library().ipcfp_shard_range(int(n), int(n_shards), int(shard), C.byref(lo), C.byref(hi))
     return int(lo.value), int(hi.value)
+
+
+def witness_cut_host(data, off, lens, cids40, block_ids):
+    """Host only: blocks `block_ids` of a host-resident witness as a packed witness of their own
+    → (data u8[], off u64[], lens u32[], cids u8[n, 40])."""
+    lib = load_library()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    cids40 = np.ascontiguousarray(cids40, dtype=np.uint8)
+    ids = np.ascontiguousarray(block_ids, dtype=np.uint32)
+    nb = C.c_uint64()
+    rc = lib.ipcfp_witness_cut_host(_p(data), data.size, _p(off), _p(lens), _p(cids40), len(lens), _p(ids), len(ids),
+                                    None, 0, None, None, None, C.byref(nb))
+    if rc:
+        raise EngineError(f"witness_cut_host: {lib.ipcfp_strerror(rc).decode()}")
+    out = np.empty(int(nb.value), dtype=np.uint8)
+    o_off = np.empty(len(ids), dtype=np.uint64)
+    o_len = np.empty(len(ids), dtype=np.uint32)
+    o_cids = np.empty((len(ids), CID_SLOT), dtype=np.uint8)
+    rc = lib.ipcfp_witness_cut_host(_p(data), data.size, _p(off), _p(lens), _p(cids40), len(lens), _p(ids), len(ids),
+                                    _p(out), out.size, _p(o_off), _p(o_len), _p(o_cids), C.byref(nb))
+    if rc:
+        raise EngineError(f"witness_cut_host: {lib.ipcfp_strerror(rc).decode()}")
+    return out, o_off, o_len, o_cids
+
+
+def route_event_claims(claims: np.ndarray, blob: np.ndarray, blob_len: int, lo: int, hi: int, last: bool):
+    """Host only: the packed claims of the receipt-range shard [lo, hi) (ipcfp_route_event_claims)
+    → (positions u64[], claims, blob u8[] + 64 B slack, blob_len)."""
+    lib = load_library()
+    claims = np.ascontiguousarray(claims)
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    n_out, b_out = C.c_uint64(), C.c_uint64()
+    args = (_p(claims), len(claims), _p(blob), int(blob_len), int(lo), int(hi), int(bool(last)))
+    rc = lib.ipcfp_route_event_claims(*args, None, None, 0, None, 0, C.byref(n_out), C.byref(b_out))
+    if rc:
+        raise EngineError(f"route_event_claims: {lib.ipcfp_strerror(rc).decode()}")
+    n, nb = int(n_out.value), int(b_out.value)
+    pos = np.empty(n, dtype=np.uint64)
+    out = np.zeros(n, dtype=CLAIM_DTYPE)
+    oblob = np.zeros(nb + 64, dtype=np.uint8)
+    rc = lib.ipcfp_route_event_claims(*args, _p(pos), _p(out), n, _p(oblob), nb, C.byref(n_out), C.byref(b_out))
+    if rc:
+        raise EngineError(f"route_event_claims: {lib.ipcfp_strerror(rc).decode()}")
+    return pos, out, oblob, nb
 
 
 def comm_unique_id() -> bytes:
@@ -744,9 +797,11 @@ class Witness:
         return int(st[0]), out
 
     def scan_events(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor=None, want_touched=True,
-                    counts_only=False):
+                    counts_only=False, caps=None):
         """K6/K8.  Returns (status, has_match u8[n_receipts], matches structured[n], touched block ids);
-        with counts_only: (status, n_receipts, n_matches, None) and nothing is copied back."""
+        with counts_only: (status, n_receipts, n_matches, None) and nothing is copied back.
+        caps = (cap_receipts, cap_matches): ONE call into buffers of that size instead of a sizing call followed by
+        the real one (a host that knows its tipset's receipt count); falls back to the two-call form on overflow."""
         # (the marshalled arguments of the last call are kept: a scan repeated with the same filter — a service polling
         # one subnet's events, the benchmark's step — pays for the numpy / ctypes conversions once)
         key = (bytes(receipts_root), bytes(topic0), bytes(topic1))
@@ -760,6 +815,13 @@ class Witness:
             self._scan_args = cached
         _, root, filt, st, nr, nm, p_root, p_filt, p_st, r_nr, r_nm = cached
         a = (0, 0) if actor is None else (1, int(actor))
+        if caps is not None and not counts_only and not want_touched:
+            has = np.zeros(int(caps[0]), dtype=np.uint8)
+            m = np.zeros(int(caps[1]), dtype=MATCH_DTYPE)
+            self.eng._check(self.lib.ipcfp_scan_events(self.eng.h, self.h, p_root, p_filt, a[0], a[1], p_st, _p(has), len(has),
+                                                       r_nr, _p(m), len(m), r_nm, None), "scan_events")
+            if st[0] != 1 or (nr.value <= len(has) and nm.value <= len(m)):
+                return int(st[0]), has[: int(nr.value)], m[: int(nm.value)], None
         # sizing call, then the real one
         self.eng._check(self.lib.ipcfp_scan_events(self.eng.h, self.h, p_root, p_filt, a[0], a[1], p_st, None, 0,
                                                    r_nr, None, 0, r_nm, None), "scan_events")
@@ -858,6 +920,21 @@ class Witness:
                                                          int(n_shards), int(shard), _p(st), C.byref(lo), C.byref(hi),
                                                          C.byref(nr), _p(ids), len(ids), C.byref(nb)), "shard_plan_tipset")
         return int(st[0]), int(lo.value), int(hi.value), int(nr.value), ids[: int(nb.value)].copy()
+
+    def shard_plan_tipset_all(self, parent_cids, child_cid: bytes, n_shards: int):
+        """Every shard's plan in one call.  Returns (status, n_receipts, receipt_bounds u64[G+1], [ids of shard 0, …])."""
+        pc = pack_cids(parent_cids)
+        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        st = np.zeros(1, dtype=np.uint8)
+        nr, nids = C.c_uint64(), C.c_uint64()
+        bounds = np.zeros(n_shards + 1, dtype=np.uint64)
+        soff = np.zeros(n_shards + 1, dtype=np.uint64)
+        ids = np.zeros(max(self.n, 1) * int(n_shards), dtype=np.uint32)
+        self.eng._check(self.lib.ipcfp_shard_plan_tipset_all(self.eng.h, self.h, _p(pc), len(parent_cids), _p(child),
+                                                             int(n_shards), _p(st), C.byref(nr), _p(bounds), _p(soff),
+                                                             _p(ids), len(ids), C.byref(nids)), "shard_plan_tipset_all")
+        lists = [ids[int(soff[s]): int(soff[s + 1])].copy() for s in range(n_shards)]
+        return int(st[0]), int(nr.value), bounds, lists
 
     def subset(self, block_ids, receipt_lo: int = 0, receipt_hi: int = (1 << 64) - 1) -> "Witness":
         """A new witness of the listed blocks (device-side copy), tagged as the receipt-range shard [lo, hi)."""

@@ -46,6 +46,13 @@ struct ScanResult {
     uint64_t n_idx = 0, n_matches = 0;
     DevBuf<uint8_t> has;
     DevBuf<ipcfp_event_match_t> matches;
+    // caller-owned HBM outputs (ipcfp_scan_events_device): when set and large enough PASS 2 writes there directly
+    // (has_p / matches_p then point into them and `has` / `matches` stay empty) — no copy kernel behind the scan
+    uint8_t* ext_has = nullptr;
+    uint64_t ext_has_cap = 0;
+    ipcfp_event_match_t* ext_matches = nullptr;  // capacity = the call's cap_matches
+    uint8_t* has_p = nullptr;
+    ipcfp_event_match_t* matches_p = nullptr;
 };
 // `cap_matches`: how many matches the caller can take.  With a known capacity PASS 2 is launched right behind
 // PASS 1 (the kernel clips its writes) and the scan has ONE synchronisation; with kAllMatches the match count is

@@ -157,9 +157,14 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     IPCFP_HIP(ctx, scratch.alloc(size_t(div_up(n, 1024)) + 2));
     IPCFP_HIP(ctx, ctl_words(ctx, total_own, total_p, 1, false));
     struct { uint64_t* p; } total{total_p};
-    IPCFP_HIP(ctx, out.has.alloc(n_idx));
+    if (out.ext_has && out.ext_has_cap >= n_idx) {
+        out.has_p = out.ext_has;
+    } else {
+        IPCFP_HIP(ctx, out.has.alloc(n_idx));
+        out.has_p = out.has.p;
+    }
     // (a dense enumeration has a leaf for every index of the map and PASS 2 writes the byte of every leaf: nothing to clear)
-    if (n_idx && !en->dense) IPCFP_HIP(ctx, hipMemsetAsync(out.has.p, 0, n_idx, ctx->stream));
+    if (n_idx && !en->dense) IPCFP_HIP(ctx, hipMemsetAsync(out.has_p, 0, n_idx, ctx->stream));
     // PASS 1: with the events tabulated once per witness (kernels/event_table.h) — the first scan builds the table
     // and counts in one kernel, a later one (another filter) counts from the records
     EventTableView tview{nullptr, nullptr};
@@ -198,11 +203,16 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         }
         cap = nm;
     }
-    IPCFP_HIP(ctx, out.matches.alloc(cap));
+    if (out.ext_matches && cap == cap_matches) {
+        out.matches_p = out.ext_matches;
+    } else {
+        IPCFP_HIP(ctx, out.matches.alloc(cap));
+        out.matches_p = out.matches.p;
+    }
     WitnessView rec = view;
     rec.touched = touched_d;
     rc = launch_scan_pass2(ctx, rec, root, leaves, n, filter, has_actor, actor, cnt, offsets.p,
-                           cap ? out.matches.p : nullptr, cap, out.has.p, n_idx, lo, tview.receipts ? &tview : nullptr);
+                           cap ? out.matches_p : nullptr, cap, out.has_p, n_idx, lo, tview.receipts ? &tview : nullptr);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // delivers nm / e1 when they were not waited for above
     if (e_table < e1) e1 = e_table;
@@ -245,12 +255,12 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
     *n_matches = res.n_matches;
     bool queued = false;  // (a sizing call copies nothing back: the scan's own synchronisation was the last one it needs)
     if (receipt_has_match && res.n_idx && cap_receipts) {
-        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match, res.has.p, res.n_idx < cap_receipts ? res.n_idx : cap_receipts,
+        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match, res.has_p, res.n_idx < cap_receipts ? res.n_idx : cap_receipts,
                                       hipMemcpyDeviceToHost, ctx->stream));
         queued = true;
     }
     if (matches && res.n_matches && cap_matches) {
-        IPCFP_HIP(ctx, hipMemcpyAsync(matches, res.matches.p,
+        IPCFP_HIP(ctx, hipMemcpyAsync(matches, res.matches_p,
                                       (res.n_matches < cap_matches ? res.n_matches : cap_matches) * sizeof(ipcfp_event_match_t),
                                       hipMemcpyDeviceToHost, ctx->stream));
         queued = true;
@@ -277,6 +287,9 @@ int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t
     *n_receipts = *n_matches = 0;
     *status_out = IPCFP_ST_ERR;
     ScanResult res;
+    res.ext_has = static_cast<uint8_t*>(receipt_has_match_d);
+    res.ext_has_cap = receipt_has_match_d ? cap_receipts : 0;
+    res.ext_matches = cap_matches ? static_cast<ipcfp_event_match_t*>(matches_d) : nullptr;
     int rc = scan_events_device(ctx, w, key_from_slot(receipts_root40), *filter, has_actor, actor, nullptr, res,
                                 matches_d ? cap_matches : 0);
     if (rc) return rc;
@@ -288,14 +301,20 @@ int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t
     if (res.status != IPCFP_ST_TRUE) return IPCFP_OK;
     *n_receipts = res.n_idx;
     *n_matches = res.n_matches;
-    if (receipt_has_match_d && res.n_idx)
-        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match_d, res.has.p, res.n_idx < cap_receipts ? res.n_idx : cap_receipts,
+    // PASS 2 wrote straight into the caller's buffers when they were large enough; otherwise a (truncating) copy
+    bool copied = false;
+    if (receipt_has_match_d && res.n_idx && res.has_p != receipt_has_match_d) {
+        IPCFP_HIP(ctx, hipMemcpyAsync(receipt_has_match_d, res.has_p, res.n_idx < cap_receipts ? res.n_idx : cap_receipts,
                                       hipMemcpyDeviceToDevice, ctx->stream));
-    if (matches_d && res.n_matches)
-        IPCFP_HIP(ctx, hipMemcpyAsync(matches_d, res.matches.p,
+        copied = true;
+    }
+    if (matches_d && res.n_matches && res.matches_p != matches_d) {
+        IPCFP_HIP(ctx, hipMemcpyAsync(matches_d, res.matches_p,
                                       (res.n_matches < cap_matches ? res.n_matches : cap_matches) * sizeof(ipcfp_event_match_t),
                                       hipMemcpyDeviceToDevice, ctx->stream));
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // `res` returns its buffers to the pool on exit
+        copied = true;
+    }
+    if (copied || summary_d) IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // `res` returns its buffers to the pool on exit
     ctl_preprime(ctx);
     return IPCFP_OK;
 }

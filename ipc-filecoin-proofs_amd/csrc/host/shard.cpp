@@ -100,27 +100,11 @@ void ipcfp_shard_range(uint64_t n, uint32_t n_shards, uint32_t shard, uint64_t* 
     if (hi) *hi = q * (shard + 1) + (r * (uint64_t(shard) + 1)) / n_shards;
 }
 
-int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
-                            const uint8_t* child_cid40, uint32_t n_shards, uint32_t shard, ipcfp_status_t* status_out,
-                            uint64_t* receipt_lo, uint64_t* receipt_hi, uint64_t* n_receipts, uint32_t* block_ids,
-                            uint64_t cap_blocks, uint64_t* n_blocks) {
-    if (!ctx || !w || w->ctx != ctx || !child_cid40 || !status_out || !receipt_lo || !receipt_hi || !n_blocks ||
-        (n_parents && !parent_cids40) || n_shards == 0 || shard >= n_shards)
-        return IPCFP_E_INVALID;
-    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
-    IPCFP_ENTER(ctx);
-    *n_blocks = 0;
-    *receipt_lo = *receipt_hi = 0;
-    if (n_receipts) *n_receipts = 0;
-    *status_out = IPCFP_ST_ERR;
-    const uint32_t words = div_up(uint32_t(w->n), 32);
-    DevBuf<uint32_t> touched;
-    IPCFP_HIP(ctx, touched.alloc(words + 1));
-    IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, size_t(words + 1) * 4, ctx->stream));
-    uint32_t* missing_d = touched.p + words;
-    const WitnessView rec = witness_view(w, touched.p);
-    // the tipset pair: child header (→ receipts root), parent headers, TxMeta, message AMTs — on every rank
-    TipsetCtxDev tc;
+// The part of a plan every shard shares, walked with the recorder `rec`: child header (→ receipts root), parent
+// headers, TxMeta, message AMTs (the execution order is global), then `Amtv0::load` of the receipts root for its count.
+// *status_out != TRUE: the traversal failed there and nothing else is valid.
+static int plan_replicated(ipcfp_ctx* ctx, const WitnessView& rec, const uint8_t* parent_cids40, uint32_t n_parents,
+                           const uint8_t* child_cid40, TipsetCtxDev& tc, uint64_t& count, ipcfp_status_t* status_out) {
     std::memset(&tc, 0, sizeof tc);
     tc.flags = TC_PARENTS_PARSED | TC_CHILD_PARSED;
     tc.n_parents = n_parents;
@@ -145,35 +129,63 @@ int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
         return IPCFP_OK;
     }
     // the receipts AMT's count decides the ranges: `Amtv0::load` of the root (recorded, like every load here)
-    uint64_t count = 0;
-    {
-        DevBuf<uint64_t> info_d;
-        IPCFP_HIP(ctx, info_d.alloc(4));
-        rc = launch_amt_root_info(ctx, rec, tc.receipts_root, 0, VK_RECEIPT, info_d.p);
-        if (rc) return rc;
-        uint64_t info[4] = {0, 0, 0, 0};  // status, height, count, bit width
-        IPCFP_HIP(ctx, d2h_small(ctx, info, info_d.p, sizeof info, ctx->stream));
-        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-        if (info[0] != IPCFP_ST_TRUE) {
-            *status_out = ipcfp_status_t(info[0]);
-            return IPCFP_OK;
-        }
-        count = info[2];
-    }
-    uint64_t lo, hi;
-    ipcfp_shard_range(count, n_shards, shard, &lo, &hi);
-    if (hi - lo >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "shard too large");
-    rc = launch_plan_receipts(ctx, rec, tc.receipts_root, lo, uint32_t(hi - lo));
+    DevBuf<uint64_t> info_d;
+    IPCFP_HIP(ctx, info_d.alloc(4));
+    rc = launch_amt_root_info(ctx, rec, tc.receipts_root, 0, VK_RECEIPT, info_d.p);
     if (rc) return rc;
+    uint64_t info[4] = {0, 0, 0, 0};  // status, height, count, bit width
+    IPCFP_HIP(ctx, d2h_small(ctx, info, info_d.p, sizeof info, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    if (info[0] != IPCFP_ST_TRUE) {
+        *status_out = ipcfp_status_t(info[0]);
+        return IPCFP_OK;
+    }
+    count = info[2];
     // the tipset pair itself
     std::vector<CidKey> base;
     for (uint32_t k = 0; k < n_parents; ++k) base.push_back(tc.parents[k]);
     base.push_back(tc.child);
     base.push_back(tc.receipts_root);
     DevBuf<CidKey> base_d;
+    DevBuf<uint32_t> missing_d;
     IPCFP_HIP(ctx, base_d.alloc(base.size()));
+    IPCFP_HIP(ctx, missing_d.alloc(1));
+    IPCFP_HIP(ctx, hipMemsetAsync(missing_d.p, 0, 4, ctx->stream));
     IPCFP_HIP(ctx, hipMemcpyAsync(base_d.p, base.data(), base.size() * sizeof(CidKey), hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_mark_cids(ctx, rec, base_d.p, uint32_t(base.size()), missing_d);
+    rc = launch_mark_cids(ctx, rec, base_d.p, uint32_t(base.size()), missing_d.p);
+    if (rc) return rc;
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // (base / base_d are read by the kernel just queued)
+    *status_out = IPCFP_ST_TRUE;
+    return IPCFP_OK;
+}
+
+int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                            const uint8_t* child_cid40, uint32_t n_shards, uint32_t shard, ipcfp_status_t* status_out,
+                            uint64_t* receipt_lo, uint64_t* receipt_hi, uint64_t* n_receipts, uint32_t* block_ids,
+                            uint64_t cap_blocks, uint64_t* n_blocks) {
+    if (!ctx || !w || w->ctx != ctx || !child_cid40 || !status_out || !receipt_lo || !receipt_hi || !n_blocks ||
+        (n_parents && !parent_cids40) || n_shards == 0 || shard >= n_shards)
+        return IPCFP_E_INVALID;
+    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
+    IPCFP_ENTER(ctx);
+    *n_blocks = 0;
+    *receipt_lo = *receipt_hi = 0;
+    if (n_receipts) *n_receipts = 0;
+    *status_out = IPCFP_ST_ERR;
+    const uint32_t words = div_up(uint32_t(w->n), 32);
+    DevBuf<uint32_t> touched;
+    IPCFP_HIP(ctx, touched.alloc(words + 1));
+    IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, size_t(words + 1) * 4, ctx->stream));
+    const WitnessView rec = witness_view(w, touched.p);
+    TipsetCtxDev tc;
+    uint64_t count = 0;
+    int rc = plan_replicated(ctx, rec, parent_cids40, n_parents, child_cid40, tc, count, status_out);
+    if (rc || *status_out != IPCFP_ST_TRUE) return rc;
+    *status_out = IPCFP_ST_ERR;
+    uint64_t lo, hi;
+    ipcfp_shard_range(count, n_shards, shard, &lo, &hi);
+    if (hi - lo >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "shard too large");
+    rc = launch_plan_receipts(ctx, rec, tc.receipts_root, lo, uint32_t(hi - lo));
     if (rc) return rc;
     std::vector<uint32_t> bits(words + 1);
     IPCFP_HIP(ctx, hipMemcpyAsync(bits.data(), touched.p, size_t(words + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -191,6 +203,63 @@ int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
     *n_blocks = nb;
     *receipt_lo = lo;
     *receipt_hi = hi;
+    if (n_receipts) *n_receipts = count;
+    *status_out = IPCFP_ST_TRUE;
+    return IPCFP_OK;
+}
+
+int ipcfp_shard_plan_tipset_all(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
+                                const uint8_t* child_cid40, uint32_t n_shards, ipcfp_status_t* status_out,
+                                uint64_t* n_receipts, uint64_t* receipt_bounds, uint64_t* shard_off, uint32_t* block_ids,
+                                uint64_t cap_ids, uint64_t* n_ids) {
+    if (!ctx || !w || w->ctx != ctx || !child_cid40 || !status_out || !receipt_bounds || !shard_off || !n_ids ||
+        (n_parents && !parent_cids40) || n_shards == 0 || n_shards > IPCFP_MAX_SHARDS)
+        return IPCFP_E_INVALID;
+    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
+    IPCFP_ENTER(ctx);
+    *n_ids = 0;
+    if (n_receipts) *n_receipts = 0;
+    for (uint32_t s = 0; s <= n_shards; ++s) receipt_bounds[s] = shard_off[s] = 0;
+    *status_out = IPCFP_ST_ERR;
+    // bitmap s < G: what shard s alone needs; bitmap G: what every shard needs
+    const uint32_t words = div_up(uint32_t(w->n), 32);
+    DevBuf<uint32_t> touched;
+    IPCFP_HIP(ctx, touched.alloc(size_t(words) * (n_shards + 1) + 1));
+    IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, (size_t(words) * (n_shards + 1) + 1) * 4, ctx->stream));
+    uint32_t* common_d = touched.p + size_t(words) * n_shards;
+    TipsetCtxDev tc;
+    uint64_t count = 0;
+    int rc = plan_replicated(ctx, witness_view(w, common_d), parent_cids40, n_parents, child_cid40, tc, count, status_out);
+    if (rc || *status_out != IPCFP_ST_TRUE) return rc;
+    *status_out = IPCFP_ST_ERR;
+    if (count >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 receipts");
+    for (uint32_t s = 0; s < n_shards; ++s) ipcfp_shard_range(count, n_shards, s, &receipt_bounds[s], &receipt_bounds[s + 1]);
+    DevBuf<uint64_t> bounds_d;
+    IPCFP_HIP(ctx, bounds_d.alloc(n_shards + 1));
+    IPCFP_HIP(ctx, hipMemcpyAsync(bounds_d.p, receipt_bounds, size_t(n_shards + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_plan_receipts_all(ctx, witness_view(w, touched.p), tc.receipts_root, uint32_t(count), bounds_d.p, n_shards, words);
+    if (rc) return rc;
+    std::vector<uint32_t> bits(size_t(words) * (n_shards + 1));
+    if (!bits.empty())
+        IPCFP_HIP(ctx, hipMemcpyAsync(bits.data(), touched.p, bits.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    const uint32_t* common = bits.data() + size_t(words) * n_shards;
+    uint64_t at = 0;
+    for (uint32_t s = 0; s < n_shards; ++s) {
+        shard_off[s] = at;
+        const uint32_t* own = bits.data() + size_t(words) * s;
+        for (uint32_t wd = 0; wd < words; ++wd) {
+            uint32_t m = own[wd] | common[wd];
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1;
+                if (block_ids && at < cap_ids) block_ids[at] = wd * 32 + uint32_t(b);
+                ++at;
+            }
+        }
+    }
+    shard_off[n_shards] = at;
+    *n_ids = at;
     if (n_receipts) *n_receipts = count;
     *status_out = IPCFP_ST_TRUE;
     return IPCFP_OK;

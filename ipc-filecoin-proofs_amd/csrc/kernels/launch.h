@@ -150,6 +150,8 @@ int launch_gather_block_cids(ipcfp_ctx* ctx, const uint8_t* cids_d, const uint32
 
 // --- shard.hip ---
 int launch_plan_receipts(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint64_t lo, uint32_t n);
+int launch_plan_receipts_all(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint32_t n,
+                             const uint64_t* bounds_d, uint32_t n_shards, uint32_t words);
 int launch_find_blocks(ipcfp_ctx* ctx, const WitnessView& w, const CidKey* keys_d, uint32_t n, uint32_t* ids_d);
 int launch_gather_values(ipcfp_ctx* ctx, const WitnessView& w, const void* locs_d /* ipcfp_value_loc_t[n] */, uint32_t n,
                          uint8_t* out_d, uint64_t stride, unsigned long long* first_bad_d);

@@ -17,14 +17,12 @@
 
 namespace ipcfp {
 
-// lane i: the path to receipt lo + i in the receipts AMT, and the whole events AMT of that receipt
-__global__ __launch_bounds__(256) void k_plan_receipts(WitnessView rec, CidKey receipts_root, uint64_t lo, uint32_t n) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+// the path to receipt `index` in the receipts AMT, and the whole events AMT of that receipt, recorded in rec.touched
+__device__ __forceinline__ void plan_one_receipt(const WitnessView& rec, const CidKey& receipts_root, uint64_t index) {
     AmtRootInfo rinfo;
     if (amt_load(rec, receipts_root, 0, VK_RECEIPT, rinfo) != IPCFP_ST_TRUE) return;
     ValueLoc rl;
-    if (amt_get(rec, rinfo, VK_RECEIPT, lo + t, rl) != IPCFP_ST_TRUE) return;
+    if (amt_get(rec, rinfo, VK_RECEIPT, index, rl) != IPCFP_ST_TRUE) return;
     Rd r;
     r.init(rec.arena + rec.off[rl.block] + rl.off, rl.len);
     uint32_t o, l;
@@ -81,6 +79,31 @@ __global__ __launch_bounds__(256) void k_plan_receipts(WitnessView rec, CidKey r
         noff[depth] = 0;
         next_sub[depth] = 0;
     }
+}
+
+// lane i: receipt lo + i, recorded in the one bitmap of the view
+__global__ __launch_bounds__(256) void k_plan_receipts(WitnessView rec, CidKey receipts_root, uint64_t lo, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    plan_one_receipt(rec, receipts_root, lo + t);
+}
+
+// Every shard's plan in one pass (ipcfp_shard_plan_tipset_all): lane i takes receipt i and records into the bitmap of
+// the shard that owns it — rec.touched is the first of n_shards bitmaps of `words` words each; bounds[s] .. bounds[s+1]
+// are shard s's receipts (ipcfp_shard_range).
+__global__ __launch_bounds__(256) void k_plan_receipts_all(WitnessView rec, CidKey receipts_root, uint32_t n,
+                                                           const uint64_t* __restrict__ bounds, uint32_t n_shards,
+                                                           uint32_t words) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t lo = 0, hi = n_shards;  // the shard s with bounds[s] <= t < bounds[s + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bounds[mid] <= t) lo = mid; else hi = mid;
+    }
+    WitnessView mine = rec;
+    mine.touched = rec.touched + size_t(lo) * words;
+    plan_one_receipt(mine, receipts_root, t);
 }
 
 // Amt::load of one root → {status, height, count, bit width}
@@ -179,6 +202,15 @@ int launch_absolute_offsets(ipcfp_ctx* ctx, const uint64_t* off_d, uint32_t n, u
 int launch_plan_receipts(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint64_t lo, uint32_t n) {
     if (n == 0) return IPCFP_OK;
     hipLaunchKernelGGL(k_plan_receipts, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, rec, receipts_root, lo, n);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_plan_receipts_all(ipcfp_ctx* ctx, const WitnessView& rec, const CidKey& receipts_root, uint32_t n,
+                             const uint64_t* bounds_d, uint32_t n_shards, uint32_t words) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_plan_receipts_all, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, rec, receipts_root, n, bounds_d,
+                       n_shards, words);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

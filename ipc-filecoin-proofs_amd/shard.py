@@ -120,9 +120,58 @@ def subset_packed_claims(claims: np.ndarray, blob: np.ndarray, positions: np.nda
     return c, out, len(t_bytes) + len(d_bytes)
 
 
+class TipsetPlan:
+    """PLAN ONCE, SCATTER: every shard's block list and receipt range of one tipset from ONE call
+    (`ipcfp_shard_plan_tipset_all`), made where the whole witness is resident — the bundle's producer, or one rank.
+    `cut` / `route` are host-only: what rank r uploads is its own blocks and claims, nothing else."""
+
+    def __init__(self, full: B.Witness, parent_cids, child_cid: bytes, n_shards: int):
+        st, n_receipts, bounds, lists = full.shard_plan_tipset_all(parent_cids, child_cid, n_shards)
+        if st != 1:
+            raise B.EngineError(f"shard plan failed with status {st}")
+        self.n_shards, self.n_receipts, self.bounds, self.block_ids = int(n_shards), n_receipts, bounds, lists
+        self.parent_cids, self.child_cid = parent_cids, child_cid
+
+    @classmethod
+    def from_parts(cls, n_shards: int, n_receipts: int, bounds, block_ids, parent_cids, child_cid: bytes):
+        """A plan received over the host's own channel (rank 0 planned, the others got the lists)."""
+        self = cls.__new__(cls)
+        self.n_shards, self.n_receipts = int(n_shards), int(n_receipts)
+        self.bounds = np.asarray(bounds, dtype=np.uint64)
+        self.block_ids = [np.asarray(x, dtype=np.uint32) for x in block_ids]
+        self.parent_cids, self.child_cid = parent_cids, child_cid
+        return self
+
+    def range(self, r: int):
+        return int(self.bounds[r]), int(self.bounds[r + 1])
+
+    def cut(self, r: int, data, off, lens, cids40):
+        """Shard r's witness as host arrays (data, off, lens, cids) — `ipcfp_witness_cut_host`."""
+        return B.witness_cut_host(data, off, lens, cids40, self.block_ids[r])
+
+    def route(self, r: int, claims: np.ndarray, blob: np.ndarray, blob_len: int):
+        """Shard r's claims → (positions, claims, blob, blob_len) — `ipcfp_route_event_claims`."""
+        lo, hi = self.range(r)
+        return B.route_event_claims(claims, blob, blob_len, lo, hi, r == self.n_shards - 1)
+
+
 class TipsetShard:
     """Rank `shard` of `n_shards` for one tipset.  `full` is a Witness holding the whole tipset on this rank's GPU
-    (setup only: it may be closed once the shard exists)."""
+    (setup only: it may be closed once the shard exists) — or see `from_plan`, which never holds more than the shard."""
+
+    @classmethod
+    def from_plan(cls, eng: B.Engine, plan: "TipsetPlan", shard: int, sub, receipts_root: bytes, witness=None):
+        """Rank `shard` from a plan made elsewhere: `sub` = plan.cut(shard, …) in host memory is uploaded (or `witness`,
+        an already created Witness of exactly those blocks, is adopted) and tagged with the receipt range."""
+        self = cls.__new__(cls)
+        self.eng, self.n_shards, self.shard = eng, plan.n_shards, int(shard)
+        self.lo, self.hi = plan.range(shard)
+        self.n_receipts_total, self.block_ids = plan.n_receipts, plan.block_ids[shard]
+        self.witness = witness if witness is not None else eng.witness(*sub)
+        self.witness.set_receipt_range(self.lo, self.hi)
+        self.receipts_root = bytes(receipts_root)
+        self.parent_cids, self.child_cid = plan.parent_cids, plan.child_cid
+        return self
 
     def __init__(self, eng: B.Engine, full: B.Witness, parent_cids, child_cid: bytes, receipts_root: bytes,
                  n_shards: int, shard: int):
@@ -135,11 +184,12 @@ class TipsetShard:
         self.receipts_root = bytes(receipts_root)
         self.parent_cids, self.child_cid = parent_cids, child_cid
 
-    def route(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray):
+    def route(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray, blob_len=None):
         """This rank's share of a packed claim batch: claims whose exec_index is one of its receipts."""
         self.tipsets = np.ascontiguousarray(tipsets)
-        self.positions = route_claims(claims["exec_index"], self.lo, self.hi, last=(self.shard == self.n_shards - 1))
-        self.claims, self.blob, self.blob_len = subset_packed_claims(claims, blob, self.positions)
+        self.positions, self.claims, self.blob, self.blob_len = B.route_event_claims(
+            claims, blob, max(len(blob) - 64, 0) if blob_len is None else blob_len, self.lo, self.hi,
+            self.shard == self.n_shards - 1)
         self.n_claims = len(self.positions)
         return self.claims, self.blob, self.blob_len
 

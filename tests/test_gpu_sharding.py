@@ -156,3 +156,63 @@ def test_rccl_single_rank_allgather(engine):
     want[200:256] = 7
     assert torch.equal(recv, want) and torch.equal(stage, want)
     comm.close()
+
+
+# ---- plan once, scatter: ipcfp_shard_plan_tipset_all + host-side cut / route (the shard is all a rank ever uploads) ----
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_plan_all_equals_the_per_shard_plans(engine, tip, G):
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        st, n_receipts, bounds, lists = w.shard_plan_tipset_all(tip.parent_cids, tip.child_cid, G)
+        assert st == 1 and n_receipts == 40_000 and bounds[0] == 0 and bounds[G] == 40_000
+        for r in range(G):
+            st1, lo, hi, nr, ids = w.shard_plan_tipset(tip.parent_cids, tip.child_cid, G, r)
+            assert st1 == 1 and (lo, hi) == (int(bounds[r]), int(bounds[r + 1])) and nr == n_receipts
+            assert np.array_equal(lists[r], ids)
+
+
+def test_plan_all_reports_the_first_error_like_the_single_plan(engine, tip):
+    # the child header is not in the witness: the traversal stops where the reference's `?` would
+    keep = np.ones(tip.n_blocks, dtype=bool)
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        has, ids = w.has([tip.child_cid])
+        keep[int(ids[0])] = False
+    sub = ipcfp.witness_cut_host(tip.data, tip.off, tip.lens, tip.cids, np.nonzero(keep)[0].astype(np.uint32))
+    with engine.witness(*sub) as w:
+        st, n_receipts, bounds, lists = w.shard_plan_tipset_all(tip.parent_cids, tip.child_cid, 4)
+        st1 = w.shard_plan_tipset(tip.parent_cids, tip.child_cid, 4, 2)[0]
+    assert st == st1 == 65 and n_receipts == 0 and all(len(x) == 0 for x in lists)
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_scattered_shards_uploaded_from_host_equal_the_unsharded_result(engine, oracle, tip, claims_packed, G):
+    """The whole witness is resident ONCE (the planner); every shard then exists only as its own host buffers, is
+    uploaded by itself, verified, and the merged verdicts equal the unsharded engine's and the oracle's."""
+    ts, cl, blob, blob_len = claims_packed
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        want = w.verify_event_claims(ts, cl, blob, blob_len)
+        ws, whas, wm, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
+        plan = shard.TipsetPlan(w, tip.parent_cids, tip.child_cid, G)
+    status = np.full(len(cl), 255, dtype=np.uint8)
+    has = np.zeros(plan.n_receipts, dtype=np.uint8)
+    n_matches, uploaded = 0, []
+    for r in range(G):
+        sub = plan.cut(r, tip.data, tip.off, tip.lens, tip.cids)
+        pos, c_r, b_r, bl_r = plan.route(r, cl, blob, blob_len)
+        s = shard.TipsetShard.from_plan(engine, plan, r, sub, tip.receipts_root)
+        uploaded.append(sub[0].size)
+        st_cid, n_bad = s.witness.verify_cids()
+        assert n_bad == 0
+        status[pos.astype(np.int64)] = s.witness.verify_event_claims(ts, c_r, b_r, bl_r)
+        sst, shas, sm, _ = s.witness.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                                 want_touched=False)
+        assert sst == 1 and len(shas) == s.hi - s.lo
+        has[s.lo: s.hi] = shas
+        n_matches += len(sm)
+        s.close()
+    assert np.array_equal(status, want) and (want != 1).sum() > 100
+    assert np.array_equal(has, whas) and n_matches == len(wm)
+    ost = oracle.store(tip.data, tip.off, tip.lens, tip.cids, threads=0)
+    assert np.array_equal(ost.verify_event_claims_packed(ts, cl, blob, threads=0), want)
+    ost.close()
+    if G == 8:  # what a rank uploads shrinks with G (the message AMTs and headers are the replicated floor)
+        assert max(uploaded) < 0.45 * tip.data.size
