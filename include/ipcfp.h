@@ -126,6 +126,14 @@ int ipcfp_abi_version(void);
  * the stream the kernels are launched on. */
 void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx);
 int ipcfp_ctx_sync(ipcfp_ctx_t* ctx);
+/* Route selection (A/B measurements; tests that drive both routes of an entry point over one corpus).  Outcomes never
+ * depend on it — every fast route only ever answers what the general one would.  Keys:
+ *   "hamt_levels"  -1 default (ipcfp_hamt_get*: level by level for batches of >= 1024 queries), 0 per-query walker only,
+ *                  k > 0 exactly k levels whatever the batch size
+ *   "hamt_coop"    0: the level path decodes ActorState nodes with one lane each instead of sixteen
+ *   "hamt_table"   1: tabulate every block of the witness as a HAMT node first
+ *   "fast_verify"  0: verify_event_proof never takes the route without mid-call synchronisation                     */
+int ipcfp_ctx_set_tuning(ipcfp_ctx_t* ctx, const char* key, int64_t value);
 /* Device properties used by the benchmarks: name (≤ 63 chars), CU count, HBM bytes. */
 int ipcfp_ctx_device_info(ipcfp_ctx_t* ctx, char name[64], int* cu_count, uint64_t* hbm_bytes);
 

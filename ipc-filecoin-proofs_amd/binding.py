@@ -187,6 +187,7 @@ def load_library() -> C.CDLL:
         "ipcfp_last_error": (C.c_char_p, [vp]),
         "ipcfp_ctx_stream": (vp, [vp]),
         "ipcfp_ctx_sync": (i32, [vp]),
+        "ipcfp_ctx_set_tuning": (i32, [vp, C.c_char_p, C.c_int64]),
         "ipcfp_ctx_device_info": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(u64)]),
         "ipcfp_profile_enable": (i32, [vp, i32]),
         "ipcfp_profile_reset": (i32, [vp]),
@@ -318,6 +319,10 @@ class Engine:
         if rc != 0:
             msg = self.lib.ipcfp_last_error(self.h).decode(errors="replace")
             raise EngineError(f"{what}: {self.lib.ipcfp_strerror(rc).decode()} ({rc}) {msg}")
+
+    def set_tuning(self, key: str, value: int):
+        """Route selection (ipcfp_ctx_set_tuning): "hamt_levels", "hamt_table", "fast_verify"."""
+        self._check(self.lib.ipcfp_ctx_set_tuning(self.h, key.encode(), int(value)), "ctx_set_tuning")
 
     def sync(self):
         self._check(self.lib.ipcfp_ctx_sync(self.h), "sync")

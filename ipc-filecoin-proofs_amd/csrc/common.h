@@ -129,6 +129,17 @@ struct ipcfp_ctx {
     bool k1_gate = false;                       // env IPCFP_K1_GATE: … and K1's stream WAITS for the main stream to get there
     hipEvent_t k1_gate_event = nullptr;
     struct ipcfp_witness* k1_deferred_w = nullptr;
+    // --- scratch of the ASYNCHRONOUS batch gets (ipcfp_hamt_get_device: node records, work lists, key hashes).  Owned by
+    // the context and only ever grown: the kernels of a call that has already returned may still be reading it, and the
+    // next call's kernels follow them on the same stream (a pooled buffer would go back to the pool on return) ---
+    int hamt_levels = -1;  // -1: level by level for batches of >= 1024 queries; 0: the per-query walker alone; k > 0: exactly k levels
+    int hamt_coop = -1;    // 0: the level path parses every node with one lane (kernels/hamt_levels.hip k_hamt_lv_parse) also for ActorState trees
+    int hamt_table = -1;   // 1: tabulate EVERY block first (hamt_table.h; A/B measurements)
+    int fast_verify = -1;  // 0: verify_event_proof never takes the no-synchronisation route (host/verify_fast.cpp)
+    void* hamt_recs = nullptr;
+    size_t hamt_recs_bytes = 0;
+    void* hamt_scratch = nullptr;
+    size_t hamt_scratch_bytes = 0;
 };
 
 namespace ipcfp {

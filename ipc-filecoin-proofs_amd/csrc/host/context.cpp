@@ -265,6 +265,10 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
     if (const char* e = std::getenv("IPCFP_K1_DEFER")) ctx->k1_defer = std::atoi(e);
     if (const char* e = std::getenv("IPCFP_K1_GATE")) ctx->k1_gate = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCFP_SPIN_SYNC")) ctx->spin_sync = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IPCFP_HAMT_LEVELS")) ctx->hamt_levels = std::atoi(e);
+    if (const char* e = std::getenv("IPCFP_HAMT_TABLE")) ctx->hamt_table = std::atoi(e);
+    if (const char* e = std::getenv("IPCFP_HAMT_COOP")) ctx->hamt_coop = std::atoi(e);
+    if (const char* e = std::getenv("IPCFP_FAST_VERIFY")) ctx->fast_verify = std::atoi(e);
     // wait_stream's polling event belongs to THIS device (created here, right after hipSetDevice(device))
     if (hipEventCreateWithFlags(&ctx->spin_event, hipEventDisableTiming) != hipSuccess) ctx->spin_event = nullptr;
     if (const char* e = std::getenv("IPCFP_B2B_MODE")) ctx->b2b_mode = (std::atoi(e) >= 0 && std::atoi(e) <= 3) ? std::atoi(e) : 0;
@@ -314,9 +318,12 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
 void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)upload_task_wait(ctx);  // a copy still crossing PCIe on its own thread writes into pool memory: join it first
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream_k1);
     (void)hipStreamSynchronize(ctx->stream_aux);
+    if (ctx->hamt_recs) (void)hipFree(ctx->hamt_recs);
+    if (ctx->hamt_scratch) (void)hipFree(ctx->hamt_scratch);
     for (auto& l : ctx->launches) {
         (void)hipEventDestroy(l.start);
         (void)hipEventDestroy(l.stop);
@@ -349,6 +356,19 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
 const char* ipcfp_last_error(const ipcfp_ctx_t* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
 void* ipcfp_ctx_stream(ipcfp_ctx_t* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+// Route selection for A/B measurements and for tests that must drive BOTH routes of one entry point through the same
+// corpus; results never depend on it (every fast route answers what the general one would).
+int ipcfp_ctx_set_tuning(ipcfp_ctx_t* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return IPCFP_E_INVALID;
+    const std::string k(key);
+    if (k == "hamt_levels") ctx->hamt_levels = int(value);
+    else if (k == "hamt_table") ctx->hamt_table = int(value);
+    else if (k == "hamt_coop") ctx->hamt_coop = int(value);
+    else if (k == "fast_verify") ctx->fast_verify = int(value);
+    else return set_error(ctx, IPCFP_E_INVALID, "unknown tuning key '%s'", key);
+    return IPCFP_OK;
+}
 
 int ipcfp_ctx_sync(ipcfp_ctx_t* ctx) {
     if (!ctx) return IPCFP_E_INVALID;

@@ -29,26 +29,47 @@ CidKey key_from_slot(const uint8_t* slot40) {
     return k;
 }
 
-// K7 for a batch: one query per lane walks the blocks (k_hamt_get).  IPCFP_HAMT_TABLE=1 (A/B measurements): first
-// tabulate every block as a HAMT node (kernels/hamt_table.h; the table lives for this call only) and walk records.
+// a context-owned buffer of at least `need` bytes (hipFree of the old one waits for the device: nothing still reads it)
+static hipError_t grow(void*& p, size_t& cap, size_t need) {
+    if (need <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = need + need / 4;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+}
+
+// K7 for a batch.  Default for a batch of ≥ 1024 queries: LEVEL BY LEVEL (kernels/hamt_levels.hip) — every node the batch
+// visits is decoded once, a query is SHA-256 + one record per level — with the per-query walker (k_hamt_get) behind it
+// for whatever that leaves pending.  IPCFP_HAMT_LEVELS=0: the walker alone (round 3's path; small batches take it
+// anyway).  IPCFP_HAMT_TABLE=1 (A/B measurements): tabulate EVERY block of the witness first (kernels/hamt_table.h).
 int hamt_get_batch(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, uint32_t bit_width, int vkind, const uint8_t* keys_d,
                    const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n, uint8_t* status_d, void* loc_d) {
-    static const int forced = [] {
-        const char* e = std::getenv("IPCFP_HAMT_TABLE");
-        return e ? std::atoi(e) : -1;
-    }();
+    const int forced_table = ctx->hamt_table, levels_mode = ctx->hamt_levels;
     const uint32_t kbit = hamt_kind_bit(vkind);
-    // (default: walk.  On configs 4/5's witness the table pass costs more than 66 k walks: profiles/r03_experiments.md)
-    const bool tabled = kbit && forced == 1;
     ProfileScope prof(ctx, IPCFP_K_HAMT_GET);
     const WitnessView view = witness_view(w);
-    if (!tabled) return launch_hamt_get(ctx, view, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d);
-    DevBuf<HamtNodeRec> table;
-    IPCFP_HIP(ctx, table.alloc(w->n));
-    int rc = launch_hamt_node_table(ctx, w->arena.p, w->k1_meta.p, uint32_t(w->n), kbit, table.p);
+    if (kbit && forced_table == 1) {
+        IPCFP_HIP(ctx, grow(ctx->hamt_recs, ctx->hamt_recs_bytes, size_t(w->n) * sizeof(HamtNodeRec)));
+        int rc = launch_hamt_node_table(ctx, w->arena.p, w->k1_meta.p, uint32_t(w->n), kbit, ctx->hamt_recs);
+        if (rc) return rc;
+        return launch_hamt_get_table(ctx, view, ctx->hamt_recs, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d);
+    }
+    const bool by_levels = levels_mode != 0 && bit_width >= 1 && bit_width <= 8 && w->n > 0 && (n >= 1024 || levels_mode > 0);
+    if (!by_levels) return launch_hamt_get(ctx, view, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d);
+    // how deep can the tree be?  A HAMT of B blocks with fan-out 2^bw has about log(B) / bw interior levels; two more
+    // for uneven buckets.  A deeper tree is not an error: its queries stay pending and the walker finishes them.
+    uint32_t levels = 2;
+    for (uint64_t reach = 1; reach < w->n && levels < 14; reach <<= bit_width) ++levels;
+    if (levels_mode > 0) levels = uint32_t(levels_mode);
+    IPCFP_HIP(ctx, grow(ctx->hamt_recs, ctx->hamt_recs_bytes, size_t(w->n) * sizeof(HamtNodeRec)));
+    IPCFP_HIP(ctx, grow(ctx->hamt_scratch, ctx->hamt_scratch_bytes, hamt_levels_scratch_words(n, uint32_t(w->n), levels) * 4));
+    int rc = launch_hamt_get_levels(ctx, view, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d, levels,
+                                    static_cast<uint32_t*>(ctx->hamt_scratch), ctx->hamt_recs, /*coop=*/ctx->hamt_coop != 0);
     if (rc) return rc;
-    return launch_hamt_get_table(ctx, view, table.p, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d);
-    // (the table goes back to the pool on return; reuse is ordered on the one stream)
+    return launch_hamt_get(ctx, view, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d, /*pending_only=*/1);
 }
 
 }  // namespace ipcfp

@@ -118,15 +118,20 @@ UploadTask* upload_task_start(ipcfp_ctx* ctx, void* dst0, const void* src0, size
     // (a stream of its own: blocking copies on the NULL stream from two threads would queue up behind each other)
     if (!ctx->stream_copy && hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking) != hipSuccess) ctx->stream_copy = nullptr;
     hipStream_t cs = ctx->stream_copy;
-    t->th = std::thread([=] {
-        hipError_t e = hipSetDevice(device);
-        auto copy = [&](void* d, const void* s, size_t n) {
-            return cs ? hipMemcpyWithStream(d, s, n, hipMemcpyHostToDevice, cs) : hipMemcpy(d, s, n, hipMemcpyHostToDevice);
-        };
-        if (e == hipSuccess && bytes0) e = copy(dst0, src0, bytes0);
-        if (e == hipSuccess && bytes1) e = copy(dst1, src1, bytes1);
-        t->err = int(e);
-    });
+    try {  // (std::thread throws std::system_error when the thread cannot be made: nothing may cross the C ABI)
+        t->th = std::thread([=] {
+            hipError_t e = hipSetDevice(device);
+            auto copy = [&](void* d, const void* s, size_t n) {
+                return cs ? hipMemcpyWithStream(d, s, n, hipMemcpyHostToDevice, cs) : hipMemcpy(d, s, n, hipMemcpyHostToDevice);
+            };
+            if (e == hipSuccess && bytes0) e = copy(dst0, src0, bytes0);
+            if (e == hipSuccess && bytes1) e = copy(dst1, src1, bytes1);
+            t->err = int(e);
+        });
+    } catch (...) {
+        delete t;
+        return nullptr;  // the caller uploads synchronously instead
+    }
     return t;
 }
 

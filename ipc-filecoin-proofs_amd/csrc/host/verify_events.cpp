@@ -296,7 +296,10 @@ int ipcfp_verify_event_proofs_with(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const i
     std::vector<ipcfp_value_loc_t> want;
     uint64_t stride = 16;
     for (uint64_t i = 0; i < n; ++i)
-        if (status[i] == IPCFP_ST_TRUE && loc[i].block != 0xffffffffu) {
+        if (status[i] == IPCFP_ST_TRUE) {
+            // a proof that verified HAS a located event; one without would skip the predicate and stay true (fail open)
+            if (loc[i].block == 0xffffffffu)
+                return set_error(ctx, IPCFP_E_HIP, "internal: proof %llu verified without a located event", (unsigned long long)i);
             who.push_back(i);
             want.push_back(loc[i]);
             stride = std::max<uint64_t>(stride, (uint64_t(loc[i].len) + 15) & ~uint64_t(15));
@@ -419,8 +422,8 @@ int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     if (beside && n * sizeof(EventClaimPacked) >= (size_t(8) << 20)) {
         IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (nothing queued earlier may still use the buffers just taken)
         ctx->upload_task = upload_task_start(ctx, cd.p, claims, n * sizeof(EventClaimPacked), bd.p, blob, blob_len);
-        if (!ctx->upload_task) return IPCFP_E_NOMEM;
-    } else {
+    }
+    if (!ctx->upload_task) {  // small batch, IPCFP_UPLOAD_MODE=1, or no thread to be had: uploaded here, first
         rc = upload(ctx, cd.p, claims, n * sizeof(EventClaimPacked), ctx->stream);
         if (rc) return rc;
         if (blob_len) {

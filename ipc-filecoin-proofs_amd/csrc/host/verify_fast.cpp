@@ -35,14 +35,31 @@ int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents);
 // → IPCFP_OK with *done = true: status_d (and where_d) hold the batch's results;
 //   IPCFP_OK with *done = false: not this route's case, or the dense walk did not hold — nothing the caller may use;
 //   anything else: an ABI error.
+static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
+                                    uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
+                                    const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done);
+
 int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
                        uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                        const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done) {
+    const int rc = verify_packed_fast_queue(ctx, w, tcs, claims_d, n, blob_d, blob_len, trust, filter, status_d, where_d, done);
+    if (rc != IPCFP_OK) {
+        // An error return may have left kernels on the main and the aux stream that still use this call's pooled scratch
+        // (the leaves, the receipts' event records, the deferred re-hash): the buffers went back to the pool when the
+        // function returned, and nothing may be handed out again before those kernels are through.
+        (void)upload_task_wait(ctx);
+        (void)hipStreamSynchronize(ctx->stream_aux);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (w->bt_valid) w->bt_joined = true;
+    }
+    return rc;
+}
+
+static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
+                                    uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
+                                    const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done) {
     static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
-    static const bool enabled = [] {
-        const char* e = std::getenv("IPCFP_FAST_VERIFY");
-        return !(e && std::atoi(e) == 0);
-    }();
+    const bool enabled = ctx->fast_verify != 0;  // (env IPCFP_FAST_VERIFY / ipcfp_ctx_set_tuning "fast_verify")
     *done = false;
     if (!enabled || !ctx->mailbox || tcs.size() != 1 || !w->use_event_table || ctx->stream_aux == ctx->stream) return IPCFP_OK;
     const TipsetCtxDev& in = tcs[0];

@@ -54,10 +54,7 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     if (n == 0) return IPCFP_OK;
     ProfileScope prof(ctx, IPCFP_K_STORAGE_VERIFY);
     const WitnessView w = witness_view(wit);
-    static const int forced = [] {
-        const char* e = std::getenv("IPCFP_HAMT_TABLE");
-        return e ? std::atoi(e) : -1;
-    }();
+    const int forced = ctx->hamt_table;  // (env IPCFP_HAMT_TABLE / ipcfp_ctx_set_tuning "hamt_table")
     const bool tabled = forced == 1 || (forced != 0 && uint64_t(n) * 16u >= wit->n);
     if (!tabled) return launch_verify_storage_lanes(ctx, w, claims_d, n, trust, status_d, 0);
     constexpr uint32_t kUndecided = 0xfdu;

@@ -88,7 +88,13 @@ int witness_finish_create_from(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* 
         if (ring) {
             rc = upload(ctx, const_cast<uint8_t*>(raw_bytes_d), host_bytes, host_nbytes, ctx->stream);
             if (rc) return rc;
-        } else {  // the runtime's blocking copy (host/upload.cpp), WITHOUT draining the stream: nothing queued reads or writes raw_bytes_d
+        } else {  // the runtime's blocking copy (host/upload.cpp), WITHOUT draining the main stream: nothing queued THERE reads or
+            // writes raw_bytes_d.  The side streams are another matter — raw_bytes_d is pooled memory, the engine's streams do
+            // not synchronise with the NULL stream, and an earlier asynchronous call may still have a kernel on one of them
+            // that uses the chunk under its previous owner: they are drained first (idle streams: a few microseconds).
+            if (ctx->stream_aux != ctx->stream) IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
+            if (ctx->stream_k1 != ctx->stream) IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
+            if (ctx->stream_copy) IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
             IPCFP_HIP(ctx, hipMemcpy(const_cast<uint8_t*>(raw_bytes_d), host_bytes, host_nbytes, hipMemcpyHostToDevice));
         }
     }

@@ -794,6 +794,75 @@ __device__ __forceinline__ void check_actor_state(Rd& r) {
     }
 }
 
+// A tag-42 link at `at` in one of the two spellings encoders write, from two fetches: → its encoded length, 0 for any
+// other spelling (the caller takes read_link, which also decides what is an error).
+//   standard   d8 2a | 58 27 | 00 | 01 71 a0 e4 02 20 | digest[32]          43 bytes (CIDv1 dag-cbor blake2b-256)
+//   short      d8 2a | 4l / 58 l | 00 | 01 | codec < 80 | hash code < 80 | n ≤ 40 | digest[n],  l = 5 + n
+//              — e.g. the builtin actors' code CIDs: raw (0x55), identity hash (0x00), the actor's name as "digest"
+// Both pass every check of read_link / cid_ok (version 1, minimal one-byte varints, the digest fills the string).
+#if !IPCFP_RD_RING
+__device__ __forceinline__ uint32_t link_fast_len(Rd& r, uint32_t at) {
+    const uint64_t w0 = r.peek64(at);
+    if (w0 == 0xa071010027582ad8ull) return (r.peek64(at + 8u) & 0xffffffull) == 0x2002e4ull ? 43u : 0u;
+    if ((w0 & 0xffffull) != 0x2ad8ull) return 0u;
+    const uint32_t hb = uint32_t(w0 >> 16) & 0xffu;
+    uint32_t l, h;  // string length, header bytes before the string
+    uint64_t body;  // the string's first bytes: 00 01 codec code n
+    if (hb >= 0x45u && hb <= 0x57u) {
+        l = hb - 0x40u;
+        h = 3u;
+        body = w0 >> 24;
+    } else if (hb == 0x58u) {
+        l = uint32_t(w0 >> 24) & 0xffu;
+        h = 4u;
+        body = w0 >> 32;
+    } else {
+        return 0u;
+    }
+    const uint32_t n = h == 3u ? uint32_t(body >> 32) & 0xffu : uint32_t(r.at(at + 8u));
+    if ((body & 0xffffull) != 0x0100ull || (body & 0x80800000ull) != 0ull || n > 40u || l != 5u + n) return 0u;
+    return h + l;
+}
+
+// One HAMT bucket entry `[key bytes, ActorState]` in the spelling every encoder writes — settled from a handful of
+// fetches instead of eight generic item headers and eight varints (a state-tree node holds ≈ 45 entries and a walk
+// decodes every entry of every node it visits: src/proofs/common/decode.rs:29-39):
+//   82 | 4k key[k ≤ 6] | 85 | link | link | sequence uint | balance 4l [sign ≤ 1, …] (l ≤ 23) | f6        (links: link_fast_len)
+// true: exactly that; r.pos is past the entry, (ko, kl) is the key, vstart the ActorState item.  Every check
+// check_actor_state makes holds for this form (the links are well-formed CIDv1s, the TokenAmount is short with a 0/1
+// sign byte, delegated_address is None).  false: some other spelling — r is UNTOUCHED (pos, err) and the caller decodes
+// the entry item by item, which also decides what is an error.
+__device__ __forceinline__ bool actor_entry_fast(Rd& r, uint32_t& ko, uint32_t& kl, uint32_t& vstart) {
+    if (r.err) return false;
+    const uint32_t at = r.pos;
+    if (at + 48u > r.n) return false;  // (far shorter than any such entry: spares the peeks near the end)
+    const uint64_t w0 = r.peek64(at);
+    const uint32_t k = (uint32_t(w0 >> 8) & 0xffu) - 0x40u;
+    if ((uint32_t(w0) & 0xffu) != 0x82u || k > 6u) return false;
+    const uint32_t p2 = at + 2u + k;
+    if (r.at(p2) != 0x85u) return false;
+    const uint32_t l1 = link_fast_len(r, p2 + 1u);
+    if (!l1) return false;
+    const uint32_t l2 = link_fast_len(r, p2 + 1u + l1);
+    if (!l2) return false;
+    const uint32_t p3 = p2 + 1u + l1 + l2;
+    const uint64_t w3 = r.peek64(p3);
+    const uint32_t b3 = uint32_t(w3) & 0xffu;
+    if (b3 > 0x1bu) return false;                                // major 0, 1/2/3/5/9 bytes
+    const uint32_t p4 = p3 + 1u + (b3 < 0x18u ? 0u : (1u << (b3 - 0x18u)));
+    const uint64_t w4 = r.peek64(p4);
+    const uint32_t l = (uint32_t(w4) & 0xffu) - 0x40u;           // TokenAmount bytes, immediate length
+    if (l > 23u || (l > 0u && (uint32_t(w4 >> 8) & 0xffu) > 1u)) return false;
+    const uint32_t p5 = p4 + 1u + l;
+    if (p5 >= r.n || r.at(p5) != 0xf6u) return false;
+    ko = at + 2u;
+    kl = k;
+    vstart = p2;
+    r.pos = p5 + 1u;
+    return true;
+}
+#endif
+
 // One element of a serde Vec<u8> (a CBOR array of small unsigned integers) out of the 8 bytes `w` fetched at the reader's
 // position, `used` bytes of which are consumed already: 00..17 is the value in one byte, 18 xx the value in two — what
 // every encoder writes.  false: the element is spelled some other way (or may straddle the fetch): take the general path.

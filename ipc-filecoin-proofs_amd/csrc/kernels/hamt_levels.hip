@@ -1,0 +1,535 @@
+// csrc/kernels/hamt_levels.hip — K7 for a batch, LEVEL BY LEVEL: every node the batch visits is decoded ONCE.
+//
+// `Hamt::get` decodes each node on a key's path completely (serde decodes the whole `[bitfield, [pointer…]]`:
+// fvm_ipld_hamt 0.10.4; src/proofs/common/decode.rs:29-39, src/proofs/storage/decode.rs:79-96), and the reference does
+// so per lookup: 66 k actor gets in a 4 M-actor state tree decode ≈ 330 k nodes of which ≈ 95 k are distinct — the root
+// 66 k times.  One query per lane walking by itself (walk.hip k_hamt_get) repeats exactly that: 8.5× the algorithmic
+// bytes fetched, 191 k instructions per wavefront (profiles/r03_hamt_storage_pmc.txt).  A node's decode is a pure
+// function of the block, so here the batch advances one tree level per step:
+//
+//   k_hamt_lv_start    lane = query: SHA-256 of the key (kept: 32 B per query), current node = the root block
+//   k_hamt_lv_parse    lane = one node of this level's WORK LIST (the distinct blocks its queries stand on): the whole
+//                      node is validated for the HAMT's value type and left as a HamtNodeRec (hamt_table.h) in a table
+//                      indexed by block id — or as "not tabulated", which decides nothing (see below)
+//   k_hamt_lv_advance  lane = query: take the level's hash bits, bitfield popcount, the pointer's offset from the record;
+//                      a link → CID → block id (index probe) → CLAIM it for the next level's work list (a bitmap over the
+//                      blocks: the first claimant appends it); a bucket → compare the ≤ 3 keys → settled
+//
+// All queries of a level have consumed the same number of hash bits, so a level is uniform.  The host queues a fixed
+// number of levels (from the witness size) with no synchronisation; whatever is still unsettled afterwards — a deeper
+// tree, a node the table does not cover (> 32 pointers, a bitfield over 64 bits, offsets beyond 64 KB, ANY decode
+// problem) — is left kStPending and the per-query walker (k_hamt_get, pending_only) takes it from the root, so an
+// outcome never depends on this path: it only ever answers what the walk would answer.
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "launch.h"
+#include "walk_dev.h"
+
+namespace ipcfp {
+
+struct HamtLevels {
+    uint32_t* cur;        // n          the block each query stands on (kNoBlock: settled, or left to the walker)
+    uint32_t* hash;       // n × 8      SHA-256 of the key, eight big-endian words
+    HamtNodeRec* recs;    // n_blocks   indexed by block id; valid where `claimed` says so and the level has been parsed
+    uint32_t* claimed;    // ⌈n_blocks / 32⌉ bits: the block is (or was) on a work list
+    uint32_t* work[2];    // work lists of even / odd levels (capacity: min(n, n_blocks))
+    uint32_t* count;      // entries of level l's list (one counter per level)
+};
+
+__device__ __forceinline__ void hamt_claim(const HamtLevels& L, uint32_t block, uint32_t level) {
+    const uint32_t bit = 1u << (block & 31u);
+    uint32_t* word = L.claimed + (block >> 5);
+    if (__builtin_nontemporal_load(word) & bit) return;  // (a stale miss only costs the atomic below)
+    if (atomicOr(word, bit) & bit) return;
+    L.work[level & 1u][atomicAdd(L.count + level, 1u)] = block;
+}
+
+__global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey root, HamtLevels L, const uint8_t* __restrict__ keys,
+                                                       const uint32_t* __restrict__ key_off, const uint32_t* __restrict__ key_len,
+                                                       uint32_t n, uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint32_t h[8];
+    sha256::hash_bytes(keys + key_off[t], key_len[t], h);
+    uint4* hp = reinterpret_cast<uint4*>(L.hash + size_t(t) * 8);
+    hp[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    hp[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    const uint32_t rb = witness_find(w, root);  // (every lane: the same probe, broadcast)
+    L.cur[t] = rb;
+    status[t] = uint8_t(rb == kNoBlock ? uint32_t(IPCFP_ST_ERR_MISSING_BLOCK) : kStPending);
+    if (loc) loc[t] = ValueLoc{kNoBlock, 0, 0};
+    if (t == 0 && rb != kNoBlock) {
+        L.claimed[rb >> 5] = 1u << (rb & 31u);  // (the bitmap was cleared before this launch)
+        L.work[0][0] = rb;
+        L.count[0] = 1u;
+    }
+}
+
+// lane = one node of level `level`'s work list
+__global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_lv_parse(WitnessView w, HamtLevels L, uint32_t level, int vkind) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.count[level]) return;
+    const uint32_t block = L.work[level & 1u][i];
+    HamtNodeRec* out = L.recs + block;
+    Rd r = open_block(w, block);
+    uint32_t status = 0, std_links = 0, np32 = 0;
+    uint64_t bf = 0;
+    do {
+        r.expect_array(2);
+        uint32_t bo, bl;
+        r.read_bytes(bo, bl);
+        if (!r.ok() || bl > 8) break;
+        if (bl) {  // big-endian integer, leading zeros stripped: the last byte holds bits 0..7
+            const uint64_t v = r.peek64(bo);
+            bf = __builtin_bswap64(v) >> (64u - 8u * bl);
+        }
+        const uint64_t np = r.read_array();
+        if (!r.ok() || np > kHamtTablePointers) break;
+        np32 = uint32_t(np);
+        bool fits = true;
+        for (uint32_t p = 0; p < np32 && r.ok(); ++p) {
+            const uint32_t at = r.pos;
+            fits = fits && at <= 0xffffu;
+            out->ptr_off[p] = uint16_t(at);
+            const uint32_t b0 = r.peek();
+            if ((b0 >> 5) == 6) {
+                uint32_t o, l;
+                r.read_link(o, l);
+                if (r.ok() && l == 38 && o == at + 5) std_links |= 1u << p;  // (read_link's own fast path saw the standard form)
+            } else if ((b0 >> 5) == 4) {
+                const uint64_t nkv = r.read_array();
+                for (uint64_t k = 0; k < nkv && r.ok(); ++k) {
+                    uint32_t ko, kl, vstart;
+                    if (vkind == VK_ACTOR_STATE && actor_entry_fast(r, ko, kl, vstart)) continue;
+                    r.expect_array(2);
+                    r.read_bytes(ko, kl);
+                    check_value(r, vkind);
+                }
+            } else {
+                r.fail();
+            }
+        }
+        r.finish();
+        if (r.ok() && fits) status = 1;
+    } while (false);
+    // a standard link must really be one: l == 38 at at + 5 is also what the long way reports for that spelling only
+    out->status = uint8_t(status);
+    out->kinds_ok = uint8_t(status);
+    out->np = uint8_t(np32);
+    out->pad = 0;
+    out->std_links = std_links;
+    out->bitfield = bf;
+}
+
+// ---- the same for `Hamt<_, ActorState>` (the state tree: src/proofs/common/decode.rs:29-39), THIRTY-TWO LANES PER NODE ----
+// One lane per node (above) is a chain of dependent loads from HBM — a 4-5 KB state-tree node is ≈ 80 pointers and bucket
+// entries, each a few round trips — run by the few hundred wavefronts a level's work list fills: 0.19 ms per level on
+// config 4's tree (profiles/r04_experiments.md), and the lanes of a wavefront sit in different kinds of pointers, so the
+// wavefront executes both the link and the bucket path for every one.  Here a wavefront takes two nodes:
+//   stage   the 32 lanes of a group copy their node into LDS with coalesced 16-byte loads (one burst, no chain);
+//   outline lane 0 of the group walks the node's OUTLINE out of LDS — item headers only: where every pointer, every
+//           bucket entry's ActorState and its optional address start — for the spellings every encoder writes;
+//   check   all 32 lanes validate the pieces side by side: each link's 11-byte CIDv1 / dag-cbor / blake2b-256 prefix, each
+//           TokenAmount's sign byte and length, each delegated address (check_address);
+//   record  the HamtNodeRec, offsets written by all lanes.
+// Whatever is not exactly `82 | 4x bitfield | 8x/98 pointers | (std link | 8x bucket of [82, key, 85, std link, std link,
+// uint, bytes, f6 | bytes])`, or does not fit the 7.4 KB stage, is left "not tabulated" — the walker decides; a node this
+// kernel accepts is one the item-by-item decode accepts, with the same record.
+// LDS: 2 × 7424 B of stage + 1.2 KB of outline = 16.0 KB per wavefront, so that FOUR wavefronts share the 64 KB a CU
+// hands out (one 35 KB workgroup per CU was measured: 8 192 wavefronts of 26 µs took 0.79 ms).  The outline reads 8
+// bytes per LDS round trip: a wavefront's time IS the outline lane's chain of dependent LDS reads.
+constexpr uint32_t kCoopLanes = 32, kCoopNodes = 2, kCoopStage = 7424, kCoopMaxEntries = 96;
+
+// the 8 bytes at S[p, p + 8) as a little-endian word (one aligned two-word LDS read)
+__device__ __forceinline__ uint64_t lds_peek64(const uint8_t* S, uint32_t p) {
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(S + (p & ~7u));
+    const uint64_t lo = q[0], hi = q[1];
+    const uint32_t sh = (p & 7u) * 8u;
+    return (lo >> sh) | ((hi << 1) << (63u - sh));
+}
+
+__device__ __forceinline__ bool lds_std_link_prefix(const uint8_t* S, uint32_t at) {
+    // d8 2a | 58 27 | 00 | 01 71 a0 e4 02 20
+    return lds_peek64(S, at) == 0xa071010027582ad8ull && (lds_peek64(S, at + 8u) & 0xffffffull) == 0x2002e4ull;
+}
+
+// one well-formed binary CID in S[off, off + len)?   (cbor_dev.h Rd::cid_ok)
+__device__ __forceinline__ bool lds_cid_ok(const uint8_t* S, uint32_t off, uint32_t len) {
+    if (len == 34 && S[off] == 0x12 && S[off + 1] == 0x20) return true;  // CIDv0
+    uint32_t q = off;
+    const uint32_t end = off + len;
+    uint64_t field[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        uint64_t v = 0;
+        bool done = false;
+        for (int shift = 0; shift < 63; shift += 7) {
+            if (q >= end) return false;
+            const uint32_t c = S[q];
+            ++q;
+            v |= uint64_t(c & 0x7f) << shift;
+            if (!(c & 0x80)) {
+                if (c == 0 && shift > 0) return false;  // non-minimal varint
+                done = true;
+                break;
+            }
+        }
+        if (!done) return false;
+        field[f] = v;
+    }
+    if (field[0] != 1) return false;
+    if (field[3] > 64) return false;
+    return uint64_t(end - q) == field[3];
+}
+
+// the tag-42 link at S[at] whose OUTLINE (d8 2a, a byte-string header) the outline pass has seen: standard prefix, or
+// the long way — 0x00 multibase byte, one well-formed CID (cbor_dev.h Rd::read_link).  *std: the 43-byte standard form.
+__device__ __forceinline__ bool lds_link_ok(const uint8_t* S, uint32_t at, bool* std_form) {
+    *std_form = lds_std_link_prefix(S, at);
+    if (*std_form) return true;
+    {   // the short spelling (cbor_dev.h link_fast_len): d8 2a | 4l | 00 01 codec code n — e.g. the builtin actors' code CIDs
+        const uint64_t w0 = lds_peek64(S, at);
+        const uint32_t hb = uint32_t(w0 >> 16) & 0xffu, l = hb - 0x40u, n = uint32_t(w0 >> 56);
+        if (hb >= 0x45u && hb <= 0x57u && ((w0 >> 24) & 0xffffull) == 0x0100ull && ((w0 >> 24) & 0x80800000ull) == 0ull && n <= 40u && l == 5u + n)
+            return true;
+    }
+    const uint32_t hb = S[at + 2];
+    const uint32_t h = hb == 0x58u ? 4u : 3u, l = hb == 0x58u ? uint32_t(S[at + 3]) : hb - 0x40u;
+    return l >= 1u && S[at + h] == 0x00u && lds_cid_ok(S, at + h + 1u, l - 1u);
+}
+
+// Address::from_bytes shape of S[off, off + n)   (cbor_dev.h check_address)
+__device__ __forceinline__ bool lds_address_ok(const uint8_t* S, uint32_t off, uint32_t n) {
+    if (n < 1) return false;
+    const uint32_t proto = S[off];
+    if (proto == 0 || proto == 4) {
+        uint32_t pos = 1;
+        bool term = false;
+        for (int k = 0; k < 10; ++k) {
+            if (pos >= n) return false;
+            if (!(S[off + pos++] & 0x80)) {
+                term = true;
+                break;
+            }
+        }
+        if (!term) return false;
+        return proto == 0 ? pos == n : n - pos <= 54;
+    }
+    if (proto == 1 || proto == 2) return n == 21;
+    if (proto == 3) return n == 49;
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kCoopNodes][kCoopStage];
+    __shared__ uint16_t s_ptr[kCoopNodes][kHamtTablePointers];   // pointer starts
+    __shared__ uint16_t s_val[kCoopNodes][kCoopMaxEntries];      // per bucket entry: where its ActorState (0x85) starts
+    __shared__ uint16_t s_l2[kCoopNodes][kCoopMaxEntries];       // … its second link (`state`) …
+    __shared__ uint16_t s_adr[kCoopNodes][kCoopMaxEntries];      // … and its delegated_address item
+    __shared__ uint32_t s_np[kCoopNodes], s_ne[kCoopNodes], s_links[kCoopNodes];
+    __shared__ uint64_t s_bf[kCoopNodes];
+    const uint32_t lane = threadIdx.x & 63u, g = lane / kCoopLanes, sub = lane % kCoopLanes;
+    const uint32_t i = blockIdx.x * kCoopNodes + g;
+    const bool have = i < L.count[level];
+    const uint32_t block = have ? L.work[level & 1u][i] : 0u;
+    const uint32_t len = have ? w.len[block] : 0u;
+    const bool staged = have && len >= 3u && len + 24u <= kCoopStage;
+    uint8_t* S = stage[g];
+    if (staged) {
+        const uint4* src = reinterpret_cast<const uint4*>(w.arena + w.off[block]);  // line-aligned, padded to a line
+        uint4* dst = reinterpret_cast<uint4*>(S);
+        const uint32_t chunks = (len + 15u) >> 4;
+        for (uint32_t c = sub; c < chunks; c += kCoopLanes) dst[c] = src[c];
+    }
+    if (sub == 0) s_np[g] = 0xffffffffu;  // "no outline"
+    __syncthreads();
+    // ---- outline: lane 0 of the group ----
+    if (staged && sub == 0) {
+        // (every unit's END is held against `len`: a header byte taken from beyond the node puts the end beyond it too)
+        // encoded length of the link whose first bytes are w (d8 2a | 4l / 58 l | …), 0: not that outline
+        auto link_len = [](uint64_t w) -> uint32_t {
+            if ((w & 0xffffull) != 0x2ad8ull) return 0u;
+            const uint32_t hb = uint32_t(w >> 16) & 0xffu;
+            if (hb >= 0x41u && hb <= 0x57u) return 3u + (hb - 0x40u);
+            if (hb == 0x58u) return 4u + (uint32_t(w >> 24) & 0xffu);
+            return 0u;
+        };
+        const uint64_t w0 = lds_peek64(S, 0);
+        bool ok = (w0 & 0xffu) == 0x82u;
+        const uint32_t bl = (uint32_t(w0 >> 8) & 0xffu) - 0x40u;  // bitfield: bytes, at most 8
+        ok = ok && bl <= 8u;
+        uint64_t bf = 0;
+        if (ok && bl) bf = __builtin_bswap64(lds_peek64(S, 2u)) >> (64u - 8u * bl);
+        uint32_t pos = 2u + bl, np = 0, ne = 0, links = 0;
+        if (ok) {
+            const uint64_t w = lds_peek64(S, pos);
+            const uint32_t b = uint32_t(w) & 0xffu;
+            if (b >= 0x80u && b <= 0x97u) {
+                np = b - 0x80u;
+                pos += 1u;
+            } else if (b == 0x98u) {
+                np = uint32_t(w >> 8) & 0xffu;
+                pos += 2u;
+            } else {
+                ok = false;
+            }
+            ok = ok && np <= kHamtTablePointers && pos <= len;
+        }
+        for (uint32_t p = 0; ok && p < np; ++p) {
+            s_ptr[g][p] = uint16_t(pos);
+            const uint64_t w = lds_peek64(S, pos);
+            const uint32_t b = uint32_t(w) & 0xffu;
+            if (b == 0xd8u) {  // a link: its bytes are checked by the lanes
+                const uint32_t ll = link_len(w);
+                ok = ll != 0u;
+                links |= 1u << p;
+                pos += ll;
+            } else if (b >= 0x80u && b <= 0x97u) {  // a bucket of b - 0x80 entries
+                const uint32_t nkv = b - 0x80u;
+                pos += 1u;
+                ok = ne + nkv <= kCoopMaxEntries;
+                for (uint32_t k = 0; ok && k < nkv; ++k) {
+                    // 82 | key: 4x … / 58 ll … | 85 link link | sequence | balance | f6 / address bytes
+                    const uint64_t e0 = k == 0 ? (w >> 8) : lds_peek64(S, pos);  // (the first entry follows the bucket's header byte)
+                    const uint32_t kb = uint32_t(e0 >> 8) & 0xffu;
+                    uint32_t q;
+                    if (kb >= 0x40u && kb <= 0x57u) q = pos + 2u + (kb - 0x40u);
+                    else if (kb == 0x58u) q = pos + 3u + (uint32_t(e0 >> 16) & 0xffu);
+                    else {
+                        ok = false;
+                        break;
+                    }
+                    const uint64_t v0 = lds_peek64(S, q);  // 85 | code link …
+                    const uint32_t l1 = link_len(v0 >> 8);
+                    const uint32_t l2 = link_len(lds_peek64(S, q + 1u + l1));  // state
+                    ok = (e0 & 0xffu) == 0x82u && (v0 & 0xffu) == 0x85u && l1 != 0u && l2 != 0u;
+                    s_val[g][ne] = uint16_t(q);
+                    s_l2[g][ne] = uint16_t(q + 1u + l1);
+                    q += 1u + l1 + l2;
+                    const uint32_t sb = uint32_t(lds_peek64(S, q)) & 0xffu;  // sequence: an unsigned integer in any width
+                    ok = ok && sb <= 0x1bu;
+                    q += 1u + (sb < 0x18u ? 0u : (1u << ((sb - 0x18u) & 3u)));
+                    const uint64_t b0 = lds_peek64(S, q);  // balance: bytes, at most 128, sign byte 0 / 1
+                    const uint32_t bb = uint32_t(b0) & 0xffu;
+                    uint32_t l, sign;
+                    if (bb >= 0x40u && bb <= 0x57u) {
+                        l = bb - 0x40u;
+                        sign = uint32_t(b0 >> 8) & 0xffu;
+                        q += 1u;
+                    } else if (bb == 0x58u) {
+                        l = uint32_t(b0 >> 8) & 0xffu;
+                        sign = uint32_t(b0 >> 16) & 0xffu;
+                        q += 2u;
+                    } else {
+                        ok = false;
+                        break;
+                    }
+                    ok = ok && l <= 128u && (l == 0u || sign <= 1u);
+                    q += l;
+                    s_adr[g][ne] = uint16_t(q);
+                    const uint64_t a0 = lds_peek64(S, q);  // delegated_address: None, or address bytes (checked by the lanes)
+                    const uint32_t ab = uint32_t(a0) & 0xffu;
+                    if (ab == 0xf6u) q += 1u;
+                    else if (ab >= 0x40u && ab <= 0x57u) q += 1u + (ab - 0x40u);
+                    else if (ab == 0x58u) q += 2u + (uint32_t(a0 >> 8) & 0xffu);
+                    else ok = false;
+                    ++ne;
+                    pos = q;
+                    ok = ok && pos <= len;
+                }
+            } else {
+                ok = false;
+            }
+            ok = ok && pos <= len;
+        }
+        ok = ok && pos == len;  // nothing after the node
+        if (ok) {
+            s_np[g] = np;
+            s_ne[g] = ne;
+            s_links[g] = links;
+            s_bf[g] = bf;
+        }
+    }
+    __syncthreads();
+    // ---- check: every lane its share of the links, the entries' links and addresses ----
+    const uint32_t np = s_np[g];
+    bool good = staged && np != 0xffffffffu;
+    if (good) {
+        const uint32_t links = s_links[g], ne = s_ne[g];
+        for (uint32_t p = sub; p < np; p += kCoopLanes)
+            if ((links >> p) & 1u) {
+                bool std_form;
+                good = good && lds_link_ok(S, s_ptr[g][p], &std_form);
+                if (!std_form) atomicAnd(&s_links[g], ~(1u << p));  // (the record's mask names the STANDARD links only)
+            }
+        for (uint32_t e = sub; e < ne; e += kCoopLanes) {
+            const uint32_t q = s_val[g][e];
+            bool std_form;
+            good = good && lds_link_ok(S, q + 1u, &std_form) && lds_link_ok(S, s_l2[g][e], &std_form);
+            const uint32_t a = s_adr[g][e], ab = S[a];
+            if (ab != 0xf6u) {
+                const uint32_t off = ab == 0x58u ? a + 2u : a + 1u, n = ab == 0x58u ? uint32_t(S[a + 1u]) : ab - 0x40u;
+                good = good && lds_address_ok(S, off, n);
+            }
+        }
+    }
+    // all thirty-two lanes of the group agree?
+    const uint64_t votes = __ballot(good);
+    const uint64_t mine = 0xffffffffull << (g * kCoopLanes);
+    const bool node_ok = (votes & mine) == mine;
+    __syncthreads();  // (s_links: the lanes' atomicAnd before lane 0 reads it back)
+    if (!have) return;
+    HamtNodeRec* out = L.recs + block;
+    if (node_ok) {
+        // offsets: sixteen dwords = thirty-two u16
+        if (sub < 16u) {
+            const uint32_t lo = 2u * sub < np ? s_ptr[g][2u * sub] : 0u, hi = 2u * sub + 1u < np ? s_ptr[g][2u * sub + 1u] : 0u;
+            reinterpret_cast<uint32_t*>(out->ptr_off)[sub] = lo | (hi << 16);
+        }
+    }
+    if (sub == 0) {
+        out->status = uint8_t(node_ok ? 1u : 0u);  // 0: not tabulated — the walker decides
+        out->kinds_ok = uint8_t(node_ok ? 1u : 0u);
+        out->np = uint8_t(node_ok ? np : 0u);
+        out->pad = 0;
+        out->std_links = node_ok ? s_links[g] : 0u;
+        out->bitfield = node_ok ? s_bf[g] : 0ull;
+    }
+}
+
+// lane = query: one level down
+__global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLevels L, uint32_t level, uint32_t bit_width, int vkind,
+                                                         const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
+                                                         const uint32_t* __restrict__ key_len, uint32_t n,
+                                                         uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t block = L.cur[t];
+    if (block == kNoBlock) return;
+    const HamtNodeRec* rec = L.recs + block;
+    const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);  // status | kinds_ok << 8 | np << 16
+    uint32_t st = kStPending, next = kNoBlock;
+    ValueLoc hit{kNoBlock, 0, 0};
+    do {
+        if ((head & 0xffu) != 1u) break;  // not tabulated: the walker decides (from the root)
+        const uint32_t np = (head >> 16) & 0xffu;
+        const uint32_t consumed = level * bit_width;
+        if (consumed + bit_width > 256u) {  // HashBits::next after the node has decoded
+            st = IPCFP_ST_ERR_MAX_DEPTH;
+            break;
+        }
+        const uint4* hp = reinterpret_cast<const uint4*>(L.hash + size_t(t) * 8);
+        const uint4 h0 = hp[0], h1 = hp[1];
+        const uint32_t h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        const uint32_t idx = sha256::take_bits(h, consumed, bit_width);
+        const uint64_t bf = rec->bitfield;
+        if (idx >= 64u || !((bf >> idx) & 1ull)) {
+            st = IPCFP_ST_NOT_FOUND;
+            break;
+        }
+        const uint32_t rank = uint32_t(__popcll(bf & ((1ull << idx) - 1ull)));
+        if (rank >= np) {
+            st = IPCFP_ST_ERR_DECODE;
+            break;
+        }
+        const uint32_t off = rec->ptr_off[rank];
+        const uint8_t* g = w.arena + w.off[block];
+        CidKey link;
+        bool is_link = true;
+        if ((rec->std_links >> rank) & 1u) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) __builtin_memcpy(&link.w[j], g + off + 5 + 8 * j, 8);  // unaligned 8-byte loads
+            link.w[4] &= (1ull << 48) - 1ull;
+        } else {
+            Rd r;
+            r.init(g, w.len[block]);
+            r.pos = off;
+            if ((r.peek() >> 5) == 6) {
+                uint32_t o, l;
+                r.read_link(o, l);
+                if (!r.ok()) break;  // (cannot happen: the node was validated) → the walker
+                link = l <= 40 ? r.key_at(o, l) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+            } else {
+                // a bucket `[[key, value]…]` of a validated node: find the key
+                is_link = false;
+                const uint8_t* key = keys + key_off[t];
+                const uint32_t key_len_t = key_len[t];
+                const uint64_t nkv = r.read_array();
+                bool found = false;
+                for (uint64_t k = 0; k < nkv && r.ok() && !found; ++k) {
+                    uint32_t ko, kl, vstart;
+                    if (!(vkind == VK_ACTOR_STATE && actor_entry_fast(r, ko, kl, vstart))) {
+                        r.expect_array(2);
+                        r.read_bytes(ko, kl);
+                        vstart = r.pos;
+                        r.skip();
+                    }
+                    if (r.ok() && kl == key_len_t && r.equal_bytes(ko, key, kl)) {
+                        found = true;
+                        hit = ValueLoc{block, vstart, r.pos - vstart};
+                    }
+                }
+                if (!r.ok()) break;  // → the walker
+                st = found ? uint32_t(IPCFP_ST_TRUE) : uint32_t(IPCFP_ST_NOT_FOUND);
+            }
+        }
+        if (is_link) {
+            next = witness_find(w, link);
+            if (next == kNoBlock) st = IPCFP_ST_ERR_MISSING_BLOCK;
+        }
+    } while (false);
+    if (next != kNoBlock) {
+        L.cur[t] = next;
+        hamt_claim(L, next, level + 1u);
+        return;
+    }
+    L.cur[t] = kNoBlock;
+    if (st != kStPending) {
+        status[t] = uint8_t(st);
+        if (loc && st == IPCFP_ST_TRUE) loc[t] = hit;
+    }
+}
+
+// Scratch of one call: [cur n | hash 8n | work0 cap | work1 cap | count (levels + 1) | claimed words] u32 + the record table.
+size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels) {
+    const size_t cap = n < n_blocks ? n : n_blocks;
+    return size_t(n) * 9 + cap * 2 + (levels + 2) + div_up(n_blocks, 32) + 8;
+}
+
+int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
+                           const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
+                           uint8_t* status_d, void* loc_d, uint32_t levels, uint32_t* scratch_d, void* recs_d, bool coop) {
+    if (n == 0) return IPCFP_OK;
+    const uint32_t cap = n < w.n ? n : w.n;
+    const uint32_t words = div_up(w.n, 32);
+    HamtLevels L;
+    L.cur = scratch_d;
+    L.hash = scratch_d + size_t(n);
+    L.work[0] = scratch_d + size_t(n) * 9;
+    L.work[1] = L.work[0] + cap;
+    L.count = L.work[1] + cap;
+    L.claimed = L.count + (levels + 2);
+    L.recs = static_cast<HamtNodeRec*>(recs_d);
+    // counters and bitmap are contiguous: one clear
+    IPCFP_HIP(ctx, hipMemsetAsync(L.count, 0, (size_t(levels) + 2 + words) * 4, ctx->stream));
+    ValueLoc* loc = static_cast<ValueLoc*>(loc_d);
+    hipLaunchKernelGGL(k_hamt_lv_start, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, root, L, keys_d, key_off_d, key_len_d,
+                       n, status_d, loc);
+    for (uint32_t lv = 0; lv < levels; ++lv) {
+        // level l holds at most min(n, 2^(bit_width · l)) distinct nodes
+        uint64_t fan = 1;
+        for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
+        const uint32_t bound = fan < cap ? uint32_t(fan) : cap;
+        if (vkind == VK_ACTOR_STATE && coop)
+            hipLaunchKernelGGL(k_hamt_lv_parse_actor, dim3(div_up(bound, kCoopNodes)), dim3(64), 0, ctx->stream, w, L, lv);
+        else
+            hipLaunchKernelGGL(k_hamt_lv_parse, dim3(div_up(bound, 256)), dim3(256), 0, ctx->stream, w, L, lv, vkind);
+        hipLaunchKernelGGL(k_hamt_lv_advance, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, L, lv, bit_width, vkind, keys_d,
+                           key_off_d, key_len_d, n, status_d, loc);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

@@ -109,12 +109,12 @@ int launch_amt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, int
 
 int launch_hamt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
                     const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
-                    uint8_t* status_d, void* loc_d) {
+                    uint8_t* status_d, void* loc_d, int pending_only) {
     if (n == 0) return IPCFP_OK;
     // (timed by the caller: host/primitives.cpp hamt_get_batch)
     const uint32_t lanes = hamt_lanes(ctx, n);
     hipLaunchKernelGGL(k_hamt_get, dim3(div_up(uint64_t(div_up(n, lanes)) * 64u, 256)), dim3(256), 0, ctx->stream, w, root, bit_width,
-                       vkind, keys_d, key_off_d, key_len_d, n, status_d, static_cast<ValueLoc*>(loc_d), 0, lanes);
+                       vkind, keys_d, key_off_d, key_len_d, n, status_d, static_cast<ValueLoc*>(loc_d), pending_only, lanes);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -309,11 +309,13 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
             } else if ((b0 >> 5) == 4) {
                 const uint64_t nkv = r.read_array();
                 for (uint64_t k = 0; k < nkv && r.ok(); ++k) {
-                    r.expect_array(2);
-                    uint32_t ko, kl;
-                    r.read_bytes(ko, kl);
-                    const uint32_t vstart = r.pos;
-                    check_value(r, vkind);
+                    uint32_t ko, kl, vstart;
+                    if (!(vkind == VK_ACTOR_STATE && actor_entry_fast(r, ko, kl, vstart))) {
+                        r.expect_array(2);
+                        r.read_bytes(ko, kl);
+                        vstart = r.pos;
+                        check_value(r, vkind);
+                    }
                     if (wanted && r.ok() && !found && kl == key_len) {
                         bool eq = true;
                         for (uint32_t c = 0; c < kl; ++c) eq &= r.at(ko + c) == key[c];

@@ -1,0 +1,185 @@
+"""GPU: every ROUTE of the HAMT entry points answers what the per-query walker answers, and the oracle.
+
+`ipcfp_hamt_get*` has three routes (ipcfp_ctx_set_tuning): the per-query walker (`hamt_levels` = 0), LEVEL BY LEVEL —
+every visited node decoded once (kernels/hamt_levels.hip; default for large batches, forced here for every batch size
+and also with too FEW levels, so that deep queries are handed to the walker mid-tree) — and the whole-witness node
+table (`hamt_table` = 1).  `ipcfp_verify_storage_proofs` has the tabled route (default for large batches) and the
+one-lane route (`hamt_table` = 0).  All are driven over the same corpora: well-formed trees of three bit widths, the
+synthetic state tree with wrong value types / bit widths, and witnesses with random byte flips in their blocks
+(src/proofs/common/decode.rs:29-39, src/proofs/storage/decode.rs:36-97 are the semantics at stake)."""
+import numpy as np
+import pytest
+
+import claims
+import pyamt
+import pyhamt
+from test_gpu_fuzz import idaddr, mutate
+from tools.synth import Tipset
+
+pytestmark = pytest.mark.gpu
+
+ROUTES = [("walker", {"hamt_levels": 0, "hamt_table": -1}), ("levels", {"hamt_levels": 14, "hamt_table": -1}),
+          ("levels-one-lane-parse", {"hamt_levels": 14, "hamt_table": -1, "hamt_coop": 0}),
+          ("levels-2-then-walker", {"hamt_levels": 2, "hamt_table": -1}), ("levels-1", {"hamt_levels": 1, "hamt_table": -1}),
+          ("table", {"hamt_levels": 0, "hamt_table": 1})]
+
+
+@pytest.fixture()
+def routed(engine):
+    def use(cfg):
+        engine.set_tuning("hamt_coop", -1)
+        for k, v in cfg.items():
+            engine.set_tuning(k, v)
+    yield use
+    engine.set_tuning("hamt_levels", -1)
+    engine.set_tuning("hamt_table", -1)
+    engine.set_tuning("hamt_coop", -1)
+
+
+def loc_bytes(data, off, loc):
+    out = []
+    for l in loc:
+        if l["block"] == 0xFFFFFFFF:
+            out.append(b"")
+        else:
+            o = int(off[l["block"]]) + int(l["off"])
+            out.append(data[o: o + int(l["len"])].tobytes())
+    return out
+
+
+@pytest.mark.parametrize("bw", [3, 5, 8])
+@pytest.mark.parametrize("n", [0, 1, 40, 2000, 30000])
+def test_python_written_trees_every_route(engine, oracle, routed, bw, n):
+    store = pyamt.Store()
+    keys = [b"\x00" + pyamt.uint(1000 + i)[0:9] + bytes([i & 0xFF, (i >> 8) & 0xFF, i >> 16]) for i in range(n)]
+    items = {k: pyamt.array([pyamt.uint(i), pyamt.bstr(bytes([i & 0xFF]) * (i % 7))]) for i, k in enumerate(keys)}
+    root = pyhamt.build_hamt(store, items, bit_width=bw)
+    data, off, lens, cids = store.tables()
+    rng = np.random.default_rng(n + bw)
+    probe = [keys[int(i)] for i in rng.integers(0, max(n, 1), min(n, 3000))] + [b"nope", b"", b"\x00\xff\xff"]
+    st = oracle.store(data, off, lens, cids)
+    os_, ov = st.hamt_get(root, bw, "any", probe)
+    st.close()
+    with engine.witness(data, off, lens, cids) as w:
+        for name, cfg in ROUTES:
+            routed(cfg)
+            gs, gl = w.hamt_get(root, bw, "any", probe)
+            assert np.array_equal(gs, os_), (name, np.nonzero(gs != os_)[0][:5])
+            assert loc_bytes(data, off, gl) == ov, name
+    for k, s in zip(probe[:-3], os_):
+        assert s == 1
+
+
+@pytest.fixture(scope="module")
+def tip():
+    return Tipset(n_receipts=300, n_parents=2, n_planted=3, variety=1, n_actors=60000, n_contracts=24, slots_per_contract=64,
+                  storage_layout_mix=1, n_actor_queries=4000, keep_full_state=0, seed=4242)
+
+
+def test_state_tree_gets_every_route_and_wrong_types(tip, engine, oracle, routed):
+    keys = [idaddr(int(i)) for i in tip.query_ids] + [b"", b"\x00", bytes(40)]
+    st = oracle.store(tip.data, tip.off, tip.lens, tip.cids)
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        for bw, kind in ((5, "actor_state"), (5, "vec_u8"), (5, "any"), (4, "actor_state"), (8, "actor_state"), (9, "actor_state"),
+                         (0, "actor_state")):
+            os_, ov = st.hamt_get(tip.actors_root, bw, kind, keys)
+            for name, cfg in ROUTES:
+                routed(cfg)
+                gs, gl = w.hamt_get(tip.actors_root, bw, kind, keys)
+                assert np.array_equal(gs, os_), (name, bw, kind, np.nonzero(gs != os_)[0][:5], gs[gs != os_][:5], os_[gs != os_][:5])
+                assert loc_bytes(tip.data, tip.off, gl) == ov, (name, bw, kind)
+        # a root that is not in the witness
+        missing = oracle.cid_for_block(b"no such root")
+        for name, cfg in ROUTES:
+            routed(cfg)
+            gs, _ = w.hamt_get(missing, 5, "actor_state", keys[:70])
+            assert (gs == 65).all(), name
+    st.close()
+    present = tip.query_present.astype(bool)
+    assert present.sum() > 3000 and (~present).sum() > 10
+
+
+def test_mutated_witnesses_every_route(tip, engine, oracle, routed):
+    """Random byte flips inside blocks (CIDs left alone: the reference's MemoryBlockstore never re-hashes): decode errors,
+    bitfield / count mismatches, broken links and type errors must come out as the same status on every route."""
+    rng = np.random.default_rng(77)
+    keys = [idaddr(int(i)) for i in tip.query_ids]
+    sc = claims.StorageClaims(tip)
+    n_diff_from_clean = 0
+    for it in range(24):
+        data, touched = mutate(tip, rng, n_flips=3 + 5 * (it % 5))
+        st = oracle.store(data, tip.off, tip.lens, tip.cids)
+        os_, ov = st.hamt_get(tip.actors_root, 5, "actor_state", keys)
+        want_sp = st.verify_storage_proofs(sc, mode=1)
+        st.close()
+        n_diff_from_clean += int((os_ >= 64).any()) + int((want_sp != 1).any())
+        with engine.witness(data, tip.off, tip.lens, tip.cids) as w:
+            for name, cfg in ROUTES:
+                routed(cfg)
+                gs, gl = w.hamt_get(tip.actors_root, 5, "actor_state", keys)
+                assert np.array_equal(gs, os_), (name, it, touched, np.nonzero(gs != os_)[0][:5], gs[gs != os_][:5], os_[gs != os_][:5])
+                assert loc_bytes(data, tip.off, gl) == ov, (name, it)
+            for table in (0, 1, -1):  # storage proofs: one-lane route, tabled route, the default choice
+                engine.set_tuning("hamt_table", table)
+                got = w.verify_storage_proofs(sc.arr, sc.n)
+                assert np.array_equal(got, want_sp), ("storage", table, it, touched, np.nonzero(got != want_sp)[0][:5])
+    assert n_diff_from_clean > 4  # the flips really reach error paths
+
+
+def actor_state(i, rng, flaw=None):
+    """One ActorState `[code, state, sequence, balance, delegated_address]` in the spellings encoders write — every
+    width of the sequence, TokenAmounts from empty to 20 bytes, with and without an f4 / f1 / f3 address — or with ONE
+    flaw the typed decode rejects (fvm_shared ActorState)."""
+    code = pyamt.link(pyamt.cid_of(b"code%d" % (i % 5)))
+    state = pyamt.link(pyamt.cid_of(b"state%d" % i))
+    seq = pyamt.uint([0, 7, 23, 24, 255, 256, 70000, 1 << 33][i % 8])
+    mag = bytes(rng.integers(1, 256, int(rng.integers(0, 20)), dtype=np.uint8))
+    bal = pyamt.bstr((bytes([i & 1]) + mag) if (len(mag) or i % 3) else b"")
+    kind = i % 4
+    if kind == 0:
+        adr = pyamt.NULL
+    elif kind == 1:
+        adr = pyamt.bstr(b"\x04\x0a" + bytes(rng.integers(0, 256, 20, dtype=np.uint8)))     # f4: namespace 10 + 20 bytes
+    elif kind == 2:
+        adr = pyamt.bstr(b"\x01" + bytes(rng.integers(0, 256, 20, dtype=np.uint8)))         # f1
+    else:
+        adr = pyamt.bstr(b"\x03" + bytes(rng.integers(0, 256, 48, dtype=np.uint8)))         # f3 (49 bytes: a 0x58 header)
+    if flaw == "sign":
+        bal = pyamt.bstr(b"\x02\x05")
+    elif flaw == "balance_len":
+        bal = pyamt.bstr(b"\x00" + b"\x01" * 129)
+    elif flaw == "address_proto":
+        adr = pyamt.bstr(b"\x05\x01\x02")
+    elif flaw == "address_len":
+        adr = pyamt.bstr(b"\x01" + b"\x07" * 19)
+    elif flaw == "arity":
+        return pyamt.array([code, state, seq, bal])
+    elif flaw == "link":
+        state = pyamt.uint(5)
+    return pyamt.array([code, state, seq, bal, adr])
+
+
+@pytest.mark.parametrize("flaw", [None, "sign", "balance_len", "address_proto", "address_len", "arity", "link"])
+def test_actor_state_spellings_and_flaws_every_route(engine, oracle, routed, flaw):
+    """The sixteen-lane node decode (k_hamt_lv_parse_actor) judges ActorStates from item headers; every spelling it
+    accepts, and every flaw it must leave to the item-by-item decode, comes out like the walker's and the oracle's
+    verdict: one flawed value poisons its whole node (serde decodes all of it), and only the paths through that node."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    keys = [idaddr(1000 + 37 * i) for i in range(n)]
+    bad_at = {} if flaw is None else {int(i): flaw for i in rng.integers(0, n, 12)}
+    items = {k: actor_state(i, rng, bad_at.get(i)) for i, k in enumerate(keys)}
+    store = pyamt.Store()
+    root = pyhamt.build_hamt(store, items, bit_width=5)
+    data, off, lens, cids = store.tables()
+    probe = keys + [idaddr(5), b"", idaddr(1 << 40)]
+    st = oracle.store(data, off, lens, cids)
+    os_, ov = st.hamt_get(root, 5, "actor_state", probe)
+    st.close()
+    assert (os_[:n] == 1).sum() > n // 2 and ((os_ == 66).any() == (flaw is not None))
+    with engine.witness(data, off, lens, cids) as w:
+        for name, cfg in ROUTES:
+            routed(cfg)
+            gs, gl = w.hamt_get(root, 5, "actor_state", probe)
+            assert np.array_equal(gs, os_), (name, flaw, np.nonzero(gs != os_)[0][:5], gs[gs != os_][:5], os_[gs != os_][:5])
+            assert loc_bytes(data, off, gl) == ov, (name, flaw)

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--timeline", action="store_true")
     ap.add_argument("--pmc", action="store_true")
+    ap.add_argument("--pmc-seq", default=None, metavar="KERNEL",
+                    help="with --pmc: every dispatch of the kernels whose name contains KERNEL, in dispatch order, one line each")
     ap.add_argument("--step-marker", default="k_index_", help="kernel that starts a bench step")
     args = ap.parse_args()
     c = sqlite3.connect(args.db)
@@ -25,6 +27,23 @@ def main():
         kcol = "kernel_name" if "kernel_name" in cols else "name"
         ncol = "counter_name" if "counter_name" in cols else "pmc_name"
         vcol = "value" if "value" in cols else "counter_value"
+        if args.pmc_seq:
+            dcol = next((x for x in ("dispatch_id", "dispatch_index", "id") if x in cols), None)
+            per = collections.OrderedDict()
+            q = f"select {dcol}, {kcol}, {ncol}, {vcol} from counters_collection order by {dcol}" if dcol else None
+            if q is None:
+                print("# no dispatch id column in counters_collection:", cols)
+                return
+            for d, k, n, v in c.execute(q):
+                if args.pmc_seq not in k:
+                    continue
+                e = per.setdefault(d, {"kernel": k.split("(")[0].replace("ipcfp::", "")})
+                e[n] = e.get(n, 0.0) + float(v)
+            names = sorted({n for e in per.values() for n in e if n != "kernel"})
+            print("# dispatch | kernel | " + " | ".join(names))
+            for d, e in per.items():
+                print(f"{d} | {e['kernel']} | " + " | ".join(f"{e.get(n, 0):.6g}" for n in names))
+            return
         agg = collections.defaultdict(lambda: [0, 0.0])
         for k, n, v in c.execute(f"select {kcol}, {ncol}, {vcol} from counters_collection"):
             a = agg[(k.split("(")[0], n)]
