@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--logical-shards", default="2,4,8",
                     help="single GPU: receipt-range shard counts G whose shards are timed one by one in windows T3 and T2 "
                          "(`scaling_projection` in the line: strong scaling of ONE tipset); empty = skip")
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="the step's verify and scan as two ABI calls (rounds 1-3) instead of ipcfp_verify_and_scan_device")
     ap.add_argument("--no-sub-records", action="store_true",
                     help="skip the compact configs[1]/[3]/[4] records the default single-GPU line carries")
     ap.add_argument("--plain", action="store_true",
@@ -202,12 +204,21 @@ def main():
     w = eng.witness_device(t_bytes.data_ptr(), tip.data.size, t_off.data_ptr(), t_len.data_ptr(), t_cids.data_ptr(),
                            tip.n_blocks)
     scan_result = {}
-    scan_mode = {"counts_only": False}
+    scan_mode = {"counts_only": False, "combined": not args.separate_calls}
 
     order = args.order.split(",")
 
     def step():
         w.rebuild_index()                                                               # K4
+        if scan_mode["combined"] and order == ["K", "V", "S"]:
+            w.verify_cids_async()                                                       # K1
+            # verify_event_proof of every claim + the event-filter scan in ONE call: the scan's tail rides on the verify
+            # call's synchronisation (ipcfp_verify_and_scan_device; same outputs as the two calls below)
+            st, _, m = w.verify_and_scan_device(ts, t_claims.data_ptr(), n_claims, t_blob.data_ptr(), blob_len,
+                                                t_status.data_ptr(), tip.topic0, tip.topic1, tip.filter_actor,
+                                                t_has.data_ptr(), args.receipts, t_matches.data_ptr(), MATCH_CAP)
+            scan_result["status"], scan_result["matches"] = st, m
+            return
         for what in order:
             if what == "S" and scan_mode["counts_only"]:
                 st, _, m, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
@@ -368,6 +379,17 @@ def main():
         fence()
         extras["ms_per_step_by_order"] = {args.order: elapsed / args.steps * 1e3, other: (time.perf_counter() - ta) / args.steps * 1e3}
         order[:] = saved
+        # verify and scan as two ABI calls (each with its own synchronisation), the scan's product delivered
+        was_combined = scan_mode["combined"]
+        scan_mode["combined"] = False
+        for _ in range(2):
+            step()
+        fence()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        extras["ms_per_step_separate_calls"] = (time.perf_counter() - ta) / args.steps * 1e3
         # the step as rounds 1-3 timed it: the scan as the ABI's sizing call (no map, no records delivered)
         scan_mode["counts_only"] = True
         for _ in range(2):
@@ -379,6 +401,7 @@ def main():
         fence()
         extras["ms_per_step_counts_only"] = (time.perf_counter() - ta) / args.steps * 1e3
         scan_mode["counts_only"] = False
+        scan_mode["combined"] = was_combined
         extras["ms_per_step_with_gather_message"] = tipset_gather_step_ms(args, eng, torch, w, tip, ts, t_claims, t_blob, blob_len, t_status, n_claims)
         if args.logical_shards:
             extras["scaling_projection"] = shard_projection(
@@ -402,8 +425,9 @@ def main():
             "config": {
                 "workload": "BASELINE.json configs[2] (the 1M-receipt tipset the metric is quoted on): %d receipts (Amtv0<Receipt> + one Amt<StampedEvent> each, 5 parent "
                             "headers with TxMeta and message AMTs), %d witness blocks, %.3f GB; one EventProof claim per "
-                            "receipt; step = CID index + Blake2b-256 CID check of every block + event-filter scan (has-match map "
-                            "and match records delivered in HBM) + exec-order reconstruction + verify_event_proof of every claim" %
+                            "receipt; step = CID index + Blake2b-256 CID check of every block + exec-order reconstruction + "
+                            "verify_event_proof of every claim + event-filter scan (has-match map and match records delivered in "
+                            "HBM); verify and scan in one ABI call (ipcfp_verify_and_scan_device) unless --separate-calls" %
                             (args.receipts, tip.n_blocks, tip.stats["payload_bytes"] / 1e9),
                 "receipts_per_gpu": args.receipts,
                 "claims_per_gpu": n_claims,

@@ -528,6 +528,18 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
                                      uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                                      const ipcfp_event_filter_t* filter, void* status_d);
 
+/* ipcfp_verify_event_claims_device FOLLOWED BY ipcfp_scan_events_device of tipsets[0]'s child block — its receipts AMT,
+ * `HeaderLite.parent_message_receipts` (src/proofs/common/decode.rs:100-118) — in ONE call: the scan's tail is queued
+ * behind the verify kernel and both results come back with one synchronisation.  Outputs and statuses are exactly those of
+ * the two calls in that order (verify_event_proof: src/proofs/events/verifier.rs:51-74; find_matching_events:
+ * src/proofs/events/generator.rs:180-307); *scan_status is the child header's error when there is no receipts root.   */
+int ipcfp_verify_and_scan_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets, uint32_t n_tipsets,
+                                 const void* claims_d, uint64_t n, const void* blob_d, uint64_t blob_len,
+                                 const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* check_filter, void* status_d,
+                                 const ipcfp_event_filter_t* scan_filter, int has_actor, uint64_t actor,
+                                 ipcfp_status_t* scan_status, void* receipt_has_match_d, uint64_t cap_receipts,
+                                 uint64_t* n_receipts, void* matches_d, uint64_t cap_matches, uint64_t* n_matches);
+
 /* The same over packed claims in HOST memory (tipsets, claims, blob, status: host): upload, verify, status bytes
  * back — the PCIe-inclusive form of verify_event_proof for callers that hold binary claims
  * (src/proofs/events/verifier.rs:51-74).                                                           */

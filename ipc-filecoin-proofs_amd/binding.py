@@ -211,6 +211,8 @@ def load_library() -> C.CDLL:
         "ipcfp_exec_order": (i32, [vp, vp, vp, C.c_uint32, vp, vp, u64, C.POINTER(u64)]),
         "ipcfp_scan_events": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
         "ipcfp_verify_event_claims_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
+        "ipcfp_verify_and_scan_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp, vp, i32, u64, vp, vp, u64,
+                                               C.POINTER(u64), vp, u64, C.POINTER(u64)]),
         "ipcfp_verify_event_claims": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
         "ipcfp_witness_has": (i32, [vp, vp, vp, u64, vp, vp]),
@@ -1088,6 +1090,29 @@ class Witness:
             self.eng.h, self.h, cached[2], cached[3], claims_ptr, n, blob_ptr, blob_len,
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, status_ptr), "verify_event_claims_device")
+
+    def verify_and_scan_device(self, tipsets: np.ndarray, claims_ptr: int, n: int, blob_ptr: int, blob_len: int, status_ptr: int,
+                               topic0: bytes, topic1: bytes, actor, has_ptr: int, cap_receipts: int, matches_ptr: int = 0,
+                               cap_matches: int = 0, trust=None, filt=None):
+        """verify_event_claims_device + scan_events_device of tipsets[0]'s child in ONE call (ipcfp_verify_and_scan_device).
+        → (scan status, n_receipts, n_matches); status bytes, has-match map and match records are in the caller's HBM."""
+        key = (id(tipsets), bytes(topic0), bytes(topic1))
+        cached = getattr(self, "_vs_args", None)
+        if cached is None or cached[0] != key:  # (the marshalled arguments of a repeated call are kept)
+            ts = np.ascontiguousarray(tipsets, dtype=TIPSET_DTYPE)
+            sf = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
+            st = np.zeros(1, dtype=np.uint8)
+            nr, nm = C.c_uint64(), C.c_uint64()
+            cached = (key, ts, sf, st, nr, nm, _p(ts), len(ts), _p(sf), _p(st), C.byref(nr), C.byref(nm), tipsets)
+            self._vs_args = cached
+        _, ts, sf, st, nr, nm, p_ts, n_ts, p_sf, p_st, r_nr, r_nm, _keep = cached
+        a = (0, 0) if actor is None else (1, int(actor))
+        self.eng._check(self.lib.ipcfp_verify_and_scan_device(
+            self.eng.h, self.h, p_ts, n_ts, claims_ptr, n, blob_ptr, blob_len,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, status_ptr, p_sf, a[0], a[1], p_st,
+            has_ptr or None, int(cap_receipts), r_nr, matches_ptr or None, int(cap_matches), r_nm), "verify_and_scan_device")
+        return int(st[0]), int(nr.value), int(nm.value)
 
     def verify_event_claims(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray, blob_len: int,
                             trust=None, filt=None) -> np.ndarray:

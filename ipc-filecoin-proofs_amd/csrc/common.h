@@ -132,6 +132,11 @@ struct ipcfp_ctx {
     // --- scratch of the ASYNCHRONOUS batch gets (ipcfp_hamt_get_device: node records, work lists, key hashes).  Owned by
     // the context and only ever grown: the kernels of a call that has already returned may still be reading it, and the
     // next call's kernels follow them on the same stream (a pooled buffer would go back to the pool on return) ---
+    // the scan tail's look-back state (kernels/event_scan.hip k_scan_tail_fused): context-owned, told apart by the epoch
+    void* scan_scratch = nullptr;
+    size_t scan_scratch_bytes = 0;
+    unsigned long long scan_epoch = 0;
+    int scan_fused = -1;   // 0: the scan's tail as separate launches with read-back copies (round 3's)
     int hamt_levels = -1;  // -1: level by level for batches of >= 1024 queries; 0: the per-query walker alone; k > 0: exactly k levels
     int hamt_coop = -1;    // 0: the level path parses every node with one lane (kernels/hamt_levels.hip k_hamt_lv_parse) also for ActorState trees
     int hamt_table = -1;   // 1: tabulate EVERY block first (hamt_table.h; A/B measurements)
@@ -155,7 +160,7 @@ int k1_flush(ipcfp_ctx* ctx, bool gated = false);  // queue the noted K1 launch,
                                       hipGetErrorString(_e), __FILE__, __LINE__);               \
     } while (0)
 
-constexpr uint32_t kCtlHalf = 1024;
+constexpr uint32_t kCtlHalf = 2048;  // (room for one TipsetCtxDev in the zero half: host/verify_fast.cpp)
 
 // `bytes` (multiple of 8) of the call's control block, pre-set to zero (`ff` = false) or to 0xff bytes; nullptr when the
 // block is used up or absent (the caller then allocates and memsets as before).

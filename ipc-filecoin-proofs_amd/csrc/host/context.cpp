@@ -268,6 +268,7 @@ int ipcfp_ctx_create(int device, ipcfp_ctx_t** out) {
     if (const char* e = std::getenv("IPCFP_HAMT_LEVELS")) ctx->hamt_levels = std::atoi(e);
     if (const char* e = std::getenv("IPCFP_HAMT_TABLE")) ctx->hamt_table = std::atoi(e);
     if (const char* e = std::getenv("IPCFP_HAMT_COOP")) ctx->hamt_coop = std::atoi(e);
+    if (const char* e = std::getenv("IPCFP_SCAN_FUSED")) ctx->scan_fused = std::atoi(e);
     if (const char* e = std::getenv("IPCFP_FAST_VERIFY")) ctx->fast_verify = std::atoi(e);
     // wait_stream's polling event belongs to THIS device (created here, right after hipSetDevice(device))
     if (hipEventCreateWithFlags(&ctx->spin_event, hipEventDisableTiming) != hipSuccess) ctx->spin_event = nullptr;
@@ -322,6 +323,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->stream_k1);
     (void)hipStreamSynchronize(ctx->stream_aux);
+    if (ctx->scan_scratch) (void)hipFree(ctx->scan_scratch);
     if (ctx->hamt_recs) (void)hipFree(ctx->hamt_recs);
     if (ctx->hamt_scratch) (void)hipFree(ctx->hamt_scratch);
     for (auto& l : ctx->launches) {
@@ -365,6 +367,7 @@ int ipcfp_ctx_set_tuning(ipcfp_ctx_t* ctx, const char* key, int64_t value) {
     if (k == "hamt_levels") ctx->hamt_levels = int(value);
     else if (k == "hamt_table") ctx->hamt_table = int(value);
     else if (k == "hamt_coop") ctx->hamt_coop = int(value);
+    else if (k == "scan_fused") ctx->scan_fused = int(value);
     else if (k == "fast_verify") ctx->fast_verify = int(value);
     else return set_error(ctx, IPCFP_E_INVALID, "unknown tuning key '%s'", key);
     return IPCFP_OK;

@@ -54,6 +54,26 @@ struct ScanResult {
     uint8_t* has_p = nullptr;
     ipcfp_event_match_t* matches_p = nullptr;
 };
+// A scan that RIDES on a verify call (ipcfp_verify_and_scan_device): the route without a mid-call synchronisation
+// (verify_fast.cpp) queues the scan's tail behind its verify kernel — the receipts enumeration and the event table are
+// that call's own — and the scan's results come back with the call's one synchronisation.  `done` false afterwards:
+// the ride did not happen (another route, an anomaly, receipts the table does not cover) and the caller scans as usual.
+struct ScanRide {
+    ipcfp_event_filter_t filter{};
+    int has_actor = 0;
+    uint64_t actor = 0;
+    uint8_t* has_d = nullptr;          // caller HBM, cap_receipts bytes (nullable)
+    uint64_t cap_receipts = 0;
+    ipcfp_event_match_t* matches_d = nullptr;  // caller HBM, cap_matches records (nullable)
+    uint64_t cap_matches = 0;
+    bool done = false;
+    uint32_t status = IPCFP_ST_ERR;
+    uint64_t n_idx = 0, n_matches = 0;
+};
+ScanParams scan_params_of(const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor);
+// the look-back state of k_scan_tail_fused for n_tiles tiles (context-owned; zeroed when (re)allocated)
+int scan_tail_scratch(ipcfp_ctx* ctx, uint32_t n_tiles, unsigned long long** out);
+
 // `cap_matches`: how many matches the caller can take.  With a known capacity PASS 2 is launched right behind
 // PASS 1 (the kernel clips its writes) and the scan has ONE synchronisation; with kAllMatches the match count is
 // read back first and out.matches is sized to it.

@@ -1,6 +1,7 @@
 // csrc/host/scan_events.cpp — `find_matching_events` over the HBM-resident tipset
 // (src/proofs/events/generator.rs:180-307): enumerate the receipts AMT, PASS 1, prefix-sum, PASS 2.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -18,7 +19,35 @@ CidKey key_from_slot(const uint8_t* slot40);
 
 namespace ipcfp {
 
-static ScanParams scan_params_of(const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor) {
+// The host's side of the mailbox (common.h): spin until the device has published sequence number `seq`.  A launch that
+// failed never publishes: after 5 s the stream is drained, which surfaces the error.
+int mailbox_wait(ipcfp_ctx* ctx, unsigned long long seq, const char* what) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(5);
+    uint32_t spins = 0;
+    while (__atomic_load_n(ctx->mailbox, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() > deadline) {
+            IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+            if (__atomic_load_n(ctx->mailbox, __ATOMIC_ACQUIRE) != seq) return set_error(ctx, IPCFP_E_HIP, "%s never reached the mailbox", what);
+        }
+    }
+    return IPCFP_OK;
+}
+
+int scan_tail_scratch(ipcfp_ctx* ctx, uint32_t n_tiles, unsigned long long** out) {
+    const size_t need = (size_t(n_tiles) + 3) * 8;
+    if (need > ctx->scan_scratch_bytes) {
+        if (ctx->scan_scratch) (void)hipFree(ctx->scan_scratch);  // (waits for the device: nothing still reads it)
+        ctx->scan_scratch = nullptr;
+        ctx->scan_scratch_bytes = 0;
+        IPCFP_HIP(ctx, hipMalloc(&ctx->scan_scratch, need * 2));
+        ctx->scan_scratch_bytes = need * 2;
+        IPCFP_HIP(ctx, hipMemsetAsync(ctx->scan_scratch, 0, need * 2, ctx->stream));  // ticket / counters start at zero
+    }
+    *out = static_cast<unsigned long long*>(ctx->scan_scratch);
+    return IPCFP_OK;
+}
+
+ScanParams scan_params_of(const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor) {
     ScanParams p{};  // (zeroed, padding included: compared with memcmp)
     p.filter = filter;
     p.actor = has_actor ? actor : 0;
@@ -170,6 +199,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     EventTableView tview{nullptr, nullptr};
     const uint32_t* cnt = counts.p;
     unsigned long long e_table = kNoEnumError;
+    const unsigned long long* table_err_d = nullptr;  // the table's own error word, when its counts are this scan's PASS 1
     if (w->use_event_table && n) {
         const EventTableCached* table = nullptr;
         rc = event_table_get(ctx, w, root, en, &table);
@@ -177,7 +207,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         tview = table->view();
         if (const uint32_t* c = event_table_counts(table, filter, has_actor, actor)) {
             cnt = c;  // counted while the table was built: PASS 1 is done
-            IPCFP_HIP(ctx, d2h_small(ctx, &e_table, table->err_word.p, 8, ctx->stream));  // ... and so is its error report
+            table_err_d = table->err_word.p;  // ... and so is its error report
         } else {
             rc = launch_count_from_table(ctx, view, leaves, n, filter, has_actor, actor, tview, counts.p, err.p);
             if (rc) return rc;
@@ -186,6 +216,46 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         rc = launch_scan_pass1(ctx, view, leaves, n, filter, has_actor, actor, counts.p, err.p);
         if (rc) return rc;
     }
+    // ---- the tail in ONE launch, results through the mailbox: no read-back copy, no stream synchronisation ----
+    if (ctx->scan_fused != 0 && ctx->mailbox && tview.receipts && !touched_d && n && cap_matches <= (1ull << 26)) {
+        unsigned long long* tail_scratch = nullptr;
+        rc = scan_tail_scratch(ctx, div_up(n, 1024), &tail_scratch);
+        if (rc) return rc;
+        if (out.ext_matches && cap_matches) {
+            out.matches_p = out.ext_matches;
+        } else {
+            IPCFP_HIP(ctx, out.matches.alloc(cap_matches));
+            out.matches_p = out.matches.p;
+        }
+        const unsigned long long seq = ++ctx->mailbox_seq;
+        rc = launch_scan_tail_fused(ctx, view, leaves, n, en->dense ? lo : ~0ull, filter, has_actor, actor, tview, cnt, offsets.p,
+                                    cap_matches ? out.matches_p : nullptr, cap_matches, out.has_p, n_idx, lo,
+                                    tail_scratch, ++ctx->scan_epoch, table_err_d, err.p,
+                                    ctx->mailbox_dev, seq);
+        if (rc) return rc;
+        rc = mailbox_wait(ctx, seq, "the scan's results");
+        if (rc) return rc;
+        const uint64_t nm = __atomic_load_n(ctx->mailbox + 1, __ATOMIC_RELAXED);
+        unsigned long long e1 = __atomic_load_n(ctx->mailbox + 3, __ATOMIC_RELAXED);
+        const unsigned long long et = __atomic_load_n(ctx->mailbox + 2, __ATOMIC_RELAXED);
+        const uint64_t walk = __atomic_load_n(ctx->mailbox + 4, __ATOMIC_RELAXED);
+        if (et < e1) e1 = et;
+        if (e1 != kNoEnumError) {
+            out.status = enum_error_code(e1);
+            return IPCFP_OK;
+        }
+        if (walk) {  // matching receipts the table does not cover: the general walk writes their matches (offsets are in place)
+            rc = launch_scan_pass2(ctx, view, root, leaves, n, filter, has_actor, actor, cnt, offsets.p,
+                                   cap_matches ? out.matches_p : nullptr, cap_matches, out.has_p, n_idx, lo, &tview);
+            if (rc) return rc;
+            IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+        }
+        out.n_idx = n_idx;
+        out.n_matches = nm;
+        out.status = IPCFP_ST_TRUE;
+        return IPCFP_OK;
+    }
+    if (table_err_d) IPCFP_HIP(ctx, d2h_small(ctx, &e_table, table_err_d, 8, ctx->stream));
     rc = launch_scan_u32(ctx, cnt, n, offsets.p, total.p, scratch.p);
     if (rc) return rc;
     uint64_t nm = 0;

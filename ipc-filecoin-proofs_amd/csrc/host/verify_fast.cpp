@@ -37,12 +37,12 @@ int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents);
 //   anything else: an ABI error.
 static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
                                     uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
-                                    const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done);
+                                    const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done, ScanRide* ride);
 
 int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
                        uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
-                       const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done) {
-    const int rc = verify_packed_fast_queue(ctx, w, tcs, claims_d, n, blob_d, blob_len, trust, filter, status_d, where_d, done);
+                       const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done, ScanRide* ride) {
+    const int rc = verify_packed_fast_queue(ctx, w, tcs, claims_d, n, blob_d, blob_len, trust, filter, status_d, where_d, done, ride);
     if (rc != IPCFP_OK) {
         // An error return may have left kernels on the main and the aux stream that still use this call's pooled scratch
         // (the leaves, the receipts' event records, the deferred re-hash): the buffers went back to the pool when the
@@ -57,7 +57,7 @@ int verify_packed_fast(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDe
 
 static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& tcs, const EventClaimPacked* claims_d,
                                     uint32_t n, const uint8_t* blob_d, uint64_t blob_len, const ipcfp_trust_policy_t* trust,
-                                    const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done) {
+                                    const ipcfp_event_filter_t* filter, uint8_t* status_d, void* where_d, bool* done, ScanRide* ride) {
     static const ipcfp_trust_policy_t accept_all = {0, 0, 0, 0};
     const bool enabled = ctx->fast_verify != 0;  // (env IPCFP_FAST_VERIFY / ipcfp_ctx_set_tuning "fast_verify")
     *done = false;
@@ -99,11 +99,24 @@ static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vecto
         IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_narrow, ctx->narrow_event, 0));
         ctx->stream = ctx->stream_narrow;
     }
-    DevBuf<TipsetCtxDev> tcs_d;
-    IPCFP_HIP(ctx, tcs_d.alloc(1));
-    {
+    // The context on the device: a slice of the control block's ZERO half when there is room (re-initialised at the end of
+    // the previous call) — its inputs then travel as a kernel argument of the prologue, which writes them in; no copy
+    // kernel at the head of the call (17.7 µs beside the side streams' grids: profiles/r03_last_commit_timeline.txt).
+    struct TcsDev {
+        DevBuf<TipsetCtxDev> own;
+        TipsetCtxDev* p = nullptr;
+    } tcs_d;
+    TipsetInputs inputs;
+    std::memcpy(&inputs, &tcs[0], sizeof inputs);
+    const bool head_or_general = (ctx->stream_head && w->index_event && w->index_done.p) ||
+                                 uint64_t(w->max_block_len) + 32u > uint64_t(kPrologueStageChunks) * 16u;
+    tcs_d.p = head_or_general ? nullptr : static_cast<TipsetCtxDev*>(ctl_take(ctx, sizeof(TipsetCtxDev), false));
+    const bool inline_inputs = tcs_d.p != nullptr;
+    if (!inline_inputs) {
+        IPCFP_HIP(ctx, tcs_d.own.alloc(1));
+        tcs_d.p = tcs_d.own.p;
         TipsetCtxDev init = tcs[0];
-        for (uint32_t b = 0; b < IPCFP_MAX_PARENTS; ++b) init.txmeta_block[b] = kNoBlock;  // (nothing left to re-hash yet)
+        for (uint32_t b = 0; b < IPCFP_MAX_PARENTS; ++b) init.txmeta_block[b] = 0;  // (nothing left to re-hash yet)
         IPCFP_HIP(ctx, h2d_small(ctx, tcs_d.p, &init, sizeof(TipsetCtxDev), ctx->stream));
     }
     ExecState ex;
@@ -126,7 +139,8 @@ static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vecto
     // general companion, which hashes inline)
     const bool defer_rehash = !need_general && ctx->rehash_event != nullptr;
     rc = head ? launch_tipset_prepare(ctx, view, &job, nullptr, 1, false, w->index_done.p, w->index_wgs, small + 2, defer_rehash)
-              : launch_tipset_prepare(ctx, view, &job, nullptr, 1, need_general, nullptr, 0, nullptr, defer_rehash);
+              : launch_tipset_prepare(ctx, view, &job, nullptr, 1, need_general, nullptr, 0, nullptr, defer_rehash,
+                                      inline_inputs ? &inputs : nullptr);
     if (rc) return rc;
     if (head) {  // hand back: the main stream (behind the inserts by its own order) waits for the prologue
         IPCFP_HIP(ctx, hipEventRecord(ctx->head_event, ctx->stream));
@@ -259,6 +273,39 @@ static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vecto
                               where_d, /*tabulated=*/true);
     if (rc) return rc;
     if ((rc = k1_flush(ctx, true))) return rc;  // (mode 3, and whatever is still noted)
+    // ---- a scan riding on this call (ipcfp_verify_and_scan_device): its tail right behind the verify kernel ----
+    DevBuf<uint32_t> ride_counts, ride_offsets;
+    DevBuf<unsigned long long> ride_err_own;
+    unsigned long long ride_seq = 0;
+    if (ride && ctx->scan_fused != 0 && ride->cap_matches <= (1ull << 26) && (!ride->has_d || ride->cap_receipts >= n_rcpt)) {
+        const ScanParams want = scan_params_of(ride->filter, ride->has_actor, ride->actor);
+        const EventTableView tview = table->view();
+        const uint32_t* cnt = nullptr;
+        const unsigned long long* table_err = nullptr;
+        unsigned long long* err_p = nullptr;
+        IPCFP_HIP(ctx, ctl_words(ctx, ride_err_own, err_p, 1, true));
+        if (table->has_counts && std::memcmp(&want, &table->counts_filter, sizeof want) == 0) {
+            cnt = table->counts.p;  // counted while the table was built (the context's scan hint was this filter)
+            table_err = table->err_word.p;
+        } else {
+            IPCFP_HIP(ctx, ride_counts.alloc(n_rcpt));
+            rc = launch_count_from_table(ctx, view, rleaves.p, n_rcpt, ride->filter, ride->has_actor, ride->actor, tview, ride_counts.p, err_p);
+            if (rc) return rc;
+            cnt = ride_counts.p;
+        }
+        IPCFP_HIP(ctx, ride_offsets.alloc(n_rcpt));
+        unsigned long long* tail_scratch = nullptr;
+        rc = scan_tail_scratch(ctx, div_up(n_rcpt, 1024), &tail_scratch);
+        if (rc) return rc;
+        ride_seq = ++ctx->mailbox_seq;
+        rc = launch_scan_tail_fused(ctx, view, rleaves.p, n_rcpt, w->receipt_lo, ride->filter, ride->has_actor, ride->actor, tview, cnt,
+                                    ride_offsets.p, ride->cap_matches ? ride->matches_d : nullptr, ride->matches_d ? ride->cap_matches : 0,
+                                    ride->has_d, ride->has_d ? n_rcpt : 0, w->receipt_lo, tail_scratch, ++ctx->scan_epoch, table_err,
+                                    err_p, ctx->mailbox_dev, ride_seq);
+        if (rc) return rc;
+        ctx->scan_hint = want;
+        ctx->has_scan_hint = true;
+    }
     if (defer_rehash) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->rehash_event, 0));  // its errors are in before the flags are read
     // ---- the one synchronisation: did the dense walk hold? ----
     uint32_t bad = 0;
@@ -266,7 +313,7 @@ static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vecto
     TipsetCtxDev facts;
     IPCFP_HIP(ctx, ctl_read(ctx, &bad, small + 2, 4));
     IPCFP_HIP(ctx, ctl_read(ctx, &e, ex.err.p, 8));
-    IPCFP_HIP(ctx, d2h_small(ctx, &facts, tcs_d.p, sizeof facts, ctx->stream));
+    IPCFP_HIP(ctx, ctl_read(ctx, &facts, tcs_d.p, sizeof facts));  // (rides on the control block's one read-back when the context lives there)
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
     IPCFP_HIP(ctx, hipGetLastError());
     if (bad || e != kNoEnumError || facts.child_status != IPCFP_ST_TRUE) {
@@ -297,6 +344,23 @@ static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vecto
         w->enum_cache.push_back(std::move(en));
         std::memcpy(table->root, facts.receipts_root.w, 40);
         w->table_cache.push_back(std::move(table));
+    }
+    if (ride_seq) {  // (published before the synchronisation above returned: the tail ran ahead of it on the same stream)
+        if (__atomic_load_n(ctx->mailbox, __ATOMIC_ACQUIRE) != ride_seq) return set_error(ctx, IPCFP_E_HIP, "the riding scan's results never reached the mailbox");
+        const uint64_t nm = __atomic_load_n(ctx->mailbox + 1, __ATOMIC_RELAXED);
+        unsigned long long e1 = __atomic_load_n(ctx->mailbox + 3, __ATOMIC_RELAXED);
+        const unsigned long long et = __atomic_load_n(ctx->mailbox + 2, __ATOMIC_RELAXED);
+        const uint64_t walk = __atomic_load_n(ctx->mailbox + 4, __ATOMIC_RELAXED);
+        if (et < e1) e1 = et;
+        if (e1 != kNoEnumError) {
+            ride->status = enum_error_code(e1);
+            ride->done = true;
+        } else if (!walk) {  // (receipts the table does not cover: the caller's ordinary scan walks them)
+            ride->status = IPCFP_ST_TRUE;
+            ride->n_idx = n_rcpt;
+            ride->n_matches = nm;
+            ride->done = true;
+        }
     }
     *done = true;
     return IPCFP_OK;

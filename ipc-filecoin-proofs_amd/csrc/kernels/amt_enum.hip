@@ -53,8 +53,8 @@ __device__ __forceinline__ void enum_root_one(const WitnessView& w, const AmtRoo
 // checks).  The block was decoded by the prologue already; its CID is the key it was found under.
 __device__ __forceinline__ void txmeta_rehash_lane(const WitnessView& w, const TipsetCtxDev& c, uint32_t b, unsigned long long* __restrict__ err) {
     if (b >= c.n_parents || b >= IPCFP_MAX_PARENTS) return;
-    const uint32_t tb = c.txmeta_block[b];
-    if (tb == kNoBlock) return;
+    if (c.txmeta_block[b] == 0u) return;  // (1 + block id: tipset_ctx.h)
+    const uint32_t tb = c.txmeta_block[b] - 1u;
     const uint32_t seq = c.n_parents + 3 * b;
     Rd r;
     r.init(w.arena + w.off[tb], w.len[tb]);

@@ -17,6 +17,7 @@
 #include "event_table.h"
 #include "events_dev.h"
 #include "launch.h"
+#include "scan_dev.h"
 
 namespace ipcfp {
 
@@ -425,6 +426,181 @@ __global__ __launch_bounds__(256) void k_scan_pass2_table(WitnessView w, const L
                                         ValueLoc{rr.block, uint32_t((e.base_flags & kEvBaseMask) - block_base), e.ev_len}, 0};
         ++k;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The scan's tail in ONE launch (find_matching_events' second half, events/generator.rs:242-301): exclusive prefix sum of
+// the per-receipt match counts, the has-match map, the match records of tabulated receipts in (exec_index, event_index)
+// order, and the call's results — match total and error words — in the MAILBOX (pinned host memory: the host reads them
+// without a stream synchronisation or a copy).  Was: tile sums, scan of tile sums, apply, pass 2, a read-back copy and
+// two host round trips — ≈ 160 µs of a 1.07 ms step for ≈ 45 µs of kernels (profiles/r03_last_commit_timeline.txt).
+//
+// The prefix sum is a single pass with DECOUPLED LOOK-BACK: a workgroup takes a ticket (tiles in ticket order: a tile only
+// ever waits for tiles that are already running), sums its 1 024 counts, publishes the aggregate, and wave 0 looks back
+// over its predecessors' published aggregates / inclusive prefixes, 64 at a time.  A tile's state word carries the
+// call's EPOCH in its high bits, so the state array is never cleared: a word of another epoch is "nothing yet".
+//   state[tile] = epoch << 34 | flag << 32 | value     flag 1: aggregate of this tile, 2: inclusive prefix up to it
+// The workgroup that finishes LAST (a completion counter behind a device-scope fence: every other tile's matches and map
+// bytes are then written) publishes the mailbox and resets ticket and counter for the next call.
+struct ScanTailCtl {
+    unsigned long long* state;    // n_tiles words (context-owned, never cleared)
+    unsigned int* ticket;         // [0] ticket, [1] completion count, both left at 0
+    unsigned long long* total;    // [0]: the match total, written by the last tile in ticket order
+    unsigned long long epoch;     // < 2^30, this call's
+    const unsigned long long* err_a;  // nullable: error words of this call's earlier kernels, forwarded to the mailbox
+    const unsigned long long* err_b;
+    unsigned long long* mailbox;  // pinned host: [0] seq, [1] total, [2] *err_a, [3] *err_b
+    unsigned long long seq;
+};
+constexpr uint32_t kScanTile = 1024;
+
+__global__ __launch_bounds__(256) void k_scan_tail_fused(WitnessView w, const LeafRef* __restrict__ receipts, uint32_t n,
+                                                         uint64_t dense_first, ScanParams sp, const ReceiptRec* __restrict__ rrecs,
+                                                         const EventRec* __restrict__ erecs, const uint32_t* __restrict__ counts,
+                                                         uint32_t* __restrict__ offsets, EventMatch* __restrict__ matches,
+                                                         uint64_t matches_cap, uint8_t* __restrict__ has_match, uint64_t has_cap,
+                                                         uint64_t has_base, ScanTailCtl ctl, unsigned int* __restrict__ untabulated) {
+    __shared__ uint64_t smem[17];
+    __shared__ uint32_t s_tile;
+    __shared__ uint64_t s_prefix;
+    const uint32_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ctl.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * kScanTile + threadIdx.x * 4u;
+    uint32_t c[4];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = base + k < n ? counts[base + k] : 0u;
+        s += c[k];
+    }
+    uint64_t tile_total;
+    const uint64_t ex = block_exclusive_scan(s, smem, &tile_total);
+    const unsigned long long tag = ctl.epoch << 34;
+    // ---- publish, look back (wave 0) ----
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(ctl.state + tile, tag | ((tile == 0 ? 2ull : 1ull) << 32) | (tile_total & 0xffffffffull),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t prefix = 0;
+        int32_t hi = int32_t(tile) - 1;  // the nearest predecessor not yet accounted for
+        while (hi >= 0) {
+            const int32_t j = hi - int32_t(lane);
+            unsigned long long v = 0;
+            bool ready = true;
+            if (j >= 0) {
+                v = __hip_atomic_load(ctl.state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ready = (v >> 34) == ctl.epoch && ((v >> 32) & 3ull) != 0ull;
+            }
+            // the window [hi - 63, hi] can be used up to its first not-yet-published word (from hi downwards)
+            const uint64_t not_ready = __ballot(!ready);
+            const uint32_t usable = not_ready ? uint32_t(__builtin_ctzll(not_ready)) : 64u;  // lanes 0 .. usable-1
+            const uint64_t is_prefix = __ballot(ready && j >= 0 && ((v >> 32) & 3ull) == 2ull);
+            const uint64_t in_use = usable >= 64u ? ~0ull : ((1ull << usable) - 1ull);
+            const uint64_t pfx_in = is_prefix & in_use;
+            const uint32_t stop = pfx_in ? uint32_t(__builtin_ctzll(pfx_in)) : 64u;  // first inclusive prefix met
+            const uint32_t take = stop < 64u ? stop + 1u : usable;                   // lanes 0 .. take-1 contribute
+            uint64_t mine = (lane < take && j >= 0) ? (v & 0xffffffffull) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+            prefix += mine;
+            if (stop < 64u) break;
+            hi -= int32_t(take);
+            if (take == 0) __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) {
+            if (tile != 0)
+                __hip_atomic_store(ctl.state + tile, tag | (2ull << 32) | ((prefix + tile_total) & 0xffffffffull), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+            // (an atomic exchange RETURNS: it has been performed at the coherence point before this lane goes on to the
+            // completion counter below — no fence, which on this chip is a write-back of the whole L2)
+            if (tile == n_tiles - 1) (void)atomicExch(ctl.total, (unsigned long long)(prefix + tile_total));
+        }
+    }
+    __syncthreads();
+    // ---- the map, the offsets, the matches of this tile ----
+    uint64_t o = s_prefix + ex;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = base + k;
+        if (t >= n) break;
+        const uint64_t index = dense_first != ~0ull ? dense_first + t : receipts[t].index;
+        if (index >= has_base && index - has_base < has_cap) has_match[index - has_base] = c[k] ? 1 : 0;
+        if (c[k]) {
+            offsets[t] = uint32_t(o);
+            const ReceiptRec rr = rrecs[t];
+            if (rr.kind != RK_TABLE) {
+                atomicAdd(untabulated, 1u);  // k_scan_pass2 (the general walk) is queued behind this launch for it
+            } else if (matches) {
+                uint32_t m = 0, ord = 0;
+                const uint64_t block_base = w.off[rr.block];
+                for (uint32_t j = 0; j < 64; ++j) {
+                    if (!((rr.bitmap >> j) & 1ull)) continue;
+                    const EventRec e = erecs[rr.first + ord++];
+                    if (!rec_matches(w.arena, e, sp)) continue;
+                    if (m < c[k] && o + m < matches_cap)
+                        matches[o + m] = EventMatch{index, j, e.emitter,
+                                                    ValueLoc{rr.block, uint32_t((e.base_flags & kEvBaseMask) - block_base), e.ev_len}, 0};
+                    ++m;
+                }
+            }
+        }
+        o += c[k];
+    }
+    // ---- the last workgroup to finish reports ----
+    // No fence: the state words carry everything the tiles tell each other, the counters below are read-modify-writes at
+    // the coherence point, and what the tiles wrote for LATER kernels and copies (matches, map) is ordered by the end of
+    // this launch — a device-scope release per tile is an L2 write-back per tile on a chip with one L2 per XCD (the first
+    // version of this kernel, with acquire / release: 159 µs).
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int done = atomicAdd(ctl.ticket + 1, 1u);
+        if (done == n_tiles - 1) {
+            const unsigned long long total = atomicAdd(ctl.total, 0ull);
+            const unsigned long long ea = ctl.err_a ? __hip_atomic_load(ctl.err_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            const unsigned long long eb = ctl.err_b ? __hip_atomic_load(ctl.err_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            const unsigned int walk = atomicExch(untabulated, 0u);
+            (void)atomicExch(ctl.ticket, 0u);
+            (void)atomicExch(ctl.ticket + 1, 0u);
+            __hip_atomic_store(ctl.mailbox + 1, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(ctl.mailbox + 2, ea, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(ctl.mailbox + 3, eb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(ctl.mailbox + 4, (unsigned long long)walk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(ctl.mailbox, ctl.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// scratch_d: [ticket u32, done u32, untabulated u32, pad | total u64 | state n_tiles u64]  (context-owned; the counters are at
+// a FIXED place and zero between calls, the state words are told apart by the epoch)
+int launch_scan_tail_fused(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n, uint64_t dense_first,
+                           const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, const EventTableView& table,
+                           const uint32_t* counts_d, uint32_t* offsets_d, void* matches_d, uint64_t matches_cap, uint8_t* has_match_d,
+                           uint64_t has_cap, uint64_t has_base, unsigned long long* scratch_d, unsigned long long epoch,
+                           const unsigned long long* err_a_d, const unsigned long long* err_b_d, unsigned long long* mailbox_dev,
+                           unsigned long long seq) {
+    const uint32_t n_tiles = div_up(n, kScanTile);
+    ScanTailCtl ctl;
+    ctl.ticket = reinterpret_cast<unsigned int*>(scratch_d);
+    ctl.total = scratch_d + 2;
+    ctl.state = scratch_d + 3;
+    ctl.epoch = epoch & ((1ull << 30) - 1ull);
+    ctl.err_a = err_a_d;
+    ctl.err_b = err_b_d;
+    ctl.mailbox = mailbox_dev;
+    ctl.seq = seq;
+    ScanParams sp{filter, actor, has_actor ? 1u : 0u, 0};
+    {
+        ProfileScope prof(ctx, IPCFP_K_REPLAY);
+        hipLaunchKernelGGL(k_scan_tail_fused, dim3(n_tiles), dim3(256), 0, ctx->stream, w, receipts_d, n, dense_first, sp,
+                           table.receipts, table.events, counts_d, offsets_d, static_cast<EventMatch*>(matches_d), matches_cap,
+                           has_match_d, has_cap, has_base, ctl, ctl.ticket + 2);
+    }
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
 }
 
 int launch_scan_pass1(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,

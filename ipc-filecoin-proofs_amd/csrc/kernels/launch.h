@@ -98,7 +98,8 @@ int launch_exec_finish(ipcfp_ctx* ctx, TipsetCtxDev* ctx_d, const uint64_t* tota
 // live_done / live_total / anomaly: the CID index is still being filled on another stream (tipset_prepare.hip LiveIndex)
 int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs, const void* jobs_d, uint32_t n_jobs,
                           bool need_general, const uint32_t* live_done = nullptr, uint32_t live_total = 0,
-                          uint32_t* anomaly = nullptr, bool defer_rehash = false);  // defer_rehash: see tipset_ctx.h txmeta_block
+                          uint32_t* anomaly = nullptr, bool defer_rehash = false,  // defer_rehash: see tipset_ctx.h txmeta_block
+                          const void* inline_inputs = nullptr);  // host TipsetInputs of the one context: sent as a kernel argument
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
                       unsigned long long* err_d, int verify_txmeta = 1);
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,
@@ -134,6 +135,13 @@ int launch_receipt_events(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* r
 int launch_block_events(ipcfp_ctx* ctx, hipStream_t stream, const uint8_t* arena, const void* meta_d, uint32_t n,
                         const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, BlockRec* brecs_d,
                         EventRec* erecs_d, uint32_t cap_events, uint32_t* pool_used_d);
+// the scan's tail in one launch (prefix sum by decoupled look-back + map + tabulated matches + results in the mailbox)
+int launch_scan_tail_fused(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n, uint64_t dense_first,
+                           const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, const EventTableView& table,
+                           const uint32_t* counts_d, uint32_t* offsets_d, void* matches_d, uint64_t matches_cap, uint8_t* has_match_d,
+                           uint64_t has_cap, uint64_t has_base, unsigned long long* scratch_d, unsigned long long epoch,
+                           const unsigned long long* err_a_d, const unsigned long long* err_b_d, unsigned long long* mailbox_dev,
+                           unsigned long long seq);
 int launch_count_from_table(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* receipts_d, uint32_t n,
                             const ipcfp_event_filter_t& filter, int has_actor, uint64_t actor, const EventTableView& table,
                             uint32_t* counts_d, unsigned long long* err_d);

@@ -10,8 +10,17 @@
 
 namespace ipcfp {
 
+// the INPUTS of a context: the head of TipsetCtxDev, which the tipset prologue can also take as a kernel argument
+// (tipset_prepare.hip: one H2D copy less at the head of a verification call — 18 µs beside the side streams' grids)
+struct TipsetInputs {
+    uint32_t flags;      // TC_* (claims_dev.h)
+    uint32_t n_parents;
+    CidKey child;
+    CidKey parents[IPCFP_MAX_PARENTS];
+};
+
 struct TipsetCtxDev {
-    // inputs
+    // inputs (= TipsetInputs)
     uint32_t flags;      // TC_* (claims_dev.h)
     uint32_t n_parents;
     CidKey child;
@@ -24,9 +33,9 @@ struct TipsetCtxDev {
     uint32_t parent0_status;   // TRUE or ERR_* for parent_cids[0]
     uint32_t prologue_general;  // bit s: slot s of the tipset prologue is left to the general kernel (a block larger than the LDS stage)
     long long parent0_height;
-    // the TxMeta block of parent b when its re-hash was LEFT to k_txmeta_rehash (amt_enum.hip; tipset_prepare.hip
-    // roots_slot with `defer_rehash`); kNoBlock: nothing to re-hash (checked inline, or never reached).  The host
-    // initialises every entry to kNoBlock.
+    // 1 + the TxMeta block of parent b when its re-hash was LEFT to k_txmeta_rehash (amt_enum.hip; tipset_prepare.hip
+    // roots_slot with `defer_rehash`); 0: nothing to re-hash (checked inline, or never reached) — so that a context
+    // taken from zeroed memory needs no initialisation.
     uint32_t txmeta_block[IPCFP_MAX_PARENTS];
     // execution order (filled by the host after the enumeration)
     uint32_t exec_status;      // TRUE or the first ERR_* of reconstruct_execution_order
@@ -45,6 +54,8 @@ struct TipsetCtxDev {
     const ReceiptRec* receipt_recs;
     const EventRec* event_recs;
 };
+
+static_assert(sizeof(TipsetInputs) == 8 + 40 * (1 + IPCFP_MAX_PARENTS), "TipsetInputs is the head of TipsetCtxDev");
 
 // what k_ctx_finish (verify_events.hip) writes into a context on the device
 struct CtxFinish {

@@ -113,15 +113,16 @@ __device__ __forceinline__ void flag_general(TipsetCtxDev& c, uint32_t slot) {
 }
 
 // slots 0 / 1: the child header / the first parent header (ctx_headers_body in verify_events.hip is the general form)
-__device__ __forceinline__ void headers_slot(const WitnessView& w, TipsetCtxDev& c, bool child_part, rd_chunk_t* stage,
-                                             AmtRootSpec* receipts_spec, LiveIndex& li) {
+// (`in`: the context's inputs — its own head in device memory, or the kernel argument)
+__device__ __forceinline__ void headers_slot(const WitnessView& w, const TipsetInputs& in, TipsetCtxDev& c, bool child_part,
+                                             rd_chunk_t* stage, AmtRootSpec* receipts_spec, LiveIndex& li) {
     const bool lead = threadIdx.x == 0;
-    const bool parsed = (c.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
+    const bool parsed = (in.flags & (TC_PARENTS_PARSED | TC_CHILD_PARSED)) == (TC_PARENTS_PARSED | TC_CHILD_PARSED);
     uint32_t status = IPCFP_ST_ERR_BAD_CLAIM, match = 0;
     long long height = 0;
-    const bool wanted = parsed && (child_part || c.n_parents > 0);
+    const bool wanted = parsed && (child_part || in.n_parents > 0);
     if (wanted) {
-        const uint32_t hb = find_block(w, li, child_part ? c.child : c.parents[0]);  // uniform across the wavefront
+        const uint32_t hb = find_block(w, li, child_part ? in.child : in.parents[0]);  // uniform across the wavefront
         if (hb == kNoBlock) {
             status = IPCFP_ST_ERR_MISSING_BLOCK;
         } else {
@@ -137,15 +138,15 @@ __device__ __forceinline__ void headers_slot(const WitnessView& w, TipsetCtxDev&
                     if (child_part) {
                         c.receipts_root = h.parent_message_receipts;
                         // `child_hdr.parents != parent_cids` (:161): same count, same CIDs in order
-                        bool same = h.n_parents == c.n_parents;
+                        bool same = h.n_parents == in.n_parents;
                         if (same) {
                             Rd q = r;
                             q.err = 0;
                             q.pos = h.parents_off;
-                            for (uint32_t i = 0; i < c.n_parents && same; ++i) {
+                            for (uint32_t i = 0; i < in.n_parents && same; ++i) {
                                 CidKey k;
                                 q.read_link_key(k);
-                                same = q.ok() && cid_equal(k, c.parents[i]);
+                                same = q.ok() && cid_equal(k, in.parents[i]);
                             }
                         }
                         match = same ? 1u : 0u;
@@ -175,18 +176,18 @@ __device__ __forceinline__ void headers_slot(const WitnessView& w, TipsetCtxDev&
 
 // slot 2 + b: parent block b → its header, its TxMeta (re-hashed), its two message-AMT roots
 // (exec_roots_body in verify_events.hip is the general form; error sequence numbers as there)
-__device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c, AmtRootSpec* __restrict__ roots,
-                                           unsigned long long* __restrict__ err, uint32_t b, rd_chunk_t* stage, LiveIndex& li,
-                                           bool defer_rehash) {
+__device__ __forceinline__ void roots_slot(const WitnessView& w, const TipsetInputs& in, TipsetCtxDev& c,
+                                           AmtRootSpec* __restrict__ roots, unsigned long long* __restrict__ err, uint32_t b,
+                                           rd_chunk_t* stage, LiveIndex& li, bool defer_rehash) {
     __shared__ CidKey s_tx;
     __shared__ uint32_t s_have_tx;
-    const uint32_t P = c.n_parents;
+    const uint32_t P = in.n_parents;
     if (b >= P) return;
     const bool lead = threadIdx.x == 0;
     auto fail = [&](uint32_t seq, uint32_t code) { atomicMin(err, (unsigned long long)pack_enum_error(seq, 0, code)); };
     // reconstruct_execution_order (utils.rs:20-27): the parent header
     if (lead) s_have_tx = 0;
-    const uint32_t hb = find_block(w, li, c.parents[b]);
+    const uint32_t hb = find_block(w, li, in.parents[b]);
     if (hb == kNoBlock) {
         if (lead) fail(b, IPCFP_ST_ERR_MISSING_BLOCK);
     } else {
@@ -235,7 +236,7 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
                     // The re-hash — re-encode, one Blake2b compression on ONE lane, ≈ 3 k instructions — gates nothing: it
                     // only ever adds an error.  A launch of its own on the aux stream does it (amt_enum.hip k_txmeta_rehash), joined
                     // at the end of the call; a mismatch reaches the same error word with the same sequence number.
-                    c.txmeta_block[b] = tb;
+                    c.txmeta_block[b] = tb + 1u;
                     bls.root = l0 <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
                     secp.root = l1 <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
                     bls.skip = secp.skip = 0;
@@ -280,24 +281,39 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, TipsetCtxDev& c
 }
 
 // `live_done` non-null: the CID index is being filled beside this launch (LiveIndex above); `anomaly`: the call's flag.
+// INLINE: the one context's inputs are the kernel ARGUMENT `in0` (scalar loads from the kernarg segment); its device copy
+// — zeroed memory, not yet written by anyone — gets them from slot 0, for the kernels behind this launch.
+template <bool INLINE>
 __global__ __launch_bounds__(64) void k_tipset_prepare(WitnessView w, PrepareJobs jobs, uint32_t n_jobs, const uint32_t* live_done,
-                                                       uint32_t live_total, uint32_t* anomaly, int defer_rehash) {
+                                                       uint32_t live_total, uint32_t* anomaly, int defer_rehash, TipsetInputs in0) {
     __shared__ rd_chunk_t stage[kPrologueStageChunks];
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
     const PrepareJob jb = prepare_job(jobs, job);
+    const TipsetInputs& in = INLINE ? in0 : *reinterpret_cast<const TipsetInputs*>(jb.ctx);
+    if (INLINE && slot == 0) {  // 688 bytes, sixteen at a time
+        static_assert(sizeof(TipsetInputs) % 8 == 0, "copied as 64-bit words");
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&in0);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(jb.ctx);
+        for (uint32_t i = threadIdx.x; i < sizeof(TipsetInputs) / 8; i += 64u) dst[i] = src[i];
+    }
     LiveIndex li{};
     li.done = live_done;
     li.total = live_total;
-    if (slot < 2) headers_slot(w, *jb.ctx, slot == 0, stage, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr, li);
-    else if (jb.roots) roots_slot(w, *jb.ctx, jb.roots, jb.err, slot - 2, stage, li, defer_rehash != 0);
+    if (slot < 2) headers_slot(w, in, *jb.ctx, slot == 0, stage, jb.roots ? jb.roots + 2u * in.n_parents : nullptr, li);
+    else if (jb.roots) roots_slot(w, in, *jb.ctx, jb.roots, jb.err, slot - 2, stage, li, defer_rehash != 0);
     live_validate(w, li, anomaly);
 }
 
 void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs,
-                               const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly, bool defer_rehash) {
-    hipLaunchKernelGGL(k_tipset_prepare, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs, n_jobs, live_done, live_total,
-                       anomaly, defer_rehash ? 1 : 0);
+                               const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly, bool defer_rehash,
+                               const TipsetInputs* inline_inputs) {
+    if (inline_inputs && n_jobs == 1)
+        hipLaunchKernelGGL(k_tipset_prepare<true>, dim3(kPrepareSlots), dim3(64), 0, stream, w, jobs, n_jobs, live_done, live_total,
+                           anomaly, defer_rehash ? 1 : 0, *inline_inputs);
+    else
+        hipLaunchKernelGGL(k_tipset_prepare<false>, dim3(n_jobs * kPrepareSlots), dim3(64), 0, stream, w, jobs, n_jobs, live_done,
+                           live_total, anomaly, defer_rehash ? 1 : 0, TipsetInputs{});
 }
 
 }  // namespace ipcfp

@@ -221,20 +221,24 @@ __global__ __launch_bounds__(64) void k_tipset_prepare_general(WitnessView w, Pr
 }
 
 void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs,
-                               const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly, bool defer_rehash);  // tipset_prepare.hip
+                               const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly, bool defer_rehash,
+                               const TipsetInputs* inline_inputs);  // tipset_prepare.hip
 
 // `jobs`: HOST array; `jobs_d`: device copy, needed (and read) only when there are more than kInlineJobs.
 // `need_general`: some block of the witness may exceed the LDS stage, so the general companion has to look.
 int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs, const void* jobs_d, uint32_t n_jobs,
                           bool need_general, const uint32_t* live_done, uint32_t live_total, uint32_t* anomaly,
-                          bool defer_rehash) {
+                          bool defer_rehash, const void* inline_inputs) {
     if (defer_rehash && need_general) return set_error(ctx, IPCFP_E_INVALID, "deferred TxMeta re-hash: LDS slots only");
     if (live_done && (need_general || !anomaly)) return set_error(ctx, IPCFP_E_INVALID, "live prologue: LDS slots only");
     if (n_jobs == 0) return IPCFP_OK;
     PrepareJobs pj{};
     if (n_jobs <= kInlineJobs) std::memcpy(pj.inline_jobs, jobs, size_t(n_jobs) * sizeof(PrepareJob));
     else pj.more = static_cast<const PrepareJob*>(jobs_d);
-    launch_tipset_prepare_lds(ctx->stream, w, pj, n_jobs, live_done, live_total, anomaly, defer_rehash);
+    // (`inline_inputs`: the ONE context's TipsetInputs on the host — they ride in the kernel arguments and the context's
+    // zeroed device copy is filled in by the launch itself)
+    launch_tipset_prepare_lds(ctx->stream, w, pj, n_jobs, live_done, live_total, anomaly, defer_rehash,
+                              static_cast<const TipsetInputs*>(inline_inputs));
     if (need_general)
         hipLaunchKernelGGL(k_tipset_prepare_general, dim3(n_jobs * kPrepareSlots), dim3(64), 0, ctx->stream, w, pj, n_jobs);
     IPCFP_HIP(ctx, hipGetLastError());

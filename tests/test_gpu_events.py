@@ -306,3 +306,246 @@ def test_headers_larger_than_the_prologue_stage(tip, engine, oracle):
     assert np.array_equal(got, want) and np.array_equal(got, plain)
     assert (got == 1).sum() > 100 and (got != 1).sum() >= 2  # (the two tampered claims among them)
     assert gs == os_ == 1 and np.array_equal(gc, oc)
+
+
+# ---- a TxMeta whose ONLY fault is the re-hash (events/utils.rs:64-73) — both message-AMT roots resolve, every block on
+# the walk decodes, only `put_cbor(&(bls, secp), Blake2b256)` disagrees with the header's `messages` CID — on every route:
+# the fast verify route re-hashes OFF the chain (k_txmeta_rehash) and must discard its results when the late error lands.
+def txmeta_blocks(tip):
+    """block ids of the parents' TxMeta blocks, in parent order (the only 87-byte block whose CID a header names)"""
+    out = []
+    for pc in tip.parent_cids:
+        hdr = tip.block(tip.find_block(pc))
+        ids = [i for i in range(tip.n_blocks) if tip.lens[i] == 87 and tip.cids[i, :38].tobytes() in hdr]
+        assert len(ids) == 1
+        out.append(ids[0])
+    return out
+
+
+def with_block(tip, block_id, new_bytes):
+    """the witness tables with ONE block's payload replaced (any length; the CID stays: nothing re-hashes a witness block)"""
+    new_bytes = np.frombuffer(bytes(new_bytes), dtype=np.uint8)
+    data = np.concatenate([tip.data, new_bytes])
+    off, lens = tip.off.copy(), tip.lens.copy()
+    off[block_id] = tip.data.size
+    lens[block_id] = len(new_bytes)
+    return data, off, lens, tip.cids
+
+
+TXMETA_FAULTS = ["roots swapped", "another parent's TxMeta", "trailing byte (88 B)", "non-minimal header (88 B)",
+                 "non-minimal link length (88 B)"]
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("fault", TXMETA_FAULTS)
+def test_txmeta_rehash_is_the_only_fault(tip, engine, oracle, fault, fast):
+    tx = txmeta_blocks(tip)
+    b1 = tip.block(tx[1])
+    assert len(b1) == 87 and b1[0] == 0x82
+    if fault == "roots swapped":              # decodes, both roots resolve, the re-encoding hashes differently
+        tables, want_exec = with_block(tip, tx[1], b1[:1] + b1[44:87] + b1[1:44]), 67
+    elif fault == "another parent's TxMeta":  # parent 0's (bls, secp) stored under parent 2's `messages` CID
+        tables, want_exec = with_block(tip, tx[2], tip.block(tx[0])), 67
+    elif fault == "trailing byte (88 B)":     # from_slice rejects trailing bytes: a decode error, not a mismatch
+        tables, want_exec = with_block(tip, tx[1], b1 + b"\x00"), 66
+    elif fault == "non-minimal header (88 B)":  # 98 02 …: decodes (non-minimal lengths are accepted), and the CANONICAL
+        tables, want_exec = with_block(tip, tx[1], b"\x98\x02" + b1[1:]), 1   # re-encoding is the 87 bytes the CID names: Ok
+    else:                                     # d8 2a 59 00 27 …: the same, inside the first link
+        tables, want_exec = with_block(tip, tx[1], b1[:3] + b"\x59\x00\x27" + b1[5:]), 1
+    data, off, lens, cids = tables
+    ec = claims.EventClaims(tip, indices=np.arange(0, 400))
+    st = oracle.store(data, off, lens, cids)
+    want = st.verify_event_proofs(ec, mode=0)
+    o_exec, o_order = st.exec_order(tip.parent_cids)
+    o_gen = st.generate_event_proof(tip.parent_cids, tip.child_cid, tip.topic0, tip.topic1, actor=tip.filter_actor)
+    st.close()
+    assert o_exec == want_exec, (fault, o_exec)
+    assert ((want == want_exec).all() if want_exec != 1 else (want == 1).sum() > 200), (fault, np.unique(want))
+    engine.set_tuning("fast_verify", fast)
+    try:
+        with engine.witness(data, off, lens, cids) as w:
+            for rep in range(2):  # (the second call finds whatever the first one cached)
+                got = w.verify_event_proofs(ec.arr, ec.n)
+                assert np.array_equal(got, want), (fault, fast, rep, np.unique(got), np.unique(want))
+            g_exec, g_order = w.exec_order(tip.parent_cids)
+            assert g_exec == o_exec and np.array_equal(g_order, o_order), (fault, fast)
+            gs, gm, gmsg, gids = w.generate_event_proofs(tip.parent_cids, tip.child_cid, tip.topic0, tip.topic1,
+                                                         actor=tip.filter_actor)
+            # the generator rebuilds the order WITHOUT the re-hash (build_execution_order, events/generator.rs:152-169)
+            assert gs == o_gen[0], (fault, fast, gs, o_gen[0])
+            if gs == 1:
+                assert np.array_equal(gmsg, o_gen[2]) and np.array_equal(cids[gids], o_gen[3])
+        # packed claims in HBM: the route the benchmark times
+        import ipc_filecoin_proofs_amd as ipcfp
+        import torch
+        sel = np.arange(0, 400)
+        ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+            tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec[sel], tip.claim_event[sel],
+            tip.claim_emitter[sel], tip.exec_order[tip.claim_exec[sel].astype(np.int64)], tip.claim_ntopics[sel],
+            tip.claim_topics[sel], tip.claim_datalen[sel], tip.claim_data[sel])
+        with engine.witness(data, off, lens, cids) as w:
+            got = w.verify_event_claims(ts, cl, blob, blob_len)
+        ost = oracle.store(data, off, lens, cids)
+        want_p = ost.verify_event_claims_packed(ts, cl, blob)
+        ost.close()
+        assert np.array_equal(got, want_p), (fault, fast, np.unique(got), np.unique(want_p))
+        assert (got == want_exec).all() if want_exec != 1 else (got == 1).sum() > 200
+    finally:
+        engine.set_tuning("fast_verify", -1)
+
+
+def packed_for(tip, sel=None):
+    import ipc_filecoin_proofs_amd as ipcfp
+    sel = np.arange(len(tip.claim_exec)) if sel is None else sel
+    return ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec[sel], tip.claim_event[sel],
+        tip.claim_emitter[sel], tip.exec_order[tip.claim_exec[sel].astype(np.int64)], tip.claim_ntopics[sel],
+        tip.claim_topics[sel], tip.claim_datalen[sel], tip.claim_data[sel])
+
+
+@pytest.mark.parametrize("fast", [1, 0])
+def test_bundle_with_two_tipset_pairs_at_size(engine, oracle, fast):
+    """`verify_proof_bundle` takes any mix of (parents, child) pairs (src/proofs/verifier.rs:12-60).  The route without a
+    mid-call synchronisation serves ONE pair per call (host/verify_fast.cpp); a batch over two pairs takes the general
+    route — 120 k claims, interleaved pair by pair, liars of several kinds in both halves, every status against the
+    multi-threaded oracle, with the fast route enabled (it must decline) and disabled."""
+    import ipc_filecoin_proofs_amd as ipcfp
+    tips = [Tipset(n_receipts=60_000, n_parents=3, dup_permille=30, n_planted=20, variety=1, max_events=4, seed=901),
+            Tipset(n_receipts=60_000, n_parents=5, dup_permille=10, n_planted=20, variety=1, max_events=3, seed=902)]
+    packs = [packed_for(t) for t in tips]
+    data = np.concatenate([t.data for t in tips])
+    off = np.concatenate([tips[0].off, tips[1].off + np.uint64(tips[0].data.size)])
+    lens = np.concatenate([t.lens for t in tips])
+    cids = np.concatenate([t.cids for t in tips])
+    ts = np.concatenate([p[0] for p in packs])
+    cl = np.concatenate([p[1] for p in packs])
+    n0, b0 = len(packs[0][1]), packs[0][3]
+    cl["tipset"][n0:] = 1
+    cl["topics_off"][n0:] += b0
+    cl["data_off"][n0:] += b0
+    blob = np.concatenate([packs[0][2][:b0], packs[1][2]])
+    blob_len = b0 + packs[1][3]
+    # interleave the two pairs claim by claim, then plant liars
+    order = np.argsort(np.concatenate([np.arange(n0) * 2, np.arange(len(cl) - n0) * 2 + 1]), kind="stable")
+    cl = np.ascontiguousarray(cl[order])
+    liars = np.arange(3, len(cl), 23)
+    cl["exec_index"][liars[0::4]] += 1
+    cl["emitter"][liars[1::4]] ^= 1
+    cl["event_index"][liars[2::4]] += 7
+    cl["tipset"][liars[3::4]] ^= 1          # the claim's own pair swapped for the other one
+    cl["tipset"][11] = 2                    # no such pair: ERR_BAD_CLAIM
+    ost = oracle.store(data, off, lens, cids, threads=0)
+    want = ost.verify_event_claims_packed(ts, cl, blob, threads=0)
+    ost.close()
+    assert (want == 1).sum() > 80_000 and len(np.unique(want)) >= 5 and len(cl) > 100_000
+    want[11] = 69  # (a pair index outside the table is the packed ABI's own error: the oracle has no such notion)
+    engine.set_tuning("fast_verify", fast)
+    try:
+        with engine.witness(data, off, lens, cids) as w:
+            got = w.verify_event_claims(ts, cl, blob, blob_len)
+            assert np.array_equal(got, want), (np.nonzero(got != want)[0][:8], got[got != want][:8], want[got != want][:8])
+            # ... and one pair alone right behind it on the same witness (the fast route's case, caches warm)
+            one = np.nonzero(cl["tipset"] == 0)[0]
+            got1 = w.verify_event_claims(ts[:1], cl[one], blob, blob_len)
+            assert np.array_equal(got1, want[one])
+    finally:
+        engine.set_tuning("fast_verify", -1)
+
+
+def test_first_contact_scan_with_another_filter_than_the_hint(tip, engine, oracle):
+    """A verify call tabulates the events counting the matches of the LAST scan's filter on the context
+    (`ctx->scan_hint`, host/scan_events.cpp); the scan that follows with ANOTHER filter must count from the records —
+    same status, map, matches and recorded blocks as the oracle's find_matching_events (events/generator.rs:180-307)."""
+    ec = claims.EventClaims(tip, indices=np.arange(0, 300))
+    other_t0 = bytes(tip.claim_topics[int(np.nonzero(tip.claim_ntopics >= 2)[0][5]), 0])
+    other_t1 = bytes(tip.claim_topics[int(np.nonzero(tip.claim_ntopics >= 2)[0][5]), 1])
+    assert (other_t0, other_t1) != (tip.topic0, tip.topic1)
+    st = oracle.store(tip.data, tip.off, tip.lens, tip.cids)
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w0:   # sets the context's hint to (topic0, topic1, actor)
+        w0.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
+    for t0, t1, actor in ((other_t0, other_t1, None), (other_t0, other_t1, 1001), (tip.topic0, tip.topic1, None)):
+        with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:  # first contact: nothing cached
+            got = w.verify_event_proofs(ec.arr, ec.n)                       # tabulates with the hint's filter
+            assert np.array_equal(got, st.verify_event_proofs(ec, mode=0))
+            gs, ghas, gm, gids = w.scan_events(tip.receipts_root, t0, t1, actor=actor)
+            os_, ohas, otrip, otouched = st.scan_events(tip.receipts_root, t0, t1, actor=actor)
+            assert gs == os_ == 1 and np.array_equal(ghas, ohas)
+            got3 = np.stack([gm["exec_index"], gm["event_index"], gm["emitter"]], axis=1) if len(gm) else np.zeros((0, 3), np.uint64)
+            assert np.array_equal(got3, otrip) and (len(otrip) > 0 or actor == 1001)
+            assert sorted_cids(tip, gids) == [bytes(c[:38]) for c in otouched]
+    st.close()
+
+
+def test_verify_and_scan_in_one_call_equals_the_two_calls(tip, engine, oracle):
+    """ipcfp_verify_and_scan_device = verify_event_claims_device followed by scan_events_device of the child's receipts
+    AMT: status bytes, scan status, has-match map and match records must be those of the two calls (and the oracle's) —
+    when the scan rides on the verify call's one synchronisation (first contact, filter = the context's hint or not),
+    when the receipts are cached already, on deep events AMTs the table does not cover, on a witness without the
+    receipts root (the scan's status is the error), with and without the no-synchronisation route."""
+    import ipc_filecoin_proofs_amd as ipcfp
+    import torch
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+
+    def both_ways(t, tables, filt, fast):
+        data, off, lens, cids = tables
+        ts, cl, blob, blob_len = packed_for(t)
+        cl["emitter"][5::31] ^= 1  # a few liars
+        d_cl, d_blob = dev(cl), dev(blob)
+        n, nr = len(cl), int(t.params["n_receipts"])
+        t0, t1, actor = filt
+        out = []
+        engine.set_tuning("fast_verify", fast)
+        for combined in (False, True, True):   # (the second combined call finds the enumeration and the table cached)
+            if len(out) < 2:   # a fresh witness for the two-call form and for the first combined call
+                if out:
+                    w.close()
+                w = engine.witness(data, off, lens, cids)
+            d_st = torch.full((n,), 77, dtype=torch.uint8, device="cuda")
+            d_has = torch.full((nr + 16,), 9, dtype=torch.uint8, device="cuda")
+            d_m = torch.zeros(4096 * 40, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            if combined:
+                sst, snr, snm = w.verify_and_scan_device(ts, d_cl.data_ptr(), n, d_blob.data_ptr(), blob_len, d_st.data_ptr(),
+                                                         t0, t1, actor, d_has.data_ptr(), nr + 16, d_m.data_ptr(), 4096)
+            else:
+                w.verify_event_claims_device(ts, d_cl.data_ptr(), n, d_blob.data_ptr(), blob_len, d_st.data_ptr())
+                sst, snr, snm = w.scan_events_device(t.receipts_root, t0, t1, actor, d_has.data_ptr(), nr + 16, d_m.data_ptr(), 4096)
+            engine.sync()
+            m = d_m.cpu().numpy()[: snm * 40].view(ipcfp.MATCH_DTYPE) if sst == 1 else None
+            out.append((d_st.cpu().numpy(), sst, snr, snm, d_has.cpu().numpy()[:snr] if sst == 1 else None,
+                        None if m is None else np.stack([m["exec_index"], m["event_index"], m["emitter"]], axis=1)))
+        w.close()
+        engine.set_tuning("fast_verify", -1)
+        st = oracle.store(data, off, lens, cids)
+        want = st.verify_event_claims_packed(ts, cl, blob)
+        os_, ohas, otrip, _ = st.scan_events(t.receipts_root, t0, t1, actor=actor, want_touched=False)
+        st.close()
+        for got in out:
+            assert np.array_equal(got[0], want), np.unique(got[0])
+            assert got[1] == os_
+            if os_ == 1:
+                assert got[2] == len(ohas) and got[3] == len(otrip) and np.array_equal(got[4], ohas)
+                assert np.array_equal(got[5], otrip) if len(otrip) else got[3] == 0
+        return os_, want
+
+    full = (tip.data, tip.off, tip.lens, tip.cids)
+    hint = (tip.topic0, tip.topic1, tip.filter_actor)
+    i = int(np.nonzero(tip.claim_ntopics >= 2)[0][5])
+    other = (bytes(tip.claim_topics[i, 0]), bytes(tip.claim_topics[i, 1]), None)
+    for fast in (1, 0):
+        s, want = both_ways(tip, full, hint, fast)
+        assert s == 1 and (want == 1).sum() > 1000
+        s, _ = both_ways(tip, full, other, fast)
+        assert s == 1
+    # no receipts root in the witness: every claim Err, the scan's status is the missing block
+    keep = np.ones(tip.n_blocks, dtype=bool)
+    keep[tip.find_block(tip.receipts_root)] = False
+    idx = np.nonzero(keep)[0]
+    s, want = both_ways(tip, (tip.data, tip.off[idx], tip.lens[idx], tip.cids[idx]), hint, 1)
+    assert s == 65 and (want >= 64).all()
+    # deep events AMTs: the table leaves them to the walkers, the riding scan hands over to the ordinary one
+    tip2 = Tipset(n_receipts=300, n_planted=6, variety=1, max_events=40, events_bit_width=2, seed=77)
+    s, _ = both_ways(tip2, (tip2.data, tip2.off, tip2.lens, tip2.cids), (tip2.topic0, tip2.topic1, tip2.filter_actor), 1)
+    assert s == 1
