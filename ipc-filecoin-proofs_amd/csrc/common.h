@@ -232,9 +232,19 @@ inline hipError_t h2d_small(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t
 // wait that lasts longer than ~2 ms falls back to the blocking call).
 hipError_t wait_stream(ipcfp_ctx* ctx, hipStream_t s);
 
-inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s) {
+// `last_of_call`: nothing of this call will read the control block on the device after this wait — so its
+// re-initialisation for the NEXT call (ctl_preprime) is queued here, behind the read-back and in front of the wait, while
+// the GPU is still awake.  Queued after the wait it is the first submission to an idle queue: ≈ 60 µs until the command
+// processor picks it up (host API trace: profiles/r04_experiments.md), which the next call's first synchronisation —
+// ipcfp_witness_rebuild_index — then sits out.
+inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s, bool last_of_call = false) {
     const bool ctl = s == ctx->stream && !ctx->ctl_reads.empty();
     if (ctl) (void)ctl_fetch(ctx);  // one copy for every control word the host asked for
+    if (last_of_call && s == ctx->stream && ctx->ctl_dev && ctx->ctl_primed && !ctx->ctl_preprimed && ctx->call_depth == 1 &&
+        hipMemcpyAsync(ctx->ctl_dev, ctx->ctl_host, 2 * kCtlHalf, hipMemcpyHostToDevice, ctx->stream) == hipSuccess) {
+        ctx->ctl_preprimed = true;
+        if (ctx->ctl_event) (void)hipEventRecord(ctx->ctl_event, ctx->stream);
+    }
     const hipError_t e = wait_stream(ctx, s);
     if (ctl) {
         if (e == hipSuccess)

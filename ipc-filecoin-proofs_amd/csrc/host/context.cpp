@@ -25,7 +25,11 @@ thread_local DevPool* g_tls_pool = nullptr;
 hipError_t wait_stream(ipcfp_ctx* ctx, hipStream_t s) {
     // (the polling event was created on the context's device by ipcfp_ctx_create; without one: the blocking call)
     if (!ctx->spin_sync || !ctx->spin_event) return hipStreamSynchronize(s);
-    hipError_t e = hipEventRecord(ctx->spin_event, s);
+    // Nothing queued since the last wait?  Then there is nothing to record an event behind: an event on an IDLE queue is a
+    // submission the command processor takes ≈ 60 µs to pick up, and the caller would sit that out for nothing.
+    hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return e;
+    e = hipEventRecord(ctx->spin_event, s);
     if (e != hipSuccess) return e;
     // poll for a bounded WALL-CLOCK time (2 ms: every wait of a verification step is shorter), then give the core back
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);

@@ -314,7 +314,7 @@ static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vecto
     IPCFP_HIP(ctx, ctl_read(ctx, &bad, small + 2, 4));
     IPCFP_HIP(ctx, ctl_read(ctx, &e, ex.err.p, 8));
     IPCFP_HIP(ctx, ctl_read(ctx, &facts, tcs_d.p, sizeof facts));  // (rides on the control block's one read-back when the context lives there)
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream, /*last_of_call=*/true));  // (a fallback below takes fresh words: still fine)
     IPCFP_HIP(ctx, hipGetLastError());
     if (bad || e != kNoEnumError || facts.child_status != IPCFP_ST_TRUE) {
         // (the aux stream may still be writing this call's buffers)
