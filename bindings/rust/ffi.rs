@@ -43,7 +43,7 @@ use crate::proofs::trust::TrustPolicy;
 
 // ---- PODs of include/ipcfp.h --------------------------------------------------------------------------------------
 pub const IPCFP_CID_SLOT: usize = 40;
-pub const IPCFP_MAX_PARENTS: usize = 16;
+pub const IPCFP_MAX_PARENTS: usize = 32;
 pub const IPCFP_ST_TRUE: u8 = 1;
 pub const IPCFP_ST_FALSE_FILTER: u8 = 17;
 /// `ipcfp_check_event_fn` of the header: the host predicate of ipcfp_verify_event_proofs_with
@@ -89,6 +89,10 @@ pub struct ipcfp_storage_proof_t {
 #[repr(C)] pub struct ipcfp_event_claim_t { pub parent_epoch: i64, pub child_epoch: i64, pub exec_index: u64, pub event_index: u64,
                                             pub emitter: u64, pub message_cid: [u8; 40], pub tipset: u32, pub flags: u32,
                                             pub n_topics: u32, pub topics_off: u32, pub data_off: u32, pub data_len: u32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct ipcfp_event_claim_group_t { pub parent_epoch: i64, pub child_epoch: i64, pub tipset: u32, pub reserved: u32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct ipcfp_event_claim_compact_t { pub emitter: u64, pub exec_index: u32, pub event_index: u32,
+                                                                          pub message_digest: [u8; 32], pub data_len: u16, pub n_topics: u8,
+                                                                          pub topic_flags: u8, pub flags: u8, pub group: u8, pub reserved: u16 }
 #[repr(C)] pub struct ipcfp_storage_claim_t { pub child_epoch: i64, pub actor_id: u64, pub child: [u8; 40], pub state_root: [u8; 40],
                                               pub actor_state: [u8; 40], pub storage_root: [u8; 40], pub slot: [u8; 32],
                                               pub value: [u8; 32], pub flags: u32, pub reserved: u32 }

@@ -187,6 +187,20 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
  * (the timed benchmarks use this: inputs resident before the clock starts).     */
 int ipcfp_witness_create_device(ipcfp_ctx_t* ctx, const void* bytes_d, uint64_t nbytes, const void* off_d,
                                 const void* len_d, const void* cids40_d, uint64_t n, ipcfp_witness_t** out);
+/* The same witness with its TABLES in transport form — what has to cross PCIe when the bundle comes from host memory
+ * (window T2 of the benchmarks; the witness blocks of a bundle are `(Cid, Vec<u8>)` pairs in `Cid: Ord` order,
+ * src/proofs/common/bundle.rs:10-16, src/proofs/common/witness.rs:34-54, and nearly every CID of a Filecoin witness is
+ * CIDv1 dag-cbor blake2b-256):
+ *   bytes / len      the blocks back to back: block i starts at len[0] + ... + len[i-1]  (no offset table: 8 bytes per block)
+ *   digests32        the multihash digest of block i's CID; the CID is cid_prefix ‖ digest  (32 instead of 40 bytes per block)
+ *   cid_prefix       prefix_len ≤ 8 bytes, e.g. 01 71 a0 e4 02 20
+ *   esc_index / esc_cids40   the blocks whose CID is NOT of that form (ascending ids) with their 40-byte slots; the
+ *                    digest rows of those blocks are ignored
+ * Offsets and CID slots are rebuilt on the device; everything after that is ipcfp_witness_create.                  */
+int ipcfp_witness_create_packed(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint32_t* len,
+                                const uint8_t* digests32, uint64_t n, const uint8_t* cid_prefix, uint32_t prefix_len,
+                                const uint32_t* esc_index, const uint8_t* esc_cids40, uint64_t n_esc,
+                                ipcfp_witness_t** out);
 void ipcfp_witness_destroy(ipcfp_witness_t* w);
 uint64_t ipcfp_witness_block_count(const ipcfp_witness_t* w);
 uint64_t ipcfp_witness_byte_count(const ipcfp_witness_t* w);
@@ -491,7 +505,7 @@ int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcf
  * already holds binary CIDs (or verifies the same bundle repeatedly) can build them itself and keep
  * them in HBM.  Semantics are identical: the flags record what `Cid::try_from(str)?` and the
  * hex compares of the reference would have observed for the original strings.               */
-#define IPCFP_MAX_PARENTS 16 /* parent blocks per tipset key (engine limit) */
+#define IPCFP_MAX_PARENTS 32 /* parent blocks per tipset key (engine limit; expected 5 per epoch, P(> 32) < 1e-15) */
 
 #define IPCFP_TIPSET_PARENTS_PARSED 1u /* every parent_tipset_cids[i] parses (events/verifier.rs:130) */
 #define IPCFP_TIPSET_CHILD_PARSED 2u   /* child_block_cid parses (:131)                               */
@@ -539,6 +553,57 @@ int ipcfp_verify_and_scan_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipc
                                  const ipcfp_event_filter_t* scan_filter, int has_actor, uint64_t actor,
                                  ipcfp_status_t* scan_status, void* receipt_has_match_d, uint64_t cap_receipts,
                                  uint64_t* n_receipts, void* matches_d, uint64_t cap_matches, uint64_t* n_matches);
+
+/* ---- event claims in TRANSPORT form: what crosses PCIe when the claims come from host memory (window T2) -----------
+ * An `EventProof` (src/proofs/events/bundle.rs:5-23) lowered to ipcfp_event_claim_t + blob is ≈ 200 bytes; most of it
+ * says the same thing a million times: the epochs and the tipset of every claim of one bundle, the six prefix bytes of
+ * the message CID, 33-byte framing for a 32-byte topic, u64 / u32 fields for indices and lengths that fit in half.
+ * The compact record keeps what differs from claim to claim (56 bytes + 32 per topic + the data bytes); the device
+ * rebuilds ipcfp_event_claim_t[n] + blob from it (ipcfp_expand_event_claims_device), byte for byte what
+ * the plain lowering produces with the claims' blob segments laid out in claim order.
+ * Representable: exec_index, event_index < 2^32; n_topics ≤ 8; data_len < 65536; at most 256 distinct
+ * (parent_epoch, child_epoch, tipset) groups; message CID = 01 71 a0 e4 02 20 ‖ digest (or not parsed at all).
+ * ipcfp_compact_event_claims returns IPCFP_E_UNSUPPORTED for a batch that is not: the caller keeps the plain form.  */
+typedef struct ipcfp_event_claim_group {
+    int64_t parent_epoch;
+    int64_t child_epoch;
+    uint32_t tipset; /* index into the ipcfp_tipset_ref_t table */
+    uint32_t reserved;
+} ipcfp_event_claim_group_t;
+#define IPCFP_COMPACT_MAX_GROUPS 256u
+#define IPCFP_COMPACT_MAX_TOPICS 8u
+typedef struct ipcfp_event_claim_compact {
+    uint64_t emitter;
+    uint32_t exec_index;
+    uint32_t event_index;
+    uint8_t message_digest[32]; /* message_cid = 01 71 a0 e4 02 20 ‖ message_digest (ignored without IPCFP_CLAIM_MSG_PARSED) */
+    uint16_t data_len;
+    uint8_t n_topics;    /* ≤ IPCFP_COMPACT_MAX_TOPICS */
+    uint8_t topic_flags; /* bit t: topic t was "0x" + 64 hex digits (the plain form's per-topic flag byte) */
+    uint8_t flags;       /* IPCFP_CLAIM_* */
+    uint8_t group;       /* index into the group table */
+    uint16_t reserved;
+} ipcfp_event_claim_compact_t; /* 56 bytes; blob: per claim, in claim order, n_topics × 32 topic bytes, then data_len bytes */
+
+/* Host-side conversion plain → compact (a caller that builds the compact form directly needs none).  `groups` holds
+ * IPCFP_COMPACT_MAX_GROUPS entries; out / out_blob hold n records / cap_blob bytes (blob_len is always enough).       */
+int ipcfp_compact_event_claims(const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob, uint64_t blob_len,
+                               ipcfp_event_claim_group_t* groups, uint32_t* n_groups, ipcfp_event_claim_compact_t* out,
+                               uint8_t* out_blob, uint64_t cap_blob, uint64_t* out_blob_len);
+/* compact → plain ON THE DEVICE (all pointers but `groups` are device pointers): claims_out_d receives n
+ * ipcfp_event_claim_t, blob_out_d (cap_blob ≥ cblob_len + 8·n bytes) their blob; *blob_len_out (host, nullable: then the
+ * call does not synchronise) the blob's length.  A record whose group, topic count or blob segment is out of range
+ * becomes a claim with tipset = 0xffffffff: IPCFP_ST_ERR_BAD_CLAIM when verified.                                   */
+int ipcfp_expand_event_claims_device(ipcfp_ctx_t* ctx, const ipcfp_event_claim_group_t* groups, uint32_t n_groups,
+                                     const void* compact_d, uint64_t n, const void* cblob_d, uint64_t cblob_len,
+                                     void* claims_out_d, void* blob_out_d, uint64_t cap_blob, uint64_t* blob_len_out);
+/* ipcfp_verify_event_claims with the claims in compact form in HOST memory: they cross PCIe beside the tipset's AMT
+ * walk, are expanded on the device, verified; status bytes back (host).                                              */
+int ipcfp_verify_event_claims_compact(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets,
+                                      uint32_t n_tipsets, const ipcfp_event_claim_group_t* groups, uint32_t n_groups,
+                                      const ipcfp_event_claim_compact_t* claims, uint64_t n, const uint8_t* cblob,
+                                      uint64_t cblob_len, const ipcfp_trust_policy_t* trust,
+                                      const ipcfp_event_filter_t* filter, ipcfp_status_t* status);
 
 /* The same over packed claims in HOST memory (tipsets, claims, blob, status: host): upload, verify, status bytes
  * back — the PCIe-inclusive form of verify_event_proof for callers that hold binary claims

@@ -36,6 +36,11 @@ __all__ = [
     "CID_UNCHECKED",
     "KERNEL_IDS",
     "pack_event_claims",
+    "PackedWitnessTables",
+    "STD_CID_PREFIX",
+    "compact_event_claims",
+    "COMPACT_DTYPE",
+    "GROUP_DTYPE",
     "pack_storage_claims",
     "SCLAIM_DTYPE",
     "cid_from_string",
@@ -118,13 +123,18 @@ class ST:
 
 VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "vec_u8": 4, "any": 5}
 LOC_DTYPE = np.dtype([("block", np.uint32), ("off", np.uint32), ("len", np.uint32)])
-MAX_PARENTS = 16
+MAX_PARENTS = 32
 TIPSET_DTYPE = np.dtype([("flags", np.uint32), ("n_parents", np.uint32), ("child", np.uint8, (CID_SLOT,)),
                          ("parents", np.uint8, (MAX_PARENTS, CID_SLOT))])
 CLAIM_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), ("exec_index", np.uint64),
                         ("event_index", np.uint64), ("emitter", np.uint64), ("message_cid", np.uint8, (CID_SLOT,)),
                         ("tipset", np.uint32), ("flags", np.uint32), ("n_topics", np.uint32),
                         ("topics_off", np.uint32), ("data_off", np.uint32), ("data_len", np.uint32)])
+# event claims in transport form (include/ipcfp.h ipcfp_event_claim_compact_t / ipcfp_event_claim_group_t)
+COMPACT_DTYPE = np.dtype([("emitter", np.uint64), ("exec_index", np.uint32), ("event_index", np.uint32),
+                          ("message_digest", np.uint8, (32,)), ("data_len", np.uint16), ("n_topics", np.uint8),
+                          ("topic_flags", np.uint8), ("flags", np.uint8), ("group", np.uint8), ("reserved", np.uint16)])
+GROUP_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), ("tipset", np.uint32), ("reserved", np.uint32)])
 SCLAIM_DTYPE = np.dtype([("child_epoch", np.int64), ("actor_id", np.uint64), ("child", np.uint8, (CID_SLOT,)),
                          ("state_root", np.uint8, (CID_SLOT,)), ("actor_state", np.uint8, (CID_SLOT,)),
                          ("storage_root", np.uint8, (CID_SLOT,)), ("slot", np.uint8, (32,)),
@@ -193,6 +203,7 @@ def load_library() -> C.CDLL:
         "ipcfp_profile_reset": (i32, [vp]),
         "ipcfp_profile_read": (i32, [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "ipcfp_witness_create": (i32, [vp, vp, u64, vp, vp, vp, u64, C.POINTER(vp)]),
+        "ipcfp_witness_create_packed": (i32, [vp, vp, u64, vp, vp, u64, vp, C.c_uint32, vp, vp, u64, C.POINTER(vp)]),
         "ipcfp_witness_create_device": (i32, [vp, vp, u64, vp, vp, vp, u64, C.POINTER(vp)]),
         "ipcfp_witness_destroy": (None, [vp]),
         "ipcfp_witness_block_count": (u64, [vp]),
@@ -214,6 +225,9 @@ def load_library() -> C.CDLL:
         "ipcfp_verify_and_scan_device": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp, vp, i32, u64, vp, vp, u64,
                                                C.POINTER(u64), vp, u64, C.POINTER(u64)]),
         "ipcfp_verify_event_claims": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
+        "ipcfp_compact_event_claims": (i32, [vp, u64, vp, u64, vp, C.POINTER(C.c_uint32), vp, vp, u64, C.POINTER(u64)]),
+        "ipcfp_expand_event_claims_device": (i32, [vp, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, u64, C.POINTER(u64)]),
+        "ipcfp_verify_event_claims_compact": (i32, [vp, vp, vp, C.c_uint32, vp, C.c_uint32, vp, u64, vp, u64, vp, vp, vp]),
         "ipcfp_witness_rebuild_index": (i32, [vp, vp]),
         "ipcfp_witness_has": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_witness_get": (i32, [vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(i32)]),
@@ -402,8 +416,57 @@ class Engine:
         data, off, lens = _table(blocks)
         return Witness(self, data, off, lens, pack_cids(cids))
 
+    def expand_event_claims_device(self, groups: np.ndarray, compact_ptr: int, n: int, cblob_ptr: int, cblob_len: int,
+                                   claims_out_ptr: int, blob_out_ptr: int, cap_blob: int) -> int:
+        """Transport form → ipcfp_event_claim_t[n] + blob, all resident in HBM; returns the blob's length."""
+        groups = np.ascontiguousarray(groups, dtype=GROUP_DTYPE)
+        bl = C.c_uint64()
+        self._check(self.lib.ipcfp_expand_event_claims_device(self.h, _p(groups), len(groups), compact_ptr, n, cblob_ptr, cblob_len,
+                                                              claims_out_ptr, blob_out_ptr, cap_blob, C.byref(bl)), "expand_event_claims")
+        return int(bl.value)
+
+    def witness_packed(self, packed: "PackedWitnessTables") -> "Witness":
+        """The witness from its tables in transport form (ipcfp_witness_create_packed): no offset table, 32-byte digests."""
+        return Witness(self, None, None, None, None, packed=packed)
+
     def witness_device(self, bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n) -> "Witness":
         return Witness(self, None, None, None, None, device=(bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n))
+
+
+STD_CID_PREFIX = bytes.fromhex("0171a0e40220")  # CIDv1, dag-cbor, blake2b-256, 32-byte digest
+
+
+class PackedWitnessTables:
+    """A witness's tables in the transport form of ipcfp_witness_create_packed: the blocks back to back (no offset
+    table), one 32-byte digest per block + the CID prefix they share, and the blocks whose CID has another form as
+    (index, 40-byte slot) escapes.  `h2d_bytes` is what crosses PCIe."""
+
+    def __init__(self, data, off, lens, cids40, prefix: bytes = STD_CID_PREFIX):
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        cids40 = np.ascontiguousarray(cids40, dtype=np.uint8).reshape(-1, CID_SLOT)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = len(lens)
+        tight = np.zeros(n, dtype=np.uint64)
+        if n:
+            tight[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        if n and not (np.array_equal(tight, off) and int(tight[-1]) + int(lens[-1]) == data.size):
+            # the caller's blocks are not back to back: lay them out so (a host copy; a bundle's blocks arrive one by one anyway)
+            out = np.empty(int(lens.sum(dtype=np.uint64)), dtype=np.uint8)
+            for i in range(n):
+                out[int(tight[i]): int(tight[i]) + int(lens[i])] = data[int(off[i]): int(off[i]) + int(lens[i])]
+            data = out
+        self.data, self.lens = data, lens
+        pl = len(prefix)
+        self.prefix = np.frombuffer(bytes(prefix), dtype=np.uint8).copy()
+        std = np.ones(n, dtype=bool)
+        if n:
+            std &= (cids40[:, :pl] == self.prefix[None, :]).all(axis=1)
+            std &= (cids40[:, pl + 32:] == 0).all(axis=1)
+        self.digests = np.ascontiguousarray(cids40[:, pl: pl + 32])
+        self.esc_index = np.ascontiguousarray(np.nonzero(~std)[0].astype(np.uint32))
+        self.esc_cids = np.ascontiguousarray(cids40[~std])
+        self.h2d_bytes = int(self.data.size + self.lens.nbytes + self.digests.nbytes + self.esc_index.nbytes + self.esc_cids.nbytes)
 
 
 def shard_range(n: int, n_shards: int, shard: int):
@@ -564,6 +627,23 @@ def pack_event_claims(parent_cids, child_cid, parent_epoch, child_epoch, exec_in
     return ts, cl, blob[: total + 64], total
 
 
+def compact_event_claims(claims: np.ndarray, blob: np.ndarray, blob_len: int):
+    """Packed claims → transport form (ipcfp_compact_event_claims, host only): (groups, compact records, blob, blob_len).
+    Raises EngineError when the batch is not representable (the caller keeps the plain form)."""
+    claims = np.ascontiguousarray(claims, dtype=CLAIM_DTYPE)
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    n = len(claims)
+    groups = np.zeros(256, dtype=GROUP_DTYPE)
+    out = np.zeros(n, dtype=COMPACT_DTYPE)
+    out_blob = np.zeros(int(blob_len) + 64, dtype=np.uint8)
+    ng, ol = C.c_uint32(), C.c_uint64()
+    rc = load_library().ipcfp_compact_event_claims(_p(claims), n, _p(blob), int(blob_len), _p(groups), C.byref(ng), _p(out),
+                                                   _p(out_blob), int(blob_len), C.byref(ol))
+    if rc:
+        raise EngineError(f"compact_event_claims: not representable in transport form ({rc})")
+    return groups[: ng.value].copy(), out, out_blob, int(ol.value)
+
+
 def pack_storage_claims(child_cid, state_root, child_epoch, actor_id, actor_state40, storage_root40, slot32, value32):
     """Binary storage claims → ipcfp_storage_claim_t[n] with every flag set."""
     n = len(actor_id)
@@ -692,11 +772,17 @@ class Bundle:
 class Witness:
     """HBM-resident witness store (``ipcfp_witness_t``)."""
 
-    def __init__(self, eng: Engine, data, off, lens, cids40, device=None):
+    def __init__(self, eng: Engine, data, off, lens, cids40, device=None, packed=None):
         self.eng = eng
         self.lib = eng.lib
         h = C.c_void_p()
-        if device is None:
+        if packed is not None:
+            pk = packed
+            n = len(pk.lens)
+            rc = self.lib.ipcfp_witness_create_packed(eng.h, _p(pk.data), pk.data.size, _p(pk.lens), _p(pk.digests), n,
+                                                      _p(pk.prefix), len(pk.prefix), _p(pk.esc_index), _p(pk.esc_cids),
+                                                      len(pk.esc_index), C.byref(h))
+        elif device is None:
             data = np.ascontiguousarray(data, dtype=np.uint8)
             off = np.ascontiguousarray(off, dtype=np.uint64)
             lens = np.ascontiguousarray(lens, dtype=np.uint32)
@@ -1125,6 +1211,21 @@ class Witness:
             self.eng.h, self.h, _p(tipsets), len(tipsets), _p(claims), len(claims), _p(blob), blob_len,
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st)), "verify_event_claims")
+        return st
+
+    def verify_event_claims_compact(self, tipsets: np.ndarray, groups: np.ndarray, claims: np.ndarray, cblob: np.ndarray,
+                                    cblob_len: int, trust=None, filt=None) -> np.ndarray:
+        """Claims in transport form in HOST memory (ipcfp_verify_event_claims_compact): upload, expand on the device,
+        verify, status bytes back."""
+        tipsets = np.ascontiguousarray(tipsets, dtype=TIPSET_DTYPE)
+        groups = np.ascontiguousarray(groups, dtype=GROUP_DTYPE)
+        claims = np.ascontiguousarray(claims, dtype=COMPACT_DTYPE)
+        cblob = np.ascontiguousarray(cblob, dtype=np.uint8)
+        st = np.zeros(len(claims), dtype=np.uint8)
+        self.eng._check(self.lib.ipcfp_verify_event_claims_compact(
+            self.eng.h, self.h, _p(tipsets), len(tipsets), _p(groups), len(groups), _p(claims), len(claims), _p(cblob), cblob_len,
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st)), "verify_event_claims_compact")
         return st
 
     @property

@@ -99,7 +99,20 @@ struct ipcfp_ctx {
     ipcfp::UploadRing* upload_ring = nullptr;  // pinned staging ring of ipcfp::upload (created on first use)
     hipStream_t stream_copy = nullptr;         // the stream of UploadTask's blocking copies (created on first use)
     ipcfp::UploadTask* upload_task = nullptr;  // claims crossing PCIe on a thread of their own (host/upload.cpp); whoever
-                                               // queues a kernel that reads them calls upload_task_wait first
+                                               // queues a kernel that reads them calls claims_ready first
+    // claims that arrive in transport form (host/claims_compact.cpp): expanded on the main stream once they are in HBM
+    struct ClaimsExpand {
+        bool pending = false;
+        const void* compact_d = nullptr;
+        const ipcfp_event_claim_group_t* groups_d = nullptr;
+        uint32_t n = 0, n_groups = 0;
+        const uint8_t* cblob_d = nullptr;
+        uint64_t cblob_len = 0, cap_blob = 0;
+        void* claims_out_d = nullptr;
+        uint8_t* blob_out_d = nullptr;
+        uint32_t* scratch_u32 = nullptr;
+        uint64_t* scan_scratch = nullptr;
+    } claims_expand;
     // --- the mailbox: a page of COHERENT pinned host memory a kernel writes while the stream keeps going (device →
     // host without a synchronisation; kernels/amt_enum.hip k_enum_roots, host/verify_fast.cpp) ---
     unsigned long long* mailbox = nullptr;      // host address
@@ -273,6 +286,9 @@ inline hipError_t sync_stream(ipcfp_ctx* ctx, hipStream_t s, bool last_of_call =
 int upload(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t bytes, hipStream_t s);
 UploadTask* upload_task_start(ipcfp_ctx* ctx, void* dst0, const void* src0, size_t bytes0, void* dst1, const void* src1, size_t bytes1);
 int upload_task_wait(ipcfp_ctx* ctx);
+// the claims a verify kernel is about to read are in HBM in the form it reads: the upload beside the walk is over
+// (upload_task_wait) and, when they crossed PCIe in transport form, their expansion is queued on the main stream
+int claims_ready(ipcfp_ctx* ctx);
 
 // RAII bracket: records an event pair around a kernel launch when profiling is on.
 struct ProfileScope {

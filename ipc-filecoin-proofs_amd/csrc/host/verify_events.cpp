@@ -247,7 +247,7 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
     if (rc) return rc;
     bool tabulated = false;
     for (auto& tc : tcs) tabulated = tabulated || tc.receipt_recs != nullptr;
-    if ((rc = upload_task_wait(ctx))) return rc;  // the claims are in HBM
+    if ((rc = claims_ready(ctx))) return rc;  // the claims are in HBM
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, uint32_t(tcs.size()), blob_d, blob_len,
                               trust ? *trust : accept_all, filter, status_d, where_d, tabulated);
     if (rc) return rc;

@@ -268,7 +268,7 @@ static int verify_packed_fast_queue(ipcfp_ctx* ctx, ipcfp_witness* w, std::vecto
     rc = event_table_join(ctx, w);
     if (rc) return rc;
     if (ctx->k1_defer == 2 && (rc = k1_flush(ctx, true))) return rc;
-    if ((rc = upload_task_wait(ctx))) return rc;  // claims that were crossing PCIe beside all of the above are in HBM
+    if ((rc = claims_ready(ctx))) return rc;  // claims that were crossing PCIe beside all of the above are in HBM
     rc = launch_verify_events(ctx, view, claims_d, n, tcs_d.p, 1, blob_d, blob_len, trust ? *trust : accept_all, filter, status_d,
                               where_d, /*tabulated=*/true);
     if (rc) return rc;

@@ -4,6 +4,8 @@
 // (src/proofs/events/verifier.rs:79-89, src/proofs/storage/verifier.rs:68-78), rebuilt
 // per storage proof by the reference (src/proofs/verifier.rs:19-28); here it is built
 // once per bundle and stays resident.
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -25,15 +27,42 @@ namespace ipcfp {
 
 constexpr uint64_t kTailSlack = 256;  // K1 may read one 128-byte chunk past a block's padded end
 
+// IPCFP_TRACE_CREATE=1: host timestamps of the phases of a witness creation on stderr (where the 1-2 ms of a from-host
+// creation that are not bytes over PCIe go; tools/gpu_t2_trace.sh)
+struct CreateTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    CreateTrace() {
+        static const bool env = [] {
+            const char* e = std::getenv("IPCFP_TRACE_CREATE");
+            return e && std::atoi(e) != 0;
+        }();
+        on = env;
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[create] %-28s +%8.1f us  (at %8.1f)\n", what, std::chrono::duration<double, std::micro>(now - last).count(),
+                     std::chrono::duration<double, std::micro>(now - t0).count());
+        last = now;
+    }
+};
+
 // Shared tail of the constructors: `raw_bytes_d/raw_off_d` hold the caller's layout on
 // the device; build the aligned arena (adopting nothing: the witness owns its copy),
 // the lane schedule and the CID index.
 // `host_bytes` (nullable): the payload is still in HOST memory and crosses PCIe here, into raw_bytes_d, once everything
 // that needs only the tables has been queued (the K1 schedule, the arena layout, the CID index run beside the copy).
+// `cuts` (nullable; n_cuts + 1 entries each): the caller's blocks are back to back, in order, and blocks
+// [cut_block[c], cut_block[c+1]) are the bytes [cut_byte[c], cut_byte[c+1]) — the payload then crosses PCIe piece by piece
+// and every piece is re-laid out into the arena while the next one is still on the link.
 int witness_finish_create_from(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
                                const uint32_t* len_d_src, const uint8_t* cids_d_src, const uint8_t* host_bytes,
-                               uint64_t host_nbytes) {
+                               uint64_t host_nbytes, const uint64_t* cut_block = nullptr, const uint64_t* cut_byte = nullptr,
+                               uint32_t n_cuts = 0) {
     const uint32_t n = uint32_t(w->n);
+    CreateTrace tr;
     if (const char* e = std::getenv("IPCFP_EVENT_TABLE")) w->use_event_table = std::atoi(e) != 0;
     IPCFP_HIP(ctx, w->off.alloc(n));
     IPCFP_HIP(ctx, w->len.alloc(n));
@@ -64,6 +93,7 @@ int witness_finish_create_from(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* 
     if (rc) return rc;
     rc = launch_gather_cids(ctx, w->order.p, w->cids.p, n, w->k1_cids.p);
     if (rc) return rc;
+    tr.mark("allocs + layout queued");
     uint64_t total = 0;
     uint64_t meta0[2] = {0, 0};  // K1Meta of the first lane of the schedule = the longest block: {off, len | id << 32}
     IPCFP_HIP(ctx, d2h_small(ctx, &total, total_d, sizeof total, ctx->stream));
@@ -74,12 +104,14 @@ int witness_finish_create_from(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* 
         const uint32_t chunks0 = len0 ? (len0 + 127u) / 128u : 1u;
         w->max_block_len = !n ? 0u : (chunks0 >= 255u ? 0xffffffffu : chunks0 * 128u);
     }
+    tr.mark("layout sync");
     w->arena_bytes = total + kTailSlack;
     IPCFP_HIP(ctx, w->arena.alloc(w->arena_bytes));
     IPCFP_HIP(ctx, hipMemsetAsync(w->arena.p + total, 0, kTailSlack, ctx->stream));
     // the CID index needs the CIDs only: its inserts run while the payload crosses PCIe (ipcfp_witness_create)
     rc = witness_build_index(ctx, w);
     if (rc) return rc;
+    tr.mark("arena alloc + index queued");
     if (host_bytes && host_nbytes) {
         static const bool ring = [] {
             const char* e = std::getenv("IPCFP_UPLOAD_MODE");
@@ -95,12 +127,30 @@ int witness_finish_create_from(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* 
             if (ctx->stream_aux != ctx->stream) IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_aux));
             if (ctx->stream_k1 != ctx->stream) IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_k1));
             if (ctx->stream_copy) IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream_copy));
+            if (n_cuts > 1 && cut_block && cut_byte) {
+                for (uint32_t c = 0; c < n_cuts; ++c) {
+                    const uint64_t b0 = cut_byte[c], b1 = cut_byte[c + 1], i0 = cut_block[c], i1 = cut_block[c + 1];
+                    if (b1 > b0)
+                        IPCFP_HIP(ctx, hipMemcpy(const_cast<uint8_t*>(raw_bytes_d) + b0, host_bytes + b0, b1 - b0, hipMemcpyHostToDevice));
+                    // (the blocking copy is over: the piece is in HBM; its re-layout runs on the main stream beside the next copy)
+                    if (i1 > i0) {
+                        rc = launch_repack(ctx, raw_bytes_d, raw_off_d + i0, w->len.p + i0, w->off.p + i0, uint32_t(i1 - i0), w->arena.p);
+                        if (rc) return rc;
+                    }
+                }
+                tr.mark("payload copy + repack, pieces");
+                IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+                tr.mark("last piece's repack + sync");
+                return IPCFP_OK;
+            }
             IPCFP_HIP(ctx, hipMemcpy(const_cast<uint8_t*>(raw_bytes_d), host_bytes, host_nbytes, hipMemcpyHostToDevice));
         }
     }
+    tr.mark("payload copy");
     rc = launch_repack(ctx, raw_bytes_d, raw_off_d, w->len.p, w->off.p, n, w->arena.p);
     if (rc) return rc;
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    tr.mark("repack + sync");
     return IPCFP_OK;
 }
 
@@ -191,6 +241,91 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
     }
     if (!rc) rc = witness_finish_create_from(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p, bytes, nbytes);
     if (rc) return rc;
+    *out = w.release();
+    return IPCFP_OK;
+}
+
+// The tables in transport form (include/ipcfp.h): no offset table, 32-byte digests + one prefix instead of 40-byte slots.
+int ipcfp_witness_create_packed(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint32_t* len,
+                                const uint8_t* digests32, uint64_t n, const uint8_t* cid_prefix, uint32_t prefix_len,
+                                const uint32_t* esc_index, const uint8_t* esc_cids40, uint64_t n_esc,
+                                ipcfp_witness_t** out) {
+    if (!ctx || !out) return IPCFP_E_INVALID;
+    *out = nullptr;
+    if (n && (!len || !digests32)) return set_error(ctx, IPCFP_E_INVALID, "null table pointer");
+    if (nbytes && !bytes) return set_error(ctx, IPCFP_E_INVALID, "null bytes pointer");
+    if (prefix_len > 8 || (prefix_len && !cid_prefix)) return set_error(ctx, IPCFP_E_INVALID, "CID prefix longer than 8 bytes");
+    if (n_esc && (!esc_index || !esc_cids40)) return set_error(ctx, IPCFP_E_INVALID, "null escape table");
+    if (n >= 0xffffffffull || n_esc > n) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
+    for (uint64_t e = 0; e < n_esc; ++e)
+        if (esc_index[e] >= n || (e && esc_index[e] <= esc_index[e - 1]))
+            return set_error(ctx, IPCFP_E_INVALID, "escape %llu: index out of range or not ascending", (unsigned long long)e);
+    // the blocks fill the buffer exactly (nothing is uploaded before this is known)
+    uint64_t payload = 0;
+    constexpr unsigned kPieces = 4;  // the pieces the payload crosses PCIe in = the parts the lengths are summed in
+    uint64_t cut_block[kPieces + 1] = {}, cut_byte[kPieces + 1] = {};
+    const unsigned T = n >= (1u << 18) ? kPieces : 1u;
+    {
+        std::vector<uint64_t> sum(T, 0);
+        auto part = [&](unsigned t) {
+            uint64_t acc = 0;
+            for (uint64_t i = n * t / T, hi = n * (t + 1) / T; i < hi; ++i) acc += len[i];
+            sum[t] = acc;
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(part, t);
+        part(0);
+        for (auto& th : pool) th.join();
+        for (unsigned t = 0; t < T; ++t) {
+            cut_block[t] = n * t / T;
+            cut_byte[t] = payload;
+            payload += sum[t];
+        }
+        cut_block[T] = n;
+        cut_byte[T] = payload;
+    }
+    CreateTrace tr;
+    tr.mark("(host) lengths summed");
+    if (payload != nbytes)
+        return set_error(ctx, IPCFP_E_INVALID, "the block lengths add up to %llu bytes, the buffer holds %llu",
+                         (unsigned long long)payload, (unsigned long long)nbytes);
+    IPCFP_ENTER(ctx);
+    std::unique_ptr<ipcfp_witness> w(new (std::nothrow) ipcfp_witness());
+    if (!w) return IPCFP_E_NOMEM;
+    w->ctx = ctx;
+    w->n = n;
+    w->nbytes = payload;
+
+    DevBuf<uint8_t> raw_bytes, raw_cids, dig, esc_c;
+    DevBuf<uint64_t> raw_off, scan_scratch;
+    DevBuf<uint32_t> raw_len, esc_i;
+    IPCFP_HIP(ctx, raw_bytes.alloc(nbytes));
+    IPCFP_HIP(ctx, raw_off.alloc(n));
+    IPCFP_HIP(ctx, raw_len.alloc(n));
+    IPCFP_HIP(ctx, raw_cids.alloc(n * IPCFP_CID_SLOT));
+    IPCFP_HIP(ctx, dig.alloc(n * 32));
+    IPCFP_HIP(ctx, scan_scratch.alloc(size_t(div_up(uint32_t(n), 1024)) + 2));
+    tr.mark("raw allocs");
+    int rc = IPCFP_OK;
+    if (n) {
+        rc = upload(ctx, raw_len.p, len, n * 4, ctx->stream);
+        if (!rc) rc = upload(ctx, dig.p, digests32, n * 32, ctx->stream);
+        if (!rc && n_esc) {
+            IPCFP_HIP(ctx, esc_i.alloc(n_esc));
+            IPCFP_HIP(ctx, esc_c.alloc(n_esc * IPCFP_CID_SLOT));
+            rc = upload(ctx, esc_i.p, esc_index, n_esc * 4, ctx->stream);
+            if (!rc) rc = upload(ctx, esc_c.p, esc_cids40, n_esc * IPCFP_CID_SLOT, ctx->stream);
+        }
+        if (!rc) rc = launch_tight_offsets(ctx, raw_len.p, uint32_t(n), raw_off.p, scan_scratch.p + div_up(uint32_t(n), 1024) + 1, scan_scratch.p);
+        if (!rc) rc = launch_expand_cids(ctx, dig.p, uint32_t(n), cid_prefix, prefix_len, esc_i.p, esc_c.p, uint32_t(n_esc), raw_cids.p);
+    }
+    tr.mark("tables up + expand queued");
+    if (!rc) rc = witness_finish_create_from(ctx, w.get(), raw_bytes.p, raw_off.p, raw_len.p, raw_cids.p, bytes, nbytes, cut_block, cut_byte, T);
+    tr.mark("finish_create");
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);  // (kernels queued above may still read the tables going back to the pool)
+        return rc;
+    }
     *out = w.release();
     return IPCFP_OK;
 }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_txmeta_rehash(WitnessView w, const Tipse
 }
 
 // roots → frontier (one entry per root, in root order)
-__global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootSpec* __restrict__ roots, uint32_t n,
+__global__ __launch_bounds__(128) void k_enum_roots(WitnessView w, const AmtRootSpec* __restrict__ roots, uint32_t n,
                                                    int vkind, EnumNode* __restrict__ frontier,
                                                    uint32_t* __restrict__ max_height,
                                                    unsigned long long* __restrict__ err,
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void k_enum_roots(WitnessView w, const AmtRootS
     // The mailbox (host/verify_fast.cpp): PINNED HOST memory the device writes while the stream keeps going.  The root
     // shapes are all the host needs to size and queue the rest of the walk, so it polls these words instead of draining
     // the stream with a synchronisation: [0] = sequence number (written last), [1 + 2t ..] = the shapes.  Single-block
-    // launches only (n ≤ 64 roots), so that "every root is through" is a __syncthreads.
+    // launches only (n ≤ 128 roots: 2 · IPCFP_MAX_PARENTS + 1 fit), so that "every root is through" is a __syncthreads.
     if (mailbox && gridDim.x == 1) {
         if (t < n) {
             __hip_atomic_store(mailbox + 1 + 2 * t, (unsigned long long)info0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1037,8 +1037,8 @@ static int enum_cache_fill(ipcfp_ctx* ctx, EnumCached* e, AmtEnumResult& en, uin
 int launch_enum_roots(ipcfp_ctx* ctx, const WitnessView& view, const AmtRootSpec* roots_d, uint32_t n_all, int vkind,
                       EnumNode* frontier_d, uint32_t* max_height_d, unsigned long long* err_d, uint64_t* root_info_d,
                       unsigned long long* mailbox, unsigned long long mailbox_seq, DenseNode* dense_frontier_d) {
-    if (n_all == 0 || n_all > 64) return IPCFP_E_INVALID;
-    hipLaunchKernelGGL(k_enum_roots, dim3(1), dim3(64), 0, ctx->stream, view, roots_d, n_all, vkind, frontier_d, max_height_d, err_d,
+    if (n_all == 0 || n_all > 128) return set_error(ctx, IPCFP_E_INVALID, "launch_enum_roots: %u roots", n_all);
+    hipLaunchKernelGGL(k_enum_roots, dim3(1), dim3(n_all <= 64 ? 64 : 128), 0, ctx->stream, view, roots_d, n_all, vkind, frontier_d, max_height_d, err_d,
                        root_info_d, mailbox, mailbox_seq, dense_frontier_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

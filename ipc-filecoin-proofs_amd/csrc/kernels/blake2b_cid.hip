@@ -224,33 +224,67 @@ __global__ void k_chunk_bin_starts(uint32_t* __restrict__ bins) {
     }
 }
 
-// Stable within a wavefront's 64 consecutive blocks per class is not required for
-// correctness; positions inside a class are handed out by atomics, aggregated per
-// wavefront so neighbouring blocks stay neighbours (DRAM page locality).
-__global__ void k_chunk_scatter(const uint32_t* __restrict__ len, uint32_t n, uint32_t* __restrict__ cursors,
-                                uint32_t* __restrict__ order) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < n;
-    uint32_t c = 0;
-    if (active) {
-        c = chunk_count(len[i]);
-        c = c > 255 ? 255 : c;
-    }
-    // wave-aggregated atomics: peel one class at a time
-    unsigned long long todo = __ballot(active);
+// Positions inside a class are handed out per TILE of 4096 consecutive blocks: the workgroup counts its tile's classes in
+// LDS, reserves one range per class with ONE global atomic each, and hands the positions out from LDS cursors, aggregated
+// per wavefront so that neighbouring blocks stay neighbours (DRAM page locality).  (Round 3 took the positions from the
+// global cursors directly, one atomic per wavefront and class: a Filecoin witness has three or four classes that matter
+// — blocks of 2-4 lines — so 20 k wavefronts queued up on the same four words of the L2: 630-790 µs for 1.3 M blocks,
+// profiles/r03_final_kernel_stats.txt, every microsecond of it in front of a from-host witness's payload copy.)
+constexpr uint32_t kScatterTile = 4096;
+__global__ __launch_bounds__(256) void k_chunk_scatter(const uint32_t* __restrict__ len, uint32_t n, uint32_t* __restrict__ cursors,
+                                                       uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[256], cur[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile0 = blockIdx.x * kScatterTile;
     const uint32_t lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t lc = __shfl(c, leader, 64);
-        const unsigned long long same = __ballot(active && c == lc) & todo;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(&cursors[lc], (uint32_t)__popcll(same));
-        base = __shfl(base, leader, 64);
-        if (active && c == lc) {
-            const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
-            order[base + rank] = i;
+    // pass 1: the tile's class counts (wave-aggregated LDS atomics: a wavefront's 64 blocks are of 1-3 classes)
+    for (uint32_t k = 0; k < kScatterTile / 256; ++k) {
+        const uint32_t i = tile0 + k * 256 + threadIdx.x;
+        const bool active = i < n;
+        uint32_t c = 0;
+        if (active) {
+            c = chunk_count(len[i]);
+            c = c > 255 ? 255 : c;
         }
-        todo &= ~same;
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lc = __shfl(c, leader, 64);
+            const unsigned long long same = __ballot(active && c == lc) & todo;
+            if ((int)lane == leader) atomicAdd(&hist[lc], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    {   // one range per class present in the tile
+        const uint32_t h = hist[threadIdx.x];
+        cur[threadIdx.x] = h ? atomicAdd(&cursors[threadIdx.x], h) : 0u;
+    }
+    __syncthreads();
+    // pass 2: positions from the LDS cursors
+    for (uint32_t k = 0; k < kScatterTile / 256; ++k) {
+        const uint32_t i = tile0 + k * 256 + threadIdx.x;
+        const bool active = i < n;
+        uint32_t c = 0;
+        if (active) {
+            c = chunk_count(len[i]);
+            c = c > 255 ? 255 : c;
+        }
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lc = __shfl(c, leader, 64);
+            const unsigned long long same = __ballot(active && c == lc) & todo;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&cur[lc], (uint32_t)__popcll(same));
+            base = __shfl(base, leader, 64);
+            if (active && c == lc) {
+                const uint32_t rank = __popcll(same & ((1ull << lane) - 1ull));
+                order[base + rank] = i;
+            }
+            todo &= ~same;
+        }
     }
 }
 
@@ -262,7 +296,7 @@ int launch_chunk_order(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint32
     const uint32_t hb = div_up(n, 256) < 2048 ? div_up(n, 256) : 2048;
     hipLaunchKernelGGL(k_chunk_histogram, dim3(hb), dim3(256), 0, ctx->stream, len_d, n, bins_d);
     hipLaunchKernelGGL(k_chunk_bin_starts, dim3(1), dim3(64), 0, ctx->stream, bins_d);
-    hipLaunchKernelGGL(k_chunk_scatter, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, len_d, n, bins_d,
+    hipLaunchKernelGGL(k_chunk_scatter, dim3(div_up(n, kScatterTile)), dim3(256), 0, ctx->stream, len_d, n, bins_d,
                        order_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;

@@ -32,9 +32,15 @@ struct EventMatch {  // == ipcfp_event_match_t
 // exactly that item, validating it as the AMT's value type (it is the type check serde performs).
 // Returns TRUE or the first ERR_* in traversal order.
 template <typename F>
+__device__ __forceinline__ uint32_t amt_for_each_lane_tall(const WitnessView& w, const AmtRootInfo& root, int vkind, F&& f);
+
+template <typename F>
 __device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, const AmtRootInfo& root, int vkind, F&& f) {
-    constexpr int kMaxDepth = 8;  // FVM event AMTs (bit width 5) are 1-2 levels deep; deeper than 8 levels is rejected
-    if (root.height >= kMaxDepth) return IPCFP_ST_ERR_DECODE;
+    // FVM event AMTs (bit width 5) are 1-2 levels deep: an explicit stack of 8 levels in registers / scratch.  The root's
+    // bit width is the WITNESS's choice (Amt::load takes whatever the root block says, events/verifier.rs:215), so a tree
+    // may be up to 64 / bit_width levels tall: those take the stackless walk below — same visits, same order.
+    constexpr int kMaxDepth = 8;
+    if (root.height >= kMaxDepth) return amt_for_each_lane_tall(w, root, vkind, f);
     uint32_t blk[kMaxDepth], noff[kMaxDepth], next_sub[kMaxDepth];
     uint64_t base[kMaxDepth];
     int depth = 0;
@@ -94,6 +100,94 @@ __device__ __forceinline__ uint32_t amt_for_each_lane(const WitnessView& w, cons
         next_sub[depth] = 0;
     }
     return IPCFP_ST_TRUE;
+}
+
+// The same traversal for trees of ANY height (≤ 64 / bit_width levels, amt_load has checked that) without a per-level
+// stack: the path from the root is kept as packed digits (the slot taken at each depth, bit_width bits apiece: at most
+// 72 bits), and going back UP a level is a descent from the root along the digits — O(height) block visits per pop, for
+// trees nobody builds except to see what the verifier does with them.  Nodes are validated when first entered, leaves
+// visited in ascending index order, the first error in traversal order returned: as amt_for_each_lane.
+template <typename F>
+__device__ __forceinline__ uint32_t amt_for_each_lane_tall(const WitnessView& w, const AmtRootInfo& root, int vkind, F&& f) {
+    const uint32_t bw = root.bit_width, width = 1u << bw;
+    unsigned __int128 path = 0;
+    auto digit = [&](uint32_t k) { return uint32_t(path >> (k * bw)) & (width - 1u); };
+    uint32_t depth = 0, blk = root.block, noff = root.node_off, next = 0;
+    uint64_t base = 0;
+    bool fresh = false;  // (the root node was validated by amt_load)
+    for (;;) {
+        const uint64_t height = root.height - uint64_t(depth);
+        Rd r = open_block(w, blk);
+        r.pos = noff;
+        if (fresh) {  // CollapsedNode::expand checks, once per node
+            AmtNode nd;
+            Rd v = r;
+            amt_read_node(v, bw, vkind, ~0u, nd);
+            v.finish();
+            if (!v.ok()) return IPCFP_ST_ERR_DECODE;
+            fresh = false;
+        }
+        r.expect_array(3);
+        uint32_t bo, bl;
+        r.read_bytes(bo, bl);
+        const uint64_t nl = r.read_array();
+        bool descend = false;
+        if (nl == 0) {  // Leaf: every value, ascending
+            const uint64_t nv = r.read_array();
+            uint32_t sub = 0;
+            for (uint64_t j = 0; j < nv; ++j) {
+                while (!((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
+                f(base + sub, blk, r);
+                ++sub;
+            }
+        } else {
+            if (height == 0) return IPCFP_ST_ERR_DECODE;  // a link node at height 0
+            uint32_t sub = next, ordinal = 0;
+            for (uint32_t i = 0; i < sub && i < width; ++i) ordinal += (r.at(bo + (i >> 3)) >> (i & 7)) & 1u;
+            while (sub < width && !((r.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
+            if (sub < width) {
+                CidKey key;
+                for (uint32_t k = 0; k <= ordinal; ++k) r.read_link_key(key);  // the ordinal-th link
+                const uint32_t child = witness_find(w, key);
+                if (child == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
+                path &= ~((unsigned __int128)(width - 1u) << (depth * bw));
+                path |= (unsigned __int128)sub << (depth * bw);
+                base += uint64_t(sub) * amt_span(bw, height);
+                ++depth;
+                blk = child;
+                noff = 0;
+                next = 0;
+                fresh = true;
+                descend = true;
+            }
+        }
+        if (descend) continue;
+        // this node is done: back to its parent — found again from the root along the digits
+        if (depth == 0) return IPCFP_ST_TRUE;
+        --depth;
+        next = digit(depth) + 1u;
+        blk = root.block;
+        noff = root.node_off;
+        base = 0;
+        for (uint32_t k = 0; k < depth; ++k) {
+            Rd q = open_block(w, blk);
+            q.pos = noff;
+            q.expect_array(3);
+            uint32_t qo, ql;
+            q.read_bytes(qo, ql);
+            (void)q.read_array();
+            const uint32_t sub = digit(k);
+            uint32_t ordinal = 0;
+            for (uint32_t i = 0; i < sub; ++i) ordinal += (q.at(qo + (i >> 3)) >> (i & 7)) & 1u;
+            CidKey key;
+            for (uint32_t j = 0; j <= ordinal; ++j) q.read_link_key(key);
+            const uint32_t child = witness_find(w, key);
+            if (child == kNoBlock || !q.ok()) return IPCFP_ST_ERR_MISSING_BLOCK;  // (it resolved on the way down)
+            base += uint64_t(sub) * amt_span(bw, root.height - uint64_t(k));
+            blk = child;
+            noff = 0;
+        }
+    }
 }
 
 // Amt::<V>::load + for_each fused for the overwhelmingly common shape — a v3 AMT whose root is a leaf (height 0:

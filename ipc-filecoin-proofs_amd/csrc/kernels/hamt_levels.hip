@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         const uint32_t links = s_links[g], ne = s_ne[g];
         for (uint32_t p = sub; p < np; p += kCoopLanes)
             if ((links >> p) & 1u) {
-                bool std_form;
+                bool std_form = true;  // (a node already found bad is not used: its mask does not matter)
                 good = good && lds_link_ok(S, s_ptr[g][p], &std_form);
                 if (!std_form) atomicAnd(&s_links[g], ~(1u << p));  // (the record's mask names the STANDARD links only)
             }

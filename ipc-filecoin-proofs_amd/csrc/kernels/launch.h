@@ -22,6 +22,12 @@ int launch_blake2b256_raw(ipcfp_ctx* ctx, const uint8_t* arena, const void* meta
 // new_off[i] = exclusive prefix sum of round_up(len[i], 16); *total_d receives the arena size.
 int launch_aligned_offsets(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint64_t* new_off_d,
                            uint64_t* total_d, uint64_t* scratch_d /* >= div_up(n,1024)+1 */);
+// off[i] = exclusive prefix sum of len[i] (blocks back to back); *total_d = the sum
+int launch_tight_offsets(ipcfp_ctx* ctx, const uint32_t* len_d, uint32_t n, uint64_t* off_d, uint64_t* total_d,
+                         uint64_t* scratch_d /* >= div_up(n,1024)+1 */);
+// cids40[i] = prefix ‖ digests32[i] (zero-padded slot), then the n_esc escape slots as given (ipcfp_witness_create_packed)
+int launch_expand_cids(ipcfp_ctx* ctx, const uint8_t* digests32_d, uint32_t n, const uint8_t* prefix, uint32_t prefix_len,
+                       const uint32_t* esc_index_d, const uint8_t* esc_cids40_d, uint32_t n_esc, uint8_t* cids40_d);
 // dst[new_off[i] .. +len[i]) = src[old_off[i] .. +len[i]); pad bytes up to the next 16 are zeroed.
 int launch_repack(ipcfp_ctx* ctx, const uint8_t* src, const uint64_t* old_off, const uint32_t* len,
                   const uint64_t* new_off, uint32_t n, uint8_t* dst);
@@ -70,6 +76,12 @@ int launch_storage_run_actors_lane(ipcfp_ctx* ctx, const WitnessView& w, const v
                                    uint32_t undecided);
 int launch_verify_storage_lanes(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,
                                 const ipcfp_trust_policy_t& trust, uint8_t* status_d, int pending_only);
+
+// --- claims_compact.hip --- compact event claims → EventClaimPacked[n] + blob; scratch_u32: 4 n words, scan_scratch: div_up(n, 1024) + 2
+// u64 whose LAST word receives the packed blob's length
+int launch_expand_claims(ipcfp_ctx* ctx, const void* compact_d, uint32_t n, const ipcfp_event_claim_group_t* groups_d, uint32_t n_groups,
+                         const uint8_t* cblob_d, uint64_t cblob_len, void* claims_out_d, uint8_t* blob_out_d, uint64_t cap_blob,
+                         uint32_t* scratch_u32, uint64_t* scan_scratch);
 
 // --- scan.hip ---
 int launch_scan_u32(ipcfp_ctx* ctx, const uint32_t* in_d, uint32_t n, uint32_t* out_d, uint64_t* total_d,

@@ -17,6 +17,74 @@
 
 namespace ipcfp {
 
+// An events AMT taller than the explicit stack below (the root's bit width is the witness's choice: up to 64 / bit_width
+// levels): the same walk without a per-level stack — the path is kept as packed digits and a step back UP is a descent
+// from the root along them (event_scan.hip amt_for_each_lane_tall).  A node that fails to decode is recorded and not
+// descended into.
+__device__ __noinline__ void plan_tall_events(const WitnessView& rec, const AmtRootInfo& einfo) {
+    const uint32_t bw = einfo.bit_width, width = 1u << bw;
+    unsigned __int128 path = 0;
+    uint32_t depth = 0, blk = einfo.block, noff = einfo.node_off, next = 0;
+    for (;;) {
+        const uint64_t height = einfo.height - uint64_t(depth);
+        Rd nr = open_block(rec, blk);
+        nr.pos = noff;
+        nr.expect_array(3);
+        uint32_t bo, bl;
+        nr.read_bytes(bo, bl);
+        const uint64_t nl = nr.read_array();
+        bool descend = false;
+        if (nr.ok() && nl != 0 && height != 0 && bl == (width + 7) / 8) {
+            uint32_t sub = next, ordinal = 0;
+            for (uint32_t i = 0; i < sub && i < width; ++i) ordinal += (nr.at(bo + (i >> 3)) >> (i & 7)) & 1u;
+            while (sub < width && !((nr.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
+            while (sub < width && ordinal < nl && !descend) {
+                Rd lr = nr;
+                CidKey key;
+                for (uint32_t k = 0; k <= ordinal && lr.ok(); ++k) lr.read_link_key(key);
+                if (!lr.ok()) break;
+                const uint32_t child = witness_find(rec, key);  // records it
+                if (child != kNoBlock) {
+                    path &= ~((unsigned __int128)(width - 1u) << (depth * bw));
+                    path |= (unsigned __int128)sub << (depth * bw);
+                    ++depth;
+                    blk = child;
+                    noff = 0;
+                    next = 0;
+                    descend = true;
+                } else {  // a link that does not resolve: on to the next set bit of this node
+                    ++sub;
+                    ++ordinal;
+                    while (sub < width && !((nr.at(bo + (sub >> 3)) >> (sub & 7)) & 1u)) ++sub;
+                }
+            }
+        }
+        if (descend) continue;
+        if (depth == 0) return;
+        --depth;
+        next = (uint32_t(path >> (depth * bw)) & (width - 1u)) + 1u;
+        blk = einfo.block;
+        noff = einfo.node_off;
+        for (uint32_t k = 0; k < depth; ++k) {
+            Rd q = open_block(rec, blk);
+            q.pos = noff;
+            q.expect_array(3);
+            uint32_t qo, ql;
+            q.read_bytes(qo, ql);
+            (void)q.read_array();
+            const uint32_t sub = uint32_t(path >> (k * bw)) & (width - 1u);
+            uint32_t ordinal = 0;
+            for (uint32_t i = 0; i < sub; ++i) ordinal += (q.at(qo + (i >> 3)) >> (i & 7)) & 1u;
+            CidKey key;
+            for (uint32_t j = 0; j <= ordinal; ++j) q.read_link_key(key);
+            const uint32_t child = witness_find(rec, key);
+            if (child == kNoBlock || !q.ok()) return;  // (it resolved on the way down)
+            blk = child;
+            noff = 0;
+        }
+    }
+}
+
 // the path to receipt `index` in the receipts AMT, and the whole events AMT of that receipt, recorded in rec.touched
 __device__ __forceinline__ void plan_one_receipt(const WitnessView& rec, const CidKey& receipts_root, uint64_t index) {
     AmtRootInfo rinfo;
@@ -39,7 +107,7 @@ __device__ __forceinline__ void plan_one_receipt(const WitnessView& rec, const C
     if (einfo.height == 0) return;  // the root block is the whole tree
     // depth-first over the links; a node that fails to decode is recorded and not descended into
     constexpr int kMaxDepth = 8;
-    if (einfo.height >= kMaxDepth) return;
+    if (einfo.height >= kMaxDepth) return plan_tall_events(rec, einfo);
     uint32_t blk[kMaxDepth], noff[kMaxDepth], next_sub[kMaxDepth];
     int depth = 0;
     blk[0] = einfo.block;

@@ -31,7 +31,8 @@ struct TipsetCtxDev {
     long long child_height;
     CidKey receipts_root;      // child_hdr.parent_message_receipts
     uint32_t parent0_status;   // TRUE or ERR_* for parent_cids[0]
-    uint32_t prologue_general;  // bit s: slot s of the tipset prologue is left to the general kernel (a block larger than the LDS stage)
+    uint32_t pad0;
+    unsigned long long prologue_general;  // bit s: slot s of the tipset prologue is left to the general kernel (a block larger than the LDS stage)
     long long parent0_height;
     // 1 + the TxMeta block of parent b when its re-hash was LEFT to k_txmeta_rehash (amt_enum.hip; tipset_prepare.hip
     // roots_slot with `defer_rehash`); 0: nothing to re-hash (checked inline, or never reached) — so that a context
@@ -81,6 +82,7 @@ struct PrepareJob {
     unsigned long long* err;
 };
 constexpr uint32_t kPrepareSlots = 2 + IPCFP_MAX_PARENTS;
+static_assert(kPrepareSlots <= 64, "TipsetCtxDev::prologue_general is one bit per slot");
 // the jobs travel as a kernel ARGUMENT when there are at most this many (a verification call has one context per
 // distinct tipset pair — usually one): one H2D copy less at the head of the call
 constexpr uint32_t kInlineJobs = 4;

@@ -109,7 +109,7 @@ __device__ __forceinline__ bool stage_block(const WitnessView& w, uint32_t b, rd
 }
 
 __device__ __forceinline__ void flag_general(TipsetCtxDev& c, uint32_t slot) {
-    if (threadIdx.x == 0) atomicOr(&c.prologue_general, 1u << slot);
+    if (threadIdx.x == 0) atomicOr(&c.prologue_general, 1ull << slot);
 }
 
 // slots 0 / 1: the child header / the first parent header (ctx_headers_body in verify_events.hip is the general form)

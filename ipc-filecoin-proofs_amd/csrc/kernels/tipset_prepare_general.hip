@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void k_tipset_prepare_general(WitnessView w, Pr
     const uint32_t job = blockIdx.x / kPrepareSlots, slot = blockIdx.x % kPrepareSlots;
     if (job >= n_jobs) return;
     const PrepareJob jb = prepare_job(jobs, job);
-    if (!((jb.ctx->prologue_general >> slot) & 1u)) return;
+    if (!((jb.ctx->prologue_general >> slot) & 1ull)) return;
     if (slot < 2) ctx_headers_body(w, *jb.ctx, slot == 0, lds, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
     else if (jb.roots) exec_roots_body(w, jb.ctx, jb.roots, jb.err, 1, slot - 2, lds);
 }

@@ -218,6 +218,78 @@ def test_scan_events_deep_event_amts(engine, oracle):
     st.close()
 
 
+@pytest.mark.parametrize("P", [17, 20, 32])
+def test_tipsets_with_more_than_sixteen_parent_blocks(engine, oracle, P):
+    """`verify_event_proof` takes any tipset key (events/verifier.rs:147-181: a header per parent, two message AMTs each).
+    Expected blocks per epoch: 5; 17 or more happen (Poisson tail ~ 2e-5 per epoch), so the engine's table holds 32
+    (IPCFP_MAX_PARENTS; round 3: 16 and IPCFP_E_UNSUPPORTED beyond)."""
+    import ipc_filecoin_proofs_amd as ipcfp
+    tp = Tipset(n_receipts=700, n_parents=P, n_planted=5, variety=1, max_events=4, dup_permille=40, seed=80 + P)
+    w = engine.witness(tp.data, tp.off, tp.lens, tp.cids)
+    st = oracle.store(tp.data, tp.off, tp.lens, tp.cids)
+    gs, gc = w.exec_order(tp.parent_cids)
+    os_, oc = st.exec_order(tp.parent_cids)
+    assert gs == os_ == 1 and np.array_equal(gc, oc) and np.array_equal(gc, tp.exec_order)
+    ec = claims.EventClaims(tp)
+    want = st.verify_event_proofs(ec, mode=1)
+    assert (want == 1).sum() > ec.n // 2
+    assert np.array_equal(w.verify_event_proofs(ec.arr, ec.n), want)
+    # the packed route (fast verify path and the general one)
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tp.parent_cids, tp.child_cid, tp.parent_epoch, tp.child_epoch, tp.claim_exec, tp.claim_event,
+        tp.claim_emitter, tp.exec_order[tp.claim_exec.astype(np.int64)], tp.claim_ntopics, tp.claim_topics,
+        tp.claim_datalen, tp.claim_data)
+    want_p = st.verify_event_claims_packed(ts, cl, blob, threads=1)
+    for fast in (1, 0):
+        engine.set_tuning("fast_verify", fast)
+        w.rebuild_index()
+        assert np.array_equal(w.verify_event_claims(ts, cl, blob, blob_len), want_p)
+    engine.set_tuning("fast_verify", -1)
+    gsg, gm, gmsg, gids = w.generate_event_proofs(tp.parent_cids, tp.child_cid, tp.topic0, tp.topic1, actor=tp.filter_actor)
+    osg, otrip, omsg, owit = st.generate_event_proof(tp.parent_cids, tp.child_cid, tp.topic0, tp.topic1, actor=tp.filter_actor)
+    assert gsg == osg == 1 and np.array_equal(gmsg, omsg) and np.array_equal(tp.cids[gids], owit)
+    w.close()
+    st.close()
+
+
+def test_scan_and_verify_event_amts_taller_than_the_lane_stack(engine, oracle):
+    """The events root's bit width is the witness's choice (`Amt::load` takes what the root block says,
+    events/verifier.rs:215): at bit width 1 a receipt with > 256 events has an AMT of height 8 and more — taller than the
+    lane walker's explicit stack.  Scan, recorded set and every claim's status must still be the oracle's (round 3: ERR_DECODE)."""
+    tip3 = Tipset(n_receipts=40, n_planted=6, variety=1, max_events=700, events_bit_width=1, seed=78)
+    assert int(tip3.claim_event.max()) >= 512  # height >= 9
+    w = engine.witness(tip3.data, tip3.off, tip3.lens, tip3.cids)
+    st = oracle.store(tip3.data, tip3.off, tip3.lens, tip3.cids)
+    gs, ghas, gm, gids = w.scan_events(tip3.receipts_root, tip3.topic0, tip3.topic1, actor=tip3.filter_actor)
+    os_, ohas, otrip, otouched = st.scan_events(tip3.receipts_root, tip3.topic0, tip3.topic1, actor=tip3.filter_actor)
+    assert gs == os_ == 1 and np.array_equal(ghas, ohas)
+    got = np.stack([gm["exec_index"], gm["event_index"], gm["emitter"]], axis=1)
+    assert np.array_equal(got, otrip) and len(otrip) >= 6
+    assert sorted_cids(tip3, gids) == [bytes(c[:38]) for c in otouched]
+    ec = claims.EventClaims(tip3)
+    want = st.verify_event_proofs(ec, mode=1)
+    assert (want == 1).sum() >= 20
+    assert np.array_equal(w.verify_event_proofs(ec.arr, ec.n), want)
+    # a node half-way down one tall tree replaced by garbage: the first error in traversal order, on both sides
+    big = int(np.argmax(tip3.lens))  # (some block; whichever it is, both sides must say the same)
+    for victim in (big, int(gids[len(gids) // 2]), int(gids[-1])):
+        data = tip3.data.copy()
+        o = int(tip3.off[victim])
+        data[o + int(tip3.lens[victim]) // 2] ^= 0xFF
+        w2 = engine.witness(data, tip3.off, tip3.lens, tip3.cids)
+        st2 = oracle.store(data, tip3.off, tip3.lens, tip3.cids)
+        g2 = w2.scan_events(tip3.receipts_root, tip3.topic0, tip3.topic1, actor=tip3.filter_actor)
+        o2 = st2.scan_events(tip3.receipts_root, tip3.topic0, tip3.topic1, actor=tip3.filter_actor)
+        assert g2[0] == o2[0]
+        if o2[0] == 1:
+            assert np.array_equal(g2[1], o2[1])
+        assert np.array_equal(w2.verify_event_proofs(ec.arr, ec.n), st2.verify_event_proofs(ec, mode=1))
+        w2.close()
+        st2.close()
+    w.close()
+    st.close()
+
+
 def test_packed_device_claims_equal_string_claims(tip, both, engine):
     """The device-resident packed path (what bench.py times) must give the same statuses as the
     string path for the same claims."""

@@ -216,3 +216,24 @@ def test_scattered_shards_uploaded_from_host_equal_the_unsharded_result(engine, 
     ost.close()
     if G == 8:  # what a rank uploads shrinks with G (the message AMTs and headers are the replicated floor)
         assert max(uploaded) < 0.45 * tip.data.size
+
+
+def test_shards_of_a_tipset_with_tall_event_amts(engine, oracle):
+    """Events AMTs of bit width 1 and height >= 8 (taller than the planner's explicit stack): every shard's witness must
+    still hold the whole tree of each of its receipts — merged statuses == unsharded == oracle."""
+    tall = Tipset(n_receipts=60, n_planted=6, variety=1, max_events=700, events_bit_width=1, seed=79)
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tall.parent_cids, tall.child_cid, tall.parent_epoch, tall.child_epoch, tall.claim_exec, tall.claim_event,
+        tall.claim_emitter, tall.exec_order[tall.claim_exec.astype(np.int64)], tall.claim_ntopics, tall.claim_topics,
+        tall.claim_datalen, tall.claim_data)
+    assert int(tall.claim_event.max()) >= 512
+    with engine.witness(tall.data, tall.off, tall.lens, tall.cids) as w:
+        want = w.verify_event_claims(ts, cl, blob, blob_len)
+        ws, whas, wm, _ = w.scan_events(tall.receipts_root, tall.topic0, tall.topic1, actor=tall.filter_actor, want_touched=False)
+    ost = oracle.store(tall.data, tall.off, tall.lens, tall.cids)
+    assert np.array_equal(ost.verify_event_claims_packed(ts, cl, blob, threads=1), want) and (want == 1).sum() >= 20
+    ost.close()
+    for G in (2, 3):
+        merged, counts, ids = run_shards(engine, tall, G, ts, cl, blob)
+        assert np.array_equal(merged["status"], want)
+        assert merged["scan_status"] == ws == 1 and np.array_equal(merged["has"], whas) and merged["n_matches"] == len(wm)
