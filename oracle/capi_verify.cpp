@@ -324,13 +324,14 @@ void orc_amt_get(void* store, const uint8_t* root_cid40, int version, int value_
     }
 }
 
-void orc_hamt_get(void* store, const uint8_t* root_cid40, uint32_t bit_width, int value_kind, const uint8_t* keys,
-                  const uint32_t* key_off, const uint32_t* key_len, uint64_t n, uint8_t* status, uint8_t* out,
-                  uint32_t cap, uint32_t* out_len) {
+// `threads`: 0 = every processor (capped by IPCFP_ORACLE_MAX_THREADS), else exactly that many (bench.py's sweep)
+void orc_hamt_get_t(void* store, const uint8_t* root_cid40, uint32_t bit_width, int value_kind, const uint8_t* keys,
+                    const uint32_t* key_off, const uint32_t* key_len, uint64_t n, uint8_t* status, uint8_t* out,
+                    uint32_t cap, uint32_t* out_len, int threads) {
     Store* s = static_cast<Store*>(store);
     Cid root{Bytes(root_cid40, root_cid40 + cid_slot_len(root_cid40))};
     ValueChecker chk = checker_for(value_kind);
-    use_threads(0);
+    use_threads(threads);
 #pragma omp parallel for schedule(dynamic, 64)
     for (int64_t i = 0; i < int64_t(n); ++i) {
         out_len[i] = 0;
@@ -342,6 +343,12 @@ void orc_hamt_get(void* store, const uint8_t* root_cid40, uint32_t bit_width, in
             return IPCFP_ST_TRUE;
         });
     }
+}
+
+void orc_hamt_get(void* store, const uint8_t* root_cid40, uint32_t bit_width, int value_kind, const uint8_t* keys,
+                  const uint32_t* key_off, const uint32_t* key_len, uint64_t n, uint8_t* status, uint8_t* out,
+                  uint32_t cap, uint32_t* out_len) {
+    orc_hamt_get_t(store, root_cid40, bit_width, value_kind, keys, key_off, key_len, n, status, out, cap, out_len, 0);
 }
 
 // reconstruct_execution_order: returns the status; on success *count and up to cap CIDs (40-byte slots).

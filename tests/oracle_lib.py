@@ -56,6 +56,8 @@ class Oracle:
         lib.orc_amt_get.argtypes = [vp, vp, C.c_int, C.c_int, vp, u64, vp, vp, C.c_uint32, vp]
         lib.orc_hamt_get.restype = None
         lib.orc_hamt_get.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp, vp, u64, vp, vp, C.c_uint32, vp]
+        lib.orc_hamt_get_t.restype = None
+        lib.orc_hamt_get_t.argtypes = [vp, vp, C.c_uint32, C.c_int, vp, vp, vp, u64, vp, vp, C.c_uint32, vp, C.c_int]
         lib.orc_exec_order.restype = C.c_uint8
         lib.orc_exec_order.argtypes = [vp, vp, C.c_uint32, vp, u64, C.POINTER(u64)]
         lib.orc_scan_events.restype = C.c_uint8
@@ -183,7 +185,7 @@ class OracleStore:
         self.lib.orc_amt_get(self.h, _p(root), version, VALUE_KINDS[kind], _p(idx), n, _p(st), _p(out), cap, _p(ol))
         return st, [out[i, : ol[i]].tobytes() for i in range(n)]
 
-    def hamt_get(self, root40: bytes, bit_width: int, kind: str, keys, cap=1024, want_values=True):
+    def hamt_get(self, root40: bytes, bit_width: int, kind: str, keys, cap=1024, want_values=True, threads=0):
         n = len(keys)
         kl = np.array([len(k) for k in keys], dtype=np.uint32)
         ko = np.zeros(n, dtype=np.uint32)
@@ -197,8 +199,8 @@ class OracleStore:
         import time as _time
 
         t0 = _time.perf_counter()
-        self.lib.orc_hamt_get(self.h, _p(root), bit_width, VALUE_KINDS[kind], _p(kb), _p(ko), _p(kl), n, _p(st),
-                              _p(out), cap, _p(ol))
+        self.lib.orc_hamt_get_t(self.h, _p(root), bit_width, VALUE_KINDS[kind], _p(kb), _p(ko), _p(kl), n, _p(st),
+                                _p(out), cap, _p(ol), int(threads))
         self.last_call_seconds = _time.perf_counter() - t0  # the C call alone (bench.py: no Python marshalling in a baseline)
         if not want_values:
             return st, None
