@@ -24,6 +24,7 @@
 
 #include "../common.h"
 #include "launch.h"
+#include "hamt_outline.h"
 #include "walk_dev.h"
 
 namespace ipcfp {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_lv_parse(Witness
 // LDS: 2 × 7424 B of stage + 1.2 KB of outline = 16.0 KB per wavefront, so that FOUR wavefronts share the 64 KB a CU
 // hands out (one 35 KB workgroup per CU was measured: 8 192 wavefronts of 26 µs took 0.79 ms).  The outline reads 8
 // bytes per LDS round trip: a wavefront's time IS the outline lane's chain of dependent LDS reads.
-constexpr uint32_t kCoopLanes = 32, kCoopNodes = 2, kCoopStage = 7424, kCoopMaxEntries = 96;
+constexpr uint32_t kCoopLanes = 32, kCoopNodes = 2, kCoopStage = 6912, kCoopMaxEntries = 96, kCoopParallelMin = 2048, kCoopParallelMinBuckets = 512;
 
 // the 8 bytes at S[p, p + 8) as a little-endian word (one aligned two-word LDS read)
 __device__ __forceinline__ uint64_t lds_peek64(const uint8_t* S, uint32_t p) {
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     __shared__ uint16_t s_val[kCoopNodes][kCoopMaxEntries];      // per bucket entry: where its ActorState (0x85) starts
     __shared__ uint16_t s_l2[kCoopNodes][kCoopMaxEntries];       // … its second link (`state`) …
     __shared__ uint16_t s_adr[kCoopNodes][kCoopMaxEntries];      // … and its delegated_address item
+    __shared__ uint16_t s_end[kCoopNodes][kCoopMaxEntries];      // … and where the entry ends (the parallel outline's tiling check)
+    __shared__ uint8_t s_gn[kCoopNodes][kCoopMaxEntries + 4], s_gc[kCoopNodes][kCoopMaxEntries + 4], s_gb[kCoopNodes][kCoopMaxEntries + 4];
     __shared__ uint32_t s_np[kCoopNodes], s_ne[kCoopNodes], s_links[kCoopNodes];
     __shared__ uint64_t s_bf[kCoopNodes];
     const uint32_t lane = threadIdx.x & 63u, g = lane / kCoopLanes, sub = lane % kCoopLanes;
@@ -242,113 +245,138 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         const uint32_t chunks = (len + 15u) >> 4;
         for (uint32_t c = sub; c < chunks; c += kCoopLanes) dst[c] = src[c];
     }
-    if (sub == 0) s_np[g] = 0xffffffffu;  // "no outline"
+    if (sub == 0) {
+        s_np[g] = 0xffffffffu;  // "no outline"
+        s_links[g] = 0u;
+    }
     __syncthreads();
-    // ---- outline: lane 0 of the group ----
-    if (staged && sub == 0) {
-        // (every unit's END is held against `len`: a header byte taken from beyond the node puts the end beyond it too)
-        // encoded length of the link whose first bytes are w (d8 2a | 4l / 58 l | …), 0: not that outline
-        auto link_len = [](uint64_t w) -> uint32_t {
-            if ((w & 0xffffull) != 0x2ad8ull) return 0u;
-            const uint32_t hb = uint32_t(w >> 16) & 0xffu;
-            if (hb >= 0x41u && hb <= 0x57u) return 3u + (hb - 0x40u);
-            if (hb == 0x58u) return 4u + (uint32_t(w >> 24) & 0xffu);
-            return 0u;
-        };
-        const uint64_t w0 = lds_peek64(S, 0);
-        bool ok = (w0 & 0xffu) == 0x82u;
-        const uint32_t bl = (uint32_t(w0 >> 8) & 0xffu) - 0x40u;  // bitfield: bytes, at most 8
-        ok = ok && bl <= 8u;
-        uint64_t bf = 0;
-        if (ok && bl) bf = __builtin_bswap64(lds_peek64(S, 2u)) >> (64u - 8u * bl);
-        uint32_t pos = 2u + bl, np = 0, ne = 0, links = 0;
-        if (ok) {
-            const uint64_t w = lds_peek64(S, pos);
-            const uint32_t b = uint32_t(w) & 0xffu;
-            if (b >= 0x80u && b <= 0x97u) {
-                np = b - 0x80u;
-                pos += 1u;
-            } else if (b == 0x98u) {
-                np = uint32_t(w >> 8) & 0xffu;
-                pos += 2u;
-            } else {
-                ok = false;
-            }
-            ok = ok && np <= kHamtTablePointers && pos <= len;
+    // ---- outline, all 32 lanes (hamt_outline.h): anchors → entries forward → gaps → the pieces must tile the node ----
+    // Worth its phases (a dozen barriers and prefix sums) only for a node with many entries: the link nodes of the upper
+    // levels (32 links, 1.4 KB) and the small overflow nodes below the bucket level are ≈ 300 instructions front to back
+    // (measured: levels of such nodes 11 µs sequential, 26-31 µs parallel) — lane 0 reads those, as in the first form.
+    // Mid-sized nodes whose first pointer is a BUCKET (the overflow nodes under a full bucket: 4-20 entries) also gain a little
+    // (a level of them: 115 µs front to back, 90 µs in parallel); which route reads a node never changes its record.
+    const outline::Header hd = staged ? outline::header(S, len) : outline::Header{false, 0, 0, 0};
+    const bool wide = staged && hd.ok && (len >= kCoopParallelMin || (len >= kCoopParallelMinBuckets && hd.pos0 < len && S[hd.pos0] != 0xd8u));
+    bool fast_ok = false;
+    if (__ballot(wide) != 0ull) {  // (wave-uniform: a wavefront of two small nodes skips the phases altogether)
+    uint32_t cnt = 0, a_from = 0, a_to = 0;
+    if (wide && hd.ok) {
+        const uint32_t span = (((len + kCoopLanes - 1u) / kCoopLanes) + 7u) & ~7u;  // a lane's share of the node, whole words
+        const uint32_t scan_end = len >= 2u ? len - 2u : 0u;
+        a_from = sub * span > hd.pos0 ? sub * span : hd.pos0;
+        a_to = (sub + 1u) * span < scan_end ? (sub + 1u) * span : scan_end;
+        if (a_from < a_to) cnt = outline::scan_anchors<false>(S, a_from, a_to, nullptr, 0);
+    }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (uint32_t d = 1; d < kCoopLanes; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, kCoopLanes);
+        if (sub >= d) incl += up;
+    }
+    const uint32_t na = __shfl(incl, kCoopLanes - 1u, kCoopLanes);  // anchors of the node
+    const bool fast = wide && hd.ok && na <= kCoopMaxEntries;
+    if (fast && cnt) (void)outline::scan_anchors<true>(S, a_from, a_to, s_val[g] + (incl - cnt), cnt);
+    __syncthreads();
+    bool okl = true;
+    // Every anchored entry forward to its end.  An anchor that does not parse is DROPPED, not held against the node: the
+    // three bytes also occur where a digest ends in 0x85 in front of another link (`… 85 | d8 2a 58 27 …`: one link
+    // node in eight has such a pair) — a sequence number can never start with that link's 0xd8.  What is kept must still
+    // tile the node below, so an entry that is wrongly dropped, or a stray anchor that does parse, sends the node to the
+    // sequential reader.
+    uint32_t ne_kept = 0;
+    for (uint32_t r = 0; r * kCoopLanes < (fast ? na : 0u); ++r) {
+        const uint32_t e = r * kCoopLanes + sub;
+        uint32_t a = 0, l2 = 0, adr = 0, end = 0;
+        bool keep = false;
+        if (e < na) {
+            a = s_val[g][e];
+            keep = outline::entry_forward(S, a, len, l2, adr, end);
         }
-        for (uint32_t p = 0; ok && p < np; ++p) {
-            s_ptr[g][p] = uint16_t(pos);
-            const uint64_t w = lds_peek64(S, pos);
-            const uint32_t b = uint32_t(w) & 0xffu;
-            if (b == 0xd8u) {  // a link: its bytes are checked by the lanes
-                const uint32_t ll = link_len(w);
-                ok = ll != 0u;
-                links |= 1u << p;
-                pos += ll;
-            } else if (b >= 0x80u && b <= 0x97u) {  // a bucket of b - 0x80 entries
-                const uint32_t nkv = b - 0x80u;
-                pos += 1u;
-                ok = ne + nkv <= kCoopMaxEntries;
-                for (uint32_t k = 0; ok && k < nkv; ++k) {
-                    // 82 | key: 4x … / 58 ll … | 85 link link | sequence | balance | f6 / address bytes
-                    const uint64_t e0 = k == 0 ? (w >> 8) : lds_peek64(S, pos);  // (the first entry follows the bucket's header byte)
-                    const uint32_t kb = uint32_t(e0 >> 8) & 0xffu;
-                    uint32_t q;
-                    if (kb >= 0x40u && kb <= 0x57u) q = pos + 2u + (kb - 0x40u);
-                    else if (kb == 0x58u) q = pos + 3u + (uint32_t(e0 >> 16) & 0xffu);
-                    else {
-                        ok = false;
-                        break;
-                    }
-                    const uint64_t v0 = lds_peek64(S, q);  // 85 | code link …
-                    const uint32_t l1 = link_len(v0 >> 8);
-                    const uint32_t l2 = link_len(lds_peek64(S, q + 1u + l1));  // state
-                    ok = (e0 & 0xffu) == 0x82u && (v0 & 0xffu) == 0x85u && l1 != 0u && l2 != 0u;
-                    s_val[g][ne] = uint16_t(q);
-                    s_l2[g][ne] = uint16_t(q + 1u + l1);
-                    q += 1u + l1 + l2;
-                    const uint32_t sb = uint32_t(lds_peek64(S, q)) & 0xffu;  // sequence: an unsigned integer in any width
-                    ok = ok && sb <= 0x1bu;
-                    q += 1u + (sb < 0x18u ? 0u : (1u << ((sb - 0x18u) & 3u)));
-                    const uint64_t b0 = lds_peek64(S, q);  // balance: bytes, at most 128, sign byte 0 / 1
-                    const uint32_t bb = uint32_t(b0) & 0xffu;
-                    uint32_t l, sign;
-                    if (bb >= 0x40u && bb <= 0x57u) {
-                        l = bb - 0x40u;
-                        sign = uint32_t(b0 >> 8) & 0xffu;
-                        q += 1u;
-                    } else if (bb == 0x58u) {
-                        l = uint32_t(b0 >> 8) & 0xffu;
-                        sign = uint32_t(b0 >> 16) & 0xffu;
-                        q += 2u;
-                    } else {
-                        ok = false;
-                        break;
-                    }
-                    ok = ok && l <= 128u && (l == 0u || sign <= 1u);
-                    q += l;
-                    s_adr[g][ne] = uint16_t(q);
-                    const uint64_t a0 = lds_peek64(S, q);  // delegated_address: None, or address bytes (checked by the lanes)
-                    const uint32_t ab = uint32_t(a0) & 0xffu;
-                    if (ab == 0xf6u) q += 1u;
-                    else if (ab >= 0x40u && ab <= 0x57u) q += 1u + (ab - 0x40u);
-                    else if (ab == 0x58u) q += 2u + (uint32_t(a0 >> 8) & 0xffu);
-                    else ok = false;
-                    ++ne;
-                    pos = q;
-                    ok = ok && pos <= len;
+        const uint32_t kept = uint32_t((__ballot(keep) >> (g * kCoopLanes)) & 0xffffffffull);
+        __syncthreads();  // (every anchor of this round has been read: the kept ones move down)
+        if (keep) {
+            const uint32_t at = ne_kept + uint32_t(__popc(kept & ((1u << sub) - 1u)));
+            s_val[g][at] = uint16_t(a);
+            s_l2[g][at] = uint16_t(l2);
+            s_adr[g][at] = uint16_t(adr);
+            s_end[g][at] = uint16_t(end);
+        }
+        ne_kept += uint32_t(__popc(kept));
+    }
+    __syncthreads();
+    if (fast) {  // every gap: how many pointers start in it, the bucket header's count (the tail is gap `na`)
+        for (uint32_t e = sub; e <= ne_kept; e += kCoopLanes) {
+            uint32_t n_ptr = 0, count = 0;
+            const uint32_t from = e ? uint32_t(s_end[g][e - 1u]) : hd.pos0, target = e < ne_kept ? uint32_t(s_val[g][e]) : len;
+            const bool ok = outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, nullptr, 0u, nullptr);
+            okl = okl && ok;
+            s_gn[g][e] = uint8_t(ok ? n_ptr : 0u);
+            s_gc[g][e] = uint8_t(ok ? count : 0u);
+        }
+    }
+    __syncthreads();
+    if (fast) {  // pointer numbers: a running sum over the gaps; the buckets' counts must hop from header to header
+        uint32_t carry = 0, headers = 0;
+        for (uint32_t r = 0; r * kCoopLanes <= ne_kept; ++r) {
+            const uint32_t e = r * kCoopLanes + sub;
+            const uint32_t v = e <= ne_kept ? uint32_t(s_gn[g][e]) : 0u;
+            uint32_t run = v;
+#pragma unroll
+            for (uint32_t d = 1; d < kCoopLanes; d <<= 1) {
+                const uint32_t up = __shfl_up(run, d, kCoopLanes);
+                if (sub >= d) run += up;
+            }
+            if (e <= ne_kept) s_gb[g][e] = uint8_t(carry + run - v);
+            carry += __shfl(run, kCoopLanes - 1u, kCoopLanes);
+            const uint64_t hb = __ballot(e < ne_kept && s_gc[g][e] != 0u);
+            headers += uint32_t(__popcll((hb >> (g * kCoopLanes)) & 0xffffffffull));
+        }
+        okl = okl && carry == hd.np;
+        if (sub == 0) {
+            uint32_t e = 0, hops = 0;
+            while (e < ne_kept && hops <= outline::kMaxPointers) {
+                const uint32_t c = s_gc[g][e];
+                if (!c) break;
+                e += c;
+                ++hops;
+            }
+            okl = okl && e == ne_kept && hops == headers;
+        }
+    }
+    __syncthreads();
+    if (fast) {  // the same walk again, now writing where every pointer starts
+        uint32_t lm = 0;
+        for (uint32_t e = sub; e <= ne_kept; e += kCoopLanes) {
+            uint32_t n_ptr = 0, count = 0;
+            const uint32_t from = e ? uint32_t(s_end[g][e - 1u]) : hd.pos0, target = e < ne_kept ? uint32_t(s_val[g][e]) : len;
+            (void)outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, s_ptr[g], uint32_t(s_gb[g][e]), &lm);
+        }
+        if (lm) atomicOr(&s_links[g], lm);
+    }
+    {   // every lane of the group content?  Then the outline stands; else lane 0 reads the node front to back
+        const uint64_t votes = __ballot(fast && okl);
+        const uint64_t mine = 0xffffffffull << (g * kCoopLanes);
+        fast_ok = (votes & mine) == mine;
+        __syncthreads();
+        if (fast_ok && sub == 0) {
+            s_np[g] = hd.np;
+            s_ne[g] = ne_kept;
+            s_bf[g] = hd.bf;
+        }
+    }
+    }  // (the parallel phases)
+    {
+        if (staged && sub == 0) {
+            if (!fast_ok) {
+                outline::Result r{0, 0, 0, 0};
+                if (outline::outline_sequential(S, len, r, s_ptr[g], s_val[g], s_l2[g], s_adr[g])) {
+                    s_np[g] = r.np;
+                    s_ne[g] = r.ne;
+                    s_bf[g] = r.bf;
+                    s_links[g] = r.links;
                 }
-            } else {
-                ok = false;
             }
-            ok = ok && pos <= len;
-        }
-        ok = ok && pos == len;  // nothing after the node
-        if (ok) {
-            s_np[g] = np;
-            s_ne[g] = ne;
-            s_links[g] = links;
-            s_bf[g] = bf;
         }
     }
     __syncthreads();
