@@ -3,7 +3,10 @@
 #include <functional>
 
 #include "../common.h"
-#include "../kernels/exec_order.h"
+#include "../kernels/amt_enum.h"
+#include "../kernels/event_table.h"
+#include "../kernels/tipset_ctx.h"
+#include "../kernels/types_dev.h"
 #include "../kernels/launch.h"
 
 namespace ipcfp {

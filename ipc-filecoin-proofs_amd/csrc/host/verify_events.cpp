@@ -14,7 +14,10 @@
 
 #include "../common.h"
 #include "../kernels/claims_dev.h"
-#include "../kernels/exec_order.h"
+#include "../kernels/amt_enum.h"
+#include "../kernels/event_table.h"
+#include "../kernels/tipset_ctx.h"
+#include "../kernels/types_dev.h"
 #include "../kernels/launch.h"
 #include "cidstr.h"
 #include "exec_state.h"

@@ -15,7 +15,8 @@
 #include "../common.h"
 #include "amt_enum.h"
 #include "event_table.h"
-#include "events_dev.h"
+#include "event_log_dev.h"
+#include "walk_dev.h"
 #include "launch.h"
 #include "scan_dev.h"
 

@@ -12,7 +12,8 @@
 
 #include "../common.h"
 #include "amt_enum.h"
-#include "events_dev.h"
+#include "event_log_dev.h"
+#include "walk_dev.h"
 #include "launch.h"
 
 namespace ipcfp {

@@ -1,5 +1,8 @@
-// csrc/kernels/tipset_ctx.h — device state of one tipset context (see exec_order.h) and the job record of the tipset
-// prologue, free of the walk primitives so that the prologue can be compiled with an LDS reader (tipset_prepare.hip).
+// csrc/kernels/tipset_ctx.h — device state of one tipset context: everything `verify_single_proof` derives from
+// (parent_tipset_cids, child_block_cid) alone — header consistency facts (src/proofs/events/verifier.rs:147-181) and the
+// reconstructed execution order (src/proofs/events/utils.rs:16-30,48-94) — computed ONCE per distinct pair instead of once
+// per proof (the reference recomputes it for every proof: events/verifier.rs:190); and the job record of the tipset
+// prologue.  Free of the walk primitives so that the prologue can be compiled with an LDS reader (tipset_prepare.hip).
 #pragma once
 #include <cstdint>
 

@@ -10,7 +10,10 @@
 #include "../common.h"
 #include "blake2b_dev.h"
 #include "claims_dev.h"
-#include "exec_order.h"
+#include "amt_enum.h"
+#include "event_table.h"
+#include "tipset_ctx.h"
+#include "types_dev.h"
 #include "launch.h"
 
 namespace ipcfp {

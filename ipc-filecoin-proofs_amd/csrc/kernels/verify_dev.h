@@ -5,7 +5,10 @@
 #pragma once
 #include "claims_dev.h"
 #include "event_table.h"
-#include "exec_order.h"
+#include "amt_enum.h"
+#include "event_table.h"
+#include "tipset_ctx.h"
+#include "types_dev.h"
 
 namespace ipcfp {
 

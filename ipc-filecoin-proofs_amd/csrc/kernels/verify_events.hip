@@ -12,8 +12,12 @@
 #include "../common.h"
 #include "blake2b_dev.h"
 #include "claims_dev.h"
-#include "events_dev.h"
-#include "exec_order.h"
+#include "event_log_dev.h"
+#include "walk_dev.h"
+#include "amt_enum.h"
+#include "event_table.h"
+#include "tipset_ctx.h"
+#include "types_dev.h"
 #include "launch.h"
 #include "scan_dev.h"
 #include "verify_dev.h"
