@@ -36,14 +36,61 @@ struct HamtLevels {
     uint32_t* claimed;    // ⌈n_blocks / 32⌉ bits: the block is (or was) on a work list
     uint32_t* work[2];    // work lists of even / odd levels (capacity: min(n, n_blocks))
     uint32_t* count;      // entries of level l's list (one counter per level)
+    uint32_t* child;      // n_blocks × 32: the block behind pointer p where p is a standard link — filled by the 32-lane parse
+                          // (HamtNodeRec::pad bit 0), so that a query's step down is one word instead of link bytes → index
+                          // probe → CID compare (three dependent random reads of the eight a step was)
 };
 
-__device__ __forceinline__ void hamt_claim(const HamtLevels& L, uint32_t block, uint32_t level) {
-    const uint32_t bit = 1u << (block & 31u);
-    uint32_t* word = L.claimed + (block >> 5);
-    if (__builtin_nontemporal_load(word) & bit) return;  // (a stale miss only costs the atomic below)
-    if (atomicOr(word, bit) & bit) return;
-    L.work[level & 1u][atomicAdd(L.count + level, 1u)] = block;
+// Blockstore::get → block id WITHOUT recording the read (the parse resolves every link of a node; which of them a query
+// follows — and so which block the RecordingBlockStore would have seen — is decided by k_hamt_lv_advance)
+__device__ __forceinline__ uint32_t witness_find_quiet(const WitnessView& w, const CidKey& key) {
+    uint32_t s = cid_hash(key) & w.mask;
+    for (;;) {
+        const uint32_t b = w.slots[s];
+        if (b == kNoBlock) return kNoBlock;
+        if (cid_equal(load_cid_slot(w.cids, b), key)) return b;
+        s = (s + 1) & w.mask;
+    }
+}
+
+// EVERY lane of the workgroup calls this (`want`: the lane has a block to claim for the level's work list).  All queries
+// of the upper levels stand on a handful of nodes — level 0's 66 k claims are 32 distinct blocks, i.e. 66 k atomics on the
+// same few words of the L2, and every appended block one more atomic on the level's ONE counter — so claims are thinned
+// out on the way: a workgroup-wide set in LDS lets one lane per distinct block through, and the lanes of a wavefront that
+// win their block append with one counter update between them.
+constexpr uint32_t kClaimSet = 512;  // LDS slots per 256-thread workgroup (a power of two ≥ 2 × the workgroup)
+__device__ __forceinline__ void hamt_claim(const HamtLevels& L, uint32_t block, uint32_t level, bool want, uint32_t* set) {
+    for (uint32_t i = threadIdx.x; i < kClaimSet; i += blockDim.x) set[i] = kNoBlock;
+    __syncthreads();
+    bool first = false;
+    if (want) {
+        uint32_t s = (block * 2654435761u) >> 23;  // 9 bits
+        for (;;) {
+            const uint32_t seen = atomicCAS(&set[s], kNoBlock, block);
+            if (seen == kNoBlock) {
+                first = true;
+                break;
+            }
+            if (seen == block) break;
+            s = (s + 1u) & (kClaimSet - 1u);
+        }
+    }
+    bool won = false;
+    if (first) {
+        const uint32_t bit = 1u << (block & 31u);
+        uint32_t* word = L.claimed + (block >> 5);
+        // (a stale miss of the plain look only costs the atomic)
+        won = !(__builtin_nontemporal_load(word) & bit) && !(atomicOr(word, bit) & bit);
+    }
+    const uint64_t winners = __ballot(won);
+    if (won) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t leader = uint32_t(__ffsll((long long)winners)) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(L.count + level, uint32_t(__popcll(winners)));
+        base = __shfl(base, leader, 64);
+        L.work[level & 1u][base + uint32_t(__popcll(winners & ((1ull << lane) - 1ull)))] = block;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey root, HamtLevels L, const uint8_t* __restrict__ keys,
@@ -416,11 +463,27 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
             reinterpret_cast<uint32_t*>(out->ptr_off)[sub] = lo | (hi << 16);
         }
     }
+    // Only for a node of links alone (the upper levels: every query that stands on it steps through one of them).  A bucket
+    // node's few links lead to overflow nodes a handful of its queries follow: resolving all of them here cost the bucket
+    // level's parse 28 µs (two more dependent reads in every wavefront) to save its advance nothing.
+    const bool resolve = node_ok && L.child != nullptr && s_ne[g] == 0u;
+    if (resolve) {  // lane p: the block behind pointer p (the 38 CID bytes of a standard link start 5 bytes in)
+        uint32_t c = kNoBlock;
+        if (sub < np && ((s_links[g] >> sub) & 1u)) {
+            const uint32_t at = uint32_t(s_ptr[g][sub]) + 5u;
+            CidKey key;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) key.w[j] = lds_peek64(S, at + 8u * uint32_t(j));
+            key.w[4] &= (1ull << 48) - 1ull;
+            c = witness_find_quiet(w, key);
+        }
+        L.child[size_t(block) * kHamtTablePointers + sub] = c;
+    }
     if (sub == 0) {
         out->status = uint8_t(node_ok ? 1u : 0u);  // 0: not tabulated — the walker decides
         out->kinds_ok = uint8_t(node_ok ? 1u : 0u);
         out->np = uint8_t(node_ok ? np : 0u);
-        out->pad = 0;
+        out->pad = uint8_t(resolve ? 1u : 0u);  // bit 0: L.child holds this node's standard links
         out->std_links = node_ok ? s_links[g] : 0u;
         out->bitfield = node_ok ? s_bf[g] : 0ull;
     }
@@ -431,15 +494,15 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
                                                          const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
                                                          const uint32_t* __restrict__ key_len, uint32_t n,
                                                          uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+    __shared__ uint32_t s_claims[kClaimSet];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const uint32_t block = L.cur[t];
-    if (block == kNoBlock) return;
-    const HamtNodeRec* rec = L.recs + block;
-    const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);  // status | kinds_ok << 8 | np << 16
+    const uint32_t block = t < n ? L.cur[t] : kNoBlock;
+    const bool live = block != kNoBlock;  // (else: settled, left to the walker, or beyond the batch — still a party to the workgroup's claims)
+    const HamtNodeRec* rec = L.recs + (live ? block : 0u);
     uint32_t st = kStPending, next = kNoBlock;
     ValueLoc hit{kNoBlock, 0, 0};
-    do {
+    if (live) do {
+        const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);  // status | kinds_ok << 8 | np << 16
         if ((head & 0xffu) != 1u) break;  // not tabulated: the walker decides (from the root)
         const uint32_t np = (head >> 16) & 0xffu;
         const uint32_t consumed = level * bit_width;
@@ -465,6 +528,12 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
         const uint8_t* g = w.arena + w.off[block];
         CidKey link;
         bool is_link = true;
+        if (((rec->std_links >> rank) & 1u) && (head & (1u << 24))) {  // resolved by the parse: one word
+            next = L.child[size_t(block) * kHamtTablePointers + rank];
+            if (next == kNoBlock) st = IPCFP_ST_ERR_MISSING_BLOCK;
+            else if (w.touched) atomicOr(&w.touched[next >> 5], 1u << (next & 31));  // (what witness_find records)
+            break;
+        }
         if ((rec->std_links >> rank) & 1u) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) __builtin_memcpy(&link.w[j], g + off + 5 + 8 * j, 8);  // unaligned 8-byte loads
@@ -507,9 +576,10 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
             if (next == kNoBlock) st = IPCFP_ST_ERR_MISSING_BLOCK;
         }
     } while (false);
+    hamt_claim(L, next, level + 1u, next != kNoBlock, s_claims);  // (the ONE place: every lane of the workgroup comes through here)
+    if (!live) return;
     if (next != kNoBlock) {
         L.cur[t] = next;
-        hamt_claim(L, next, level + 1u);
         return;
     }
     L.cur[t] = kNoBlock;
@@ -522,7 +592,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
 // Scratch of one call: [cur n | hash 8n | work0 cap | work1 cap | count (levels + 1) | claimed words] u32 + the record table.
 size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels) {
     const size_t cap = n < n_blocks ? n : n_blocks;
-    return size_t(n) * 9 + cap * 2 + (levels + 2) + div_up(n_blocks, 32) + 8;
+    return size_t(n) * 9 + cap * 2 + (levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers;
 }
 
 int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
@@ -538,6 +608,7 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     L.work[1] = L.work[0] + cap;
     L.count = L.work[1] + cap;
     L.claimed = L.count + (levels + 2);
+    L.child = vkind == VK_ACTOR_STATE && coop ? L.claimed + words + 8 : nullptr;  // (the 32-lane parse fills it)
     L.recs = static_cast<HamtNodeRec*>(recs_d);
     // counters and bitmap are contiguous: one clear
     IPCFP_HIP(ctx, hipMemsetAsync(L.count, 0, (size_t(levels) + 2 + words) * 4, ctx->stream));
