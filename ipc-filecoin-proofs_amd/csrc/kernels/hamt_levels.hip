@@ -187,7 +187,13 @@ __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_lv_parse(Witness
 // LDS: 2 × 7424 B of stage + 1.2 KB of outline = 16.0 KB per wavefront, so that FOUR wavefronts share the 64 KB a CU
 // hands out (one 35 KB workgroup per CU was measured: 8 192 wavefronts of 26 µs took 0.79 ms).  The outline reads 8
 // bytes per LDS round trip: a wavefront's time IS the outline lane's chain of dependent LDS reads.
-constexpr uint32_t kCoopLanes = 32, kCoopNodes = 2, kCoopStage = 6912, kCoopMaxEntries = 96, kCoopParallelMin = 2048, kCoopParallelMinBuckets = 512;
+constexpr uint32_t kCoopLanes = 32, kCoopNodes = 2, kCoopParallelMin = 2048, kCoopParallelMinBuckets = 512;
+// Two instances of the kernel share a level's work list: nodes of up to kCoopSmallStage - 24 bytes (the link nodes of the upper
+// levels, the overflow nodes under a full bucket: 0.3-1.4 KB) go to the one with a 1.5 KB stage — 3.7 KB of LDS per wavefront,
+// so that a CU keeps 32 of them resident instead of 9: such a wavefront's time is three dependent random reads (work list →
+// length / offset → the node) and what hides them is the number of wavefronts in flight — everything else to the one with
+// the 6.9 KB stage.  Each skips the other's nodes.
+constexpr uint32_t kCoopBigStage = 6912, kCoopBigEntries = 96, kCoopSmallStage = 1536, kCoopSmallEntries = 24;
 
 // the 8 bytes at S[p, p + 8) as a little-endian word (one aligned two-word LDS read)
 __device__ __forceinline__ uint64_t lds_peek64(const uint8_t* S, uint32_t p) {
@@ -269,6 +275,7 @@ __device__ __forceinline__ bool lds_address_ok(const uint8_t* S, uint32_t off, u
     return false;
 }
 
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL>
 __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kCoopNodes][kCoopStage];
     __shared__ uint16_t s_ptr[kCoopNodes][kHamtTablePointers];   // pointer starts
@@ -281,9 +288,10 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     __shared__ uint64_t s_bf[kCoopNodes];
     const uint32_t lane = threadIdx.x & 63u, g = lane / kCoopLanes, sub = lane % kCoopLanes;
     const uint32_t i = blockIdx.x * kCoopNodes + g;
-    const bool have = i < L.count[level];
-    const uint32_t block = have ? L.work[level & 1u][i] : 0u;
-    const uint32_t len = have ? w.len[block] : 0u;
+    const bool listed = i < L.count[level];
+    const uint32_t block = listed ? L.work[level & 1u][i] : 0u;
+    const uint32_t len = listed ? w.len[block] : 0u;
+    const bool have = listed && (len + 24u <= kCoopSmallStage) == SMALL;  // (the other instance's node otherwise)
     const bool staged = have && len >= 3u && len + 24u <= kCoopStage;
     uint8_t* S = stage[g];
     if (staged) {
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         if (staged && sub == 0) {
             if (!fast_ok) {
                 outline::Result r{0, 0, 0, 0};
-                if (outline::outline_sequential(S, len, r, s_ptr[g], s_val[g], s_l2[g], s_adr[g])) {
+                if (outline::outline_sequential(S, len, r, s_ptr[g], s_val[g], s_l2[g], s_adr[g], kCoopMaxEntries)) {
                     s_np[g] = r.np;
                     s_ne[g] = r.ne;
                     s_bf[g] = r.bf;
@@ -620,8 +628,12 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
         uint64_t fan = 1;
         for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
         const uint32_t bound = fan < cap ? uint32_t(fan) : cap;
-        if (vkind == VK_ACTOR_STATE && coop)
-            hipLaunchKernelGGL(k_hamt_lv_parse_actor, dim3(div_up(bound, kCoopNodes)), dim3(64), 0, ctx->stream, w, L, lv);
+        if (vkind == VK_ACTOR_STATE && coop) {
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(div_up(bound, kCoopNodes)), dim3(64), 0,
+                               ctx->stream, w, L, lv);
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(div_up(bound, kCoopNodes)), dim3(64), 0,
+                               ctx->stream, w, L, lv);
+        }
         else
             hipLaunchKernelGGL(k_hamt_lv_parse, dim3(div_up(bound, 256)), dim3(256), 0, ctx->stream, w, L, lv, vkind);
         hipLaunchKernelGGL(k_hamt_lv_advance, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, L, lv, bit_width, vkind, keys_d,

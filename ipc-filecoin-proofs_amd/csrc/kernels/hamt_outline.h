@@ -140,8 +140,9 @@ struct Result {
     uint64_t bf;
 };
 // ptr[p]: where pointer p starts; val / l2 / adr[e]: entry e's ActorState header, second link, address item
+// (max_entries: what val / l2v / adrv hold)
 IPCFP_OL_FN bool outline_sequential(const uint8_t* S, uint32_t len, Result& r, uint16_t* ptr, uint16_t* val, uint16_t* l2v,
-                                    uint16_t* adrv) {
+                                    uint16_t* adrv, uint32_t max_entries = kMaxEntries) {
     const Header h = header(S, len);
     bool ok = h.ok;
     uint32_t pos = h.pos0, ne = 0, links = 0;
@@ -158,7 +159,7 @@ IPCFP_OL_FN bool outline_sequential(const uint8_t* S, uint32_t len, Result& r, u
         } else if (b >= 0x80u && b <= 0x97u) {  // a bucket of b - 0x80 entries
             const uint32_t nkv = b - 0x80u;
             pos += 1u;
-            ok = ne + nkv <= kMaxEntries;
+            ok = ne + nkv <= max_entries;
             for (uint32_t k = 0; ok && k < nkv; ++k) {
                 const uint64_t e0 = peek64(S, pos);
                 uint32_t q = 0;
