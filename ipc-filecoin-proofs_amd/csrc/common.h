@@ -158,6 +158,8 @@ struct ipcfp_ctx {
     size_t hamt_recs_bytes = 0;
     void* hamt_scratch = nullptr;
     size_t hamt_scratch_bytes = 0;
+    void* hamt_etabs = nullptr;  // entry tables of the level path's visited nodes (kernels/hamt_table.h HamtEntryTab)
+    size_t hamt_etabs_bytes = 0;
 };
 
 namespace ipcfp {

@@ -330,6 +330,7 @@ void ipcfp_ctx_destroy(ipcfp_ctx_t* ctx) {
     if (ctx->scan_scratch) (void)hipFree(ctx->scan_scratch);
     if (ctx->hamt_recs) (void)hipFree(ctx->hamt_recs);
     if (ctx->hamt_scratch) (void)hipFree(ctx->hamt_scratch);
+    if (ctx->hamt_etabs) (void)hipFree(ctx->hamt_etabs);
     for (auto& l : ctx->launches) {
         (void)hipEventDestroy(l.start);
         (void)hipEventDestroy(l.stop);

@@ -66,8 +66,13 @@ int hamt_get_batch(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, uint32_
     if (levels_mode > 0) levels = uint32_t(levels_mode);
     IPCFP_HIP(ctx, grow(ctx->hamt_recs, ctx->hamt_recs_bytes, size_t(w->n) * sizeof(HamtNodeRec)));
     IPCFP_HIP(ctx, grow(ctx->hamt_scratch, ctx->hamt_scratch_bytes, hamt_levels_scratch_words(n, uint32_t(w->n), levels) * 4));
+    // entry tables: one per visited node, in work-list order (a level's list holds at most min(n, blocks) nodes; the upper
+    // levels' lists are short) — what lies beyond the pool keeps the reader's bucket search
+    const uint32_t etab_cap = uint32_t(std::min<uint64_t>(3ull * n + 4096, w->n));
+    IPCFP_HIP(ctx, grow(ctx->hamt_etabs, ctx->hamt_etabs_bytes, size_t(etab_cap) * sizeof(HamtEntryTab)));
     int rc = launch_hamt_get_levels(ctx, view, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d, levels,
-                                    static_cast<uint32_t*>(ctx->hamt_scratch), ctx->hamt_recs, /*coop=*/ctx->hamt_coop != 0);
+                                    static_cast<uint32_t*>(ctx->hamt_scratch), ctx->hamt_recs, /*coop=*/ctx->hamt_coop != 0, ctx->hamt_etabs,
+                                    etab_cap);
     if (rc) return rc;
     return launch_hamt_get(ctx, view, root, bit_width, vkind, keys_d, key_off_d, key_len_d, n, status_d, loc_d, /*pending_only=*/1);
 }

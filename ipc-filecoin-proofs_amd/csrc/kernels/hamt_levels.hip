@@ -36,6 +36,9 @@ struct HamtLevels {
     uint32_t* claimed;    // ⌈n_blocks / 32⌉ bits: the block is (or was) on a work list
     uint32_t* work[2];    // work lists of even / odd levels (capacity: min(n, n_blocks))
     uint32_t* count;      // entries of level l's list (one counter per level)
+    HamtEntryTab* etabs;  // entry tables of the visited nodes that hold entries (`etab_cap` of them; null: none kept)
+    uint32_t* etab_of;    // n_blocks: 1 + the node's table, 0: none (written for every node the 32-lane parse takes)
+    uint32_t etab_cap;
     uint32_t* child;      // n_blocks × 32: the block behind pointer p where p is a standard link — filled by the 32-lane parse
                           // (HamtNodeRec::pad bit 0), so that a query's step down is one word instead of link bytes → index
                           // probe → CID compare (three dependent random reads of the eight a step was)
@@ -284,7 +287,8 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     __shared__ uint16_t s_adr[kCoopNodes][kCoopMaxEntries];      // … and its delegated_address item
     __shared__ uint16_t s_end[kCoopNodes][kCoopMaxEntries];      // … and where the entry ends (the parallel outline's tiling check)
     __shared__ uint8_t s_gn[kCoopNodes][kCoopMaxEntries + 4], s_gc[kCoopNodes][kCoopMaxEntries + 4], s_gb[kCoopNodes][kCoopMaxEntries + 4];
-    __shared__ uint32_t s_np[kCoopNodes], s_ne[kCoopNodes], s_links[kCoopNodes];
+    __shared__ uint8_t s_klen[kCoopNodes][kCoopMaxEntries + 4], s_first[kCoopNodes][kHamtTablePointers];  // (the entry table's extras)
+    __shared__ uint32_t s_np[kCoopNodes], s_ne[kCoopNodes], s_links[kCoopNodes], s_lall[kCoopNodes], s_slot[kCoopNodes];
     __shared__ uint64_t s_bf[kCoopNodes];
     const uint32_t lane = threadIdx.x & 63u, g = lane / kCoopLanes, sub = lane % kCoopLanes;
     const uint32_t i = blockIdx.x * kCoopNodes + g;
@@ -362,10 +366,11 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     __syncthreads();
     if (fast) {  // every gap: how many pointers start in it, the bucket header's count (the tail is gap `na`)
         for (uint32_t e = sub; e <= ne_kept; e += kCoopLanes) {
-            uint32_t n_ptr = 0, count = 0;
+            uint32_t n_ptr = 0, count = 0, kl = 0;
             const uint32_t from = e ? uint32_t(s_end[g][e - 1u]) : hd.pos0, target = e < ne_kept ? uint32_t(s_val[g][e]) : len;
-            const bool ok = outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, nullptr, 0u, nullptr);
+            const bool ok = outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, nullptr, 0u, nullptr, &kl);
             okl = okl && ok;
+            if (e < ne_kept) s_klen[g][e] = uint8_t(kl);
             s_gn[g][e] = uint8_t(ok ? n_ptr : 0u);
             s_gc[g][e] = uint8_t(ok ? count : 0u);
         }
@@ -405,7 +410,8 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         for (uint32_t e = sub; e <= ne_kept; e += kCoopLanes) {
             uint32_t n_ptr = 0, count = 0;
             const uint32_t from = e ? uint32_t(s_end[g][e - 1u]) : hd.pos0, target = e < ne_kept ? uint32_t(s_val[g][e]) : len;
-            (void)outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, s_ptr[g], uint32_t(s_gb[g][e]), &lm);
+            (void)outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, s_ptr[g], uint32_t(s_gb[g][e]), &lm, nullptr,
+                                    s_first[g], e);
         }
         if (lm) atomicOr(&s_links[g], lm);
     }
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
             s_np[g] = hd.np;
             s_ne[g] = ne_kept;
             s_bf[g] = hd.bf;
+            s_lall[g] = s_links[g];  // (every link; the check phase below leaves the STANDARD ones in s_links)
         }
     }
     }  // (the parallel phases)
@@ -425,11 +432,13 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         if (staged && sub == 0) {
             if (!fast_ok) {
                 outline::Result r{0, 0, 0, 0};
-                if (outline::outline_sequential(S, len, r, s_ptr[g], s_val[g], s_l2[g], s_adr[g], kCoopMaxEntries)) {
+                if (outline::outline_sequential(S, len, r, s_ptr[g], s_val[g], s_l2[g], s_adr[g], kCoopMaxEntries, s_end[g], s_klen[g],
+                                                s_first[g])) {
                     s_np[g] = r.np;
                     s_ne[g] = r.ne;
                     s_bf[g] = r.bf;
                     s_links[g] = r.links;
+                    s_lall[g] = r.links;
                 }
             }
         }
@@ -461,8 +470,39 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     const uint64_t votes = __ballot(good);
     const uint64_t mine = 0xffffffffull << (g * kCoopLanes);
     const bool node_ok = (votes & mine) == mine;
-    __syncthreads();  // (s_links: the lanes' atomicAnd before lane 0 reads it back)
+    if (have && sub == 0 && L.etab_of) {  // a table for the node's entries, if it has any (and the pool reaches that far)
+        // The node's place in the pool is its place in the call's work lists — the earlier levels' counts + its index —
+        // not a ticket from a counter: thirty thousand nodes of a level drawing tickets from ONE word of the L2 took
+        // 270 µs where the level's parse takes 70 (profiles/r04_experiments.md).
+        uint32_t slot = 0;
+        if (node_ok && s_ne[g] != 0u) {
+            uint32_t base = 0;
+            for (uint32_t l = 0; l < level; ++l) base += L.count[l];
+            slot = base + i < L.etab_cap ? base + i + 1u : 0u;
+        }
+        s_slot[g] = slot;
+        L.etab_of[block] = slot;
+    }
+    __syncthreads();  // (s_links: the lanes' atomicAnd before lane 0 reads it back; s_slot)
     if (!have) return;
+    if (L.etab_of && s_slot[g]) {
+        HamtEntryTab* T = L.etabs + (s_slot[g] - 1u);
+        const uint32_t ne = s_ne[g], lall = s_lall[g];
+        for (uint32_t e = sub; e < ne; e += kCoopLanes) {
+            const uint32_t v = s_val[g][e], kl = s_klen[g][e];
+            T->e[e] = HamtEntryTab::Entry{uint16_t(v - kl), uint16_t(v), uint16_t(uint32_t(s_end[g][e]) - v), uint8_t(kl), 0};
+        }
+        {   // lane p: pointer p
+            const bool bucket = sub < np && !((lall >> sub) & 1u);
+            const uint32_t cnt = bucket ? uint32_t(S[s_ptr[g][sub]]) - 0x80u : 0u;
+            T->first[sub] = uint8_t(cnt ? s_first[g][sub] : 0u);
+            T->count[sub] = uint8_t(cnt);
+        }
+        if (sub == 0) {
+            T->links = lall;
+            T->n_entries = ne;
+        }
+    }
     HamtNodeRec* out = L.recs + block;
     if (node_ok) {
         // offsets: sixteen dwords = thirty-two u16
@@ -507,6 +547,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
     const uint32_t block = t < n ? L.cur[t] : kNoBlock;
     const bool live = block != kNoBlock;  // (else: settled, left to the walker, or beyond the batch — still a party to the workgroup's claims)
     const HamtNodeRec* rec = L.recs + (live ? block : 0u);
+    const uint32_t etab = live && L.etab_of ? L.etab_of[block] : 0u;
     uint32_t st = kStPending, next = kNoBlock;
     ValueLoc hit{kNoBlock, 0, 0};
     if (live) do {
@@ -532,8 +573,37 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
             st = IPCFP_ST_ERR_DECODE;
             break;
         }
-        const uint32_t off = rec->ptr_off[rank];
         const uint8_t* g = w.arena + w.off[block];
+        if (etab && !((L.etabs[etab - 1u].links >> rank) & 1u)) {  // a bucket of a node whose entries the parse kept
+            const HamtEntryTab* T = L.etabs + (etab - 1u);
+            const uint32_t c = T->count[rank], e0 = T->first[rank];
+            const uint8_t* key = keys + key_off[t];
+            const uint32_t key_len_t = key_len[t];
+            bool found = false;
+            for (uint32_t k = 0; k < c && !found; ++k) {
+                const HamtEntryTab::Entry en = T->e[e0 + k];
+                if (en.key_len != key_len_t) continue;
+                uint64_t diff = 0;
+                for (uint32_t i = 0; i < key_len_t; i += 8u) {
+                    const uint32_t valid = key_len_t - i;
+                    uint64_t a, b = 0;
+                    __builtin_memcpy(&a, g + en.key_off + i, 8);  // (the arena has slack behind every block)
+                    if (valid >= 8u) __builtin_memcpy(&b, key + i, 8);
+                    else
+                        for (uint32_t j = 0; j < valid; ++j) b |= uint64_t(key[i + j]) << (8u * j);  // never read past the key
+                    uint64_t d = a ^ b;
+                    if (valid < 8u) d &= (1ull << (8u * valid)) - 1ull;
+                    diff |= d;
+                }
+                if (diff == 0) {
+                    found = true;
+                    hit = ValueLoc{block, en.val_off, en.val_len};
+                }
+            }
+            st = found ? uint32_t(IPCFP_ST_TRUE) : uint32_t(IPCFP_ST_NOT_FOUND);
+            break;
+        }
+        const uint32_t off = rec->ptr_off[rank];
         CidKey link;
         bool is_link = true;
         if (((rec->std_links >> rank) & 1u) && (head & (1u << 24))) {  // resolved by the parse: one word
@@ -600,12 +670,13 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
 // Scratch of one call: [cur n | hash 8n | work0 cap | work1 cap | count (levels + 1) | claimed words] u32 + the record table.
 size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels) {
     const size_t cap = n < n_blocks ? n : n_blocks;
-    return size_t(n) * 9 + cap * 2 + (levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers;
+    return size_t(n) * 9 + cap * 2 + (levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
 }
 
 int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
                            const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
-                           uint8_t* status_d, void* loc_d, uint32_t levels, uint32_t* scratch_d, void* recs_d, bool coop) {
+                           uint8_t* status_d, void* loc_d, uint32_t levels, uint32_t* scratch_d, void* recs_d, bool coop, void* etabs_d,
+                           uint32_t etab_cap) {
     if (n == 0) return IPCFP_OK;
     const uint32_t cap = n < w.n ? n : w.n;
     const uint32_t words = div_up(w.n, 32);
@@ -617,6 +688,10 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     L.count = L.work[1] + cap;
     L.claimed = L.count + (levels + 2);
     L.child = vkind == VK_ACTOR_STATE && coop ? L.claimed + words + 8 : nullptr;  // (the 32-lane parse fills it)
+    const bool tabs = L.child != nullptr && etabs_d != nullptr && etab_cap != 0;
+    L.etab_of = tabs ? L.claimed + words + 8 + size_t(w.n) * kHamtTablePointers : nullptr;
+    L.etabs = tabs ? static_cast<HamtEntryTab*>(etabs_d) : nullptr;
+    L.etab_cap = tabs ? etab_cap : 0u;
     L.recs = static_cast<HamtNodeRec*>(recs_d);
     // counters and bitmap are contiguous: one clear
     IPCFP_HIP(ctx, hipMemsetAsync(L.count, 0, (size_t(levels) + 2 + words) * 4, ctx->stream));

@@ -141,8 +141,11 @@ struct Result {
 };
 // ptr[p]: where pointer p starts; val / l2 / adr[e]: entry e's ActorState header, second link, address item
 // (max_entries: what val / l2v / adrv hold)
+// endv / klen / first_of (nullable, for the entry table of hamt_levels.hip): where entry e ends, the length of its key (the key's
+// bytes end where the ActorState starts), and for a bucket pointer p the index of its first entry.
 IPCFP_OL_FN bool outline_sequential(const uint8_t* S, uint32_t len, Result& r, uint16_t* ptr, uint16_t* val, uint16_t* l2v,
-                                    uint16_t* adrv, uint32_t max_entries = kMaxEntries) {
+                                    uint16_t* adrv, uint32_t max_entries = kMaxEntries, uint16_t* endv = nullptr, uint8_t* klen = nullptr,
+                                    uint8_t* first_of = nullptr) {
     const Header h = header(S, len);
     bool ok = h.ok;
     uint32_t pos = h.pos0, ne = 0, links = 0;
@@ -160,6 +163,7 @@ IPCFP_OL_FN bool outline_sequential(const uint8_t* S, uint32_t len, Result& r, u
             const uint32_t nkv = b - 0x80u;
             pos += 1u;
             ok = ne + nkv <= max_entries;
+            if (first_of && nkv) first_of[p] = uint8_t(ne);  // (an empty bucket has no first entry)
             for (uint32_t k = 0; ok && k < nkv; ++k) {
                 const uint64_t e0 = peek64(S, pos);
                 uint32_t q = 0;
@@ -175,6 +179,8 @@ IPCFP_OL_FN bool outline_sequential(const uint8_t* S, uint32_t len, Result& r, u
                 val[ne] = uint16_t(q);
                 l2v[ne] = uint16_t(l2);
                 adrv[ne] = uint16_t(adr);
+                if (endv) endv[ne] = uint16_t(end);
+                if (klen) klen[ne] = uint8_t(q - pos - ((uint32_t(e0 >> 8) & 0xffu) == 0x58u ? 3u : 2u));
                 ++ne;
                 pos = end;
             }
@@ -221,8 +227,10 @@ IPCFP_OL_FN uint32_t scan_anchors(const uint8_t* S, uint32_t from, uint32_t to, 
 // header `8c` + the entry's `82 key`, or — continuing the previous entry's bucket — `82 key` alone.
 //   n_ptr  pointers that START in the gap (links, empty buckets, the header);   count: c of the header, 0 = none
 //   ptr / links (nullable): the second pass writes the pointers' positions from index `first` on
+//   key_len: of the entry's key;   first_of (nullable, with ptr): first_of[p] = entry for the bucket header's pointer p
 IPCFP_OL_FN bool gap_walk(const uint8_t* S, uint32_t from, uint32_t target, uint32_t len, bool tail, bool first_gap, uint32_t& n_ptr,
-                          uint32_t& count, uint16_t* ptr, uint32_t first, uint32_t* links) {
+                          uint32_t& count, uint16_t* ptr, uint32_t first, uint32_t* links, uint32_t* key_len = nullptr,
+                          uint8_t* first_of = nullptr, uint32_t entry = 0) {
     uint32_t pos = from, n = 0;
     count = 0;
     n_ptr = 0;
@@ -259,6 +267,7 @@ IPCFP_OL_FN bool gap_walk(const uint8_t* S, uint32_t from, uint32_t target, uint
         if (header) {
             if (first + n >= kMaxPointers) return false;
             if (ptr) ptr[first + n] = uint16_t(pos);
+            if (first_of) first_of[first + n] = uint8_t(entry);
             ++n;
             count = b - 0x80u;
             pos += 1u;
@@ -269,6 +278,7 @@ IPCFP_OL_FN bool gap_walk(const uint8_t* S, uint32_t from, uint32_t target, uint
         uint32_t q = 0;
         if ((e0 & 0xffu) != 0x82u || !key_end(e0, pos, q)) return false;
         n_ptr = n;
+        if (key_len) *key_len = q - pos - ((uint32_t(e0 >> 8) & 0xffu) == 0x58u ? 3u : 2u);
         return q == target;
     }
     return false;

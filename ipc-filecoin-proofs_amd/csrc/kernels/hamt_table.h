@@ -35,4 +35,21 @@ struct HamtNodeRec {
 };
 static_assert(sizeof(HamtNodeRec) == 80, "record layout");
 
+// The bucket entries of ONE visited state-tree node (kernels/hamt_levels.hip): what the 32-lane parse knows anyway — where
+// every entry's key and ActorState lie — kept for the queries that stand on the node, so that a query's bucket search is
+// its pointer's ≤ 3 entries out of this table and one key compare each, instead of a CBOR reader walking the bucket again
+// (6.1 k instructions and 100 dependent reads per wavefront of 64 queries: profiles/r04_experiments.md).
+constexpr uint32_t kHamtTabEntries = 96;
+struct HamtEntryTab {
+    uint32_t links;                 // bit p: pointer p is a link (of any spelling) — everything else is a bucket
+    uint32_t n_entries;
+    uint8_t first[kHamtTablePointers];  // bucket pointer p: index of its first entry …
+    uint8_t count[kHamtTablePointers];  // … and how many it holds (0: a link, or an empty bucket)
+    struct Entry {
+        uint16_t key_off, val_off, val_len;  // inside the block: the key's bytes, the ActorState item
+        uint8_t key_len, pad;
+    } e[kHamtTabEntries];
+};
+static_assert(sizeof(HamtEntryTab) == 8 + 64 + 8 * kHamtTabEntries, "entry table layout");
+
 }  // namespace ipcfp

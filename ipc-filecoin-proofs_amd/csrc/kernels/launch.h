@@ -50,7 +50,9 @@ int launch_hamt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, ui
 size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels);
 int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
                            const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
-                           uint8_t* status_d, void* loc_d, uint32_t levels, uint32_t* scratch_d, void* recs_d, bool coop = true);
+                           uint8_t* status_d, void* loc_d, uint32_t levels, uint32_t* scratch_d, void* recs_d, bool coop = true,
+                           void* etabs_d = nullptr /* etab_cap × HamtEntryTab (hamt_table.h): the visited nodes' bucket entries */,
+                           uint32_t etab_cap = 0);
 
 // --- hamt_table.hip / walk.hip --- the HAMT node table of a witness (hamt_table.h) and K7 over it
 int launch_hamt_node_table(ipcfp_ctx* ctx, const uint8_t* arena, const void* k1_meta_d, uint32_t n_blocks, uint32_t kinds, void* recs_d);

@@ -30,11 +30,13 @@ struct Stage {
 extern "C" {
 
 // out: np, ne, links, bf low, bf high.  Returns 1 when the node has this outline.
-int outline_seq(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out, uint16_t* ptr, uint16_t* val, uint16_t* l2, uint16_t* adr) {
+// endv / klen / first_of: the entry table's extras (where entry e ends, its key's length, a bucket pointer's first entry)
+int outline_seq(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out, uint16_t* ptr, uint16_t* val, uint16_t* l2, uint16_t* adr,
+                uint16_t* endv, uint8_t* klen, uint8_t* first_of) {
     if (len < 3 || len + 24 > kStage) return 0;
     Stage st(node, len, seed);
     outline::Result r{0, 0, 0, 0};
-    const bool ok = outline::outline_sequential(st.bytes, len, r, ptr, val, l2, adr);
+    const bool ok = outline::outline_sequential(st.bytes, len, r, ptr, val, l2, adr, outline::kMaxEntries, endv, klen, first_of);
     out[0] = r.np;
     out[1] = r.ne;
     out[2] = r.links;
@@ -45,7 +47,7 @@ int outline_seq(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out,
 
 // the parallel outline alone (no fallback): 1 = accepted.  *n_anchors: how many `85 d8 2a` were found.
 int outline_par(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out, uint16_t* ptr, uint16_t* val, uint16_t* l2, uint16_t* adr,
-                uint32_t* n_anchors) {
+                uint32_t* n_anchors, uint16_t* endv, uint8_t* klen, uint8_t* first_of) {
     *n_anchors = 0;
     out[5] = 0;  // which check declined (bits: 1 entry, 2 gap, 4 pointer count, 8 bucket hops) — diagnostics of the tests
     if (len < 3 || len + 24 > kStage) return 0;
@@ -92,9 +94,10 @@ int outline_par(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out,
     }
     // phase 3: gaps
     for (uint32_t e = 0; e <= na; ++e) {
-        uint32_t n_ptr = 0, count = 0;
+        uint32_t n_ptr = 0, count = 0, kl = 0;
         const uint32_t f = e ? uint32_t(end[e - 1]) : hd.pos0, target = e < na ? uint32_t(val[e]) : len;
-        const bool ok = outline::gap_walk(S, f, target, len, e == na, e == 0u, n_ptr, count, nullptr, 0u, nullptr);
+        const bool ok = outline::gap_walk(S, f, target, len, e == na, e == 0u, n_ptr, count, nullptr, 0u, nullptr, &kl);
+        if (e < na) klen[e] = uint8_t(kl);
         ok_all = ok_all && ok;
         if (!ok) out[5] |= 2u;
         gn[e] = uint8_t(ok ? n_ptr : 0u);
@@ -125,8 +128,9 @@ int outline_par(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out,
     for (uint32_t e = 0; e <= na; ++e) {
         uint32_t n_ptr = 0, count = 0;
         const uint32_t f = e ? uint32_t(end[e - 1]) : hd.pos0, target = e < na ? uint32_t(val[e]) : len;
-        (void)outline::gap_walk(S, f, target, len, e == na, e == 0u, n_ptr, count, ptr, uint32_t(gb[e]), &links);
+        (void)outline::gap_walk(S, f, target, len, e == na, e == 0u, n_ptr, count, ptr, uint32_t(gb[e]), &links, nullptr, first_of, e);
     }
+    for (uint32_t e = 0; e < na; ++e) endv[e] = end[e];
     out[0] = hd.np;
     out[1] = na;
     out[2] = links;

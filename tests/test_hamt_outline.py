@@ -28,28 +28,32 @@ def harness():
     lib = C.CDLL(LIB)
     vp = C.c_void_p
     lib.outline_seq.restype = C.c_int
-    lib.outline_seq.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.outline_seq.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.outline_par.restype = C.c_int
-    lib.outline_par.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.outline_par.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
 
 
 def run(lib, node: np.ndarray, seed=1):
     def bufs():
         return (np.zeros(6, np.uint32), np.zeros(32, np.uint16), np.zeros(100, np.uint16), np.zeros(100, np.uint16),
-                np.zeros(100, np.uint16))
+                np.zeros(100, np.uint16), np.zeros(100, np.uint16), np.zeros(100, np.uint8), np.full(32, 255, np.uint8))
     node = np.ascontiguousarray(node, dtype=np.uint8)
-    so, sp, sv, s2, sa = bufs()
-    po, pp, pv, p2, pa = bufs()
+    so, sp, sv, s2, sa, se, sk, sf = bufs()
+    po, pp, pv, p2, pa, pe, pk, pf = bufs()
     na = C.c_uint32()
-    s_ok = lib.outline_seq(node.ctypes.data, len(node), seed, so.ctypes.data, sp.ctypes.data, sv.ctypes.data, s2.ctypes.data, sa.ctypes.data)
+    s_ok = lib.outline_seq(node.ctypes.data, len(node), seed, so.ctypes.data, sp.ctypes.data, sv.ctypes.data, s2.ctypes.data, sa.ctypes.data,
+                           se.ctypes.data, sk.ctypes.data, sf.ctypes.data)
     p_ok = lib.outline_par(node.ctypes.data, len(node), seed, po.ctypes.data, pp.ctypes.data, pv.ctypes.data, p2.ctypes.data, pa.ctypes.data,
-                           C.byref(na))
+                           C.byref(na), pe.ctypes.data, pk.ctypes.data, pf.ctypes.data)
 
-    def rec(o, p, v, l2, a):
+    def rec(o, p, v, l2, a, en, kl, fo):
+        # (np, ne, links, bitfield, pointer offsets, entry: ActorState / second link / address offsets; then the entry table's
+        # extras: entry ends, key lengths, each bucket pointer's first entry — 255 where the pointer is no bucket with entries)
         np_, ne = int(o[0]), int(o[1])
-        return (np_, ne, int(o[2]), int(o[3]), int(o[4]), p[:np_].tolist(), v[:ne].tolist(), l2[:ne].tolist(), a[:ne].tolist())
-    return bool(s_ok), rec(so, sp, sv, s2, sa), bool(p_ok), rec(po, pp, pv, p2, pa), int(na.value)
+        return (np_, ne, int(o[2]), int(o[3]), int(o[4]), p[:np_].tolist(), v[:ne].tolist(), l2[:ne].tolist(), a[:ne].tolist(),
+                en[:ne].tolist(), kl[:ne].tolist(), fo[:np_].tolist())
+    return bool(s_ok), rec(so, sp, sv, s2, sa, se, sk, sf), bool(p_ok), rec(po, pp, pv, p2, pa, pe, pk, pf), int(na.value)
 
 
 @pytest.fixture(scope="module")
