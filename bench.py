@@ -1308,11 +1308,11 @@ def run_hamt(args, eng, info, torch, ranks, state=None):
                                   "width 5; step = one ipcfp_hamt_get_device call (keys, statuses and locations resident in HBM, "
                                   "witness resident)%s" % (4_000_000, n, int((~present).sum()), _gather_line(world, width)),
                       "gets_per_gpu": m, "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
-           "roofline": {"bound": "hbm", "limiter": "latency", "kernel": "k_hamt_get", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
+           "roofline": {"bound": "hbm", "limiter": "latency + instruction issue", "kernel": "k_hamt_lv_start + per level k_hamt_lv_parse_actor (two instances) + k_hamt_lv_advance, k_hamt_get behind them (the K7 group: one HIP-event bracket)", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel_avg_ms": k_avg_ms, "launches": cnt, "algorithmic_bytes_per_launch": algo,
                         "value_kernel_only_gets_per_s": m / (k_avg_ms * 1e-3),
-                        "note": "0.55 KB walked per get (§8d cfg 4 (ii)); a chain of ~6 dependent node decodes per query"},
+                        "note": "0.55 KB walked per get (§8d cfg 4 (ii)); level by level: every VISITED node decoded once by 32 lanes (a visited node is decoded completely, as the reference does: the distinct nodes alone are 3.7x these bytes), a query = SHA-256 + one record per level"},
            "window": "T3"}
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         orc, march = oracle_lib.load_native()

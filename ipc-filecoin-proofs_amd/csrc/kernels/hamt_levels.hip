@@ -98,8 +98,22 @@ __device__ __forceinline__ void hamt_claim(const HamtLevels& L, uint32_t block, 
 
 __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey root, HamtLevels L, const uint8_t* __restrict__ keys,
                                                        const uint32_t* __restrict__ key_off, const uint32_t* __restrict__ key_len,
-                                                       uint32_t n, uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+                                                       uint32_t n, uint8_t* __restrict__ status, ValueLoc* __restrict__ loc,
+                                                       uint32_t n_clear /* counters + bitmap words, contiguous from L.count */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    {   // The call's counters and claim bitmap start out clear but for the root (every lane knows it: the same probe).  A
+        // hipMemsetAsync of this unaligned range is three fill kernels of the runtime, ≈ 25 µs in front of a 0.6 ms call.
+        const uint32_t rb0 = witness_find(w, root);
+        const uint32_t stride = gridDim.x * blockDim.x, n_count = uint32_t(L.claimed - L.count);
+        for (uint32_t j = t; j < n_clear; j += stride) {
+            uint32_t v = 0;
+            if (rb0 != kNoBlock) {
+                if (j == 0u) v = 1u;                                           // count[0]: the root is level 0's work list
+                else if (j == n_count + (rb0 >> 5)) v = 1u << (rb0 & 31u);    // … and claimed
+            }
+            L.count[j] = v;
+        }
+    }
     if (t >= n) return;
     uint32_t h[8];
     sha256::hash_bytes(keys + key_off[t], key_len[t], h);
@@ -110,11 +124,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey roo
     L.cur[t] = rb;
     status[t] = uint8_t(rb == kNoBlock ? uint32_t(IPCFP_ST_ERR_MISSING_BLOCK) : kStPending);
     if (loc) loc[t] = ValueLoc{kNoBlock, 0, 0};
-    if (t == 0 && rb != kNoBlock) {
-        L.claimed[rb >> 5] = 1u << (rb & 31u);  // (the bitmap was cleared before this launch)
-        L.work[0][0] = rb;
-        L.count[0] = 1u;
-    }
+    if (t == 0 && rb != kNoBlock) L.work[0][0] = rb;
 }
 
 // lane = one node of level `level`'s work list
@@ -693,11 +703,10 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     L.etabs = tabs ? static_cast<HamtEntryTab*>(etabs_d) : nullptr;
     L.etab_cap = tabs ? etab_cap : 0u;
     L.recs = static_cast<HamtNodeRec*>(recs_d);
-    // counters and bitmap are contiguous: one clear
-    IPCFP_HIP(ctx, hipMemsetAsync(L.count, 0, (size_t(levels) + 2 + words) * 4, ctx->stream));
+    // counters and bitmap are contiguous: cleared by the first launch
     ValueLoc* loc = static_cast<ValueLoc*>(loc_d);
     hipLaunchKernelGGL(k_hamt_lv_start, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, root, L, keys_d, key_off_d, key_len_d,
-                       n, status_d, loc);
+                       n, status_d, loc, levels + 2u + words);
     for (uint32_t lv = 0; lv < levels; ++lv) {
         // level l holds at most min(n, 2^(bit_width · l)) distinct nodes
         uint64_t fan = 1;
