@@ -330,13 +330,15 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     bool fast_ok = false;
     if (__ballot(wide) != 0ull) {  // (wave-uniform: a wavefront of two small nodes skips the phases altogether)
     uint32_t cnt = 0, a_from = 0, a_to = 0;
+    uint64_t packed = 0;  // the lane's first four anchors (one pass); more than four: the group scans again, writing
     if (wide && hd.ok) {
         const uint32_t span = (((len + kCoopLanes - 1u) / kCoopLanes) + 7u) & ~7u;  // a lane's share of the node, whole words
         const uint32_t scan_end = len >= 2u ? len - 2u : 0u;
         a_from = sub * span > hd.pos0 ? sub * span : hd.pos0;
         a_to = (sub + 1u) * span < scan_end ? (sub + 1u) * span : scan_end;
-        if (a_from < a_to) cnt = outline::scan_anchors<false>(S, a_from, a_to, nullptr, 0);
+        if (a_from < a_to) cnt = outline::scan_anchors_packed(S, a_from, a_to, packed);
     }
+    const bool crowded = ((__ballot(cnt > 4u) >> (g * kCoopLanes)) & 0xffffffffull) != 0ull;
     uint32_t incl = cnt;
 #pragma unroll
     for (uint32_t d = 1; d < kCoopLanes; d <<= 1) {
@@ -345,7 +347,11 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     }
     const uint32_t na = __shfl(incl, kCoopLanes - 1u, kCoopLanes);  // anchors of the node
     const bool fast = wide && hd.ok && na <= kCoopMaxEntries;
-    if (fast && cnt) (void)outline::scan_anchors<true>(S, a_from, a_to, s_val[g] + (incl - cnt), cnt);
+    if (fast && cnt) {
+        if (crowded) (void)outline::scan_anchors<true>(S, a_from, a_to, s_val[g] + (incl - cnt), cnt);
+        else
+            for (uint32_t k = 0; k < cnt; ++k) s_val[g][incl - cnt + k] = uint16_t(packed >> (16u * k));
+    }
     __syncthreads();
     bool okl = true;
     // Every anchored entry forward to its end.  An anchor that does not parse is DROPPED, not held against the node: the
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     }
     __syncthreads();
     if (fast) {  // pointer numbers: a running sum over the gaps; the buckets' counts must hop from header to header
-        uint32_t carry = 0, headers = 0;
+        uint32_t carry = 0;
         for (uint32_t r = 0; r * kCoopLanes <= ne_kept; ++r) {
             const uint32_t e = r * kCoopLanes + sub;
             const uint32_t v = e <= ne_kept ? uint32_t(s_gn[g][e]) : 0u;
@@ -399,20 +405,9 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
             }
             if (e <= ne_kept) s_gb[g][e] = uint8_t(carry + run - v);
             carry += __shfl(run, kCoopLanes - 1u, kCoopLanes);
-            const uint64_t hb = __ballot(e < ne_kept && s_gc[g][e] != 0u);
-            headers += uint32_t(__popcll((hb >> (g * kCoopLanes)) & 0xffffffffull));
         }
         okl = okl && carry == hd.np;
-        if (sub == 0) {
-            uint32_t e = 0, hops = 0;
-            while (e < ne_kept && hops <= outline::kMaxPointers) {
-                const uint32_t c = s_gc[g][e];
-                if (!c) break;
-                e += c;
-                ++hops;
-            }
-            okl = okl && e == ne_kept && hops == headers;
-        }
+        for (uint32_t e = sub; e < ne_kept; e += kCoopLanes) okl = okl && outline::bucket_spans(s_gc[g], e, ne_kept);
     }
     __syncthreads();
     if (fast) {  // the same walk again, now writing where every pointer starts
@@ -420,8 +415,14 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         for (uint32_t e = sub; e <= ne_kept; e += kCoopLanes) {
             uint32_t n_ptr = 0, count = 0;
             const uint32_t from = e ? uint32_t(s_end[g][e - 1u]) : hd.pos0, target = e < ne_kept ? uint32_t(s_val[g][e]) : len;
-            (void)outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, s_ptr[g], uint32_t(s_gb[g][e]), &lm, nullptr,
-                                    s_first[g], e);
+            const uint32_t gn = s_gn[g][e], gb = s_gb[g][e];
+            if (gn == 0u) continue;
+            if (gn == 1u && s_gc[g][e] != 0u && gb < kHamtTablePointers) {  // the gap's one pointer is the bucket's header, at its start
+                s_ptr[g][gb] = uint16_t(from);
+                s_first[g][gb] = uint8_t(e);
+                continue;
+            }
+            (void)outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, s_ptr[g], gb, &lm, nullptr, s_first[g], e);
         }
         if (lm) atomicOr(&s_links[g], lm);
     }

@@ -222,6 +222,42 @@ IPCFP_OL_FN uint32_t scan_anchors(const uint8_t* S, uint32_t from, uint32_t to, 
     return n;
 }
 
+// One pass: the lane's first FOUR anchors packed 16 bits apiece (a lane's share of a node holds two or three entries), the
+// count of all of them returned — a lane that meets more makes its group take the two-pass form above.
+IPCFP_OL_FN uint32_t scan_anchors_packed(const uint8_t* S, uint32_t from, uint32_t to, uint64_t& packed) {
+    uint32_t n = 0;
+    packed = 0;
+    for (uint32_t p = from & ~7u; p < to; p += 8u) {
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(S + p);
+        const uint64_t x = q[0], y = q[1];
+        const uint64_t z = x ^ 0x8585858585858585ull;
+        uint64_t m = ~(((z & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | z | 0x7f7f7f7f7f7f7f7full);
+        while (m) {
+            const uint32_t k = uint32_t(__builtin_ctzll(m)) >> 3;
+            m &= m - 1ull;
+            const uint32_t at = p + k;
+            if (at < from || at >= to) continue;
+            const uint64_t next = k == 7u ? y : ((x >> (8u * (k + 1u))) | ((y << 1) << (55u - 8u * k)));
+            if ((next & 0xffffull) != 0x2ad8ull) continue;
+            if (n < 4u) packed |= uint64_t(at) << (16u * n);
+            ++n;
+        }
+    }
+    return n;
+}
+
+// The buckets' counts must hop from header to header: entry e opens a bucket of c = gc[e] entries, so the c - 1 entries
+// behind it open none and the one behind those does (or the entries end there).  Checked for every header by itself, this
+// is the walk `e = 0; while (e < ne) e += gc[e]` landing on every header and on ne (entry 0 always opens a bucket: gap_walk).
+IPCFP_OL_FN bool bucket_spans(const uint8_t* gc, uint32_t e, uint32_t ne) {
+    const uint32_t c = gc[e];
+    if (!c) return true;
+    if (e + c > ne) return false;
+    for (uint32_t j = 1; j < c; ++j)
+        if (gc[e + j]) return false;
+    return e + c == ne || gc[e + c] != 0;
+}
+
 // The gap in front of entry e — from `from` (the previous entry's end, or the first pointer) to the entry's anchor — or, with
 // tail, behind the last entry up to the end of the node: link pointers and empty buckets, then (not tail) either a bucket
 // header `8c` + the entry's `82 key`, or — continuing the previous entry's bucket — `82 key` alone.

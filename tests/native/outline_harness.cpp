@@ -59,10 +59,14 @@ int outline_par(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out,
     const uint32_t span = (((len + kLanes - 1u) / kLanes) + 7u) & ~7u;
     const uint32_t scan_end = len >= 2u ? len - 2u : 0u;
     uint32_t cnt[kLanes], from[kLanes], to[kLanes], na = 0;
+    uint64_t packed[kLanes];
+    bool crowded = false;  // (a lane with more than four anchors: the group scans again, writing)
     for (uint32_t sub = 0; sub < kLanes; ++sub) {
         from[sub] = sub * span > hd.pos0 ? sub * span : hd.pos0;
         to[sub] = (sub + 1u) * span < scan_end ? (sub + 1u) * span : scan_end;
-        cnt[sub] = from[sub] < to[sub] ? outline::scan_anchors<false>(S, from[sub], to[sub], nullptr, 0) : 0u;
+        packed[sub] = 0;
+        cnt[sub] = from[sub] < to[sub] ? outline::scan_anchors_packed(S, from[sub], to[sub], packed[sub]) : 0u;
+        crowded = crowded || cnt[sub] > 4u;
         na += cnt[sub];
     }
     *n_anchors = na;
@@ -72,7 +76,9 @@ int outline_par(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out,
     {
         uint32_t at = 0;
         for (uint32_t sub = 0; sub < kLanes; ++sub) {
-            if (cnt[sub]) (void)outline::scan_anchors<true>(S, from[sub], to[sub], val + at, cnt[sub]);
+            if (cnt[sub] && crowded) (void)outline::scan_anchors<true>(S, from[sub], to[sub], val + at, cnt[sub]);
+            else
+                for (uint32_t k = 0; k < cnt[sub]; ++k) val[at + k] = uint16_t(packed[sub] >> (16u * k));
             at += cnt[sub];
         }
     }
@@ -104,30 +110,29 @@ int outline_par(const uint8_t* node, uint32_t len, uint32_t seed, uint32_t* out,
         gc[e] = uint8_t(ok ? count : 0u);
     }
     // phase 4: pointer numbers, bucket hops
-    uint32_t carry = 0, headers = 0;
+    uint32_t carry = 0;
     for (uint32_t e = 0; e <= na; ++e) {
         gb[e] = uint8_t(carry);
         carry += gn[e];
-        if (e < na && gc[e]) ++headers;
     }
     ok_all = ok_all && carry == hd.np;
     if (carry != hd.np) out[5] |= 4u;
-    {
-        uint32_t e = 0, hops = 0;
-        while (e < na && hops <= outline::kMaxPointers) {
-            const uint32_t c = gc[e];
-            if (!c) break;
-            e += c;
-            ++hops;
+    for (uint32_t e = 0; e < na; ++e)
+        if (!outline::bucket_spans(gc, e, na)) {
+            ok_all = false;
+            out[5] |= 8u;
         }
-        ok_all = ok_all && e == na && hops == headers;
-        if (!(e == na && hops == headers)) out[5] |= 8u;
-    }
     // phase 5: pointer positions
     uint32_t links = 0;
     for (uint32_t e = 0; e <= na; ++e) {
         uint32_t n_ptr = 0, count = 0;
         const uint32_t f = e ? uint32_t(end[e - 1]) : hd.pos0, target = e < na ? uint32_t(val[e]) : len;
+        if (gn[e] == 0) continue;
+        if (gn[e] == 1 && gc[e] != 0 && gb[e] < outline::kMaxPointers) {  // (the kernel's shortcut: the gap's one pointer is the header at its start)
+            ptr[gb[e]] = uint16_t(f);
+            first_of[gb[e]] = uint8_t(e);
+            continue;
+        }
         (void)outline::gap_walk(S, f, target, len, e == na, e == 0u, n_ptr, count, ptr, uint32_t(gb[e]), &links, nullptr, first_of, e);
     }
     for (uint32_t e = 0; e < na; ++e) endv[e] = end[e];
