@@ -158,19 +158,31 @@ impl Engine {
         anyhow!("{what}: {rc} {msg}")
     }
 
-    /// replaces `load_witness_store(blocks)` (src/proofs/events/verifier.rs:79-89, src/proofs/storage/verifier.rs:68-78)
+    /// replaces `load_witness_store(blocks)` (src/proofs/events/verifier.rs:79-89, src/proofs/storage/verifier.rs:68-78).
+    /// The blocks are laid back to back as they come, so the tables cross PCIe in transport form
+    /// (`ipcfp_witness_create_packed`): lengths instead of offsets, 32-byte digests + the chain's CID prefix instead of
+    /// 40-byte slots, and the few CIDs of another form as escapes.
     pub fn load_witness_store(&self, blocks: &[ProofBlock]) -> Result<Witness<'_>> {
-        let (mut bytes, mut off, mut len, mut cids) = (Vec::new(), Vec::new(), Vec::new(), Vec::new());
-        for b in blocks {
-            off.push(bytes.len() as u64);
+        const STD: [u8; 6] = [0x01, 0x71, 0xa0, 0xe4, 0x02, 0x20];  // CIDv1, dag-cbor, blake2b-256, 32-byte digest
+        let (mut bytes, mut len, mut digests) = (Vec::new(), Vec::new(), Vec::new());
+        let (mut esc_index, mut esc_cids) = (Vec::<u32>::new(), Vec::<u8>::new());
+        for (i, b) in blocks.iter().enumerate() {
             len.push(u32::try_from(b.data.len())?);
             bytes.extend_from_slice(&b.data);
-            cids.extend_from_slice(&cid_slot(&b.cid)?);
+            let slot = cid_slot(&b.cid)?;
+            if slot[..6] == STD && slot[38..] == [0, 0] {
+                digests.extend_from_slice(&slot[6..38]);
+            } else {
+                digests.extend_from_slice(&[0u8; 32]);
+                esc_index.push(i as u32);
+                esc_cids.extend_from_slice(&slot);
+            }
         }
         let mut w = std::ptr::null_mut();
-        let rc = unsafe { ipcfp_witness_create(self.ctx, bytes.as_ptr(), bytes.len() as u64, off.as_ptr(), len.as_ptr(),
-                                               cids.as_ptr(), blocks.len() as u64, &mut w) };
-        if rc != 0 { return Err(self.err("ipcfp_witness_create", rc)); }
+        let rc = unsafe { ipcfp_witness_create_packed(self.ctx, bytes.as_ptr(), bytes.len() as u64, len.as_ptr(), digests.as_ptr(),
+                                                      blocks.len() as u64, STD.as_ptr(), STD.len() as u32, esc_index.as_ptr(),
+                                                      esc_cids.as_ptr(), esc_index.len() as u64, &mut w) };
+        if rc != 0 { return Err(self.err("ipcfp_witness_create_packed", rc)); }
         Ok(Witness { eng: self, w: RefCell::new(w) })
     }
 
