@@ -961,16 +961,19 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev, ranks):
     # ---- window T2 of the cut: every rank uploads ITS shard from host memory at the same time (barrier first) ----
     t2_ms, h2d_bytes = None, None
     if args.t2_reps > 0:
-        h2d_bytes = int(sub[0].size + sub[1].nbytes + sub[2].nbytes + sub[3].nbytes + sh.claims.nbytes + sh.blob_len)
+        # (the shard's tables and claims in transport form, like the unsharded T2: built once, untimed)
+        pk_r = ipcfp.PackedWitnessTables(*sub)
+        g_r, cc_r, cb_r, cbl_r = ipcfp.compact_event_claims(sh.claims, sh.blob, sh.blob_len)
+        h2d_bytes = int(pk_r.h2d_bytes + g_r.nbytes + cc_r.nbytes + cbl_r)
         own = merged["status"][sh.positions.astype(np.int64)]
         reps = []
         for _ in range(args.t2_reps + 1):
             fence()
             t0 = time.perf_counter()
-            w2 = eng.witness(*sub)
+            w2 = eng.witness_packed(pk_r)
             w2.set_receipt_range(sh.lo, sh.hi)
             w2.verify_cids_async()
-            st2 = w2.verify_event_claims(ts, sh.claims, sh.blob, sh.blob_len)
+            st2 = w2.verify_event_claims_compact(ts, g_r, cc_r, cb_r, cbl_r)
             sst, has2, m2, _ = w2.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
                                               want_touched=False, caps=(sh.hi - sh.lo, MATCH_CAP))
             cs2, nbad2 = w2.cid_results()
