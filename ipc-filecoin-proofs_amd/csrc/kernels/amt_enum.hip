@@ -18,6 +18,10 @@ __device__ __forceinline__ void enum_error(unsigned long long* err, uint32_t seq
     atomicMin(err, (unsigned long long)pack_enum_error(seq, base, code));
 }
 
+// Amt::load of a root whose node is the canonical DENSE link node (defined behind the dense walk's helpers, below): TRUE with
+// `info` filled, or "not this shape" — the item-by-item amt_load then decides (and is the only one to report an error).
+__device__ __forceinline__ bool amt_load_dense_root(const WitnessView& w, const CidKey& root, int version, AmtRootInfo& info);
+
 // one root → its frontier entry and its shape {height | bw << 32, count} (~0: the root did not load)
 __device__ __forceinline__ void enum_root_one(const WitnessView& w, const AmtRootSpec& spec, int vkind, EnumNode* __restrict__ slot,
                                               uint32_t* __restrict__ max_height, unsigned long long* __restrict__ err,
@@ -28,7 +32,9 @@ __device__ __forceinline__ void enum_root_one(const WitnessView& w, const AmtRoo
     info1 = 0;
     if (!spec.skip) {
         AmtRootInfo info;
-        const uint32_t st = amt_load(w, spec.root, int(spec.version), spec.kind_p1 ? int(spec.kind_p1) - 1 : vkind, info);
+        const uint32_t st = amt_load_dense_root(w, spec.root, int(spec.version), info)
+                                ? uint32_t(IPCFP_ST_TRUE)
+                                : amt_load(w, spec.root, int(spec.version), spec.kind_p1 ? int(spec.kind_p1) - 1 : vkind, info);
         if (st != IPCFP_ST_TRUE) {
             if (!spec.kind_p1) enum_error(err, spec.seq, 0, st);  // (the extra root: left to its own enumeration)
         } else {
@@ -409,6 +415,79 @@ __device__ __forceinline__ CidKey std_link_key(const uint8_t* p) {
     for (int j = 0; j < 5; ++j) k.w[j] = load_u64_any(p + 5 + 8 * j);
     k.w[4] &= (1ull << 48) - 1ull;  // 38 = 4·8 + 6 bytes
     return k;
+}
+
+// The root block of a big list — `83 | height | count | node` (Amtv0) or `84 | bit width | height | count | node` (Amt) with
+// the node a canonical dense LINK node: `83 | 4x bitmap = low m bits | 8m / 98 m | m standard 43-byte links | 80` and nothing
+// behind it — settled from a dozen loads that do not depend on each other.  Exactly what amt_load accepts for these bytes
+// (array heads, minimal uints, bitmap of the width's length whose popcount is the link count, well-formed links, no values,
+// nothing after the node, height ≤ 64 / bit width); any other spelling or shape returns false and amt_load takes the block.
+// Item by item the ten message-list roots and the receipts root of a tipset were 3.7 k instructions of ONE wavefront at
+// 30-50 cycles each beside the side streams: 79 µs on the verify call's critical path (profiles/r04_final_timeline.txt).
+__device__ __forceinline__ bool amt_load_dense_root(const WitnessView& w, const CidKey& root, int version, AmtRootInfo& info) {
+    const uint32_t b = witness_find(w, root);
+    if (b == kNoBlock) return false;
+    const uint8_t* p = w.arena + w.off[b];
+    const uint32_t len = w.len[b];
+    if (len < 8u) return false;
+    const uint64_t g0 = load_u64_any(p), g1 = load_u64_any(p + 8);  // (blocks sit on 128-byte lines with tail slack)
+    auto byte_at = [&](uint32_t i) { return uint32_t((i < 8u ? g0 >> (8u * i) : g1 >> (8u * (i - 8u))) & 0xffull); };
+    uint32_t pos = 1, bw = 3;
+    if (version == 0) {
+        if (byte_at(0) != 0x83u) return false;
+    } else {
+        if (byte_at(0) != 0x84u) return false;
+        bw = byte_at(1);
+        if (bw < 1u || bw > 6u) return false;  // (an immediate uint; the dense walk spells headers up to width 6)
+        pos = 2;
+    }
+    const uint32_t height = byte_at(pos);
+    if (height < 1u || height > 23u || height > 64u / bw) return false;  // immediate uint; a link node at the root
+    ++pos;
+    // count: a minimal unsigned integer
+    const uint32_t cb = byte_at(pos);
+    uint64_t count;
+    uint32_t cl;
+    if (cb < 0x18u) {
+        count = cb;
+        cl = 1;
+    } else if (cb == 0x18u) {
+        count = byte_at(pos + 1);
+        cl = 2;
+        if (count < 24u) return false;
+    } else if (cb == 0x19u) {
+        count = (uint64_t(byte_at(pos + 1)) << 8) | byte_at(pos + 2);
+        cl = 3;
+        if (count < 256u) return false;
+    } else if (cb == 0x1au) {
+        count = (uint64_t(byte_at(pos + 1)) << 24) | (uint64_t(byte_at(pos + 2)) << 16) | (uint64_t(byte_at(pos + 3)) << 8) | byte_at(pos + 4);
+        cl = 5;
+        if (count < 65536u) return false;
+    } else {
+        return false;  // (≥ 2^32 entries, or not an unsigned integer: the long way)
+    }
+    pos += cl;
+    if (pos > 8u) return false;  // (cannot happen: 2 + 1 + 5)
+    const uint32_t W = 1u << bw;
+    const uint64_t span = amt_span(bw, height);  // indices under one link of the root
+    if (count == 0 || span == ~0ULL) return false;
+    const uint64_t m64 = (count + span - 1) / span;
+    if (m64 > W) return false;  // (more entries than the height holds: not a dense tree)
+    const uint32_t m = uint32_t(m64);
+    uint64_t h0, h1;
+    const uint32_t hdr = dense_header(W, m, false, h0, h1);
+    const uint8_t* node = p + pos;
+    const uint32_t end = pos + hdr + 43u * m + 1u;  // … links, then the empty values array
+    if (hdr == 0 || end != len || !header_matches(node, hdr, h0, h1)) return false;
+    bool ok = node[hdr + 43u * m] == 0x80u;
+    for (uint32_t i = 0; i < m; ++i) ok = ok && std_link_at(node + hdr + 43u * i);
+    if (!ok) return false;
+    info.block = b;
+    info.node_off = pos;
+    info.bit_width = bw;
+    info.height = height;
+    info.count = count;
+    return true;
 }
 
 // which root does frontier entry j of `level` belong to (dense trees side by side), and where do its entries start?
