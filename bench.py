@@ -336,7 +336,10 @@ def main():
                        "witness tables and claims in TRANSPORT form (ipcfp_witness_create_packed: block lengths + 32-byte digests + one CID "
                        "prefix, offsets and 40-byte slots rebuilt on the device; ipcfp_verify_event_claims_compact: 56-byte claim records + "
                        "unframed topics, expanded on the device); calls in the order of the resident step (K, V, S); uploads are the runtime's "
-                       "blocking copies (56 GB/s measured, tools/ubench/h2d_paths), the claims cross beside the verify call's AMT walk")
+                       "blocking copies (56 GB/s measured, tools/ubench/h2d_paths), the claims cross beside the verify call's AMT walk; "
+                       "verify and scan are separate calls here and the context remembers the last scan's filter (ctx scan hint), so the "
+                       "verify call counts this filter's matches while it tabulates the events: a first-contact bundle scanned with ANOTHER "
+                       "filter pays one more counting pass over the event records (k_count_from_table, ~27 us; INTEGRATION.md §4)")
         t2["plain_forms"] = t2_window(False, plain_bytes,
                                       "the same pass with the full tables (off[], 40-byte CID slots) and ipcfp_event_claim_t + framed blob: "
                                       "round 3's T2")
