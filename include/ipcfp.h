@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define IPCFP_ABI_VERSION 1
+/* Bumped whenever the layout of a public struct or the meaning of an argument changes; a binding compares it with
+ * ipcfp_abi_version() before its first call.  2: IPCFP_MAX_PARENTS 16 -> 32 (sizeof(ipcfp_tipset_ref_t) 648 -> 1288). */
+#define IPCFP_ABI_VERSION 2
 
 /* ---- return codes ------------------------------------------------------- */
 #define IPCFP_OK 0

@@ -12,6 +12,7 @@ from typing import Optional
 import numpy as np
 
 __all__ = [
+    "ABI_VERSION",
     "Engine",
     "EventProofSpec",
     "STORAGE_SPEC_DTYPE",
@@ -131,6 +132,7 @@ CLAIM_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), (
                         ("tipset", np.uint32), ("flags", np.uint32), ("n_topics", np.uint32),
                         ("topics_off", np.uint32), ("data_off", np.uint32), ("data_len", np.uint32)])
 # event claims in transport form (include/ipcfp.h ipcfp_event_claim_compact_t / ipcfp_event_claim_group_t)
+ABI_VERSION = 2  # == IPCFP_ABI_VERSION of include/ipcfp.h (tests/test_abi_symbols.py holds the three together)
 COMPACT_DTYPE = np.dtype([("emitter", np.uint64), ("exec_index", np.uint32), ("event_index", np.uint32),
                           ("message_digest", np.uint8, (32,)), ("data_len", np.uint16), ("n_topics", np.uint8),
                           ("topic_flags", np.uint8), ("flags", np.uint8), ("group", np.uint8), ("reserved", np.uint16)])
@@ -189,6 +191,9 @@ def load_library() -> C.CDLL:
     except OSError as e:  # pragma: no cover - depends on the box
         raise EngineError(f"cannot load {path}: {e}") from e
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    lib.ipcfp_abi_version.restype = i32
+    if lib.ipcfp_abi_version() != ABI_VERSION:  # struct layouts below would be strided wrongly
+        raise EngineError(f"{path} speaks ABI {lib.ipcfp_abi_version()}, this binding ABI {ABI_VERSION}: rebuild the library")
     sigs = {
         "ipcfp_abi_version": (i32, []),
         "ipcfp_strerror": (C.c_char_p, [i32]),

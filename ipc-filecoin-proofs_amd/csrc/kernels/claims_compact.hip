@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_compact_sizes(const ClaimCompact* __res
 __global__ __launch_bounds__(256) void k_compact_expand(const ClaimCompact* __restrict__ cc, uint32_t n, ClaimGroups groups,
                                                         const uint8_t* __restrict__ cblob, uint64_t cblob_len,
                                                         const uint32_t* __restrict__ coff, const uint32_t* __restrict__ poff,
+                                                        const uint64_t* __restrict__ total_c, const uint64_t* __restrict__ total_p,
                                                         EventClaimPacked* __restrict__ out, uint8_t* __restrict__ blob_out,
                                                         uint64_t cap_blob) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,8 +51,13 @@ __global__ __launch_bounds__(256) void k_compact_expand(const ClaimCompact* __re
     const ClaimCompact c = cc[i];
     const uint32_t nt = c.n_topics, dl = c.data_len;
     const uint32_t co = coff[i], po = poff[i];
-    const bool ok = nt <= IPCFP_COMPACT_MAX_TOPICS && c.group < groups.n && uint64_t(co) + 32u * nt + dl <= cblob_len &&
-                    uint64_t(po) + 33u * nt + dl <= cap_blob;
+    // The offsets are 32-bit prefix sums of sizes an untrusted record declares (up to 8 * 33 + 65 535 bytes each): once
+    // the 64-bit totals pass 2^32 they have wrapped somewhere, a wrapped offset can pass the range checks below and two
+    // records would move bytes into one segment.  Nobody can then say which records still own theirs: all of them are
+    // ERR_BAD_CLAIM.  Below 2^32 nothing wrapped and the per-record checks are exact.
+    const bool wrapped = (*total_c >> 32) != 0 || (*total_p >> 32) != 0;
+    const bool ok = !wrapped && nt <= IPCFP_COMPACT_MAX_TOPICS && c.group < groups.n &&
+                    uint64_t(co) + 32u * nt + dl <= cblob_len && uint64_t(po) + 33u * nt + dl <= cap_blob;
     EventClaimPacked p;
     p.parent_epoch = ok ? groups.table[c.group].parent_epoch : 0;
     p.child_epoch = ok ? groups.table[c.group].child_epoch : 0;
@@ -106,7 +112,7 @@ int launch_expand_claims(ipcfp_ctx* ctx, const void* compact_d, uint32_t n, cons
     rc = launch_scan_u32(ctx, psize, n, poff, total_p, scan_scratch);
     if (rc) return rc;
     hipLaunchKernelGGL(k_compact_expand, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, cc, n, ClaimGroups{groups_d, n_groups}, cblob_d,
-                       cblob_len, coff, poff, static_cast<EventClaimPacked*>(claims_out_d), blob_out_d, cap_blob);
+                       cblob_len, coff, poff, total_c, total_p, static_cast<EventClaimPacked*>(claims_out_d), blob_out_d, cap_blob);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

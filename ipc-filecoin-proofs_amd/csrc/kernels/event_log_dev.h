@@ -114,9 +114,18 @@ __device__ __forceinline__ bool decode_event_head_fast(Rd& r, uint64_t& emitter,
 
 // Decode one StampedEvent `[emitter, [[flags, key, codec, value]…]]` located at r (already
 // type-checked by the AMT walk) and extract the EVM log view.  Offsets are relative to r.p.
+//
+// The last occurrence of each of the seven keys is kept as SCALARS (an offset and a length per key, a bit per key in
+// `have`) and every update is a select on a scalar.  Round 1-4 kept them as seven {off, len, present} structs updated by
+// `slot = is_key ? v : slot`: hipcc turns a select between two structs into a load from a SELECTED ADDRESS, so all seven
+// lived in scratch memory and every entry of every event cost 14 scratch loads and 7 scratch stores, each behind its
+// own s_waitcnt vmcnt(0) — the "121 load instructions per wavefront" and the 45 % of wave cycles spent waiting that
+// profiles/r04_final_pmc.txt shows for k_block_events were mostly these, not the reader's line refills.
 __device__ __forceinline__ void decode_event_log(Rd& r, uint64_t& emitter, EvmLogLoc& log) {
-    ByteRange topics{0, 0, false}, data{0, 0, false}, d{0, 0, false};
-    ByteRange t[4] = {{0, 0, false}, {0, 0, false}, {0, 0, false}, {0, 0, false}};
+    // key slots: 0..3 = "t1".."t4", 4 = "d", 5 = "data", 6 = "topics"
+    uint32_t have = 0;
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o_d = 0, o_data = 0, o_topics = 0;
+    uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0, l_d = 0, l_data = 0, l_topics = 0;
     uint64_t ne;
     if (!decode_event_head_fast(r, emitter, ne)) {
         r.expect_array(2);
@@ -136,17 +145,27 @@ __device__ __forceinline__ void decode_event_log(Rd& r, uint64_t& emitter, EvmLo
         // keys that matter are at most 6 bytes: ONE fetch, compared as little-endian words; every outcome is a
         // select (the lanes of a wavefront sit on different keys: a branch per key would run them all)
         const uint64_t kw = kl <= 6 ? (r.peek64(ko) & ((1ull << (8u * (kl & 7u))) - 1ull)) : 0ull;
-        const ByteRange v{vo, vl, true};
+        const uint32_t digit = uint32_t(kw >> 8) & 0xffu;
         const bool is_d = kl == 1 && kw == 0x64ull;                                   // "d"
         const bool is_data = kl == 4 && kw == 0x61746164ull;                          // "data"
         const bool is_topics = kl == 6 && kw == 0x736369706f74ull;                    // "topics"
-        const uint32_t digit = uint32_t(kw >> 8) & 0xffu;
         const bool is_t = kl == 2 && (kw & 0xffull) == 0x74ull && digit >= '1' && digit <= '4';  // "t1".."t4"
-        d = is_d ? v : d;
-        data = is_data ? v : data;
-        topics = is_topics ? v : topics;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = (is_t && digit == uint32_t('1' + q)) ? v : t[q];
+        const uint32_t bit = is_t ? (1u << ((digit - uint32_t('1')) & 3u)) : (is_d ? 16u : (is_data ? 32u : (is_topics ? 64u : 0u)));
+        have |= bit;
+        o0 = (bit & 1u) ? vo : o0;
+        l0 = (bit & 1u) ? vl : l0;
+        o1 = (bit & 2u) ? vo : o1;
+        l1 = (bit & 2u) ? vl : l1;
+        o2 = (bit & 4u) ? vo : o2;
+        l2 = (bit & 4u) ? vl : l2;
+        o3 = (bit & 8u) ? vo : o3;
+        l3 = (bit & 8u) ? vl : l3;
+        o_d = (bit & 16u) ? vo : o_d;
+        l_d = (bit & 16u) ? vl : l_d;
+        o_data = (bit & 32u) ? vo : o_data;
+        l_data = (bit & 32u) ? vl : l_data;
+        o_topics = (bit & 64u) ? vo : o_topics;
+        l_topics = (bit & 64u) ? vl : l_topics;
     }
     log.is_log = false;
     log.case_a = false;
@@ -155,30 +174,30 @@ __device__ __forceinline__ void decode_event_log(Rd& r, uint64_t& emitter, EvmLo
 #pragma unroll
     for (int q = 0; q < 4; ++q) log.topic_off[q] = 0;
     if (!r.ok()) return;
-    if (topics.present) {  // Case A (evm.rs:19-30): wins whenever the key exists, even when empty
-        if (topics.len % 32u != 0) return;
+    if (have & 64u) {  // Case A (evm.rs:19-30): wins whenever the key exists, even when empty
+        if (l_topics % 32u != 0) return;
         log.is_log = true;
         log.case_a = true;
-        log.n_topics = topics.len / 32u;
-        log.topic_off[0] = topics.off;
-        if (data.present) log.data = data;
+        log.n_topics = l_topics / 32u;
+        log.topic_off[0] = o_topics;
+        if (have & 32u) log.data = ByteRange{o_data, l_data, true};
         return;
     }
-    // Case B (evm.rs:32-58): t1, t2, … until the first missing one; every present one must be 32 bytes
-    uint32_t n = 0;
-    bool bad = false, stop = false;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (!stop) {
-            if (!t[q].present) stop = true;
-            else if (t[q].len != 32) { bad = true; stop = true; }
-            else { log.topic_off[q] = t[q].off; n = uint32_t(q) + 1; }
-        }
-    }
-    if (bad || n == 0) return;
+    // Case B (evm.rs:32-58): t1, t2, … until the first missing one; every present one must be 32 bytes.
+    // g_q: t(q+1) is there with 32 bytes.  n = the run of good ones from t1; the key that ends the run spoils the log
+    // when it is there (then its length is wrong), and ends it quietly when it is missing.
+    const bool g0 = (have & 1u) && l0 == 32u, g1 = (have & 2u) && l1 == 32u, g2 = (have & 4u) && l2 == 32u,
+               g3 = (have & 8u) && l3 == 32u;
+    const uint32_t n = !g0 ? 0u : (!g1 ? 1u : (!g2 ? 2u : (!g3 ? 3u : 4u)));
+    const bool bad = n < 4u && ((have >> n) & 1u) != 0u;
+    if (bad || n == 0u) return;
     log.is_log = true;
     log.n_topics = n;
-    if (d.present) log.data = d;
+    log.topic_off[0] = o0;
+    log.topic_off[1] = n > 1u ? o1 : 0u;
+    log.topic_off[2] = n > 2u ? o2 : 0u;
+    log.topic_off[3] = n > 3u ? o3 : 0u;
+    if (have & 16u) log.data = ByteRange{o_d, l_d, true};
 }
 
 __device__ __forceinline__ bool bytes32_equal(const uint8_t* a, const uint8_t* b) {

@@ -27,7 +27,9 @@ def test_library_exports_every_declared_symbol():
     lib = ipcfp.load_library()
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in ipcfp.h but not exported by libipcfp.so: {missing}"
-    assert lib.ipcfp_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "ipcfp.h")).read()
+    declared = int(re.search(r"#define IPCFP_ABI_VERSION (\d+)", header).group(1))
+    assert lib.ipcfp_abi_version() == declared == ipcfp.ABI_VERSION
 
 
 def test_no_cpu_fallback_without_gpu():

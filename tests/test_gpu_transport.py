@@ -139,6 +139,42 @@ def test_device_expansion_is_byte_exact(engine, packed_claims):
     assert out["tipset"][5] == out["tipset"][9] == 0xFFFFFFFF and out["n_topics"][9] == 0 and (out["tipset"][:5] == 0).all()
 
 
+def test_device_expansion_with_sizes_that_wrap_32_bits(engine, packed_claims):
+    """70 000 records that each DECLARE 65 535 data bytes add up to 4.6 GB — the 32-bit offsets wrap, and a
+    wrapped offset would pass the range checks against a 1 MB blob.  Every record must come out ERR_BAD_CLAIM
+    (tipset 0xffffffff, nothing moved), and nothing may be written outside the output blob."""
+    ts, cl, blob, blob_len = packed_claims
+    groups, cc, cblob, cblob_len = ipcfp.compact_event_claims(cl, blob, blob_len)
+    n = 70_000
+    liar = np.zeros(n, dtype=ipcfp.COMPACT_DTYPE)
+    liar[:] = cc[0]
+    liar["n_topics"] = 0
+    liar["data_len"] = 65535
+    assert n * 65535 > 2**32
+    small = np.full(1 << 20, 0xAB, dtype=np.uint8)
+    d_cc, d_cb = dev(liar), dev(small)
+    cap = 1 << 20
+    guard = 4096
+    d_out = torch.zeros(n * ipcfp.CLAIM_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    d_blob = torch.full((cap + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    engine.expand_event_claims_device(groups, d_cc.data_ptr(), n, d_cb.data_ptr(), len(small), d_out.data_ptr(), d_blob.data_ptr(), cap)
+    out = d_out.cpu().numpy().view(ipcfp.CLAIM_DTYPE)
+    assert (out["tipset"] == 0xFFFFFFFF).all() and (out["data_len"] == 0).all()
+    assert (d_blob.cpu().numpy() == 0x5A).all()
+    # just under the wrap (65 000 such records = 4.26e9 < 2^32 … no: still above 4 GiB? 65 000 * 65 535 = 4 259 775 000 < 4 294 967 296):
+    # nothing wrapped, the per-record range check decides — the first 16 records fit the 1 MB blob, the rest do not
+    m = 65_000
+    assert m * 65535 < 2**32
+    d_out.zero_()
+    engine.expand_event_claims_device(groups, d_cc.data_ptr(), m, d_cb.data_ptr(), len(small), d_out.data_ptr(), d_blob.data_ptr(), cap)
+    out = d_out.cpu().numpy().view(ipcfp.CLAIM_DTYPE)[:m]
+    fit = (1 << 20) // 65535
+    assert (out["tipset"][:fit] == 0).all() and (out["tipset"][fit:] == 0xFFFFFFFF).all()
+    got = d_blob.cpu().numpy()
+    assert (got[: fit * 65535] == 0xAB).all() and (got[cap:] == 0x5A).all()
+
+
 @pytest.mark.parametrize("fast", [1, 0])
 def test_compact_claims_verify_like_the_plain_ones(engine, oracle, tip, packed_claims, fast):
     ts, cl, blob, blob_len = packed_claims

@@ -1,6 +1,6 @@
 """CPU: the arithmetic of the two head fast paths of the event parse — `decode_event_head_fast`
 (csrc/kernels/event_log_dev.h: `82`, emitter, entries-array header of a StampedEvent) and `amt_leaf_root_fast`
-(csrc/kernels/block_events_body.h: the root of an events AMT whose node is a leaf) — transcribed line by line and held
+(csrc/kernels/block_events.hip: the root of an events AMT whose node is a leaf) — transcribed line by line and held
 against the item-by-item decode the kernels fall back to, on random and mutated inputs.  The claim the kernels rely on:
 whenever a fast path accepts, the general decode accepts too and yields the same values and the same position; whenever
 it declines, nothing was consumed.  (The device code itself is exercised by the GPU parity and fuzz suites; this test
