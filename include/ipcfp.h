@@ -692,6 +692,41 @@ int ipcfp_shard_plan_tipset_all(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
                                 uint64_t* n_receipts, uint64_t* receipt_bounds, uint64_t* shard_off, uint32_t* block_ids,
                                 uint64_t cap_ids, uint64_t* n_ids);
 
+/* SELF-PLANNED SHARD.  Rank `shard` of n_shards builds its shard of ONE tipset straight out of the bundle in ITS host
+ * memory: no rank ever holds the whole witness in HBM, no plan is made elsewhere, the host cuts no block lists.  The
+ * bundle is given in the transport form of ipcfp_witness_create_packed (blocks back to back, lengths, 32-byte digests +
+ * the CID prefix they share, escapes for other CID forms).  What crosses PCIe: the tables (36 bytes per block of the
+ * bundle) and the shard's own blocks — which the DEVICE reads out of `bytes` itself, level by level along the links
+ * (child header → receipts AMT paths to the rank's receipts → their events AMTs; parent headers → TxMeta → message AMTs,
+ * replicated: reconstruct_execution_order is global, src/proofs/events/utils.rs:16-30), so `bytes` must be host memory
+ * the device can read: hipHostMalloc'd, or registered once (hipHostRegister / ipcfp_host_register below — an ingest buffer
+ * is registered when it is made, not per bundle: 19 ms for 640 MB on the MI355X box).  Cuts the loops of
+ * src/proofs/verifier.rs:19-28,49-54 and src/proofs/events/verifier.rs:62-71; the shard equals what
+ * ipcfp_shard_plan_tipset + ipcfp_witness_create_subset make of the whole witness.
+ *   *status_out   IPCFP_ST_TRUE: *out is the shard, tagged [*receipt_lo, *receipt_hi) = ipcfp_shard_range(count);
+ *                 IPCFP_ST_ERR_MISSING_BLOCK: the child header or the receipts root is not in the bundle or does not
+ *                 decode — there is no receipt range to cut by (*out = NULL; verify on the whole bundle instead)
+ *   stats         (nullable) what the call moved and how long its phases took on the host's clock               */
+typedef struct ipcfp_shard_pull_stats {
+    uint32_t rounds;      /* link levels followed                                          */
+    uint32_t blocks;      /* blocks of the shard                                           */
+    uint64_t table_bytes; /* bytes of the bundle's tables uploaded                         */
+    uint64_t block_bytes; /* bytes of blocks read over PCIe (each block padded to 128)     */
+    double tables_ms;     /* tables up, CID slots, index                                   */
+    double pull_ms;       /* the rounds                                                    */
+    double create_ms;     /* the shard's own arena, schedule and index                     */
+} ipcfp_shard_pull_stats_t;
+int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint32_t* len,
+                                    const uint8_t* digests32, uint64_t n, const uint8_t* cid_prefix, uint32_t prefix_len,
+                                    const uint32_t* esc_index, const uint8_t* esc_cids40, uint64_t n_esc,
+                                    const uint8_t* parent_cids40, uint32_t n_parents, const uint8_t* child_cid40,
+                                    uint32_t n_shards, uint32_t shard, ipcfp_status_t* status_out, uint64_t* receipt_lo,
+                                    uint64_t* receipt_hi, uint64_t* n_receipts, ipcfp_shard_pull_stats_t* stats,
+                                    ipcfp_witness_t** out);
+/* hipHostRegister / hipHostUnregister for hosts that do not link HIP themselves (a Rust caller's ingest buffer). */
+int ipcfp_host_register(void* p, uint64_t bytes);
+int ipcfp_host_unregister(void* p);
+
 /* Host only (no context, no device): blocks block_ids[0..n) of a witness that lies in HOST memory, packed back to back
  * as a witness of their own — out_off[i] / out_len[i] / out_cids40[i] describe block block_ids[i], its bytes at
  * out_bytes + out_off[i].  *nbytes_out = the payload size; call with every out pointer NULL to size the buffers.

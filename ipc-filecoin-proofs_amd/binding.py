@@ -13,6 +13,8 @@ import numpy as np
 
 __all__ = [
     "ABI_VERSION",
+    "host_register",
+    "host_unregister",
     "Engine",
     "EventProofSpec",
     "STORAGE_SPEC_DTYPE",
@@ -251,6 +253,11 @@ def load_library() -> C.CDLL:
         "ipcfp_route_event_claims": (i32, [vp, u64, vp, u64, u64, u64, i32, vp, vp, u64, vp, u64, C.POINTER(u64),
                                            C.POINTER(u64)]),
         "ipcfp_witness_create_subset": (i32, [vp, vp, vp, u64, u64, u64, C.POINTER(vp)]),
+        "ipcfp_witness_create_shard_pull": (i32, [vp, vp, u64, vp, vp, u64, vp, C.c_uint32, vp, vp, u64, vp, C.c_uint32, vp,
+                                                  C.c_uint32, C.c_uint32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), vp,
+                                                  C.POINTER(vp)]),
+        "ipcfp_host_register": (i32, [vp, u64]),
+        "ipcfp_host_unregister": (i32, [vp]),
         "ipcfp_witness_set_receipt_range": (i32, [vp, u64, u64]),
         "ipcfp_witness_receipt_range": (None, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "ipcfp_comm_unique_id": (i32, [vp]),
@@ -434,8 +441,47 @@ class Engine:
         """The witness from its tables in transport form (ipcfp_witness_create_packed): no offset table, 32-byte digests."""
         return Witness(self, None, None, None, None, packed=packed)
 
+    def witness_shard_pull(self, packed: "PackedWitnessTables", parent_cids, child_cid: bytes, n_shards: int, shard: int):
+        """Rank `shard` of `n_shards` pulls its receipt-range shard of one tipset out of the bundle `packed` in host memory
+        (ipcfp_witness_create_shard_pull; packed.data must be device-readable: `host_register(packed.data)` or pinned).
+        Returns (status, Witness | None, receipt_lo, receipt_hi, n_receipts, stats dict)."""
+        pk = packed
+        pc = pack_cids(parent_cids)
+        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        st = np.zeros(1, dtype=np.uint8)
+        lo, hi, nr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        stats = ShardPullStats()
+        h = C.c_void_p()
+        self._check(self.lib.ipcfp_witness_create_shard_pull(
+            self.h, _p(pk.data), pk.data.size, _p(pk.lens), _p(pk.digests), len(pk.lens), _p(pk.prefix), len(pk.prefix),
+            _p(pk.esc_index), _p(pk.esc_cids), len(pk.esc_index), _p(pc), len(parent_cids), _p(child), int(n_shards), int(shard),
+            _p(st), C.byref(lo), C.byref(hi), C.byref(nr), C.cast(C.pointer(stats), C.c_void_p), C.byref(h)), "witness_create_shard_pull")
+        w = None
+        if h.value:
+            w = Witness.__new__(Witness)
+            w.eng, w.lib, w.h, w.n = self, self.lib, h, int(stats.blocks)
+        sd = {f: getattr(stats, f) for f, _ in ShardPullStats._fields_}
+        return int(st[0]), w, int(lo.value), int(hi.value), int(nr.value), sd
+
     def witness_device(self, bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n) -> "Witness":
         return Witness(self, None, None, None, None, device=(bytes_ptr, nbytes, off_ptr, len_ptr, cids_ptr, n))
+
+
+class ShardPullStats(C.Structure):  # == ipcfp_shard_pull_stats_t
+    _fields_ = [("rounds", C.c_uint32), ("blocks", C.c_uint32), ("table_bytes", C.c_uint64), ("block_bytes", C.c_uint64),
+                ("tables_ms", C.c_double), ("pull_ms", C.c_double), ("create_ms", C.c_double)]
+
+
+def host_register(arr: np.ndarray):
+    """Map a host array for device reads (ipcfp_host_register = hipHostRegister): what ipcfp_witness_create_shard_pull's
+    `bytes` must be.  An ingest buffer is registered once, when it is made."""
+    rc = load_library().ipcfp_host_register(_p(arr), arr.nbytes)
+    if rc:
+        raise EngineError(f"host_register: {load_library().ipcfp_strerror(rc).decode()}")
+
+
+def host_unregister(arr: np.ndarray):
+    load_library().ipcfp_host_unregister(_p(arr))
 
 
 STD_CID_PREFIX = bytes.fromhex("0171a0e40220")  # CIDv1, dag-cbor, blake2b-256, 32-byte digest

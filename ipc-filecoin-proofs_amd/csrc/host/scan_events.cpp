@@ -21,6 +21,17 @@ namespace ipcfp {
 
 // The host's side of the mailbox (common.h): spin until the device has published sequence number `seq`.  A launch that
 // failed never publishes: after 5 s the stream is drained, which surfaces the error.
+// The stream's last kernel has told the host (mailbox) that it is done but may not have retired yet: poll until the queue
+// is empty — normally the first or second query — and fall back to the ordinary wait after 50 µs.
+hipError_t settle_stream(ipcfp_ctx* ctx, hipStream_t s) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(50);
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 7u) == 7u && std::chrono::steady_clock::now() > deadline) return wait_stream(ctx, s);
+    }
+}
+
 int mailbox_wait(ipcfp_ctx* ctx, unsigned long long seq, const char* what) {
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(5);
     uint32_t spins = 0;
@@ -384,7 +395,16 @@ int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t
                                       hipMemcpyDeviceToDevice, ctx->stream));
         copied = true;
     }
-    if (copied || summary_d) IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // `res` returns its buffers to the pool on exit
+    if (copied || summary_d) {
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));  // `res` returns its buffers to the pool on exit
+    } else {
+        // PASS 2 wrote straight into the caller's buffers and the counts came through the mailbox, which the tail kernel
+        // publishes from its last workgroup WITHOUT a release fence (event_scan.hip k_scan_tail_fused): its writes are
+        // visible to other streams and to blocking copies once the kernel has ENDED — a few hundred nanoseconds after the
+        // host saw the mailbox.  The call is documented as synchronous (ipcfp.h), so it waits for that end: a query loop,
+        // not an event (an event on a queue that has just gone idle is picked up ≈ 60 µs later).  ADVICE r4.
+        IPCFP_HIP(ctx, settle_stream(ctx, ctx->stream));
+    }
     ctl_preprime(ctx);
     return IPCFP_OK;
 }

@@ -1,0 +1,226 @@
+// csrc/host/shard_pull.cpp — ipcfp_witness_create_shard_pull: rank r of G builds ITS shard of one tipset straight out of
+// the bundle in host memory.  No rank ever holds the whole witness in HBM, nothing is planned elsewhere, the host cuts
+// no block lists: the bundle's CID table is uploaded (36 bytes per block), the device finds the shard's blocks level by
+// level and reads exactly those out of the host buffer (kernels/shard_pull.hip).
+//
+// The loops being cut: src/proofs/verifier.rs:19-28,49-54, src/proofs/events/verifier.rs:62-71; what a shard holds:
+// src/proofs/events/generator.rs:122-177,195-301 (the receipts [lo, hi), their events AMTs), src/proofs/events/utils.rs:48-94
+// (headers, TxMeta, message AMTs: replicated, the execution order is global).
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "../common.h"
+#include "../kernels/launch.h"
+#include "../kernels/shard_pull.h"
+
+using namespace ipcfp;
+
+namespace ipcfp {
+int witness_finish_create(ipcfp_ctx* ctx, ipcfp_witness* w, const uint8_t* raw_bytes_d, const uint64_t* raw_off_d,
+                          const uint32_t* len_d_src, const uint8_t* cids_d_src);
+int mailbox_wait(ipcfp_ctx* ctx, unsigned long long seq, const char* what);
+CidKey key_from_slot(const uint8_t* slot40);
+}  // namespace ipcfp
+
+extern "C" {
+
+int ipcfp_host_register(void* p, uint64_t bytes) {
+    if (!p || !bytes) return IPCFP_E_INVALID;
+    return hipHostRegister(p, size_t(bytes), hipHostRegisterDefault) == hipSuccess ? IPCFP_OK : IPCFP_E_HIP;
+}
+
+int ipcfp_host_unregister(void* p) {
+    if (!p) return IPCFP_E_INVALID;
+    return hipHostUnregister(p) == hipSuccess ? IPCFP_OK : IPCFP_E_HIP;
+}
+
+int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes, const uint32_t* len,
+                                    const uint8_t* digests32, uint64_t n, const uint8_t* cid_prefix, uint32_t prefix_len,
+                                    const uint32_t* esc_index, const uint8_t* esc_cids40, uint64_t n_esc,
+                                    const uint8_t* parent_cids40, uint32_t n_parents, const uint8_t* child_cid40,
+                                    uint32_t n_shards, uint32_t shard, ipcfp_status_t* status_out, uint64_t* receipt_lo,
+                                    uint64_t* receipt_hi, uint64_t* n_receipts, ipcfp_shard_pull_stats_t* stats,
+                                    ipcfp_witness_t** out) {
+    if (!ctx || !out || !status_out || !receipt_lo || !receipt_hi || !child_cid40 || (n_parents && !parent_cids40) || n_shards == 0 ||
+        shard >= n_shards)
+        return IPCFP_E_INVALID;
+    *out = nullptr;
+    *status_out = IPCFP_ST_ERR;
+    *receipt_lo = *receipt_hi = 0;
+    if (n_receipts) *n_receipts = 0;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0 || !len || !digests32 || !bytes) return set_error(ctx, IPCFP_E_INVALID, "empty bundle or null table pointer");
+    if (prefix_len > 8 || (prefix_len && !cid_prefix)) return set_error(ctx, IPCFP_E_INVALID, "CID prefix longer than 8 bytes");
+    if (n_esc && (!esc_index || !esc_cids40)) return set_error(ctx, IPCFP_E_INVALID, "null escape table");
+    if (n >= 0xffffffffull || n_esc > n) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
+    if (n_parents > IPCFP_MAX_PARENTS) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", unsigned(IPCFP_MAX_PARENTS));
+    if (!ctx->mailbox) return set_error(ctx, IPCFP_E_UNSUPPORTED, "the context has no mailbox page (IPCFP_MAILBOX=0)");
+    IPCFP_ENTER(ctx);
+    // the device reads the blocks itself: the buffer must be mapped for it (hipHostMalloc / hipHostRegister / ipcfp_host_register)
+    uint8_t* bytes_dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&bytes_dev), const_cast<uint8_t*>(bytes), 0) != hipSuccess || !bytes_dev) {
+        (void)hipGetLastError();
+        return set_error(ctx, IPCFP_E_INVALID, "the bundle's bytes are not device-readable host memory: register the buffer first (ipcfp_host_register)");
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint32_t N = uint32_t(n);
+    // ---- the bundle's tables: lengths, digests → offsets in the host buffer, 40-byte CID slots, the index over them ----
+    DevBuf<uint32_t> glen, esc_i, slots, resident, pulled, copy_len;
+    DevBuf<uint64_t> goff, scan_scratch, stage_off, copy_src, copy_dst;
+    DevBuf<uint8_t> dig, esc_c, gcids, stage;
+    DevBuf<PullItem> fa, fb;
+    DevBuf<PullCtl> ctl;
+    IPCFP_HIP(ctx, glen.alloc(N));
+    IPCFP_HIP(ctx, goff.alloc(N));
+    IPCFP_HIP(ctx, dig.alloc(size_t(N) * 32));
+    IPCFP_HIP(ctx, gcids.alloc(size_t(N) * IPCFP_CID_SLOT));
+    IPCFP_HIP(ctx, scan_scratch.alloc(size_t(div_up(N, 1024)) + 2));
+    int rc = upload(ctx, glen.p, len, size_t(N) * 4, ctx->stream);
+    if (!rc) rc = upload(ctx, dig.p, digests32, size_t(N) * 32, ctx->stream);
+    if (!rc && n_esc) {
+        IPCFP_HIP(ctx, esc_i.alloc(n_esc));
+        IPCFP_HIP(ctx, esc_c.alloc(n_esc * IPCFP_CID_SLOT));
+        rc = upload(ctx, esc_i.p, esc_index, n_esc * 4, ctx->stream);
+        if (!rc) rc = upload(ctx, esc_c.p, esc_cids40, n_esc * IPCFP_CID_SLOT, ctx->stream);
+    }
+    if (rc) return rc;
+    uint64_t* total_d = scan_scratch.p + div_up(N, 1024) + 1;
+    rc = launch_tight_offsets(ctx, glen.p, N, goff.p, total_d, scan_scratch.p);
+    if (!rc) rc = launch_expand_cids(ctx, dig.p, N, cid_prefix, prefix_len, esc_i.p, esc_c.p, uint32_t(n_esc), gcids.p);
+    if (rc) return rc;
+    uint32_t size = 64;
+    while (size < 2ull * N) size <<= 1;
+    IPCFP_HIP(ctx, slots.alloc(size));
+    IPCFP_HIP(ctx, hipMemsetAsync(slots.p, 0xff, size_t(size) * 4, ctx->stream));
+    rc = launch_index_insert(ctx, gcids.p, N, slots.p, size - 1);
+    if (rc) return rc;
+    // ---- the pull's own state ----
+    const uint32_t words = div_up(N, 32);
+    const uint32_t fcap = N + 1024u;                          // items of one frontier (tree positions of one level)
+    const uint64_t stage_cap = nbytes + 128ull * N + 256ull;  // every block of the bundle on lines of its own: the upper bound
+    IPCFP_HIP(ctx, resident.alloc(words));
+    IPCFP_HIP(ctx, stage_off.alloc(N));
+    IPCFP_HIP(ctx, pulled.alloc(N));
+    IPCFP_HIP(ctx, copy_src.alloc(fcap));
+    IPCFP_HIP(ctx, copy_dst.alloc(fcap));
+    IPCFP_HIP(ctx, copy_len.alloc(fcap));
+    IPCFP_HIP(ctx, fa.alloc(fcap));
+    IPCFP_HIP(ctx, fb.alloc(fcap));
+    IPCFP_HIP(ctx, ctl.alloc(1));
+    IPCFP_HIP(ctx, stage.alloc(stage_cap));
+    IPCFP_HIP(ctx, hipMemsetAsync(resident.p, 0, size_t(words) * 4, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(stage_off.p, 0, size_t(N) * 8, ctx->stream));
+    IPCFP_HIP(ctx, hipMemsetAsync(ctl.p, 0, sizeof(PullCtl), ctx->stream));
+    // the payload must add up to the buffer (the device trusts goff + len inside [0, nbytes))
+    uint64_t total = 0;
+    IPCFP_HIP(ctx, d2h_small(ctx, &total, total_d, sizeof total, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    if (total != nbytes)
+        return set_error(ctx, IPCFP_E_INVALID, "the block lengths add up to %llu bytes, the buffer holds %llu", (unsigned long long)total,
+                         (unsigned long long)nbytes);
+    const auto t_tables = std::chrono::steady_clock::now();
+    WitnessView view{};
+    view.arena = stage.p;
+    view.off = stage_off.p;
+    view.len = glen.p;
+    view.cids = gcids.p;
+    view.slots = slots.p;
+    view.mask = size - 1;
+    view.n = N;
+    view.touched = nullptr;
+    PullTables t{};
+    t.len = glen.p;
+    t.goff = goff.p;
+    t.resident = resident.p;
+    t.stage_off = stage_off.p;
+    t.pulled = pulled.p;
+    t.pulled_cap = N;
+    t.stage = stage.p;
+    t.stage_cap = stage_cap;
+    t.copy_src = copy_src.p;
+    t.copy_dst = copy_dst.p;
+    t.copy_len = copy_len.p;
+    PullSeeds seeds;
+    std::memset(&seeds, 0, sizeof seeds);
+    seeds.child = key_from_slot(child_cid40);
+    seeds.n_parents = n_parents;
+    for (uint32_t k = 0; k < n_parents; ++k) seeds.parents[k] = key_from_slot(parent_cids40 + size_t(k) * IPCFP_CID_SLOT);
+    PullFrontier cur{fa.p, fcap}, next{fb.p, fcap};
+    rc = launch_pull_seed(ctx, view, seeds, cur, ctl.p);
+    if (rc) return rc;
+    // ---- rounds: the frontier's size comes back through the mailbox, nothing else does ----
+    uint32_t n_items = 0, rounds = 0;
+    {
+        const unsigned long long seq = ++ctx->mailbox_seq;
+        rc = launch_pull_round(ctx, view, bytes_dev, t, cur, 0, next, ctl.p, n_shards, shard, ctx->mailbox_dev, seq);  // (publishes the seeds' count)
+        if (rc) return rc;
+        rc = mailbox_wait(ctx, seq, "the pull's first frontier");
+        if (rc) return rc;
+        n_items = uint32_t(__atomic_load_n(ctx->mailbox + 1, __ATOMIC_RELAXED));
+    }
+    constexpr uint32_t kMaxRounds = 160;  // headers, TxMeta, roots + the tallest AMT anything here loads (64 / bit width levels)
+    while (n_items) {
+        if (++rounds > kMaxRounds) return set_error(ctx, IPCFP_E_UNSUPPORTED, "the shard's blocks are more than %u links deep", kMaxRounds);
+        const unsigned long long seq = ++ctx->mailbox_seq;
+        rc = launch_pull_round(ctx, view, bytes_dev, t, cur, n_items, next, ctl.p, n_shards, shard, ctx->mailbox_dev, seq);
+        if (rc) return rc;
+        rc = mailbox_wait(ctx, seq, "a pull round");
+        if (rc) return rc;
+        const uint32_t overflow = uint32_t(__atomic_load_n(ctx->mailbox + 2, __ATOMIC_RELAXED));
+        if (overflow) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return set_error(ctx, IPCFP_E_UNSUPPORTED, "the shard's walk outgrew its buffers (%s): not a tree of this bundle",
+                             (overflow & 1u) ? "frontier" : "staging arena");
+        }
+        n_items = uint32_t(__atomic_load_n(ctx->mailbox + 1, __ATOMIC_RELAXED));
+        std::swap(cur, next);
+    }
+    PullCtl h{};
+    IPCFP_HIP(ctx, d2h_small(ctx, &h, ctl.p, sizeof h, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    const auto t_pulled = std::chrono::steady_clock::now();
+    if (stats) {
+        stats->rounds = rounds;
+        stats->blocks = h.n_pulled;
+        stats->table_bytes = uint64_t(N) * 36 + n_esc * 44;
+        stats->block_bytes = h.stage_used;
+        stats->tables_ms = std::chrono::duration<double, std::milli>(t_tables - t_start).count();
+        stats->pull_ms = std::chrono::duration<double, std::milli>(t_pulled - t_tables).count();
+    }
+    if (!h.have_range) {  // no receipts root: there is no receipt range to cut by (the caller verifies on the whole bundle)
+        *status_out = IPCFP_ST_ERR_MISSING_BLOCK;
+        return IPCFP_OK;
+    }
+    // ---- the shard as a witness of its own: its blocks' tables, then the ordinary constructor over the staging arena ----
+    const uint32_t np = h.n_pulled;
+    std::unique_ptr<ipcfp_witness> w(new (std::nothrow) ipcfp_witness());
+    if (!w) return IPCFP_E_NOMEM;
+    w->ctx = ctx;
+    w->n = np;
+    w->nbytes = h.stage_used;  // (an upper bound: the lengths are not summed on the host)
+    w->receipt_lo = h.lo;
+    w->receipt_hi = h.hi;
+    DevBuf<uint32_t> plen, bad;
+    DevBuf<uint64_t> poff;
+    DevBuf<uint8_t> pcids;
+    IPCFP_HIP(ctx, plen.alloc(np));
+    IPCFP_HIP(ctx, poff.alloc(np));
+    IPCFP_HIP(ctx, pcids.alloc(size_t(np) * IPCFP_CID_SLOT));
+    IPCFP_HIP(ctx, bad.alloc(1));
+    IPCFP_HIP(ctx, hipMemsetAsync(bad.p, 0, 4, ctx->stream));
+    rc = launch_subset_tables(ctx, pulled.p, np, N, stage_off.p, glen.p, gcids.p, poff.p, plen.p, pcids.p, bad.p);
+    if (rc) return rc;
+    rc = witness_finish_create(ctx, w.get(), stage.p, poff.p, plen.p, pcids.p);
+    if (rc) return rc;
+    if (stats) stats->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_pulled).count();
+    *receipt_lo = h.lo;
+    *receipt_hi = h.hi;
+    if (n_receipts) *n_receipts = h.n_receipts;
+    *status_out = IPCFP_ST_TRUE;
+    *out = w.release();
+    return IPCFP_OK;
+}
+
+}  // extern "C"

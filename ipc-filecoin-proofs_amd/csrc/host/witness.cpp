@@ -266,16 +266,28 @@ int ipcfp_witness_create_packed(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t
     uint64_t cut_block[kPieces + 1] = {}, cut_byte[kPieces + 1] = {};
     const unsigned T = n >= (1u << 18) ? kPieces : 1u;
     {
-        std::vector<uint64_t> sum(T, 0);
+        uint64_t sum[kPieces] = {};
         auto part = [&](unsigned t) {
             uint64_t acc = 0;
             for (uint64_t i = n * t / T, hi = n * (t + 1) / T; i < hi; ++i) acc += len[i];
             sum[t] = acc;
         };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; ++t) pool.emplace_back(part, t);
+        // (no exception may cross the C ABI: a thread that cannot be made — std::system_error, std::bad_alloc — leaves
+        // its part to this thread, as shard_host.cpp's parallel_ranges does)
+        std::thread pool[kPieces];
+        bool started[kPieces] = {};
+        for (unsigned t = 1; t < T; ++t) {
+            try {
+                pool[t] = std::thread(part, t);
+                started[t] = true;
+            } catch (...) {
+            }
+        }
         part(0);
-        for (auto& th : pool) th.join();
+        for (unsigned t = 1; t < T; ++t) {
+            if (started[t]) pool[t].join();
+            else part(t);
+        }
         for (unsigned t = 0; t < T; ++t) {
             cut_block[t] = n * t / T;
             cut_byte[t] = payload;

@@ -35,6 +35,14 @@ __global__ __launch_bounds__(256) void k_index_insert(const uint8_t* __restrict_
     }
 }
 
+int launch_index_insert(ipcfp_ctx* ctx, const uint8_t* cids_d, uint32_t n, uint32_t* slots_d, uint32_t mask) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_index_insert<true>, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, cids_d, n, slots_d, mask,
+                       static_cast<uint32_t*>(nullptr));
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 // (The same table in two passes — every key first STORES its id on its home slot, then only the keys that find another
 // id there resolve the collision with CAS / atomicMax — was built to spare 70 % of the atomics and is slower: 0.29 ms
 // against 0.15 ms.  Random 4-byte stores and a second random read of the table cost more than the atomics they

@@ -610,9 +610,14 @@ __global__ __launch_bounds__(256) void k_scan_tail_fused(WitnessView w, const Le
                 __hip_atomic_store(ctl.state + tile, tag | (2ull << 32) | ((prefix + tile_total) & 0xffffffffull), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             s_prefix = prefix;
-            // (an atomic exchange RETURNS: it has been performed at the coherence point before this lane goes on to the
-            // completion counter below — no fence, which on this chip is a write-back of the whole L2)
-            if (tile == n_tiles - 1) (void)atomicExch(ctl.total, (unsigned long long)(prefix + tile_total));
+            // (an atomic exchange that RETURNS has been performed at the coherence point before this lane goes on to the
+            // completion counter below — no fence, which on this chip is a write-back of the whole L2.  The empty asm
+            // consumes the returned value: with the result discarded the compiler may emit the no-return form, which
+            // orders nothing against the later read-modify-write of another address — ADVICE r4)
+            if (tile == n_tiles - 1) {
+                const unsigned long long before = atomicExch(ctl.total, (unsigned long long)(prefix + tile_total));
+                asm volatile("" ::"v"(before));
+            }
         }
     }
     __syncthreads();

@@ -188,6 +188,18 @@ int launch_subset_tables(ipcfp_ctx* ctx, const uint32_t* ids_d, uint32_t n, uint
                          const uint32_t* src_len, const uint8_t* src_cids, uint64_t* off_d, uint32_t* len_d,
                          uint8_t* cids_d, uint32_t* bad_d);
 
+// --- shard_pull.hip (shard_pull.h) --- a rank pulls its shard out of a bundle in host memory, level by level
+struct PullSeeds;
+struct PullFrontier;
+struct PullTables;
+struct PullCtl;
+int launch_pull_seed(ipcfp_ctx* ctx, const WitnessView& w, const PullSeeds& seeds, const PullFrontier& first, PullCtl* ctl_d);
+int launch_pull_round(ipcfp_ctx* ctx, const WitnessView& w, const uint8_t* host_bytes_dev, const PullTables& t, const PullFrontier& cur,
+                      uint32_t n_items, const PullFrontier& next, PullCtl* ctl_d, uint32_t n_shards, uint32_t shard,
+                      unsigned long long* mailbox_dev, unsigned long long seq);
+// --- cid_index.hip --- the CID → block table over any (cids, n): slots_d holds mask + 1 words, cleared to 0xff by the caller
+int launch_index_insert(ipcfp_ctx* ctx, const uint8_t* cids_d, uint32_t n, uint32_t* slots_d, uint32_t mask);
+
 // device view of a witness (host helper, witness.cpp)
 WitnessView witness_view(const ipcfp_witness* w, uint32_t* touched_bits = nullptr);
 

@@ -1,0 +1,321 @@
+// csrc/kernels/shard_pull.hip — a rank PULLS its receipt-range shard out of a bundle that lies in HOST memory
+// (ipcfp_witness_create_shard_pull, host/shard_pull.cpp): nobody holds the whole witness in HBM, nobody cuts block
+// lists on the host.
+//
+// The loops being cut are the reference's sequential ones (src/proofs/verifier.rs:19-28,49-54,
+// src/proofs/events/verifier.rs:62-71); what a rank needs for the receipts [lo, hi) is what the reference's generator
+// records for them (src/proofs/events/generator.rs:122-177,195-301, src/proofs/events/utils.rs:48-94): child header →
+// receipts AMT (the paths to [lo, hi)) → those receipts' events AMTs; parent headers → TxMeta → both message AMTs
+// (whole: the execution order is global).  That set is a reachability closure, so it is found level by level:
+//
+//   round k   CLAIM   every block of the frontier that is not in HBM yet gets a place in the staging arena
+//             COPY    the device reads those blocks straight out of the (pinned / registered) host buffer — half a
+//                     wavefront per block, 48 GB/s for ≈ 350-byte blocks on this box against 56 GB/s for one bulk DMA
+//                     (tools/ubench/zero_copy.hip) — so the only bytes that cross PCIe are the shard's own
+//             EXPAND  one lane per frontier item parses its block by KIND and appends the blocks it links to (resolved by
+//                     the index over the bundle's CID table, which is all of the bundle that was uploaded) to round k + 1
+//
+// A block that does not parse as its kind is simply not expanded: it is in the shard, and verify / scan give the
+// reference's verdict about it there.  A link that resolves to no block of the bundle is nothing to pull (the verdict will
+// be "missing block", as without the cut).  Expansion is per tree POSITION (a block reached on two paths is copied once
+// and expanded twice, as a tree walk does); the frontier's capacity bounds what a hostile DAG can ask for.
+#include <hip/hip_runtime.h>
+
+#include "../common.h"
+#include "header_dev.h"
+#include "launch.h"
+#include "shard_pull.h"
+#include "walk_dev.h"
+
+namespace ipcfp {
+
+namespace {
+
+__device__ __forceinline__ void pull_emit(const PullFrontier& next, PullCtl* ctl, uint32_t id, uint32_t kind, uint32_t height,
+                                          uint64_t base) {
+    if (id == kNoBlock) return;
+    const uint32_t at = atomicAdd(&ctl->n_next, 1u);
+    if (at >= next.cap) {
+        atomicOr(&ctl->overflow, 1u);
+        return;
+    }
+    next.items[at] = PullItem{id, kind | (height << 8), base};
+}
+
+// `[bmap, [links…], [values…]]` at r, a node at `height` of a tree that is needed whole: every link → an item of
+// `node_kind` one level down, or PK_LEAF when that level is the leaves (values only: copied, never parsed — a walk that
+// finds links at height 0 fails there and follows none of them)
+__device__ __forceinline__ void expand_node_all(const WitnessView& w, Rd& r, const PullFrontier& next, PullCtl* ctl,
+                                                uint32_t node_kind, uint32_t height) {
+    if (height == 0) return;
+    r.expect_array(3);
+    uint32_t bo, bl;
+    r.read_bytes(bo, bl);
+    const uint64_t nl = r.read_array();
+    const uint32_t child_kind = height == 1u ? uint32_t(PK_LEAF) : node_kind;
+    for (uint64_t k = 0; k < nl && r.ok(); ++k) {
+        CidKey key;
+        if (!r.read_link_key(key)) break;
+        pull_emit(next, ctl, witness_find(w, key), child_kind, height - 1u, 0);
+    }
+}
+
+// a node of the receipts AMT (v0: bit width 3) at `height` whose first index is `base`: the links whose subtree meets
+// [lo, hi), or — a leaf — the events roots of the receipts inside it
+__device__ __forceinline__ void expand_receipts_node(const WitnessView& w, Rd& r, const PullFrontier& next, PullCtl* ctl,
+                                                     uint32_t height, uint64_t base, uint64_t lo, uint64_t hi) {
+    r.expect_array(3);
+    uint32_t bo, bl;
+    r.read_bytes(bo, bl);
+    if (!r.ok() || bl != 1u) return;
+    const uint32_t bmap = r.at(bo);
+    const uint64_t nl = r.read_array();
+    if (!r.ok()) return;
+    if (height > 0) {
+        if (height > 20u) return;                       // (8^21 indices: no such tree; Amt::load refuses it as well)
+        const uint64_t span = 1ull << (3u * height);    // indices under one link
+        uint32_t k = 0;
+        for (uint32_t j = 0; j < 8u && k < nl && r.ok(); ++j) {
+            if (!((bmap >> j) & 1u)) continue;
+            CidKey key;
+            if (!r.read_link_key(key)) break;
+            ++k;
+            const uint64_t first = base + uint64_t(j) * span;
+            if (first < hi && first + span > lo) pull_emit(next, ctl, witness_find(w, key), PK_RCPT_NODE, height - 1u, first);
+        }
+        return;
+    }
+    if (nl != 0) return;
+    const uint64_t nv = r.read_array();
+    uint32_t k = 0;
+    for (uint32_t j = 0; j < 8u && k < nv && r.ok(); ++j) {
+        if (!((bmap >> j) & 1u)) continue;
+        ++k;
+        // Receipt [exit_code, return_data, gas_used, events_root | null]
+        r.expect_array(4);
+        (void)r.read_uint();
+        uint32_t o, l;
+        r.read_bytes(o, l);
+        (void)r.read_uint();
+        if (!r.ok()) break;
+        if (r.at_null()) {
+            r.read_null();
+            continue;
+        }
+        CidKey key;
+        if (!r.read_link_key(key)) break;
+        const uint64_t index = base + j;
+        if (index >= lo && index < hi) pull_emit(next, ctl, witness_find(w, key), PK_EV_ROOT, 0, 0);
+    }
+}
+
+}  // namespace
+
+// the tipset key → the first frontier
+__global__ void k_pull_seed(WitnessView w, PullSeeds seeds, PullFrontier first, PullCtl* __restrict__ ctl) {
+    const uint32_t t = threadIdx.x;
+    if (blockIdx.x != 0 || t > seeds.n_parents) return;
+    const bool child = t == seeds.n_parents;
+    pull_emit(first, ctl, witness_find(w, child ? seeds.child : seeds.parents[t]), child ? PK_HDR_CHILD : PK_HDR_PARENT, 0, 0);
+}
+
+// CLAIM: lane = frontier item.  A block nobody has claimed yet gets the next lines of the staging arena and an entry of
+// this round's copy list; the three counters are advanced once per wavefront (every lane of the chip on one address of
+// the L2 was 787 µs in another kernel of this library: profiles/r04_experiments.md).
+__global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, uint32_t n_items, PullTables t, PullCtl* __restrict__ ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool mine = false;
+    uint32_t id = 0, len = 0;
+    if (i < n_items) {
+        id = cur.items[i].id;
+        const uint32_t bit = 1u << (id & 31u);
+        mine = (atomicOr(&t.resident[id >> 5], bit) & bit) == 0u;
+        if (mine) len = t.len[id];
+    }
+    const uint64_t want = mine ? (len == 0 ? 128ull : (uint64_t(len) + 127ull) & ~127ull) : 0ull;
+    uint64_t incl = want;
+    uint32_t cnt = mine ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t up = __shfl_up(incl, d, 64);
+        const uint32_t uc = __shfl_up(cnt, d, 64);
+        if (lane >= uint32_t(d)) {
+            incl += up;
+            cnt += uc;
+        }
+    }
+    const uint64_t wave_bytes = __shfl(incl, 63, 64);
+    const uint32_t wave_cnt = __shfl(cnt, 63, 64);
+    if (wave_cnt == 0) return;
+    unsigned long long base_bytes = 0;
+    uint32_t base_copy = 0, base_pulled = 0;
+    if (lane == 63) {
+        base_bytes = atomicAdd(&ctl->stage_used, (unsigned long long)wave_bytes);
+        base_copy = atomicAdd(&ctl->n_copy, wave_cnt);
+        base_pulled = atomicAdd(&ctl->n_pulled, wave_cnt);
+    }
+    base_bytes = __shfl(base_bytes, 63, 64);
+    base_copy = __shfl(base_copy, 63, 64);
+    base_pulled = __shfl(base_pulled, 63, 64);
+    if (!mine) return;
+    const uint64_t dst = base_bytes + incl - want;
+    const uint32_t k = base_copy + cnt - 1u, p = base_pulled + cnt - 1u;
+    if (dst + want > t.stage_cap || p >= t.pulled_cap) {
+        atomicOr(&ctl->overflow, 2u);
+        return;
+    }
+    t.stage_off[id] = dst;
+    t.pulled[p] = id;
+    t.copy_src[k] = t.goff[id];
+    t.copy_dst[k] = dst;
+    t.copy_len[k] = len;
+}
+
+// COPY: this round's blocks, host memory → staging arena.  The body is k_repack's (half a wavefront per block, 16
+// destination bytes per lane, aligned 8-byte reads funnel-shifted: nothing is read beyond the aligned word of a block's
+// last byte, so the host buffer needs no slack); the count comes from the device.
+__global__ __launch_bounds__(256) void k_pull_copy(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
+                                                   const uint32_t* __restrict__ len, const uint64_t* __restrict__ dst_off,
+                                                   const PullCtl* __restrict__ ctl, uint8_t* __restrict__ dst) {
+    const uint32_t n = ctl->n_copy;
+    const uint32_t sub = threadIdx.x & 31;
+    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const uint32_t ngroups = (gridDim.x * blockDim.x) >> 5;
+    for (uint32_t i = group; i < n; i += ngroups) {
+        const uint64_t so = src_off[i];
+        const uint32_t L = len[i];
+        uint8_t* d = dst + dst_off[i];
+        const uint32_t padded = L == 0 ? 128u : (L + 127u) & ~127u;
+        const uintptr_t s = reinterpret_cast<uintptr_t>(src) + so;
+        const uintptr_t last_word = L ? ((s + L - 1u) & ~uintptr_t(7)) : 0;
+        for (uint32_t u = sub * 16u; u < padded; u += 512u) {
+            uint64_t w0 = 0, w1 = 0;
+            if (u < L) {
+                const uintptr_t a = s + u;
+                const uintptr_t q = a & ~uintptr_t(7);
+                const uint32_t sh = uint32_t(a & 7u) * 8u;
+                const uint64_t q0 = *reinterpret_cast<const uint64_t*>(q);
+                const uint64_t q1 = q + 8u <= last_word ? *reinterpret_cast<const uint64_t*>(q + 8u) : 0ull;
+                const uint64_t q2 = q + 16u <= last_word ? *reinterpret_cast<const uint64_t*>(q + 16u) : 0ull;
+                w0 = (q0 >> sh) | ((q1 << 1) << (63u - sh));
+                w1 = (q1 >> sh) | ((q2 << 1) << (63u - sh));
+                const uint32_t valid = L - u;
+                if (valid < 8u) {
+                    w0 &= (1ull << (8u * valid)) - 1ull;
+                    w1 = 0;
+                } else if (valid < 16u) {
+                    w1 &= valid == 8u ? 0ull : (1ull << (8u * (valid - 8u))) - 1ull;
+                }
+            }
+            *reinterpret_cast<ulonglong2*>(d + u) = make_ulonglong2(w0, w1);
+        }
+    }
+}
+
+// EXPAND: lane = frontier item; its block is in the staging arena now.
+__global__ __launch_bounds__(256) void k_pull_expand(WitnessView w, PullFrontier cur, uint32_t n_items, PullFrontier next,
+                                                     PullCtl* __restrict__ ctl, uint32_t n_shards, uint32_t shard) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const PullItem it = cur.items[i];
+    const uint32_t kind = it.kind & 0xffu, height = (it.kind >> 8) & 0xffu;
+    if (kind == PK_LEAF) return;
+    Rd r = open_block(w, it.id);
+    switch (kind) {
+        case PK_HDR_CHILD:
+        case PK_HDR_PARENT: {
+            HeaderLite h;
+            if (decode_header(r, h) != IPCFP_ST_TRUE) return;
+            if (kind == PK_HDR_CHILD) pull_emit(next, ctl, witness_find(w, h.parent_message_receipts), PK_RCPT_ROOT, 0, 0);
+            else pull_emit(next, ctl, witness_find(w, h.messages), PK_TXMETA, 0, 0);
+            return;
+        }
+        case PK_TXMETA: {  // [bls_root, secp_root]  (src/proofs/events/utils.rs:61)
+            CidKey a, b;
+            r.expect_array(2);
+            r.read_link_key(a);
+            r.read_link_key(b);
+            if (!r.ok()) return;
+            pull_emit(next, ctl, witness_find(w, a), PK_MSG_ROOT, 0, 0);
+            pull_emit(next, ctl, witness_find(w, b), PK_MSG_ROOT, 0, 0);
+            return;
+        }
+        case PK_MSG_ROOT: {  // Amtv0 root [height, count, node]: the whole tree is needed
+            r.expect_array(3);
+            const uint64_t ht = r.read_uint();
+            (void)r.read_uint();
+            if (!r.ok() || ht > 64u) return;
+            expand_node_all(w, r, next, ctl, PK_MSG_NODE, uint32_t(ht));
+            return;
+        }
+        case PK_MSG_NODE:
+        case PK_EV_NODE:
+            expand_node_all(w, r, next, ctl, kind, height);
+            return;
+        case PK_RCPT_ROOT: {  // Amtv0 root of the receipts: its count decides the cut
+            r.expect_array(3);
+            const uint64_t ht = r.read_uint();
+            const uint64_t count = r.read_uint();
+            if (!r.ok() || ht > 20u) return;
+            const uint64_t q = count / n_shards, rem = count % n_shards;  // == ipcfp_shard_range
+            const uint64_t lo = q * shard + (rem * shard) / n_shards;
+            const uint64_t hi = q * (shard + 1u) + (rem * (uint64_t(shard) + 1u)) / n_shards;
+            ctl->lo = lo;
+            ctl->hi = hi;
+            ctl->n_receipts = count;
+            ctl->have_range = 1u;
+            expand_receipts_node(w, r, next, ctl, uint32_t(ht), 0, lo, hi);
+            return;
+        }
+        case PK_RCPT_NODE:
+            expand_receipts_node(w, r, next, ctl, height, it.base, ctl->lo, ctl->hi);
+            return;
+        case PK_EV_ROOT: {  // Amt (v3) root [bit_width, height, count, node]: taller than a leaf ⇒ every node below it
+            r.expect_array(4);
+            (void)r.read_uint();
+            const uint64_t ht = r.read_uint();
+            (void)r.read_uint();
+            if (!r.ok() || ht > 64u) return;
+            expand_node_all(w, r, next, ctl, PK_EV_NODE, uint32_t(ht));
+            return;
+        }
+        default:
+            return;
+    }
+}
+
+// between two rounds: the next frontier's size goes to the host (mailbox), the round counters start again
+__global__ void k_pull_round_end(PullCtl* __restrict__ ctl, unsigned long long* __restrict__ mailbox, unsigned long long seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t n_next = ctl->n_next;
+    ctl->n_next = 0;
+    ctl->n_copy = 0;
+    __hip_atomic_store(mailbox + 1, (unsigned long long)n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox + 2, (unsigned long long)ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mailbox, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int launch_pull_seed(ipcfp_ctx* ctx, const WitnessView& w, const PullSeeds& seeds, const PullFrontier& first, PullCtl* ctl_d) {
+    hipLaunchKernelGGL(k_pull_seed, dim3(1), dim3(64), 0, ctx->stream, w, seeds, first, ctl_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_pull_round(ipcfp_ctx* ctx, const WitnessView& w, const uint8_t* host_bytes_dev, const PullTables& t, const PullFrontier& cur,
+                      uint32_t n_items, const PullFrontier& next, PullCtl* ctl_d, uint32_t n_shards, uint32_t shard,
+                      unsigned long long* mailbox_dev, unsigned long long seq) {
+    if (n_items) {
+        hipLaunchKernelGGL(k_pull_claim, dim3(div_up(n_items, 256)), dim3(256), 0, ctx->stream, cur, n_items, t, ctl_d);
+        const uint32_t groups = n_items < 8192u * 8u ? n_items : 8192u * 8u;  // half-wavefronts (at most n_items blocks are new)
+        hipLaunchKernelGGL(k_pull_copy, dim3(div_up(groups, 8)), dim3(256), 0, ctx->stream, host_bytes_dev, t.copy_src, t.copy_len,
+                           t.copy_dst, ctl_d, t.stage);
+        hipLaunchKernelGGL(k_pull_expand, dim3(div_up(n_items, 256)), dim3(256), 0, ctx->stream, w, cur, n_items, next, ctl_d, n_shards,
+                           shard);
+    }
+    hipLaunchKernelGGL(k_pull_round_end, dim3(1), dim3(64), 0, ctx->stream, ctl_d, mailbox_dev, seq);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+}  // namespace ipcfp

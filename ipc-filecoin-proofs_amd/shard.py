@@ -6,6 +6,8 @@ src/proofs/events/verifier.rs:62-71).  Here rank r of G
   * plans   — `ipcfp_shard_plan_tipset`: the blocks it needs for the receipts [lo, hi) of the tipset (their events
               AMTs + the receipts-AMT paths; headers, TxMeta and message AMTs replicated),
   * places  — `ipcfp_witness_create_subset`: its own witness, tagged with the range,
+              (or both in one call that needs nothing but the bundle in the rank's own host memory:
+              `ipcfp_witness_create_shard_pull`, `TipsetShard.from_pull`)
   * routes  — the claims whose exec_index falls in [lo, hi),
   * steps   — CID index, K1, range-restricted scan, verify_event_proof of its claims — all through the same
               entry points a single-GPU host uses,
@@ -171,6 +173,22 @@ class TipsetShard:
         self.witness.set_receipt_range(self.lo, self.hi)
         self.receipts_root = bytes(receipts_root)
         self.parent_cids, self.child_cid = plan.parent_cids, plan.child_cid
+        return self
+
+    @classmethod
+    def from_pull(cls, eng: B.Engine, packed: "B.PackedWitnessTables", parent_cids, child_cid: bytes, receipts_root: bytes,
+                  n_shards: int, shard: int):
+        """Rank `shard` plans and fetches ITS shard by itself out of the bundle `packed` in (device-readable) host memory —
+        `ipcfp_witness_create_shard_pull`: nobody holds the whole witness, no plan comes from elsewhere."""
+        st, w, lo, hi, n_receipts, stats = eng.witness_shard_pull(packed, parent_cids, child_cid, n_shards, shard)
+        if st != 1:
+            raise B.EngineError(f"shard pull failed with status {st}")
+        self = cls.__new__(cls)
+        self.eng, self.n_shards, self.shard = eng, int(n_shards), int(shard)
+        self.lo, self.hi, self.n_receipts_total, self.block_ids = lo, hi, n_receipts, None
+        self.witness, self.pull_stats = w, stats
+        self.receipts_root = bytes(receipts_root)
+        self.parent_cids, self.child_cid = parent_cids, child_cid
         return self
 
     def __init__(self, eng: B.Engine, full: B.Witness, parent_cids, child_cid: bytes, receipts_root: bytes,

@@ -1,0 +1,137 @@
+"""GPU: the SELF-PLANNED shard — ipcfp_witness_create_shard_pull.  Rank r of G gets nothing but the bundle in host memory
+(transport form: blocks back to back, lengths, digests) and the tipset key; the device follows the links level by level
+and reads its blocks out of the host buffer itself.  The shard must be exactly what the planner that sees the whole
+witness makes (ipcfp_shard_plan_tipset), and G such shards must give the unsharded engine's and the oracle's results.
+Reference loops being cut: src/proofs/verifier.rs:19-28,49-54, src/proofs/events/verifier.rs:62-71."""
+import numpy as np
+import pytest
+
+import ipc_filecoin_proofs_amd as ipcfp
+from ipc_filecoin_proofs_amd import shard
+from tools.synth import Tipset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tip():
+    return Tipset(n_receipts=40_000, n_parents=4, dup_permille=30, n_planted=40, max_events=4, no_events_permille=50,
+                  variety=1, seed=77)
+
+
+@pytest.fixture(scope="module")
+def bundle(tip):
+    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
+    ipcfp.host_register(pk.data)   # an ingest buffer is registered once, when it is made
+    yield pk
+    ipcfp.host_unregister(pk.data)
+
+
+@pytest.fixture(scope="module")
+def claims_packed(tip):
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec, tip.claim_event,
+        tip.claim_emitter, tip.exec_order[tip.claim_exec.astype(np.int64)], tip.claim_ntopics, tip.claim_topics,
+        tip.claim_datalen, tip.claim_data)
+    n = len(cl)
+    liars = np.arange(5, n, 17)
+    cl["exec_index"][liars[0::3]] += 1
+    cl["emitter"][liars[1::3]] ^= 1
+    with_data = liars[2::3][cl["data_len"][liars[2::3]] > 0]
+    blob[cl["data_off"][with_data]] ^= 0x40
+    cl["exec_index"][n - 2] = 40_000 + 3          # names no receipt: the last shard's
+    return ts, cl, blob, blob_len
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_pulled_shard_holds_exactly_the_planned_blocks(engine, tip, bundle, G):
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as full:
+        for r in range(G):
+            st, lo, hi, n_receipts, ids = full.shard_plan_tipset(tip.parent_cids, tip.child_cid, G, r)
+            pst, w, plo, phi, pn, stats = engine.witness_shard_pull(bundle, tip.parent_cids, tip.child_cid, G, r)
+            assert st == pst == 1 and (lo, hi, n_receipts) == (plo, phi, pn) and w.receipt_range == (lo, hi)
+            assert w.block_count == len(ids) == stats["blocks"]
+            has, _ = w.has([bytes(tip.cids[i]) for i in ids[:: max(1, len(ids) // 4000)]])
+            assert has.all()
+            # what crossed PCIe: the tables of the bundle + the shard's own blocks (each on lines of its own)
+            assert stats["table_bytes"] == 36 * tip.n_blocks
+            want_bytes = int(((tip.lens[ids].astype(np.int64) + 127) // 128 * 128).sum())
+            assert stats["block_bytes"] == want_bytes and stats["rounds"] >= 5
+            st_cid, n_bad = w.verify_cids()
+            assert n_bad == 0
+            w.close()
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_pulled_shards_equal_the_unsharded_result(engine, oracle, tip, bundle, claims_packed, G):
+    ts, cl, blob, blob_len = claims_packed
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        want = w.verify_event_claims(ts, cl, blob, blob_len)
+        ws, whas, wm, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
+    status = np.full(len(cl), 255, dtype=np.uint8)
+    has = np.zeros(40_000, dtype=np.uint8)
+    n_matches = 0
+    for r in range(G):
+        s = shard.TipsetShard.from_pull(engine, bundle, tip.parent_cids, tip.child_cid, tip.receipts_root, G, r)
+        assert s.n_receipts_total == 40_000
+        s.route(ts, cl, blob, blob_len)
+        status[s.positions.astype(np.int64)] = s.witness.verify_event_claims(ts, s.claims, s.blob, s.blob_len)
+        sst, shas, sm, _ = s.witness.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                                 want_touched=False)
+        assert sst == 1 and len(shas) == s.hi - s.lo
+        has[s.lo: s.hi] = shas
+        n_matches += len(sm)
+        s.close()
+    assert np.array_equal(status, want) and (want != 1).sum() > 100
+    assert np.array_equal(has, whas) and n_matches == len(wm)
+    ost = oracle.store(tip.data, tip.off, tip.lens, tip.cids, threads=0)
+    assert np.array_equal(ost.verify_event_claims_packed(ts, cl, blob, threads=0), want)
+    ost.close()
+
+
+def test_pull_of_tall_event_amts(engine):
+    """Events AMTs of bit width 1 and height >= 8: every node of every tree of the rank's receipts is a level of its own."""
+    tall = Tipset(n_receipts=60, n_planted=6, variety=1, max_events=700, events_bit_width=1, seed=79)
+    pk = ipcfp.PackedWitnessTables(tall.data, tall.off, tall.lens, tall.cids)
+    ipcfp.host_register(pk.data)
+    try:
+        with engine.witness(tall.data, tall.off, tall.lens, tall.cids) as full:
+            for G in (1, 3):
+                for r in range(G):
+                    st, lo, hi, nr, ids = full.shard_plan_tipset(tall.parent_cids, tall.child_cid, G, r)
+                    pst, w, plo, phi, pn, stats = engine.witness_shard_pull(pk, tall.parent_cids, tall.child_cid, G, r)
+                    assert pst == st == 1 and (plo, phi) == (lo, hi) and w.block_count == len(ids) and stats["rounds"] >= 12
+                    has, _ = w.has([bytes(tall.cids[i]) for i in ids])
+                    assert has.all()
+                    w.close()
+    finally:
+        ipcfp.host_unregister(pk.data)
+
+
+def test_pull_without_a_receipts_root_has_no_range_to_cut_by(engine, tip):
+    keep = np.ones(tip.n_blocks, dtype=bool)
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        _, ids = w.has([tip.child_cid])
+        keep[int(ids[0])] = False
+    sub = ipcfp.witness_cut_host(tip.data, tip.off, tip.lens, tip.cids, np.nonzero(keep)[0].astype(np.uint32))
+    pk = ipcfp.PackedWitnessTables(*sub)
+    ipcfp.host_register(pk.data)
+    try:
+        st, w, lo, hi, nr, stats = engine.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, 4, 2)
+        assert st == 65 and w is None and (lo, hi, nr) == (0, 0, 0)
+    finally:
+        ipcfp.host_unregister(pk.data)
+
+
+def test_pull_refuses_a_buffer_the_device_cannot_read(engine, tip):
+    pk = ipcfp.PackedWitnessTables(tip.data.copy(), tip.off, tip.lens, tip.cids)   # pageable, not registered
+    with pytest.raises(ipcfp.EngineError, match="device-readable"):
+        engine.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, 2, 0)
+    pk.lens = pk.lens.copy()
+    pk.lens[7] += 1                                                         # tables that do not add up
+    ipcfp.host_register(pk.data)
+    try:
+        with pytest.raises(ipcfp.EngineError, match="add up"):
+            engine.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, 2, 0)
+    finally:
+        ipcfp.host_unregister(pk.data)
