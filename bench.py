@@ -633,17 +633,35 @@ def tipset_gather_step_ms(args, eng, torch, w, tip, ts, t_claims, t_blob, blob_l
     return (time.perf_counter() - t0) / args.steps * 1e3
 
 
+def host_read_bandwidth(buf, thread_counts=(4, 16, 32)):
+    """What the host's memory system delivers to CPU threads streaming through `buf` (numpy reductions release the GIL),
+    under whatever CPU quota the container has: a LOWER bound of what G PCIe links can read out of it by DMA."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    words = buf[: buf.size // 8 * 8].view(np.uint64)
+    res = {}
+    for t in thread_counts:
+        parts = np.array_split(words, t)
+        with ThreadPoolExecutor(t) as ex:
+            list(ex.map(lambda a: int(np.bitwise_xor.reduce(a)), parts))  # warm
+            t0 = time.perf_counter()
+            list(ex.map(lambda a: int(np.bitwise_xor.reduce(a)), parts))
+            res[str(t)] = round(words.nbytes / (time.perf_counter() - t0) / 1e9, 1)
+    return res
+
+
 def shard_projection(args, eng, torch, dev, tip, ts, cl, blob, blob_len, w_full, status_full, has_full, t3_ms_1, t2_ms_1,
                      shard_counts=(2, 4, 8), steps=5, t2_reps=2):
-    """STRONG scaling of ONE tipset, measured on the one GPU there is: for G in shard_counts the
-    receipt cut of north_star / SURVEY.md §8(e) is planned ONCE on the resident whole witness
-    (ipcfp_shard_plan_tipset_all), each shard r = 0..G-1 is cut out of the HOST copy of the bundle
-    (ipcfp_witness_cut_host, ipcfp_route_event_claims) and run BY ITSELF, one after the other:
-      T3  shard resident in HBM; step = shard.TipsetShard.step = CID index + K1 + verify of the shard's claims (the
-          execution order is rebuilt on every rank) + range-restricted scan + the packed step message (the all-gather
-          itself is degenerate on one rank: the device-side packing is in, the xGMI transfer is not);
-      T2  the same pass from pageable HOST memory — the rank uploads ONLY its shard over its own PCIe link —
-          with the status bytes, CID verdicts, has-match map and match records back on the host.
+    """STRONG scaling of ONE tipset, measured on the one GPU there is: for G in shard_counts every rank r = 0..G-1 of the
+    receipt cut of north_star / SURVEY.md §8(e) is run BY ITSELF, one after the other, as a SELF-PLANNED shard
+    (ipcfp_witness_create_shard_pull): the rank is given the bundle in registered host memory and the tipset key, nothing
+    else — no plan from elsewhere, no whole witness in anybody's HBM, no block lists or claims cut on the host.
+      T2  ONE figure per rank, everything inside: tables of the bundle up (36 B per block), the device walks the links level
+          by level and reads the shard's blocks out of host memory itself, the shard's arena / schedule / index, K1, the
+          rank's claims (two binary searches into the exec_index-ordered batch, uploaded as a slice, rebased on the device),
+          verify, range-restricted scan, status bytes + CID verdicts + has-match map + match records back on the host.
+      T3  the shard resident in HBM; step = shard.TipsetShard.step = CID index + K1 + verify of the shard's claims (the
+          execution order is rebuilt on every rank) + range-restricted scan + the packed step message.
     A G-GPU run's step is max over ranks (+ the collective); `projected_speedup` = t(G = 1) / max_r t_r.  Every shard's
     verdicts are merged and compared with the unsharded run's before anything is reported."""
     from ipc_filecoin_proofs_amd import shard
@@ -656,104 +674,120 @@ def shard_projection(args, eng, torch, dev, tip, ts, cl, blob, blob_len, w_full,
     def dev_bytes(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
 
-    for G in shard_counts:
-        ta = time.perf_counter()
-        plan = shard.TipsetPlan(w_full, tip.parent_cids, tip.child_cid, G)
-        plan_ms = (time.perf_counter() - ta) * 1e3
-        routed = [plan.route(r, cl, blob, blob_len) for r in range(G)]
-        layout = shard.Layout(max(len(x[0]) for x in routed), max(plan.range(r)[1] - plan.range(r)[0] for r in range(G)),
-                              max(len(x) for x in plan.block_ids))
-        status = np.full(len(cl), 255, dtype=np.uint8)
-        has = np.zeros(plan.n_receipts, dtype=np.uint8)
-        n_matches, per = 0, []
-        for r in range(G):
-            lo, hi = plan.range(r)
-            tc0 = time.perf_counter()
-            sub = plan.cut(r, tip.data, tip.off, tip.lens, tip.cids)
-            cut_ms = (time.perf_counter() - tc0) * 1e3
-            pos, c_r, b_r, bl_r = routed[r]
-            # ---- T3: the shard resident
-            d_b, d_o, d_l, d_c = dev_bytes(sub[0]), dev_bytes(sub[1]), dev_bytes(sub[2]), dev_bytes(sub[3])
-            d_cl, d_blob = dev_bytes(c_r), dev_bytes(b_r)
-            d_status = torch.zeros(layout.w_status, dtype=torch.uint8, device=dev)
-            d_has = torch.zeros(layout.w_has, dtype=torch.uint8, device=dev)
-            d_stage = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
-            d_recv = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
-            torch.cuda.synchronize()
-            wd = eng.witness_device(d_b.data_ptr(), sub[0].size, d_o.data_ptr(), d_l.data_ptr(), d_c.data_ptr(), len(sub[2]))
-            sh = shard.TipsetShard.from_plan(eng, plan, r, None, tip.receipts_root, witness=wd)
-            sh.tipsets, sh.positions, sh.claims, sh.blob, sh.blob_len, sh.n_claims = ts, pos, c_r, b_r, bl_r, len(pos)
-            d_hdr = dev_bytes(sh.header())
-            torch.cuda.synchronize()
+    # the bundle as a rank finds it: transport form in an ingest buffer that was registered when it was made
+    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
+    t0 = time.perf_counter()
+    ipcfp.host_register(pk.data)
+    out["host_register_ms_once_untimed"] = round((time.perf_counter() - t0) * 1e3, 2)
+    if not np.all(cl["exec_index"][1:] >= cl["exec_index"][:-1]):
+        raise SystemExit("bench: the claim batch is not in exec_index order")
+    out["host_memory_read_GBps"] = host_read_bandwidth(pk.data)
+    try:
+        for G in shard_counts:
+            status = np.full(len(cl), 255, dtype=np.uint8)
+            has = np.zeros(len(has_full), dtype=np.uint8)
+            per, rows = [], []
+            for r in range(G):
+                # ---- T2: everything a rank does, from the bundle in host memory to the verdicts on the host ----
+                reps, stats_last = [], None
+                for rep in range(t2_reps + 1):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    st, w2, lo, hi, n_receipts, stats = eng.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, G, r)
+                    if st != 1:
+                        raise SystemExit("bench self-check failed: shard %d of %d could not be pulled (status %d)" % (r, G, st))
+                    t1 = time.perf_counter()
+                    w2.verify_cids_async()
+                    a, st2 = w2.verify_event_claims_range(ts, cl, blob, blob_len, lo, hi, r == G - 1)
+                    t2_ = time.perf_counter()
+                    sst, has2, m2, _ = w2.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
+                                                      want_touched=False, caps=(hi - lo, MATCH_CAP))
+                    t3_ = time.perf_counter()
+                    cs2, nbad2 = w2.cid_results()
+                    t4_ = time.perf_counter()
+                    reps.append(t4_ - t0)
+                    stats_last = dict(stats, phases_ms={"shard_pull": round((t1 - t0) * 1e3, 3), "claims_verify": round((t2_ - t1) * 1e3, 3),
+                                                        "scan": round((t3_ - t2_) * 1e3, 3), "cid_results": round((t4_ - t3_) * 1e3, 3)})
+                    if sst != 1 or nbad2:
+                        raise SystemExit("bench self-check failed: shard %d of %d: scan status %d, %d bad CIDs" % (r, G, sst, nbad2))
+                    if rep < t2_reps:
+                        w2.close()
+                status[a: a + len(st2)] = st2
+                has[lo:hi] = has2
+                n_claims_r, n_blocks_r = len(st2), w2.n
+                # ---- T3: the same shard, resident (the witness of the last T2 pass), claims in HBM ----
+                s_obj = shard.TipsetShard.__new__(shard.TipsetShard)
+                s_obj.eng, s_obj.n_shards, s_obj.shard = eng, G, r
+                s_obj.lo, s_obj.hi, s_obj.n_receipts_total, s_obj.block_ids = lo, hi, n_receipts, None
+                s_obj.witness, s_obj.receipts_root = w2, bytes(tip.receipts_root)
+                s_obj.parent_cids, s_obj.child_cid = tip.parent_cids, tip.child_cid
+                s_obj.route(ts, cl, blob, blob_len)
+                rows.append((s_obj, a))
+                per.append({"shard": r, "receipts": [lo, hi], "blocks": int(n_blocks_r), "claims": int(n_claims_r),
+                            "h2d_bytes": int(stats_last["table_bytes"] + stats_last["block_bytes"] + n_claims_r * cl.dtype.itemsize +
+                                             s_obj.blob_len),
+                            "pull": {"rounds": stats_last["rounds"], "table_bytes": int(stats_last["table_bytes"]),
+                                     "block_bytes": int(stats_last["block_bytes"]), "tables_ms": round(stats_last["tables_ms"], 3),
+                                     "pull_ms": round(stats_last["pull_ms"], 3), "create_ms": round(stats_last["create_ms"], 3)},
+                            "T2_phases_ms_last_pass": stats_last["phases_ms"],
+                            "T2_ms": round(min(reps[1:]) * 1e3, 3)})
+            layout = shard.Layout(max(s.n_claims for s, _ in rows), max(s.hi - s.lo for s, _ in rows), max(s.witness.n for s, _ in rows))
+            for (s_obj, a), rec in zip(rows, per):
+                d_cl, d_blob = dev_bytes(s_obj.claims), dev_bytes(s_obj.blob)
+                d_status = torch.zeros(layout.w_status, dtype=torch.uint8, device=dev)
+                d_has = torch.zeros(layout.w_has, dtype=torch.uint8, device=dev)
+                d_stage = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+                d_recv = torch.zeros(layout.bytes_per_rank, dtype=torch.uint8, device=dev)
+                d_hdr = dev_bytes(s_obj.header())
+                torch.cuda.synchronize()
 
-            def step():
-                sh.step(layout, None, filt, d_cl.data_ptr(), d_blob.data_ptr(), d_status.data_ptr(), d_has.data_ptr(),
-                        d_hdr.data_ptr(), d_stage.data_ptr(), d_recv.data_ptr())
+                def step():
+                    s_obj.step(layout, None, filt, d_cl.data_ptr(), d_blob.data_ptr(), d_status.data_ptr(), d_has.data_ptr(),
+                               d_hdr.data_ptr(), d_stage.data_ptr(), d_recv.data_ptr())
 
-            for _ in range(2):
-                step()
-            eng.sync()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            eng.sync()
-            torch.cuda.synchronize()
-            t3_ms = (time.perf_counter() - t0) / steps * 1e3
-            msg = d_recv.cpu().numpy()
-            hdr = msg[:shard.HEADER_BYTES].view(np.uint64)
-            if int(hdr[0]) != len(pos) or int(hdr[3]) != 1:
-                raise SystemExit("bench self-check failed: shard %d of %d reports claims %d / scan status %d" % (r, G, int(hdr[0]), int(hdr[3])))
-            status[pos.astype(np.int64)] = msg[layout.off_status: layout.off_status + len(pos)]
-            has[lo:hi] = msg[layout.off_has: layout.off_has + (hi - lo)]
-            n_matches += int(hdr[4])
-            bits = np.unpackbits(msg[layout.off_bits: layout.off_bits + (len(sub[2]) + 31) // 32 * 4], bitorder="little")[: len(sub[2])]
-            if int(bits.sum()) != len(sub[2]):
-                raise SystemExit("bench self-check failed: shard %d of %d has blocks whose CID did not verify" % (r, G))
-            sh.close()
-            del d_b, d_o, d_l, d_c, d_cl, d_blob, d_status, d_has, d_stage, d_recv, d_hdr
-            # ---- T2: the shard from host memory (what rank r's own PCIe link carries)
-            reps = []
-            # (tables and claims in transport form, like the unsharded T2 this is compared with: built once, untimed)
-            pk_r = ipcfp.PackedWitnessTables(*sub)
-            g_r, cc_r, cb_r, cbl_r = ipcfp.compact_event_claims(c_r, b_r, bl_r)
-            for _ in range(t2_reps + 1):
+                for _ in range(2):
+                    step()
+                eng.sync()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                w2 = eng.witness_packed(pk_r)
-                w2.set_receipt_range(lo, hi)
-                w2.verify_cids_async()
-                st2 = w2.verify_event_claims_compact(ts, g_r, cc_r, cb_r, cbl_r)
-                sst, has2, m2, _ = w2.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor,
-                                                  want_touched=False, caps=(hi - lo, MATCH_CAP))
-                cs2, nbad2 = w2.cid_results()
-                reps.append(time.perf_counter() - t0)
-                w2.close()
-                if sst != 1 or nbad2 or not np.array_equal(st2, status[pos.astype(np.int64)]) or not np.array_equal(has2, has[lo:hi]):
-                    raise SystemExit("bench self-check failed: shard %d of %d from host differs from the resident one" % (r, G))
-            h2d = int(pk_r.h2d_bytes + g_r.nbytes + cc_r.nbytes + cbl_r)
-            del pk_r, cc_r, cb_r
-            per.append({"shard": r, "receipts": [lo, hi], "blocks": int(len(sub[2])), "claims": int(len(pos)),
-                        "witness_bytes": int(sub[0].size), "h2d_bytes": h2d, "T3_ms_per_step": round(t3_ms, 4),
-                        "T2_ms": round(min(reps[1:]) * 1e3, 3), "host_cut_ms_untimed": round(cut_ms, 1)})
-            del sub
-        if not np.array_equal(status, status_full) or not np.array_equal(has, has_full):
-            raise SystemExit("bench self-check failed: the merged verdicts of %d shards differ from the unsharded run" % G)
-        t3_max, t2_max = max(p["T3_ms_per_step"] for p in per), max(p["T2_ms"] for p in per)
-        out["shards"][str(G)] = {
-            "plan_all_ms_once_untimed": round(plan_ms, 2), "allgather_bytes_per_rank": layout.bytes_per_rank,
-            "T3_ms_max_over_shards": t3_max, "T2_ms_max_over_shards": t2_max,
-            "projected_speedup_T3": round(t3_ms_1 / t3_max, 3), "projected_speedup_T2": round(t2_ms_1 / t2_max, 3) if t2_ms_1 else None,
-            "projected_proofs_per_s_T3": len(cl) / (t3_max * 1e-3), "projected_proofs_per_s_T2": len(cl) / (t2_max * 1e-3),
-            "h2d_bytes_max": max(p["h2d_bytes"] for p in per), "merged_equals_unsharded": True, "per_shard": per,
-        }
-    out["note"] = ("ONE 1M-receipt tipset cut by receipt range (north_star's cut), each logical shard timed by itself on this GPU; "
-                   "a G-GPU step = max over shards + the xGMI all-gather of `allgather_bytes_per_rank` per rank (KiB-MiB scale, "
-                   "latency-bound; NOT measurable here: one GPU) — the projection leaves the link time out and assumes each rank "
-                   "has its own PCIe link and enough host memory bandwidth (G x 56 GB/s).  The plan is made once where the whole "
-                   "witness is resident (ipcfp_shard_plan_tipset_all) and is outside both windows, as is the host-side cut.  "
-                   "T3 does not scale: the execution order (five parents' message AMTs: a chain of dependent block reads) is "
-                   "rebuilt on every rank.  T2 is upload-bound and divides.")
+                for _ in range(steps):
+                    step()
+                eng.sync()
+                torch.cuda.synchronize()
+                rec["T3_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+                msg = d_recv.cpu().numpy()
+                hdr = msg[:shard.HEADER_BYTES].view(np.uint64)
+                pos = s_obj.positions.astype(np.int64)
+                if int(hdr[0]) != len(pos) or int(hdr[3]) != 1:
+                    raise SystemExit("bench self-check failed: shard %d of %d reports claims %d / scan status %d" % (rec["shard"], G, int(hdr[0]), int(hdr[3])))
+                if not np.array_equal(msg[layout.off_status: layout.off_status + len(pos)], status[pos]) or \
+                        not np.array_equal(msg[layout.off_has: layout.off_has + (s_obj.hi - s_obj.lo)], has[s_obj.lo: s_obj.hi]):
+                    raise SystemExit("bench self-check failed: shard %d of %d resident differs from its PCIe-inclusive pass" % (rec["shard"], G))
+                s_obj.close()
+                del d_cl, d_blob, d_status, d_has, d_stage, d_recv, d_hdr
+            if not np.array_equal(status, status_full) or not np.array_equal(has, has_full):
+                raise SystemExit("bench self-check failed: the merged verdicts of %d shards differ from the unsharded run" % G)
+            t3_max, t2_max = max(p["T3_ms_per_step"] for p in per), max(p["T2_ms"] for p in per)
+            out["shards"][str(G)] = {
+                "allgather_bytes_per_rank": layout.bytes_per_rank,
+                "T3_ms_max_over_shards": t3_max, "T2_ms_max_over_shards": t2_max,
+                "projected_speedup_T3": round(t3_ms_1 / t3_max, 3), "projected_speedup_T2": round(t2_ms_1 / t2_max, 3) if t2_ms_1 else None,
+                "projected_proofs_per_s_T3": len(cl) / (t3_max * 1e-3), "projected_proofs_per_s_T2": len(cl) / (t2_max * 1e-3),
+                "h2d_bytes_max": max(p["h2d_bytes"] for p in per), "merged_equals_unsharded": True, "per_shard": per,
+            }
+    finally:
+        ipcfp.host_unregister(pk.data)
+    out["note"] = ("ONE 1M-receipt tipset cut by receipt range (north_star's cut); every rank is SELF-PLANNED "
+                   "(ipcfp_witness_create_shard_pull) and timed by itself on this GPU.  T2 is ONE figure per rank with everything "
+                   "inside: plan (the device follows the links), cut (the device reads its blocks out of the registered host buffer: "
+                   "no host memcpy, no CPU in the data path — the box's 16-CPU quota does not bound it), upload, shard build, K1, "
+                   "claims (a slice of the exec_index-ordered batch), verify, scan, results on the host.  Outside: registering the "
+                   "ingest buffer (`host_register_ms_once_untimed`: done when the buffer is made, not per bundle) and the xGMI "
+                   "all-gather of `allgather_bytes_per_rank` per rank (latency-bound; not measurable on one GPU).  The projection "
+                   "assumes each rank's PCIe link reads host memory at the rate one link does alone: G x 50 GB/s of host DRAM reads "
+                   "(`host_memory_read_GBps` is what the host's memory system delivers to CPU threads under the quota — a lower "
+                   "bound of what its DMA paths can).  T3 divides only as far as the replicated execution order lets it: five "
+                   "parents' message AMTs are walked on every rank.")
     return out
 
 

@@ -614,6 +614,21 @@ int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
                               uint32_t n_tipsets, const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob,
                               uint64_t blob_len, const ipcfp_trust_policy_t* trust,
                               const ipcfp_event_filter_t* filter, ipcfp_status_t* status);
+/* The claims of the receipts [receipt_lo, receipt_hi) out of a batch that is in exec_index order — the order
+ * generate_event_proof emits them in (src/proofs/events/generator.rs:242-301) — and stays where it is in host memory: a rank
+ * of a receipt cut takes its share with two binary searches, NO pass over the batch.  The records cross PCIe as they are;
+ * the window of the blob they point into is found on the device and uploaded beside the walk; the offsets are rebased in
+ * front of the verify kernel (a record that points outside the batch's blob: IPCFP_ST_ERR_BAD_CLAIM).  last_shard != 0:
+ * the claims with exec_index >= receipt_hi are this rank's too (every claim has one owner: ipcfp_route_event_claims).
+ *   *first_out, *count_out   the records verified are claims[*first_out .. *first_out + *count_out)
+ *   status                   receives *count_out bytes (room for n)
+ * IPCFP_E_INVALID when the batch is visibly out of order at the slice's ends; a batch in another order goes through
+ * ipcfp_route_event_claims.                                                                                          */
+int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets,
+                                    uint32_t n_tipsets, const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob,
+                                    uint64_t blob_len, uint64_t receipt_lo, uint64_t receipt_hi, int last_shard,
+                                    const ipcfp_trust_policy_t* trust, const ipcfp_event_filter_t* filter,
+                                    uint64_t* first_out, uint64_t* count_out, ipcfp_status_t* status);
 
 /* Host-only lowering of the reference's structs to the packed form (no context, no device; parallel over
  * claims): what ipcfp_verify_event_proofs does before its upload, for callers that keep claims packed or

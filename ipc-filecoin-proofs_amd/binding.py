@@ -253,6 +253,8 @@ def load_library() -> C.CDLL:
         "ipcfp_route_event_claims": (i32, [vp, u64, vp, u64, u64, u64, i32, vp, vp, u64, vp, u64, C.POINTER(u64),
                                            C.POINTER(u64)]),
         "ipcfp_witness_create_subset": (i32, [vp, vp, vp, u64, u64, u64, C.POINTER(vp)]),
+        "ipcfp_verify_event_claims_range": (i32, [vp, vp, vp, C.c_uint32, vp, u64, vp, u64, u64, u64, i32, vp, vp, C.POINTER(u64),
+                                                  C.POINTER(u64), vp]),
         "ipcfp_witness_create_shard_pull": (i32, [vp, vp, u64, vp, vp, u64, vp, C.c_uint32, vp, vp, u64, vp, C.c_uint32, vp,
                                                   C.c_uint32, C.c_uint32, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), vp,
                                                   C.POINTER(vp)]),
@@ -1263,6 +1265,24 @@ class Witness:
             C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
             C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, _p(st)), "verify_event_claims")
         return st
+
+    def verify_event_claims_range(self, tipsets: np.ndarray, claims: np.ndarray, blob: np.ndarray, blob_len: int, lo: int, hi: int,
+                                  last: bool, trust=None, filt=None):
+        """The claims of the receipts [lo, hi) out of a packed batch in exec_index order (ipcfp_verify_event_claims_range: two
+        binary searches, no host pass, offsets rebased on the device).  `last`: the last shard also owns the claims that name
+        no receipt.  Returns (first position, status u8[count])."""
+        tipsets = np.ascontiguousarray(tipsets, dtype=TIPSET_DTYPE)
+        if not (claims.flags.c_contiguous and claims.dtype == CLAIM_DTYPE and blob.flags.c_contiguous):
+            raise EngineError("verify_event_claims_range: the batch must be contiguous ipcfp_event_claim_t records")
+        st = np.zeros(len(claims), dtype=np.uint8)
+        first, count = C.c_uint64(), C.c_uint64()
+        self.eng._check(self.lib.ipcfp_verify_event_claims_range(
+            self.eng.h, self.h, _p(tipsets), len(tipsets), claims.ctypes.data_as(C.c_void_p), len(claims),
+            blob.ctypes.data_as(C.c_void_p), int(blob_len), int(lo), int(hi), int(bool(last)),
+            C.cast(C.pointer(trust), C.c_void_p) if trust is not None else None,
+            C.cast(C.pointer(filt), C.c_void_p) if filt is not None else None, C.byref(first), C.byref(count), _p(st)),
+            "verify_event_claims_range")
+        return int(first.value), st[: int(count.value)]
 
     def verify_event_claims_compact(self, tipsets: np.ndarray, groups: np.ndarray, claims: np.ndarray, cblob: np.ndarray,
                                     cblob_len: int, trust=None, filt=None) -> np.ndarray:

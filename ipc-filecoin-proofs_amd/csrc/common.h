@@ -113,6 +113,13 @@ struct ipcfp_ctx {
         uint32_t* scratch_u32 = nullptr;
         uint64_t* scan_scratch = nullptr;
     } claims_expand;
+    // claims that are a slice of a larger batch (ipcfp_verify_event_claims_slice): blob offsets rebased once they are in HBM
+    struct ClaimsRebase {
+        bool pending = false;
+        void* claims_d = nullptr;
+        uint32_t n = 0;
+        uint64_t base = 0, blob_len = 0;
+    } claims_rebase;
     // --- the mailbox: a page of COHERENT pinned host memory a kernel writes while the stream keeps going (device →
     // host without a synchronisation; kernels/amt_enum.hip k_enum_roots, host/verify_fast.cpp) ---
     unsigned long long* mailbox = nullptr;      // host address

@@ -22,6 +22,12 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
 
 int claims_ready(ipcfp_ctx* ctx) {
     int rc = upload_task_wait(ctx);
+    if (ctx->claims_rebase.pending) {  // a slice of a larger batch: its blob offsets become offsets into what was uploaded
+        ipcfp_ctx::ClaimsRebase& rb = ctx->claims_rebase;
+        rb.pending = false;
+        if (rc) return rc;
+        rc = launch_rebase_claims(ctx, rb.claims_d, rb.n, rb.base, rb.blob_len);
+    }
     ipcfp_ctx::ClaimsExpand& x = ctx->claims_expand;
     if (!x.pending) return rc;
     x.pending = false;

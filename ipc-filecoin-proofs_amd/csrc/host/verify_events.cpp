@@ -524,6 +524,95 @@ int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     return IPCFP_OK;
 }
 
+// The claims of the receipts [receipt_lo, receipt_hi) out of a batch in exec_index order, which stays where it is in host
+// memory: two binary searches find the records, they are uploaded as they are, the window of the blob they point into is
+// found ON THE DEVICE (one reduction, one read-back), uploaded beside the walk, and the records' offsets are rebased in
+// front of the verify kernel (kernels/claims_compact.hip).  No pass over the batch on the host.
+int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets, uint32_t n_tipsets,
+                                    const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob, uint64_t blob_len,
+                                    uint64_t receipt_lo, uint64_t receipt_hi, int last_shard, const ipcfp_trust_policy_t* trust,
+                                    const ipcfp_event_filter_t* filter, uint64_t* first_out, uint64_t* count_out,
+                                    ipcfp_status_t* status) {
+    if (!ctx || !w || w->ctx != ctx || !first_out || !count_out || (n && (!claims || !status || !tipsets)) || (blob_len && !blob) ||
+        receipt_lo > receipt_hi)
+        return IPCFP_E_INVALID;
+    if (n >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "batch too large");
+    auto lower_bound = [&](uint64_t key) {
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (claims[mid].exec_index < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const uint64_t a = lower_bound(receipt_lo), b = last_shard ? n : lower_bound(receipt_hi);
+    *first_out = a;
+    *count_out = b > a ? b - a : 0;
+    if (b <= a) return IPCFP_OK;
+    const uint64_t m = b - a;
+    // (the order is the caller's promise; what can be checked for nothing is checked: the slice's ends)
+    if (claims[a].exec_index > claims[b - 1].exec_index || (a && claims[a - 1].exec_index > claims[a].exec_index) ||
+        (b < n && claims[b - 1].exec_index > claims[b].exec_index))
+        return set_error(ctx, IPCFP_E_INVALID, "the claim batch is not in exec_index order (ipcfp_route_event_claims takes any order)");
+    IPCFP_ENTER(ctx);
+    std::vector<TipsetCtxDev> tcs(n_tipsets);
+    for (uint32_t k = 0; k < n_tipsets; ++k) {
+        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
+        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
+        tcs[k].flags = tipsets[k].flags;
+        tcs[k].n_parents = tipsets[k].n_parents;
+        tcs[k].child = key_from_slot(tipsets[k].child);
+        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
+    }
+    DevBuf<EventClaimPacked> cd;
+    DevBuf<uint8_t> bd, sd;
+    DevBuf<unsigned long long> win_d;
+    IPCFP_HIP(ctx, cd.alloc(m));
+    IPCFP_HIP(ctx, sd.alloc(m));
+    IPCFP_HIP(ctx, win_d.alloc(2));
+    const unsigned long long win0[2] = {~0ull, 0ull};
+    IPCFP_HIP(ctx, h2d_small(ctx, win_d.p, win0, sizeof win0, ctx->stream));
+    int rc = upload(ctx, cd.p, claims + a, m * sizeof(EventClaimPacked), ctx->stream);
+    if (rc) return rc;
+    rc = launch_claims_window(ctx, cd.p, uint32_t(m), win_d.p);
+    if (rc) return rc;
+    unsigned long long win[2] = {0, 0};
+    IPCFP_HIP(ctx, d2h_small(ctx, win, win_d.p, sizeof win, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    uint64_t o0 = win[0] == ~0ull ? 0 : win[0], o1 = win[1];
+    if (o0 > blob_len) o0 = blob_len;  // (records that point outside the batch's blob: the window is clamped, they are refused)
+    if (o1 > blob_len) o1 = blob_len;
+    if (o1 < o0) o1 = o0;
+    const uint64_t wlen = o1 - o0;
+    IPCFP_HIP(ctx, bd.alloc(wlen + 64));
+    if (wlen >= (size_t(4) << 20)) ctx->upload_task = upload_task_start(ctx, bd.p, blob + o0, wlen, nullptr, nullptr, 0);
+    if (!ctx->upload_task && wlen) {
+        rc = upload(ctx, bd.p, blob + o0, wlen, ctx->stream);
+        if (rc) return rc;
+    }
+    ctx->claims_rebase.pending = true;  // (queued by claims_ready: behind the copy, in front of whichever kernel reads the claims first)
+    ctx->claims_rebase.claims_d = cd.p;
+    ctx->claims_rebase.n = uint32_t(m);
+    ctx->claims_rebase.base = o0;
+    ctx->claims_rebase.blob_len = wlen;
+    rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(m), bd.p, wlen, trust, filter, sd.p);
+    {
+        const int rc_up = upload_task_wait(ctx);
+        if (rc == IPCFP_OK) rc = rc_up;
+        if (ctx->claims_rebase.pending) {  // no route reached its verify kernel: nothing may be reported
+            ctx->claims_rebase.pending = false;
+            if (rc == IPCFP_OK) rc = set_error(ctx, IPCFP_E_INVALID, "the claim slice was never rebased (no route reached its verify kernel)");
+        }
+    }
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, m, hipMemcpyDeviceToHost, ctx->stream));
+    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    return IPCFP_OK;
+}
+
 // reconstruct_execution_order(bs, parent_hdr_cids) (src/proofs/events/utils.rs:16-30).
 //   *status_out  IPCFP_ST_TRUE or the ERR_* the reference's `?` would surface first
 //   *count       number of messages in execution order

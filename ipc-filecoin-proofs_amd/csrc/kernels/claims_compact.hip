@@ -97,6 +97,69 @@ __global__ __launch_bounds__(256) void k_compact_expand(const ClaimCompact* __re
     for (uint32_t b = 0; b < dl; ++b) dst[33u * nt + b] = src[32u * nt + b];
 }
 
+// ipcfp_verify_event_claims_slice: the records are consecutive claims of a larger batch and their blob offsets count from
+// the start of THAT batch's blob, of which bytes [base, base + blob_len) were uploaded: rebase them; a claim whose topics
+// or data do not lie inside that window is marked out of range (ERR_BAD_CLAIM, never followed).
+__global__ __launch_bounds__(256) void k_rebase_claims(EventClaimPacked* __restrict__ claims, uint32_t n, uint64_t base, uint64_t blob_len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    EventClaimPacked c = claims[i];
+    const uint64_t t0 = c.topics_off, t1 = t0 + 33ull * c.n_topics, d0 = c.data_off, d1 = d0 + c.data_len;
+    const bool t_ok = c.n_topics == 0 || (t0 >= base && t1 <= base + blob_len);
+    const bool d_ok = c.data_len == 0 || (d0 >= base && d1 <= base + blob_len);
+    if (t_ok && d_ok) {
+        c.topics_off = c.n_topics ? uint32_t(t0 - base) : 0u;
+        c.data_off = c.data_len ? uint32_t(d0 - base) : 0u;
+    } else {
+        c.context = 0xffffffffu;
+        c.n_topics = c.topics_off = c.data_off = c.data_len = 0u;
+    }
+    claims[i] = c;
+}
+
+// the window of the blob a run of records points into: win[0] = min start, win[1] = max end (win starts {~0, 0})
+__global__ __launch_bounds__(256) void k_claims_window(const EventClaimPacked* __restrict__ claims, uint32_t n, unsigned long long* __restrict__ win) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long lo = ~0ull, hi = 0ull;
+    if (i < n) {
+        const EventClaimPacked c = claims[i];
+        if (c.n_topics) {
+            lo = c.topics_off;
+            hi = uint64_t(c.topics_off) + 33ull * c.n_topics;
+        }
+        if (c.data_len) {
+            lo = lo < c.data_off ? lo : (unsigned long long)c.data_off;
+            const unsigned long long e = uint64_t(c.data_off) + c.data_len;
+            hi = hi > e ? hi : e;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
+        lo = lo < l2 ? lo : l2;
+        hi = hi > h2 ? hi : h2;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (lo != ~0ull) atomicMin(win, lo);
+        if (hi) atomicMax(win + 1, hi);
+    }
+}
+
+int launch_claims_window(ipcfp_ctx* ctx, const void* claims_d, uint32_t n, unsigned long long* win_d) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_claims_window, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, static_cast<const EventClaimPacked*>(claims_d), n, win_d);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
+int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len) {
+    if (n == 0) return IPCFP_OK;
+    hipLaunchKernelGGL(k_rebase_claims, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, static_cast<EventClaimPacked*>(claims_d), n, base,
+                       blob_len);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 // scratch_u32: 4 × n words (sizes and offsets); scan_scratch: div_up(n, 1024) + 2 u64 (the last one receives the packed blob's length)
 int launch_expand_claims(ipcfp_ctx* ctx, const void* compact_d, uint32_t n, const ipcfp_event_claim_group_t* groups_d, uint32_t n_groups,
                          const uint8_t* cblob_d, uint64_t cblob_len, void* claims_out_d, uint8_t* blob_out_d, uint64_t cap_blob,

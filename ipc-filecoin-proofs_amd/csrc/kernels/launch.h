@@ -188,6 +188,8 @@ int launch_subset_tables(ipcfp_ctx* ctx, const uint32_t* ids_d, uint32_t n, uint
                          const uint32_t* src_len, const uint8_t* src_cids, uint64_t* off_d, uint32_t* len_d,
                          uint8_t* cids_d, uint32_t* bad_d);
 
+int launch_claims_window(ipcfp_ctx* ctx, const void* claims_d, uint32_t n, unsigned long long* win_d);         // claims_compact.hip
+int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len);  // claims_compact.hip
 // --- shard_pull.hip (shard_pull.h) --- a rank pulls its shard out of a bundle in host memory, level by level
 struct PullSeeds;
 struct PullFrontier;

@@ -31,6 +31,7 @@ struct PullFrontier {
 };
 
 struct PullCtl {
+    uint32_t n_cur;     // items of the frontier being read
     uint32_t n_next;    // items of the frontier being written
     uint32_t n_copy;    // blocks claimed this round
     uint32_t n_pulled;  // blocks claimed so far
@@ -38,7 +39,6 @@ struct PullCtl {
     unsigned long long stage_used;
     unsigned long long lo, hi, n_receipts;
     uint32_t have_range;  // the receipts root was found and decoded: lo / hi / n_receipts are set
-    uint32_t pad;
 };
 
 struct PullSeeds {

@@ -21,6 +21,8 @@
 // and expanded twice, as a tree walk does); the frontier's capacity bounds what a hostile DAG can ask for.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "../common.h"
 #include "header_dev.h"
 #include "launch.h"
@@ -122,9 +124,12 @@ __global__ void k_pull_seed(WitnessView w, PullSeeds seeds, PullFrontier first, 
 // CLAIM: lane = frontier item.  A block nobody has claimed yet gets the next lines of the staging arena and an entry of
 // this round's copy list; the three counters are advanced once per wavefront (every lane of the chip on one address of
 // the L2 was 787 µs in another kernel of this library: profiles/r04_experiments.md).
-__global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, uint32_t n_items, PullTables t, PullCtl* __restrict__ ctl) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, PullTables t, PullCtl* __restrict__ ctl) {
+    const uint32_t n_items = ctl->n_cur;
     const uint32_t lane = threadIdx.x & 63u;
+    // (whole wavefronts stride through the frontier: the shuffles below need all 64 lanes in every pass)
+    for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; i0 < n_items; i0 += gridDim.x * blockDim.x) {
+    const uint32_t i = i0 + lane;
     bool mine = false;
     uint32_t id = 0, len = 0;
     if (i < n_items) {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, uint32_t n
     }
     const uint64_t wave_bytes = __shfl(incl, 63, 64);
     const uint32_t wave_cnt = __shfl(cnt, 63, 64);
-    if (wave_cnt == 0) return;
+    if (wave_cnt == 0) continue;
     unsigned long long base_bytes = 0;
     uint32_t base_copy = 0, base_pulled = 0;
     if (lane == 63) {
@@ -158,23 +163,27 @@ __global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, uint32_t n
     base_bytes = __shfl(base_bytes, 63, 64);
     base_copy = __shfl(base_copy, 63, 64);
     base_pulled = __shfl(base_pulled, 63, 64);
-    if (!mine) return;
+    if (!mine) continue;
     const uint64_t dst = base_bytes + incl - want;
     const uint32_t k = base_copy + cnt - 1u, p = base_pulled + cnt - 1u;
     if (dst + want > t.stage_cap || p >= t.pulled_cap) {
         atomicOr(&ctl->overflow, 2u);
-        return;
+        continue;
     }
     t.stage_off[id] = dst;
     t.pulled[p] = id;
     t.copy_src[k] = t.goff[id];
     t.copy_dst[k] = dst;
     t.copy_len[k] = len;
+    }
 }
 
-// COPY: this round's blocks, host memory → staging arena.  The body is k_repack's (half a wavefront per block, 16
-// destination bytes per lane, aligned 8-byte reads funnel-shifted: nothing is read beyond the aligned word of a block's
-// last byte, so the host buffer needs no slack); the count comes from the device.
+// COPY: this round's blocks, host memory → staging arena: half a wavefront per block, 16 destination bytes per lane.
+// Every SOURCE byte crosses PCIe once: lane j loads the ALIGNED 16-byte chunk j of the block's span, takes chunk j + 1
+// from its neighbour (a shuffle; the last lane of the half loads it itself) and funnel-shifts the pair by the block's
+// misalignment.  (k_repack's three overlapping 8-byte words per lane are fine out of HBM, where the overlap is an L2 hit;
+// host memory is not cached, and the overlap went over the link again: 36 GB/s against 48 for this form.)  Only chunks
+// that hold at least one byte of the block are read, so the host buffer needs no slack beyond its last 16-byte chunk.
 __global__ __launch_bounds__(256) void k_pull_copy(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
                                                    const uint32_t* __restrict__ len, const uint64_t* __restrict__ dst_off,
                                                    const PullCtl* __restrict__ ctl, uint8_t* __restrict__ dst) {
@@ -182,43 +191,54 @@ __global__ __launch_bounds__(256) void k_pull_copy(const uint8_t* __restrict__ s
     const uint32_t sub = threadIdx.x & 31;
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const uint32_t ngroups = (gridDim.x * blockDim.x) >> 5;
-    for (uint32_t i = group; i < n; i += ngroups) {
-        const uint64_t so = src_off[i];
-        const uint32_t L = len[i];
-        uint8_t* d = dst + dst_off[i];
-        const uint32_t padded = L == 0 ? 128u : (L + 127u) & ~127u;
+    const uint32_t rounds = (n + ngroups - 1) / ngroups;  // (every lane of a wavefront runs the same number of rounds: shuffles)
+    for (uint32_t it = 0; it < rounds; ++it) {
+        const uint32_t i = group + it * ngroups;
+        const bool live = i < n;
+        const uint64_t so = live ? src_off[i] : 0;
+        const uint32_t L = live ? len[i] : 0;
+        uint8_t* d = dst + (live ? dst_off[i] : 0);
+        const uint32_t padded = !live ? 0u : (L == 0 ? 128u : (L + 127u) & ~127u);
         const uintptr_t s = reinterpret_cast<uintptr_t>(src) + so;
-        const uintptr_t last_word = L ? ((s + L - 1u) & ~uintptr_t(7)) : 0;
-        for (uint32_t u = sub * 16u; u < padded; u += 512u) {
-            uint64_t w0 = 0, w1 = 0;
-            if (u < L) {
-                const uintptr_t a = s + u;
-                const uintptr_t q = a & ~uintptr_t(7);
-                const uint32_t sh = uint32_t(a & 7u) * 8u;
-                const uint64_t q0 = *reinterpret_cast<const uint64_t*>(q);
-                const uint64_t q1 = q + 8u <= last_word ? *reinterpret_cast<const uint64_t*>(q + 8u) : 0ull;
-                const uint64_t q2 = q + 16u <= last_word ? *reinterpret_cast<const uint64_t*>(q + 16u) : 0ull;
-                w0 = (q0 >> sh) | ((q1 << 1) << (63u - sh));
-                w1 = (q1 >> sh) | ((q2 << 1) << (63u - sh));
-                const uint32_t valid = L - u;
-                if (valid < 8u) {
-                    w0 &= (1ull << (8u * valid)) - 1ull;
-                    w1 = 0;
-                } else if (valid < 16u) {
-                    w1 &= valid == 8u ? 0ull : (1ull << (8u * (valid - 8u))) - 1ull;
-                }
+        const uint32_t mis = uint32_t(s & 15u);
+        const ulonglong2* chunks = reinterpret_cast<const ulonglong2*>(s - mis);
+        const uint32_t span = live ? mis + L : 0u;  // bytes from the first chunk's start to the block's end
+        const uint32_t steps = (padded + 511u) / 512u;
+        const uint32_t max_steps = max(__shfl(steps, 0, 64), __shfl(steps, 32, 64));  // the two halves of the wavefront in step
+        for (uint32_t st = 0; st < max_steps; ++st) {
+            const uint32_t j = st * 32u + sub;  // destination chunk
+            ulonglong2 c = make_ulonglong2(0, 0);
+            if (16u * j < span) c = chunks[j];
+            ulonglong2 nx;
+            nx.x = __shfl_down(c.x, 1, 32);
+            nx.y = __shfl_down(c.y, 1, 32);
+            if (sub == 31u) {
+                nx = make_ulonglong2(0, 0);
+                if (16u * (j + 1u) < span) nx = chunks[j + 1u];
             }
-            *reinterpret_cast<ulonglong2*>(d + u) = make_ulonglong2(w0, w1);
+            // 16 bytes that start `mis` bytes into chunk j
+            const uint64_t w0 = mis < 8u ? c.x : c.y, w1 = mis < 8u ? c.y : nx.x, w2 = mis < 8u ? nx.x : nx.y;
+            const uint32_t sh = (mis & 7u) * 8u;
+            uint64_t o0 = (w0 >> sh) | ((w1 << 1) << (63u - sh));
+            uint64_t o1 = (w1 >> sh) | ((w2 << 1) << (63u - sh));
+            const uint32_t u = 16u * j;  // destination byte
+            if (u < padded) {
+                const uint32_t valid = u < L ? L - u : 0u;
+                if (valid < 8u) {
+                    o0 &= valid ? (1ull << (8u * valid)) - 1ull : 0ull;
+                    o1 = 0;
+                } else if (valid < 16u) {
+                    o1 &= valid == 8u ? 0ull : (1ull << (8u * (valid - 8u))) - 1ull;
+                }
+                *reinterpret_cast<ulonglong2*>(d + u) = make_ulonglong2(o0, o1);
+            }
         }
     }
 }
 
 // EXPAND: lane = frontier item; its block is in the staging arena now.
-__global__ __launch_bounds__(256) void k_pull_expand(WitnessView w, PullFrontier cur, uint32_t n_items, PullFrontier next,
-                                                     PullCtl* __restrict__ ctl, uint32_t n_shards, uint32_t shard) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    const PullItem it = cur.items[i];
+__device__ __forceinline__ void pull_expand_item(const WitnessView& w, const PullItem& it, const PullFrontier& next, PullCtl* ctl,
+                                                 uint32_t n_shards, uint32_t shard) {
     const uint32_t kind = it.kind & 0xffu, height = (it.kind >> 8) & 0xffu;
     if (kind == PK_LEAF) return;
     Rd r = open_block(w, it.id);
@@ -285,15 +305,25 @@ __global__ __launch_bounds__(256) void k_pull_expand(WitnessView w, PullFrontier
     }
 }
 
+__global__ __launch_bounds__(256) void k_pull_expand(WitnessView w, PullFrontier cur, PullFrontier next, PullCtl* __restrict__ ctl,
+                                                     uint32_t n_shards, uint32_t shard) {
+    const uint32_t n_items = ctl->n_cur;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x)
+        pull_expand_item(w, cur.items[i], next, ctl, n_shards, shard);
+}
+
 // between two rounds: the next frontier's size goes to the host (mailbox), the round counters start again
 __global__ void k_pull_round_end(PullCtl* __restrict__ ctl, unsigned long long* __restrict__ mailbox, unsigned long long seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t n_next = ctl->n_next;
+    ctl->n_cur = n_next;
     ctl->n_next = 0;
     ctl->n_copy = 0;
-    __hip_atomic_store(mailbox + 1, (unsigned long long)n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mailbox + 2, (unsigned long long)ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(mailbox, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (rounds are queued ahead of the host's reading: each publishes into the slot of its own parity, the sequence number last)
+    unsigned long long* slot = mailbox + 8u * (seq & 3ull);
+    __hip_atomic_store(slot + 1, (unsigned long long)n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot + 2, (unsigned long long)ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(slot, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 int launch_pull_seed(ipcfp_ctx* ctx, const WitnessView& w, const PullSeeds& seeds, const PullFrontier& first, PullCtl* ctl_d) {
@@ -302,16 +332,19 @@ int launch_pull_seed(ipcfp_ctx* ctx, const WitnessView& w, const PullSeeds& seed
     return IPCFP_OK;
 }
 
+// One round, sized by `n_hint` (the host's last word on the frontier: the exact size when it has waited for the round
+// before, an upper bound / guess when rounds are queued ahead — every kernel takes the true count from the device and
+// strides, so a wrong guess costs time, not results).
 int launch_pull_round(ipcfp_ctx* ctx, const WitnessView& w, const uint8_t* host_bytes_dev, const PullTables& t, const PullFrontier& cur,
-                      uint32_t n_items, const PullFrontier& next, PullCtl* ctl_d, uint32_t n_shards, uint32_t shard,
+                      uint32_t n_hint, const PullFrontier& next, PullCtl* ctl_d, uint32_t n_shards, uint32_t shard,
                       unsigned long long* mailbox_dev, unsigned long long seq) {
-    if (n_items) {
-        hipLaunchKernelGGL(k_pull_claim, dim3(div_up(n_items, 256)), dim3(256), 0, ctx->stream, cur, n_items, t, ctl_d);
-        const uint32_t groups = n_items < 8192u * 8u ? n_items : 8192u * 8u;  // half-wavefronts (at most n_items blocks are new)
+    if (n_hint) {
+        const uint32_t wgs = std::min(div_up(n_hint, 256), 4096u);
+        hipLaunchKernelGGL(k_pull_claim, dim3(wgs), dim3(256), 0, ctx->stream, cur, t, ctl_d);
+        const uint32_t groups = std::min(n_hint, 8192u * 8u);  // half-wavefronts (at most one new block per item)
         hipLaunchKernelGGL(k_pull_copy, dim3(div_up(groups, 8)), dim3(256), 0, ctx->stream, host_bytes_dev, t.copy_src, t.copy_len,
                            t.copy_dst, ctl_d, t.stage);
-        hipLaunchKernelGGL(k_pull_expand, dim3(div_up(n_items, 256)), dim3(256), 0, ctx->stream, w, cur, n_items, next, ctl_d, n_shards,
-                           shard);
+        hipLaunchKernelGGL(k_pull_expand, dim3(wgs), dim3(256), 0, ctx->stream, w, cur, next, ctl_d, n_shards, shard);
     }
     hipLaunchKernelGGL(k_pull_round_end, dim3(1), dim3(64), 0, ctx->stream, ctl_d, mailbox_dev, seq);
     IPCFP_HIP(ctx, hipGetLastError());

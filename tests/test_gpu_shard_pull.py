@@ -89,6 +89,37 @@ def test_pulled_shards_equal_the_unsharded_result(engine, oracle, tip, bundle, c
     ost.close()
 
 
+@pytest.mark.parametrize("G", [2, 8])
+def test_claim_slices_of_a_sorted_batch_equal_the_routed_claims(engine, tip, bundle, claims_packed, G):
+    """A batch in exec_index order (what generate_event_proof emits) is cut by two binary searches, no host pass; the
+    offsets are rebased on the device: same statuses as ipcfp_route_event_claims + ipcfp_verify_event_claims."""
+    ts, cl, blob, blob_len = claims_packed
+    cs = np.ascontiguousarray(cl[np.argsort(cl["exec_index"], kind="stable")])  # (the liars moved exec_index by one: sort again)
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        want = w.verify_event_claims(ts, cs, blob, blob_len)
+    status = np.full(len(cs), 255, dtype=np.uint8)
+    for r in range(G):
+        s = shard.TipsetShard.from_pull(engine, bundle, tip.parent_cids, tip.child_cid, tip.receipts_root, G, r)
+        a, st = s.witness.verify_event_claims_range(ts, cs, blob, blob_len, s.lo, s.hi, r == G - 1)
+        status[a: a + len(st)] = st
+        s.close()
+    assert np.array_equal(status, want) and (want != 1).sum() > 100
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w, pytest.raises(ipcfp.EngineError, match="exec_index order"):
+        w.verify_event_claims_range(ts, np.ascontiguousarray(cs[::-1]), blob, blob_len, 100, 200, True)
+    # a slice whose blob window does not hold a record's bytes: ERR_BAD_CLAIM (66) for that record, the rest unharmed
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        bad = cs.copy()
+        k = int(np.nonzero(bad["data_len"][len(bad) // 2:] > 0)[0][0]) + len(bad) // 2
+        lo, hi = int(bad["exec_index"][k - 5]), int(bad["exec_index"][k + 5]) + 1
+        a, st = w.verify_event_claims_range(ts, bad, blob, blob_len, lo, hi, False)
+        assert np.array_equal(st, want[a: a + len(st)])
+        # offsets beyond what the blob holds: the window is clamped to the blob, the record is refused
+        bad["data_off"][k] = blob_len + 1000
+        a, st = w.verify_event_claims_range(ts, bad, blob, blob_len, lo, hi, False)
+        i = k - a
+        assert st[i] == 69 and np.array_equal(np.delete(st, i), np.delete(want[a: a + len(st)], i))
+
+
 def test_pull_of_tall_event_amts(engine):
     """Events AMTs of bit width 1 and height >= 8: every node of every tree of the rank's receipts is a level of its own."""
     tall = Tipset(n_receipts=60, n_planted=6, variety=1, max_events=700, events_bit_width=1, seed=79)
