@@ -59,8 +59,21 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     if (!tabled) return launch_verify_storage_lanes(ctx, w, claims_d, n, trust, status_d, 0);
     constexpr uint32_t kUndecided = 0xfdu;
     DevBuf<HamtNodeRec> table;
+    DevBuf<uint32_t> long_list, long_count;
     IPCFP_HIP(ctx, table.alloc(wit->n));
-    int rc = launch_hamt_node_table(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+    static const bool ring = [] { const char* e = std::getenv("IPCFP_HAMT_TABLE_FORM"); return e && e[0] == 'r'; }();
+    int rc = IPCFP_OK;
+    if (ring) {  // (round 3's form, for A/B runs: eight lanes per block with the ring reader, every block)
+        rc = launch_hamt_node_table(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+    } else {
+        // the long blocks (4-5 KB state-tree nodes: the head of the schedule) as a work list for the 32-lane outline …
+        IPCFP_HIP(ctx, long_list.alloc(wit->n));
+        IPCFP_HIP(ctx, long_count.alloc(1));
+        IPCFP_HIP(ctx, hipMemsetAsync(long_count.p, 0, 4, ctx->stream));
+        rc = launch_hamt_list_long(ctx, wit->k1_meta.p, uint32_t(wit->n), long_list.p, long_count.p);
+        // … everything shorter: one block per lane, line-staged reader
+        if (!rc) rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+    }
     if (rc) return rc;
     DevBuf<uint32_t> flag, pos, run_of;
     DevBuf<uint64_t> scratch, total_d;
@@ -74,14 +87,28 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     rc = launch_scan_u32(ctx, flag.p, n, pos.p, total_d.p, scratch.p);
     if (rc) return rc;
     uint64_t n_runs = 0;
+    uint32_t n_long = 0;
     IPCFP_HIP(ctx, d2h_small(ctx, &n_runs, total_d.p, 8, ctx->stream));
+    if (!ring) IPCFP_HIP(ctx, d2h_small(ctx, &n_long, long_count.p, 4, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    // (behind the one synchronisation the call has anyway — the grid is the list's size — and on the aux stream: the main
+    // stream has just been drained, so nothing there is still writing the table, and the runs' typed decodes below — one lane
+    // per run, 157 wavefronts — fill the chip no better than the outline's single-wavefront workgroups do: side by side)
+    const bool aux = n_long && ctx->stream_aux != ctx->stream && ctx->aux_event;
+    if (n_long) {
+        hipStream_t s = aux ? ctx->stream_aux : ctx->stream;
+        rc = launch_hamt_outline_list(ctx, s, w, table.p, long_list.p, long_count.p, n_long);
+        if (!rc) rc = launch_hamt_node_table_rest(ctx, s, w, long_list.p, long_count.p, n_long, HK_ACTOR_STATE | HK_VEC_U8, table.p);
+        if (rc) return rc;
+        if (aux) IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream_aux));
+    }
     DevBuf<StorageRun> runs;
     IPCFP_HIP(ctx, runs.alloc(n_runs));
     rc = launch_storage_run_heads(ctx, flag.p, pos.p, n, run_of.p, runs.p);
     if (rc) return rc;
     rc = launch_storage_run_facts(ctx, w, claims_d, runs.p, uint32_t(n_runs));
     if (rc) return rc;
+    if (aux) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));  // the table is whole from here on
     rc = launch_storage_run_actors_table(ctx, w, table.p, claims_d, runs.p, uint32_t(n_runs), kUndecided);
     if (rc) return rc;
     rc = launch_storage_run_actors_lane(ctx, w, claims_d, runs.p, uint32_t(n_runs), kUndecided);

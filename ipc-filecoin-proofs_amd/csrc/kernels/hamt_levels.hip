@@ -684,6 +684,26 @@ size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels)
     return size_t(n) * 9 + cap * 2 + (levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
 }
 
+// The 32-lane outline over ANY list of blocks (not a level of a walk): every block of `work_d[0 .. *count_d)` whose length
+// the big-stage instance takes (kHamtOutlineMinLen ≤ len, hamt_table.h) gets its HamtNodeRec in recs_d[block] — status 1
+// and kinds_ok = HK_ACTOR_STATE when it is a state-tree node in the spellings the outline reads, status 0 ("not tabulated:
+// the walker decides") otherwise.  The per-call node table of the storage proofs uses it for the 4-5 KB nodes, which one
+// lane per block parses for a third of a millisecond while the rest of the chip idles (host/verify_storage.cpp).
+int launch_hamt_outline_list(ipcfp_ctx* ctx, hipStream_t stream, const WitnessView& w, void* recs_d, uint32_t* work_d, uint32_t* count_d,
+                             uint32_t bound) {
+    if (bound == 0) return IPCFP_OK;
+    HamtLevels L{};
+    L.recs = static_cast<HamtNodeRec*>(recs_d);
+    L.work[0] = work_d;
+    L.work[1] = work_d;
+    L.count = count_d;
+    static_assert(kHamtOutlineMinLen + 24u > kCoopSmallStage, "every listed block is the big-stage instance's");
+    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(div_up(bound, kCoopNodes)), dim3(64), 0, stream, w, L,
+                       0u);
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
+}
+
 int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
                            const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
                            uint8_t* status_d, void* loc_d, uint32_t levels, uint32_t* scratch_d, void* recs_d, bool coop, void* etabs_d,

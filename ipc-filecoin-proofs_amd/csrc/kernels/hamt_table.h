@@ -22,6 +22,10 @@
 namespace ipcfp {
 
 constexpr uint32_t kHamtTablePointers = 32;
+// The per-call node table is made by two kernels (hamt_table_lane.hip): blocks of at least this many bytes — the 4-5 KB
+// bucket nodes of a state tree — go to the 32-lane outline (hamt_levels.hip), shorter ones to one lane each; a long block
+// the outline does not take (it reads ActorState buckets only) gets its lane afterwards.
+constexpr uint32_t kHamtOutlineMinLen = 2048;
 enum : uint32_t { HK_ACTOR_STATE = 1u << 0, HK_VEC_U8 = 1u << 1, HK_ANY = 1u << 2 };
 
 struct HamtNodeRec {

@@ -189,6 +189,13 @@ int launch_subset_tables(ipcfp_ctx* ctx, const uint32_t* ids_d, uint32_t n, uint
                          uint8_t* cids_d, uint32_t* bad_d);
 
 int launch_claims_window(ipcfp_ctx* ctx, const void* claims_d, uint32_t n, unsigned long long* win_d);         // claims_compact.hip
+// --- the per-call HAMT node table in two kernels (hamt_table_lane.hip, hamt_levels.hip) ---
+int launch_hamt_list_long(ipcfp_ctx* ctx, const void* meta_d, uint32_t n, uint32_t* work_d, uint32_t* count_d);
+int launch_hamt_outline_list(ipcfp_ctx* ctx, hipStream_t stream, const WitnessView& w, void* recs_d, uint32_t* work_d, uint32_t* count_d,
+                             uint32_t bound);
+int launch_hamt_node_table_lane(ipcfp_ctx* ctx, const uint8_t* arena, const void* meta_d, uint32_t n, uint32_t kinds, void* recs_d);
+int launch_hamt_node_table_rest(ipcfp_ctx* ctx, hipStream_t stream, const WitnessView& w, const uint32_t* work_d, const uint32_t* count_d,
+                                uint32_t bound, uint32_t kinds, void* recs_d);
 int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len);  // claims_compact.hip
 // --- shard_pull.hip (shard_pull.h) --- a rank pulls its shard out of a bundle in host memory, level by level
 struct PullSeeds;
