@@ -727,6 +727,7 @@ typedef struct ipcfp_shard_pull_stats {
     uint32_t blocks;      /* blocks of the shard                                           */
     uint64_t table_bytes; /* bytes of the bundle's tables uploaded                         */
     uint64_t block_bytes; /* bytes of blocks read over PCIe (each block padded to 128)     */
+    uint64_t payload_bytes; /* … of which the blocks themselves (the sum of their lengths) */
     double tables_ms;     /* tables up, CID slots, index                                   */
     double pull_ms;       /* the rounds                                                    */
     double create_ms;     /* the shard's own arena, schedule and index                     */

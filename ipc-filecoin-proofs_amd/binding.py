@@ -471,7 +471,7 @@ class Engine:
 
 class ShardPullStats(C.Structure):  # == ipcfp_shard_pull_stats_t
     _fields_ = [("rounds", C.c_uint32), ("blocks", C.c_uint32), ("table_bytes", C.c_uint64), ("block_bytes", C.c_uint64),
-                ("tables_ms", C.c_double), ("pull_ms", C.c_double), ("create_ms", C.c_double)]
+                ("payload_bytes", C.c_uint64), ("tables_ms", C.c_double), ("pull_ms", C.c_double), ("create_ms", C.c_double)]
 
 
 def host_register(arr: np.ndarray):

@@ -221,6 +221,7 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
         stats->blocks = h.n_pulled;
         stats->table_bytes = uint64_t(N) * 36 + n_esc * 44;
         stats->block_bytes = h.stage_used;
+        stats->payload_bytes = h.payload;
         stats->tables_ms = std::chrono::duration<double, std::milli>(t_tables - t_start).count();
         stats->pull_ms = std::chrono::duration<double, std::milli>(t_pulled - t_tables).count();
     }

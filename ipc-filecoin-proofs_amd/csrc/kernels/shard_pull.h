@@ -37,6 +37,7 @@ struct PullCtl {
     uint32_t n_pulled;  // blocks claimed so far
     uint32_t overflow;  // bit 0: a frontier was full, bit 1: the staging arena / the pulled list was
     unsigned long long stage_used;
+    unsigned long long payload;  // bytes of the claimed blocks themselves (Σ len)
     unsigned long long lo, hi, n_receipts;
     uint32_t have_range;  // the receipts root was found and decoded: lo / hi / n_receipts are set
 };

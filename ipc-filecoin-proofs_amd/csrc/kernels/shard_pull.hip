@@ -139,14 +139,15 @@ __global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, PullTables
         if (mine) len = t.len[id];
     }
     const uint64_t want = mine ? (len == 0 ? 128ull : (uint64_t(len) + 127ull) & ~127ull) : 0ull;
-    uint64_t incl = want;
+    uint64_t incl = want, raw = mine ? uint64_t(len) : 0ull;
     uint32_t cnt = mine ? 1u : 0u;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t up = __shfl_up(incl, d, 64);
+        const uint64_t up = __shfl_up(incl, d, 64), ur = __shfl_up(raw, d, 64);
         const uint32_t uc = __shfl_up(cnt, d, 64);
         if (lane >= uint32_t(d)) {
             incl += up;
+            raw += ur;
             cnt += uc;
         }
     }
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, PullTables
     uint32_t base_copy = 0, base_pulled = 0;
     if (lane == 63) {
         base_bytes = atomicAdd(&ctl->stage_used, (unsigned long long)wave_bytes);
+        (void)atomicAdd(&ctl->payload, (unsigned long long)raw);
         base_copy = atomicAdd(&ctl->n_copy, wave_cnt);
         base_pulled = atomicAdd(&ctl->n_pulled, wave_cnt);
     }

@@ -57,6 +57,7 @@ def test_pulled_shard_holds_exactly_the_planned_blocks(engine, tip, bundle, G):
             assert stats["table_bytes"] == 36 * tip.n_blocks
             want_bytes = int(((tip.lens[ids].astype(np.int64) + 127) // 128 * 128).sum())
             assert stats["block_bytes"] == want_bytes and stats["rounds"] >= 5
+            assert stats["payload_bytes"] == int(tip.lens[ids].astype(np.int64).sum())
             st_cid, n_bad = w.verify_cids()
             assert n_bad == 0
             w.close()

@@ -7,7 +7,7 @@
 #   2. the default bench line (cpu_baseline, T2 window, sub-records), per-config lines, the receipt-cut path on one GPU,
 #      the other call order (the S,K,V figure is also inside the default line)
 #   3. kernel trace (stats + one-step timeline), two SQ PMC passes (own runs, no trace flags)
-#   4. configs[3] / [4]: kernel stats + PMC of their own kernels (tools/gpu_pmc_workload.sh)
+#   1b. configs[1] / [3] / [4]: kernel stats + PMC of their own kernels (tools/gpu_pmc_workload.sh) → traffic_workloads.json
 # Every stage is bounded by `timeout`.  ≈ 6 minutes of box time.
 out=${1:-gpurun_out/final}
 rnd=${2:-0}
@@ -25,6 +25,12 @@ if [ -z "$SKIP_FETCH" ]; then
     if [ -n "$TRAFFIC_INTO_PROFILES" ] && [ -s "$out/traffic.json" ] && [ "$rnd" != 0 ]; then cp "$out/traffic.json" "profiles/r$(printf %02d "$rnd")_traffic.json"; fi
   fi
 fi
+# ---- 1b: the per-config benches' FETCH_SIZE passes → profiles/rNN_traffic_workloads.json (the sub-records' roofline.traffic) ----
+if [ -z "$SKIP_WORKLOAD_PMC" ]; then
+  for wl in cid hamt storage; do bash tools/gpu_pmc_workload.sh "$out" $wl > /dev/null 2>&1; done
+  python tools/pmc_traffic_workload.py "$rnd" cid="$out/cid_pmc1.txt" hamt="$out/hamt_pmc1.txt" storage="$out/storage_pmc1.txt" > "$out/traffic_workloads.json" 2> "$out/traffic_workloads.err"
+  if [ -n "$TRAFFIC_INTO_PROFILES" ] && [ -s "$out/traffic_workloads.json" ] && [ "$rnd" != 0 ]; then cp "$out/traffic_workloads.json" "profiles/r$(printf %02d "$rnd")_traffic_workloads.json"; fi
+fi
 # ---- 2 ----
 ( time timeout 400 python bench.py --steps 20 --warmup 5 ) > "$out/bench.log" 2>&1; json_line "$out/bench.log" > "$out/bench.json"; head -c 400 "$out/bench.json"; echo
 for wl in cid hamt storage; do ( timeout 200 python bench.py --workload $wl --steps 10 --warmup 3 ) > "$out/bench_$wl.log" 2>&1; json_line "$out/bench_$wl.log" > "$out/bench_$wl.json"; head -c 300 "$out/bench_$wl.json"; echo; done
@@ -33,9 +39,5 @@ for wl in cid hamt storage; do ( timeout 200 python bench.py --workload $wl --st
 bash tools/gpu_prof.sh "$out"
 bash tools/gpu_pmc.sh "$out" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
 bash tools/gpu_pmc.sh "$out" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_IFETCH GRBM_GUI_ACTIVE"
-# ---- 4 ----
-if [ -z "$SKIP_WORKLOAD_PMC" ]; then
-  bash tools/gpu_pmc_workload.sh "$out" hamt > /dev/null 2>&1
-  bash tools/gpu_pmc_workload.sh "$out" storage > /dev/null 2>&1
-fi
+# (4: configs[3] / [4] kernel stats + PMC are stage 1b's files)
 ls "$out"
