@@ -717,6 +717,7 @@ def shard_projection(args, eng, torch, dev, tip, ts, cl, blob, blob_len, w_full,
     pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
     t0 = time.perf_counter()
     ipcfp.host_register(pk.data)
+    ipcfp.host_register(pk.digests)
     out["host_register_ms_once_untimed"] = round((time.perf_counter() - t0) * 1e3, 2)
     if not np.all(cl["exec_index"][1:] >= cl["exec_index"][:-1]):
         raise SystemExit("bench: the claim batch is not in exec_index order")
@@ -816,6 +817,7 @@ def shard_projection(args, eng, torch, dev, tip, ts, cl, blob, blob_len, w_full,
             }
     finally:
         ipcfp.host_unregister(pk.data)
+        ipcfp.host_unregister(pk.digests)
     out["note"] = ("ONE 1M-receipt tipset cut by receipt range (north_star's cut); every rank is SELF-PLANNED "
                    "(ipcfp_witness_create_shard_pull) and timed by itself on this GPU.  T2 is ONE figure per rank with everything "
                    "inside: plan (the device follows the links), cut (the device reads its blocks out of the registered host buffer: "
@@ -959,6 +961,7 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev, ranks):
     # was made) and the tipset key — nothing else; it finds and fetches its shard itself (ipcfp_witness_create_shard_pull)
     pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
     ipcfp.host_register(pk.data)
+    ipcfp.host_register(pk.digests)
     sh = shard.TipsetShard.from_pull(eng, pk, tip.parent_cids, tip.child_cid, tip.receipts_root, world, rank)
     sh.route(ts, cl, blob, blob_len)
     t_gen = time.perf_counter() - t_gen
@@ -1086,6 +1089,7 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev, ranks):
                                         "cut and claim slice are inside the window, registering the ingest buffer is not"}
     sh.close()
     ipcfp.host_unregister(pk.data)
+    ipcfp.host_unregister(pk.digests)
     return out if rank == 0 else None
 
 

@@ -715,7 +715,8 @@ int ipcfp_shard_plan_tipset_all(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
  * (child header → receipts AMT paths to the rank's receipts → their events AMTs; parent headers → TxMeta → message AMTs,
  * replicated: reconstruct_execution_order is global, src/proofs/events/utils.rs:16-30), so `bytes` must be host memory
  * the device can read: hipHostMalloc'd, or registered once (hipHostRegister / ipcfp_host_register below — an ingest buffer
- * is registered when it is made, not per bundle: 19 ms for 640 MB on the MI355X box).  Cuts the loops of
+ * is registered when it is made, not per bundle: 19 ms for 640 MB on the MI355X box).  `digests32` MAY be such memory too:
+ * the table is then read where it lies instead of being copied first.  Cuts the loops of
  * src/proofs/verifier.rs:19-28,49-54 and src/proofs/events/verifier.rs:62-71; the shard equals what
  * ipcfp_shard_plan_tipset + ipcfp_witness_create_subset make of the whole witness.
  *   *status_out   IPCFP_ST_TRUE: *out is the shard, tagged [*receipt_lo, *receipt_hi) = ipcfp_shard_range(count);

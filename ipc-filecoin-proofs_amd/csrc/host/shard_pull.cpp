@@ -76,11 +76,23 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     DevBuf<PullCtl> ctl;
     IPCFP_HIP(ctx, glen.alloc(N));
     IPCFP_HIP(ctx, goff.alloc(N));
-    IPCFP_HIP(ctx, dig.alloc(size_t(N) * 32));
     IPCFP_HIP(ctx, gcids.alloc(size_t(N) * IPCFP_CID_SLOT));
     IPCFP_HIP(ctx, scan_scratch.alloc(size_t(div_up(N, 1024)) + 2));
     int rc = upload(ctx, glen.p, len, size_t(N) * 4, ctx->stream);
-    if (!rc) rc = upload(ctx, dig.p, digests32, size_t(N) * 32, ctx->stream);
+    // The digest table is read ONCE, by the kernel that widens it to 40-byte slots: when it lies in device-readable host
+    // memory too (the same ingest buffer) that kernel reads it where it is — 41 MB for a 1M-receipt tipset at the link's
+    // rate instead of a staged copy in front of the kernel.
+    const uint8_t* dig_src = nullptr;
+    {
+        uint8_t* dp = nullptr;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dp), const_cast<uint8_t*>(digests32), 0) == hipSuccess && dp) dig_src = dp;
+        else (void)hipGetLastError();
+    }
+    if (!rc && !dig_src) {
+        IPCFP_HIP(ctx, dig.alloc(size_t(N) * 32));
+        rc = upload(ctx, dig.p, digests32, size_t(N) * 32, ctx->stream);
+        dig_src = dig.p;
+    }
     if (!rc && n_esc) {
         IPCFP_HIP(ctx, esc_i.alloc(n_esc));
         IPCFP_HIP(ctx, esc_c.alloc(n_esc * IPCFP_CID_SLOT));
@@ -90,7 +102,7 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     if (rc) return rc;
     uint64_t* total_d = scan_scratch.p + div_up(N, 1024) + 1;
     rc = launch_tight_offsets(ctx, glen.p, N, goff.p, total_d, scan_scratch.p);
-    if (!rc) rc = launch_expand_cids(ctx, dig.p, N, cid_prefix, prefix_len, esc_i.p, esc_c.p, uint32_t(n_esc), gcids.p);
+    if (!rc) rc = launch_expand_cids(ctx, dig_src, N, cid_prefix, prefix_len, esc_i.p, esc_c.p, uint32_t(n_esc), gcids.p);
     if (rc) return rc;
     uint32_t size = 64;
     while (size < 2ull * N) size <<= 1;
