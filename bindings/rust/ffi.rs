@@ -44,6 +44,8 @@ use crate::proofs::trust::TrustPolicy;
 // ---- PODs of include/ipcfp.h --------------------------------------------------------------------------------------
 pub const IPCFP_CID_SLOT: usize = 40;
 pub const IPCFP_MAX_PARENTS: usize = 32;
+/// == `IPCFP_ABI_VERSION` of include/ipcfp.h: the struct layouts below are this version's (2: IPCFP_MAX_PARENTS 16 -> 32)
+pub const IPCFP_ABI_VERSION: c_int = 2;
 pub const IPCFP_ST_TRUE: u8 = 1;
 pub const IPCFP_ST_FALSE_FILTER: u8 = 17;
 /// `ipcfp_check_event_fn` of the header: the host predicate of ipcfp_verify_event_proofs_with
@@ -150,6 +152,9 @@ pub struct Witness<'e> { eng: &'e Engine, w: RefCell<*mut ipcfp_witness_t> }
 
 impl Engine {
     pub fn new(device: i32) -> Result<Self> {
+        // a library built from another header strides arrays of these structs wrongly: refuse it before the first call
+        let abi = unsafe { ipcfp_abi_version() };
+        if abi != IPCFP_ABI_VERSION { return Err(anyhow!("libipcfp speaks ABI {abi}, this binding ABI {IPCFP_ABI_VERSION}")); }
         let mut ctx = std::ptr::null_mut();
         match unsafe { ipcfp_ctx_create(device, &mut ctx) } { 0 => Ok(Self { ctx }), rc => Err(anyhow!("ipcfp_ctx_create: {rc}")) }
     }

@@ -52,3 +52,15 @@ def test_wrappers_only_call_declared_functions_and_cover_the_reference_api():
         assert wrapper in text, wrapper
     # interior NULs are an Err, not a panic
     assert "CString::new" not in text or ".unwrap()" not in text.split("CString::new", 1)[1].split(";", 1)[0]
+
+
+def test_rust_constants_follow_the_header():
+    """a struct whose size depends on a header constant (ipcfp_tipset_ref_t: IPCFP_MAX_PARENTS) must move the ABI
+    version, and every binding compares versions before its first call."""
+    header = open(os.path.join(ROOT, "include", "ipcfp.h")).read()
+    text = open(os.path.join(RUST, "ffi.rs"), "rb").read().decode("utf-8", "replace")
+    for name in ("IPCFP_ABI_VERSION", "IPCFP_MAX_PARENTS", "IPCFP_CID_SLOT"):
+        h = int(re.search(r"#define %s (\d+)" % name, header).group(1))
+        r = int(re.search(r"pub const %s: \w+ = (\d+);" % name, text).group(1))
+        assert h == r, name
+    assert "ipcfp_abi_version()" in text.split("pub fn new(device: i32)", 1)[1].split("ipcfp_ctx_create", 1)[0]

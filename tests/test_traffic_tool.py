@@ -49,3 +49,21 @@ def test_bench_reads_the_newest_traffic_file_of_the_same_workload():
     assert tr is not None and tr["file"].startswith("profiles/r") and tr["file"].endswith("_traffic.json")
     assert tr["workload"]["witness_blocks"] == n_blocks
     assert bench.load_traffic(n_blocks + 1) is None  # another workload: no figure rather than a wrong one
+
+
+def test_workload_traffic_tool_on_a_small_pmc_table(tmp_path):
+    """tools/pmc_traffic_workload.py: FETCH_SIZE KB (summed over dispatches) x 1024 x 2.00 / steps, over the library's kernels
+    only; the steps are the dispatch count of the workload's once-per-step kernel."""
+    pmc = tmp_path / "hamt_pmc1.txt"
+    pmc.write_text("# kernel | counter | samples | sum | per-dispatch-sample mean\n"
+                   "ipcfp::k_hamt_lv_start | FETCH_SIZE | 7 | 700 | 100\n"
+                   "ipcfp::k_hamt_lv_advance | FETCH_SIZE | 42 | 84000 | 2000\n"
+                   "void ipcfp::k_hamt_lv_parse_actor<6912u, 96u, false> | FETCH_SIZE | 42 | 420000 | 10000\n"
+                   "__amd_rocclr_fillBufferAligned | FETCH_SIZE | 9 | 900 | 100\n"
+                   "ipcfp::k_hamt_lv_start | SQ_WAVES | 7 | 7 | 1\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_workload.py"), "5", "hamt=%s" % pmc],
+                         check=True, capture_output=True, text=True).stdout
+    made = json.loads(out)
+    w = made["workloads"]["hamt"]
+    assert made["round"] == 5 and w["steps_in_pass"] == 7 and len(w["kernels"]) == 3
+    assert abs(w["traffic_bytes_per_step"] - (700 + 84000 + 420000) * 1024 * 2.0 / 7) < 1e-3
