@@ -66,6 +66,8 @@ struct DenseRoot {
 };
 constexpr uint32_t kMaxDenseRoots = 2 * IPCFP_MAX_PARENTS + 1;  // BLS + secp per parent block, + the receipts AMT
 constexpr uint32_t kMaxDenseLevels = 24;
+// interior levels of at most this many entries at the top of the walk share ONE single-workgroup launch (k_dense_top)
+constexpr uint32_t kDenseTopMax = 1024;
 struct DenseRoots {  // travels as a kernel ARGUMENT (1.6 KB): no copy at the head of the walk
     DenseRoot r[kMaxDenseRoots];
     uint32_t n;

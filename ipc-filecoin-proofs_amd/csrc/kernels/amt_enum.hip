@@ -589,6 +589,30 @@ __global__ __launch_bounds__(256) void k_dense_level(WitnessView w, const DenseN
     if (j < n_next) dense_level_one(w, cur, roots_arg.r, level, j, next, anomaly);
 }
 
+// The NARROW interior levels at the top of the trees (a few hundred entries: 14, 71 and 495 for the 1M-receipt tipset) in ONE
+// launch of ONE workgroup, a __syncthreads between levels — the frontier of a level is written and read back by this
+// workgroup alone, so workgroup-scope ordering is all it needs; no grid barrier (the persistent all-levels form lost to its
+// barriers: launch_dense_walk).  What a level of so few entries costs beside K1 and the event parse is not its three
+// dependent loads but getting a workgroup ONTO the chip (k_enum_roots: one wavefront, 29 loads, 40-55 µs in the step): here
+// that is paid once for the levels together.  `n[i]`: entries of the frontier entering level_hi - 1 - i.
+struct DenseTopCounts {
+    uint32_t n[8];
+};
+__global__ __launch_bounds__(256) void k_dense_top(WitnessView w, const DenseNode* frontier, const DenseRoots roots_arg, uint32_t level_hi,
+                                                   uint32_t n_levels, DenseTopCounts counts, DenseNode* a, DenseNode* b,
+                                                   uint32_t* __restrict__ anomaly) {
+    const DenseNode* src = frontier;
+    for (uint32_t i = 0; i < n_levels; ++i) {
+        const uint32_t n_next = counts.n[i];
+        for (uint32_t j = threadIdx.x; j < n_next; j += blockDim.x) dense_level_one(w, src, roots_arg.r, level_hi - i, j, a, anomaly);
+        __syncthreads();  // (the level's entries are in place for every wavefront of the workgroup)
+        src = a;
+        DenseNode* t = a;
+        a = b;
+        b = t;
+    }
+}
+
 // leaf level of the trees whose values are LINKS taken as witness keys (Amtv0<Cid>: the message lists) — one lane per
 // VALUE.  The leaf is validated by its values' lanes exactly as an interior node by its children's.
 __global__ __launch_bounds__(256) void k_dense_link_leaves(WitnessView w, const DenseNode* __restrict__ cur, const DenseRoots roots_arg,
@@ -821,7 +845,33 @@ int launch_dense_walk(ipcfp_ctx* ctx, const WitnessView& view, const DenseNode* 
     // slower: 382 µs against 238 µs for the six launches.  What stretches a level beside K1 and the event parse is the
     // latency of its three dependent loads under their memory traffic, not the dispatch; a barrier adds an L2
     // write-back and an L1 invalidate per level on top.  profiles/r03_experiments.md)
-    for (uint32_t level = plan.max_height; level >= 1; --level) {
+    uint32_t level_from = plan.max_height;
+    {   // the narrow levels at the top: one launch (k_dense_top).  IPCFP_DENSE_TOP = the widest level it takes (0: none)
+        static const uint32_t top_max = [] {
+            const char* e = std::getenv("IPCFP_DENSE_TOP");
+            return e ? uint32_t(std::atoi(e)) : kDenseTopMax;
+        }();
+        DenseTopCounts counts{};
+        uint32_t n_top = 0;
+        while (n_top < 8 && level_from - n_top >= 1 && plan.n_level[level_from - n_top - 1] <= top_max) {
+            counts.n[n_top] = uint32_t(plan.n_level[level_from - n_top - 1]);
+            ++n_top;
+        }
+        if (n_top >= 2) {  // (one level alone is k_dense_level's)
+            hipLaunchKernelGGL(k_dense_top, dim3(1), dim3(256), 0, ctx->stream, view, src, plan.roots, level_from, n_top, counts, a, b, anomaly_d);
+            // the last level written: a for an odd number of levels, b for an even one — and the next writes the other
+            if (n_top & 1u) {
+                src = a;
+                DenseNode* t = a;
+                a = b;
+                b = t;
+            } else {
+                src = b;
+            }
+            level_from -= n_top;
+        }
+    }
+    for (uint32_t level = level_from; level >= 1; --level) {
         const uint32_t nn = uint32_t(plan.n_level[level - 1]);
         if (div_up(nn, 256) > narrow_max_wg) IPCFP_HIP(ctx, widen());
         hipLaunchKernelGGL(k_dense_level, dim3(div_up(nn, 256)), dim3(256), 0, ctx->stream, view, src, plan.roots, level, nn, a, anomaly_d);
