@@ -51,3 +51,11 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setenv("IPCFP_LIB", str(tmp_path / "nope.so"))
     with pytest.raises(b.EngineError):
         b.load_library()
+
+
+def test_graft_entry_build_passes_on_the_built_tree():
+    """`__graft_entry__.build()` is the driver's "does it build" check: with the tree built it is a no-op make plus the import
+    and the ABI-version check — which must follow the header's constant, not a number written down once."""
+    import __graft_entry__ as entry
+
+    entry.build()
