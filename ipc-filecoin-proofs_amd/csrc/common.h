@@ -119,6 +119,8 @@ struct ipcfp_ctx {
         void* claims_d = nullptr;
         uint32_t n = 0;
         uint64_t base = 0, blob_len = 0;
+        uint64_t full_len = 0;       // the whole batch's blob (what a record may point into at all)
+        uint32_t* miss_d = nullptr;  // set to 1 when a record lies inside the batch's blob but outside the uploaded window (nullable)
     } claims_rebase;
     // --- the mailbox: a page of COHERENT pinned host memory a kernel writes while the stream keeps going (device →
     // host without a synchronisation; kernels/amt_enum.hip k_enum_roots, host/verify_fast.cpp) ---

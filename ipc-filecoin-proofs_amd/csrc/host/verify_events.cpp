@@ -564,53 +564,115 @@ int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const 
         tcs[k].child = key_from_slot(tipsets[k].child);
         for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
     }
-    DevBuf<EventClaimPacked> cd;
-    DevBuf<uint8_t> bd, sd;
-    DevBuf<unsigned long long> win_d;
-    IPCFP_HIP(ctx, cd.alloc(m));
-    IPCFP_HIP(ctx, sd.alloc(m));
-    IPCFP_HIP(ctx, win_d.alloc(2));
-    const unsigned long long win0[2] = {~0ull, 0ull};
-    IPCFP_HIP(ctx, h2d_small(ctx, win_d.p, win0, sizeof win0, ctx->stream));
-    int rc = upload(ctx, cd.p, claims + a, m * sizeof(EventClaimPacked), ctx->stream);
-    if (rc) return rc;
-    rc = launch_claims_window(ctx, cd.p, uint32_t(m), win_d.p);
-    if (rc) return rc;
-    unsigned long long win[2] = {0, 0};
-    IPCFP_HIP(ctx, d2h_small(ctx, win, win_d.p, sizeof win, ctx->stream));
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    uint64_t o0 = win[0] == ~0ull ? 0 : win[0], o1 = win[1];
-    if (o0 > blob_len) o0 = blob_len;  // (records that point outside the batch's blob: the window is clamped, they are refused)
-    if (o1 > blob_len) o1 = blob_len;
-    if (o1 < o0) o1 = o0;
-    const uint64_t wlen = o1 - o0;
-    IPCFP_HIP(ctx, bd.alloc(wlen + 64));
-    if (wlen >= (size_t(4) << 20)) ctx->upload_task = upload_task_start(ctx, bd.p, blob + o0, wlen, nullptr, nullptr, 0);
-    if (!ctx->upload_task && wlen) {
-        rc = upload(ctx, bd.p, blob + o0, wlen, ctx->stream);
-        if (rc) return rc;
-    }
-    ctx->claims_rebase.pending = true;  // (queued by claims_ready: behind the copy, in front of whichever kernel reads the claims first)
-    ctx->claims_rebase.claims_d = cd.p;
-    ctx->claims_rebase.n = uint32_t(m);
-    ctx->claims_rebase.base = o0;
-    ctx->claims_rebase.blob_len = wlen;
-    rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(m), bd.p, wlen, trust, filter, sd.p);
-    {
-        const int rc_up = upload_task_wait(ctx);
-        if (rc == IPCFP_OK) rc = rc_up;
-        if (ctx->claims_rebase.pending) {  // no route reached its verify kernel: nothing may be reported
-            ctx->claims_rebase.pending = false;
-            if (rc == IPCFP_OK) rc = set_error(ctx, IPCFP_E_INVALID, "the claim slice was never rebased (no route reached its verify kernel)");
+    // Two ways to the window of the blob the slice points into.
+    //   guessed   from the slice's two ends on the host (a bundle's blob is written in claim order: the first records'
+    //             smallest offset, the last records' largest end) — records AND window then cross PCIe on a thread of their
+    //             own while this one queues the tipset prologue, the AMT walks and the execution order, and the rebase
+    //             kernel in front of the verify kernel says whether any record lay inside the batch's blob but outside
+    //             the guess (`miss`);
+    //   exact     records first, one reduction over them on the device, one synchronisation, then the window — the
+    //             fallback when the guess missed (a blob in another order), and the only way for a slice too small to be
+    //             worth a thread.
+    auto window_of = [&](uint64_t i0, uint64_t i1, uint64_t& lo, uint64_t& hi) {
+        for (uint64_t i = i0; i < i1; ++i) {
+            const ipcfp_event_claim_t& c = claims[i];
+            if (c.n_topics) {
+                lo = std::min<uint64_t>(lo, c.topics_off);
+                hi = std::max<uint64_t>(hi, uint64_t(c.topics_off) + 33ull * c.n_topics);
+            }
+            if (c.data_len) {
+                lo = std::min<uint64_t>(lo, c.data_off);
+                hi = std::max<uint64_t>(hi, uint64_t(c.data_off) + c.data_len);
+            }
         }
+    };
+    auto attempt = [&](bool guessed, bool* missed) -> int {
+        DevBuf<EventClaimPacked> cd;
+        DevBuf<uint8_t> bd, sd;
+        DevBuf<unsigned long long> win_d;
+        DevBuf<uint32_t> miss_d;
+        IPCFP_HIP(ctx, cd.alloc(m));
+        IPCFP_HIP(ctx, sd.alloc(m));
+        uint64_t o0 = ~0ull, o1 = 0;
+        int rc = IPCFP_OK;
+        if (guessed) {
+            constexpr uint64_t kEnds = 256;  // records looked at on either end
+            window_of(a, std::min(b, a + kEnds), o0, o1);
+            window_of(b > a + kEnds ? std::max(a + kEnds, b - kEnds) : b, b, o0, o1);
+            IPCFP_HIP(ctx, miss_d.alloc(1));
+            IPCFP_HIP(ctx, hipMemsetAsync(miss_d.p, 0, 4, ctx->stream));
+        } else {
+            IPCFP_HIP(ctx, win_d.alloc(2));
+            const unsigned long long win0[2] = {~0ull, 0ull};
+            IPCFP_HIP(ctx, h2d_small(ctx, win_d.p, win0, sizeof win0, ctx->stream));
+            rc = upload(ctx, cd.p, claims + a, m * sizeof(EventClaimPacked), ctx->stream);
+            if (rc) return rc;
+            rc = launch_claims_window(ctx, cd.p, uint32_t(m), win_d.p);
+            if (rc) return rc;
+            unsigned long long win[2] = {0, 0};
+            IPCFP_HIP(ctx, d2h_small(ctx, win, win_d.p, sizeof win, ctx->stream));
+            IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+            o0 = win[0];
+            o1 = win[1];
+        }
+        if (o0 == ~0ull) o0 = 0;
+        if (o0 > blob_len) o0 = blob_len;  // (records that point outside the batch's blob: the window is clamped, they are refused)
+        if (o1 > blob_len) o1 = blob_len;
+        if (o1 < o0) o1 = o0;
+        const uint64_t wlen = o1 - o0;
+        IPCFP_HIP(ctx, bd.alloc(wlen + 64));
+        if (guessed) {
+            IPCFP_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (nothing queued earlier may still use the buffers just taken)
+            ctx->upload_task = upload_task_start(ctx, cd.p, claims + a, m * sizeof(EventClaimPacked), bd.p, blob + o0, wlen);
+            if (!ctx->upload_task) {
+                rc = upload(ctx, cd.p, claims + a, m * sizeof(EventClaimPacked), ctx->stream);
+                if (!rc && wlen) rc = upload(ctx, bd.p, blob + o0, wlen, ctx->stream);
+                if (rc) return rc;
+            }
+        } else {
+            if (wlen >= (size_t(4) << 20)) ctx->upload_task = upload_task_start(ctx, bd.p, blob + o0, wlen, nullptr, nullptr, 0);
+            if (!ctx->upload_task && wlen) {
+                rc = upload(ctx, bd.p, blob + o0, wlen, ctx->stream);
+                if (rc) return rc;
+            }
+        }
+        ctx->claims_rebase.pending = true;  // (queued by claims_ready: behind the copy, in front of whichever kernel reads the claims first)
+        ctx->claims_rebase.claims_d = cd.p;
+        ctx->claims_rebase.n = uint32_t(m);
+        ctx->claims_rebase.base = o0;
+        ctx->claims_rebase.blob_len = wlen;
+        ctx->claims_rebase.full_len = blob_len;
+        ctx->claims_rebase.miss_d = guessed ? miss_d.p : nullptr;
+        rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(m), bd.p, wlen, trust, filter, sd.p);
+        {
+            const int rc_up = upload_task_wait(ctx);
+            if (rc == IPCFP_OK) rc = rc_up;
+            if (ctx->claims_rebase.pending) {  // no route reached its verify kernel: nothing may be reported
+                ctx->claims_rebase.pending = false;
+                if (rc == IPCFP_OK) rc = set_error(ctx, IPCFP_E_INVALID, "the claim slice was never rebased (no route reached its verify kernel)");
+            }
+        }
+        if (rc) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return rc;
+        }
+        uint32_t miss = 0;
+        if (guessed) IPCFP_HIP(ctx, d2h_small(ctx, &miss, miss_d.p, 4, ctx->stream));
+        IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, m, hipMemcpyDeviceToHost, ctx->stream));
+        IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+        *missed = miss != 0;
+        return IPCFP_OK;
+    };
+    static const bool allow_guess = [] {
+        const char* e = std::getenv("IPCFP_CLAIMS_WINDOW_GUESS");
+        return !(e && std::atoi(e) == 0);
+    }();
+    bool missed = false;
+    if (allow_guess && m * sizeof(EventClaimPacked) >= (size_t(1) << 20)) {  // (below: a thread and a join cost what the synchronisation does)
+        const int rc = attempt(true, &missed);
+        if (rc || !missed) return rc;
     }
-    if (rc) {
-        (void)hipStreamSynchronize(ctx->stream);
-        return rc;
-    }
-    IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, m, hipMemcpyDeviceToHost, ctx->stream));
-    IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    return IPCFP_OK;
+    return attempt(false, &missed);
 }
 
 // reconstruct_execution_order(bs, parent_hdr_cids) (src/proofs/events/utils.rs:16-30).

@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void k_compact_expand(const ClaimCompact* __re
 // ipcfp_verify_event_claims_slice: the records are consecutive claims of a larger batch and their blob offsets count from
 // the start of THAT batch's blob, of which bytes [base, base + blob_len) were uploaded: rebase them; a claim whose topics
 // or data do not lie inside that window is marked out of range (ERR_BAD_CLAIM, never followed).
-__global__ __launch_bounds__(256) void k_rebase_claims(EventClaimPacked* __restrict__ claims, uint32_t n, uint64_t base, uint64_t blob_len) {
+// `miss` (nullable): the window was GUESSED (from the slice's ends, before the records were in HBM) — a record that lies inside
+// the batch's blob [0, full_len) but outside the window sets *miss, and the caller repeats the call with the exact window.
+__global__ __launch_bounds__(256) void k_rebase_claims(EventClaimPacked* __restrict__ claims, uint32_t n, uint64_t base, uint64_t blob_len,
+                                                       uint64_t full_len, uint32_t* __restrict__ miss) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     EventClaimPacked c = claims[i];
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void k_rebase_claims(EventClaimPacked* __restr
         c.topics_off = c.n_topics ? uint32_t(t0 - base) : 0u;
         c.data_off = c.data_len ? uint32_t(d0 - base) : 0u;
     } else {
+        if (miss && (c.n_topics == 0 || t1 <= full_len) && (c.data_len == 0 || d1 <= full_len)) *miss = 1u;  // (any lane: the same value)
         c.context = 0xffffffffu;
         c.n_topics = c.topics_off = c.data_off = c.data_len = 0u;
     }
@@ -152,10 +156,10 @@ int launch_claims_window(ipcfp_ctx* ctx, const void* claims_d, uint32_t n, unsig
     return IPCFP_OK;
 }
 
-int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len) {
+int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len, uint64_t full_len, uint32_t* miss_d) {
     if (n == 0) return IPCFP_OK;
     hipLaunchKernelGGL(k_rebase_claims, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, static_cast<EventClaimPacked*>(claims_d), n, base,
-                       blob_len);
+                       blob_len, full_len, miss_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -121,6 +121,39 @@ def test_claim_slices_of_a_sorted_batch_equal_the_routed_claims(engine, tip, bun
         assert st[i] == 69 and np.array_equal(np.delete(st, i), np.delete(want[a: a + len(st)], i))
 
 
+def test_claim_slices_over_a_blob_in_another_order(engine, tip, claims_packed):
+    """A large slice's blob window is GUESSED from the slice's two ends so that records and window can cross PCIe beside
+    the walks; a blob that is not in claim order makes the guess miss — the rebase kernel says so and the call repeats
+    with the exact window (one reduction on the device): the statuses are the unsharded call's either way."""
+    ts, cl, blob, blob_len = claims_packed
+    cs = np.ascontiguousarray(cl[np.argsort(cl["exec_index"], kind="stable")])
+    rng = np.random.default_rng(5)
+    blob2 = np.zeros(len(blob) + 64, dtype=np.uint8)
+    pos = 7  # (offsets need no alignment)
+    for i in rng.permutation(len(cs)):
+        nt, dl = int(cs["n_topics"][i]), int(cs["data_len"][i])
+        if nt:
+            o = int(cs["topics_off"][i])
+            blob2[pos: pos + 33 * nt] = blob[o: o + 33 * nt]
+            cs["topics_off"][i] = pos
+            pos += 33 * nt
+        if dl:
+            o = int(cs["data_off"][i])
+            blob2[pos: pos + dl] = blob[o: o + dl]
+            cs["data_off"][i] = pos
+            pos += dl
+    assert pos <= len(blob2)
+    with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
+        want = w.verify_event_claims(ts, cs, blob2, pos)
+        assert (want == 1).sum() > 20_000 and (want != 1).sum() > 100
+        n = len(cs)
+        assert n * cs.dtype.itemsize // 2 >= 1 << 20  # (half the batch is still a slice the guess is made for)
+        for lo, hi, last in ((0, int(cs["exec_index"][n // 2]), False), (int(cs["exec_index"][n // 2]), 1 << 40, True),
+                             (int(cs["exec_index"][n // 3]), int(cs["exec_index"][n // 3 + 50]), False)):
+            a, st = w.verify_event_claims_range(ts, cs, blob2, pos, lo, hi, last)
+            assert len(st) > 40 and np.array_equal(st, want[a: a + len(st)])
+
+
 def test_pull_of_tall_event_amts(engine):
     """Events AMTs of bit width 1 and height >= 8: every node of every tree of the rank's receipts is a level of its own."""
     tall = Tipset(n_receipts=60, n_planted=6, variety=1, max_events=700, events_bit_width=1, seed=79)
