@@ -346,12 +346,23 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
 
 /* ipcfp_scan_events with DEVICE outputs: receipt_has_match_d (cap_receipts bytes) and matches_d (cap_matches
  * ipcfp_event_match_t) are HBM buffers of the caller (nullable); status and the two counts come back to the host.
- * summary_d (nullable): device u64[2] that receives {status, n_matches}, stream-ordered after the scan.
+ * summary_d (nullable): device u64[2] that receives {status | phase << 8, n_matches}, stream-ordered after the scan
+ * (phase: IPCFP_SCAN_PHASE_* below, 0 with status TRUE).
  * A multi-GPU host all-gathers the map without a round trip through host memory (ipcfp_allgather_segments).     */
 int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* receipts_root40,
                              const ipcfp_event_filter_t* filter, int has_actor, uint64_t actor, ipcfp_status_t* status_out,
                              void* receipt_has_match_d, uint64_t cap_receipts, uint64_t* n_receipts, void* matches_d,
                              uint64_t cap_matches, uint64_t* n_matches, void* summary_d);
+
+/* Where the Err of the last ipcfp_scan_events* call on this witness arose (0: it returned TRUE).  The scan enumerates the
+ * receipts of the WHOLE tipset before it opens any events AMT (the enumeration stands in for the reference's
+ * ChainGetParentReceipts call, src/proofs/events/generator.rs:199-204), so an Err of the enumeration precedes every Err
+ * of the events passes whatever the receipt index.  Receipt-range shards each see a part of the enumeration: their
+ * merge takes the first shard (in range order) with a RECEIPTS-phase Err, and only without one the first shard with
+ * an EVENTS-phase Err — the unsharded call's verdict (INTEGRATION.md "Multi-GPU"). */
+#define IPCFP_SCAN_PHASE_RECEIPTS 1
+#define IPCFP_SCAN_PHASE_EVENTS 2
+int ipcfp_witness_last_scan_phase(const ipcfp_witness_t* w);
 
 /* ---- proof claims (string form, exactly the reference's structs) ----------
  * CIDs and hex values are NUL-terminated strings, as in the reference's serde

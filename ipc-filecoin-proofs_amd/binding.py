@@ -13,6 +13,9 @@ import numpy as np
 
 __all__ = [
     "ABI_VERSION",
+    "SCAN_PHASE_RECEIPTS",
+    "SCAN_PHASE_EVENTS",
+    "merge_scan_status",
     "host_register",
     "host_unregister",
     "Engine",
@@ -134,7 +137,21 @@ CLAIM_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), (
                         ("tipset", np.uint32), ("flags", np.uint32), ("n_topics", np.uint32),
                         ("topics_off", np.uint32), ("data_off", np.uint32), ("data_len", np.uint32)])
 # event claims in transport form (include/ipcfp.h ipcfp_event_claim_compact_t / ipcfp_event_claim_group_t)
-ABI_VERSION = 2  # == IPCFP_ABI_VERSION of include/ipcfp.h (tests/test_abi_symbols.py holds the three together)
+ABI_VERSION = 2
+SCAN_PHASE_RECEIPTS, SCAN_PHASE_EVENTS = 1, 2
+
+
+def merge_scan_status(per_shard):
+    """The scan status of ONE tipset from its receipt-range shards' (status, phase) pairs in range order: the unsharded scan
+    enumerates every receipt before it opens an events AMT, so the first shard with an Err of the RECEIPTS phase decides, and
+    only when there is none the first shard with any Err (include/ipcfp.h ipcfp_witness_last_scan_phase)."""
+    for st, ph in per_shard:
+        if st != 1 and ph == SCAN_PHASE_RECEIPTS:
+            return st
+    for st, _ in per_shard:
+        if st != 1:
+            return st
+    return 1  # == IPCFP_ABI_VERSION of include/ipcfp.h (tests/test_abi_symbols.py holds the three together)
 COMPACT_DTYPE = np.dtype([("emitter", np.uint64), ("exec_index", np.uint32), ("event_index", np.uint32),
                           ("message_digest", np.uint8, (32,)), ("data_len", np.uint16), ("n_topics", np.uint8),
                           ("topic_flags", np.uint8), ("flags", np.uint8), ("group", np.uint8), ("reserved", np.uint16)])
@@ -270,6 +287,7 @@ def load_library() -> C.CDLL:
         "ipcfp_allgather_device": (i32, [vp, vp, vp, vp, u64]),
         "ipcfp_allgather_segments": (i32, [vp, vp, vp, vp, C.c_uint32, vp, vp, u64]),
         "ipcfp_scan_events_device": (i32, [vp, vp, vp, vp, i32, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64), vp]),
+        "ipcfp_witness_last_scan_phase": (i32, [vp]),
         "ipcfp_verify_storage_claims_device": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_cid_from_string": (i32, [C.c_char_p, vp]),
         "ipcfp_cid_to_string": (i32, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]),
@@ -986,6 +1004,12 @@ class Witness:
             bits = np.unpackbits(touched.view(np.uint8), bitorder="little")[: self.n]
             ids = np.nonzero(bits)[0]
         return int(st[0]), has, m, ids
+
+    def last_scan_phase(self) -> int:
+        """Where the Err of the last scan on this witness arose: 0 (it returned TRUE), SCAN_PHASE_RECEIPTS (the enumeration of
+        the tipset's receipts, which precedes every events AMT) or SCAN_PHASE_EVENTS — what a merge of receipt-range shards
+        needs to name the unsharded call's Err (merge_scan_status)."""
+        return int(self.eng.lib.ipcfp_witness_last_scan_phase(self.h))
 
     def scan_events_device(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor, has_ptr: int, cap_receipts: int,
                            matches_ptr: int = 0, cap_matches: int = 0, summary_ptr: int = 0):

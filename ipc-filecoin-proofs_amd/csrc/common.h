@@ -441,6 +441,7 @@ struct EventTableCached {
 // The opaque witness of the C ABI: the whole witness resident in HBM as SoA.
 struct ipcfp_witness {
     ipcfp_ctx* ctx = nullptr;
+    uint32_t last_scan_phase = 0;  // IPCFP_SCAN_PHASE_* of the last ipcfp_scan_events* on this witness (0: it returned TRUE)
     uint64_t n = 0;        // blocks
     uint64_t nbytes = 0;   // payload bytes (sum of len)
     uint64_t arena_bytes = 0;

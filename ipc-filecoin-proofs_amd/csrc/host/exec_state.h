@@ -46,6 +46,9 @@ int exec_state_prepare(ipcfp_ctx* ctx, ExecState& ex, uint32_t n_parents);
 // device-resident result of one two-pass event scan (scan_events.cpp)
 struct ScanResult {
     uint32_t status = IPCFP_ST_ERR;
+    // where an Err status arose (include/ipcfp.h IPCFP_SCAN_PHASE_*): the receipts enumeration comes first for the WHOLE
+    // tipset, so the merge of receipt-range shards prefers an enumeration error of any shard to an events error of a lower one
+    uint32_t phase = 0;
     uint64_t n_idx = 0, n_matches = 0;
     DevBuf<uint8_t> has;
     DevBuf<ipcfp_event_match_t> matches;

@@ -175,6 +175,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     if (rc) return rc;
     if (en->error != kNoEnumError) {
         out.status = enum_error_code(en->error);
+        out.phase = IPCFP_SCAN_PHASE_RECEIPTS;
         return IPCFP_OK;
     }
     const LeafRef* leaves = reinterpret_cast<const LeafRef*>(en->leaves.p);
@@ -253,6 +254,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         if (et < e1) e1 = et;
         if (e1 != kNoEnumError) {
             out.status = enum_error_code(e1);
+            out.phase = IPCFP_SCAN_PHASE_EVENTS;
             return IPCFP_OK;
         }
         if (walk) {  // matching receipts the table does not cover: the general walk writes their matches (offsets are in place)
@@ -280,6 +282,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
         if (e_table < e1) e1 = e_table;
         if (e1 != kNoEnumError) {
             out.status = enum_error_code(e1);
+            out.phase = IPCFP_SCAN_PHASE_EVENTS;
             return IPCFP_OK;
         }
         cap = nm;
@@ -299,6 +302,7 @@ int scan_events_device(ipcfp_ctx* ctx, ipcfp_witness* w, const CidKey& root, con
     if (e_table < e1) e1 = e_table;
     if (e1 != kNoEnumError) {  // PASS 2 ran on a tipset PASS 1 rejected: its output is discarded
         out.status = enum_error_code(e1);
+        out.phase = IPCFP_SCAN_PHASE_EVENTS;
         return IPCFP_OK;
     }
     out.n_idx = n_idx;
@@ -331,6 +335,7 @@ int ipcfp_scan_events(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* recei
                                 touched_bits ? touched.p : nullptr, res, matches ? cap_matches : 0);
     if (rc) return rc;
     *status_out = ipcfp_status_t(res.status);
+    w->last_scan_phase = res.status == IPCFP_ST_TRUE ? 0u : res.phase;
     if (res.status != IPCFP_ST_TRUE) return IPCFP_OK;
     *n_receipts = res.n_idx;
     *n_matches = res.n_matches;
@@ -375,8 +380,9 @@ int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t
                                 matches_d ? cap_matches : 0);
     if (rc) return rc;
     *status_out = ipcfp_status_t(res.status);
-    if (summary_d) {  // {status, n_matches} for the step message of a multi-GPU host
-        const uint64_t sm[2] = {uint64_t(res.status), res.status == IPCFP_ST_TRUE ? res.n_matches : 0};
+    w->last_scan_phase = res.status == IPCFP_ST_TRUE ? 0u : res.phase;
+    if (summary_d) {  // {status | phase << 8, n_matches} for the step message of a multi-GPU host
+        const uint64_t sm[2] = {uint64_t(res.status) | (uint64_t(w->last_scan_phase) << 8), res.status == IPCFP_ST_TRUE ? res.n_matches : 0};
         IPCFP_HIP(ctx, h2d_small(ctx, summary_d, sm, sizeof sm, ctx->stream));
     }
     if (res.status != IPCFP_ST_TRUE) return IPCFP_OK;
@@ -408,5 +414,7 @@ int ipcfp_scan_events_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t
     ctl_preprime(ctx);
     return IPCFP_OK;
 }
+
+int ipcfp_witness_last_scan_phase(const ipcfp_witness_t* w) { return w ? int(w->last_scan_phase) : 0; }
 
 }  // extern "C"

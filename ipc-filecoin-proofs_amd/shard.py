@@ -24,7 +24,7 @@ import numpy as np
 
 from . import binding as B
 
-HEADER_BYTES = 64  # u64 x 8: n_claims, n_receipts, n_blocks, scan_status, n_matches, n_bad_cids(filled by merge), lo, hi
+HEADER_BYTES = 64  # u64 x 8: n_claims, n_receipts, n_blocks, scan_status | scan_phase << 8, n_matches, n_bad_cids(filled by merge), lo, hi
 
 
 class Layout:
@@ -71,23 +71,25 @@ def merge(gathered: np.ndarray, layout: Layout, n_ranks: int, claim_positions, n
     g = np.asarray(gathered, dtype=np.uint8).reshape(n_ranks, layout.bytes_per_rank)
     status = np.full(n_claims_total, 255, dtype=np.uint8)  # (every claim has an owner: nothing stays 255 — route_claims)
     has = np.zeros(n_receipts_total, dtype=np.uint8)
-    scan_status, n_matches, n_bad, per_rank = 1, 0, 0, []
+    n_matches, n_bad, per_rank, scans = 0, 0, [], []
     for r in range(n_ranks):
         hdr = g[r, :HEADER_BYTES].view(np.uint64)
-        nc, nr, nb, sst, nm, _, lo, hi = [int(x) for x in hdr]
+        nc, nr, nb, sword, nm, _, lo, hi = [int(x) for x in hdr]
+        sst, phase = sword & 0xFF, (sword >> 8) & 0xFF  # (ipcfp_scan_events_device summary_d: status | phase << 8)
+        scans.append((sst, phase))
         pos = np.asarray(claim_positions[r])
         assert len(pos) == nc, "claim routing differs from what the rank reported"
         status[pos] = g[r, layout.off_status: layout.off_status + nc]
         has[lo: lo + nr] = g[r, layout.off_has: layout.off_has + nr]
         bits = np.unpackbits(g[r, layout.off_bits: layout.off_bits + (nb + 31) // 32 * 4], bitorder="little")[:nb]
         bad = int(nb - bits.sum())
-        # the first Err in traversal order is the one of the lowest receipt range
-        if scan_status == 1 and sst != 1:
-            scan_status = sst
         n_matches += nm
         n_bad += bad
-        per_rank.append({"claims": nc, "receipts": nr, "blocks": nb, "scan_status": sst, "matches": nm, "bad_cids": bad,
-                         "lo": lo, "hi": hi})
+        per_rank.append({"claims": nc, "receipts": nr, "blocks": nb, "scan_status": sst, "scan_phase": phase, "matches": nm,
+                         "bad_cids": bad, "lo": lo, "hi": hi})
+    # an Err of the receipts enumeration (any shard: the unsharded scan enumerates the whole tipset first) before an Err of
+    # the events passes; inside a phase the lowest receipt range's
+    scan_status = B.merge_scan_status(scans)
     return {"status": status, "has": has, "scan_status": scan_status, "n_matches": n_matches, "n_bad_cids": n_bad,
             "per_rank": per_rank}
 

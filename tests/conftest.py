@@ -23,6 +23,12 @@ if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def fuzz_seed(base: int) -> int:
+    """The differential fuzzers' seeds are fixed (a failure must reproduce); IPCFP_FUZZ_SEED=k moves every one of them
+    by k, so that spare minutes on a GPU box can run the same tests over other corpora (tools/gpu_fuzz_seeds.sh)."""
+    return base + int(os.environ.get("IPCFP_FUZZ_SEED", "0"))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

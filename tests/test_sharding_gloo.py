@@ -110,6 +110,28 @@ def test_shard_range_partitions():
         assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
 
 
+def test_scan_status_of_merged_shards_prefers_the_enumeration_phase():
+    """The unsharded scan enumerates every receipt before it opens an events AMT: an Err of the enumeration in ANY shard
+    precedes an Err of the events passes in a lower one; inside a phase the lowest receipt range decides; a header word is
+    status | phase << 8 (ipcfp_scan_events_device summary_d)."""
+    from ipc_filecoin_proofs_amd import shard
+    import ipc_filecoin_proofs_amd as ipcfp
+
+    R, E = ipcfp.SCAN_PHASE_RECEIPTS, ipcfp.SCAN_PHASE_EVENTS
+    assert ipcfp.merge_scan_status([(1, 0), (1, 0)]) == 1
+    assert ipcfp.merge_scan_status([(65, E), (1, 0), (66, R)]) == 66
+    assert ipcfp.merge_scan_status([(65, E), (66, E), (1, 0)]) == 65
+    assert ipcfp.merge_scan_status([(1, 0), (70, R), (66, R)]) == 70
+    assert ipcfp.merge_scan_status([(1, 0), (67, 0)]) == 67  # (a message written without a phase: any Err, in range order)
+    lay = shard.Layout(4, 8, 40)
+    msg = np.zeros((3, lay.bytes_per_rank), dtype=np.uint8)
+    for r, (st, ph) in enumerate([(65, E), (1, 0), (66, R)]):
+        hdr = msg[r, : shard.HEADER_BYTES].view(np.uint64)
+        hdr[:] = [0, 2, 40, st | (ph << 8), 0, 0, 2 * r, 2 * r + 2]
+    merged = shard.merge(msg.reshape(-1), lay, 3, [np.zeros(0, dtype=np.int64)] * 3, 0, 6)
+    assert merged["scan_status"] == 66 and [p["scan_phase"] for p in merged["per_rank"]] == [E, 0, R]
+
+
 def test_layout_and_claim_subsetting():
     from ipc_filecoin_proofs_amd import shard
     import ipc_filecoin_proofs_amd as ipcfp
