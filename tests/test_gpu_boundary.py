@@ -5,6 +5,8 @@ closure (src/proofs/events/verifier.rs:51-56,247-251), and `generate_proof_bundl
 import numpy as np
 import pytest
 
+from conftest import fuzz_seed
+
 import claims
 import ipc_filecoin_proofs_amd as ipcfp
 from tools.synth import Tipset
@@ -15,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def tip():
     return Tipset(n_receipts=2500, n_parents=3, dup_permille=40, n_planted=9, variety=1, max_events=4, n_actors=2500,
-                  n_contracts=6, slots_per_contract=10, storage_layout_mix=1, n_actor_queries=8, seed=515)
+                  n_contracts=6, slots_per_contract=10, storage_layout_mix=1, n_actor_queries=8, seed=fuzz_seed(515))
 
 
 def test_blockstore_get_has(engine, tip):

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import fuzz_seed
+
 import ipc_filecoin_proofs_amd as ipcfp
 from tools.synth import Tipset
 
@@ -59,7 +61,7 @@ def same_scan(a, b):
 @pytest.mark.parametrize("bit_width", [5, 3, 6, 7])
 def test_table_and_walk_agree_with_the_oracle(engine, oracle, bit_width):
     tip = Tipset(n_receipts=6000, n_parents=3, n_planted=25, variety=1, max_events=9 if bit_width == 3 else 5,
-                 no_events_permille=80, events_bit_width=bit_width, seed=900 + bit_width)
+                 no_events_permille=80, events_bit_width=bit_width, seed=fuzz_seed(900 + bit_width))
     ts, cl, blob, blob_len = packed(tip)
     ost = oracle.store(tip.data, tip.off, tip.lens, tip.cids, threads=0)
     want = ost.verify_event_claims_packed(ts, cl, blob, threads=0)
@@ -85,7 +87,7 @@ def test_table_and_walk_agree_with_the_oracle(engine, oracle, bit_width):
 def test_damaged_events_blocks(engine, oracle):
     """An events AMT root that no longer decodes (byte flipped inside an event; block cut short) is an Err for every
     claim on that receipt and stops the scan at that receipt — identically with and without the table."""
-    tip = Tipset(n_receipts=3000, n_parents=3, n_planted=12, variety=0, max_events=4, no_events_permille=0, seed=31)
+    tip = Tipset(n_receipts=3000, n_parents=3, n_planted=12, variety=0, max_events=4, no_events_permille=0, seed=fuzz_seed(31))
     ts, cl, blob, blob_len = packed(tip, lie=False)
     with engine.witness(tip.data, tip.off, tip.lens, tip.cids) as w:
         _, _, m, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=None, want_touched=False)

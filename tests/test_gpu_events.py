@@ -4,6 +4,8 @@ of SURVEY.md A.10 that a claim or a tampered witness can reach."""
 import numpy as np
 import pytest
 
+from conftest import fuzz_seed
+
 import claims
 from tools.synth import Tipset
 
@@ -203,7 +205,7 @@ def test_scan_events_other_filters(tip, both, engine):
 
 def test_scan_events_deep_event_amts(engine, oracle):
     """Events AMTs with bit width 2 are several levels deep: exercises the per-lane depth-first walk."""
-    tip2 = Tipset(n_receipts=300, n_planted=6, variety=1, max_events=40, events_bit_width=2, seed=77)
+    tip2 = Tipset(n_receipts=300, n_planted=6, variety=1, max_events=40, events_bit_width=2, seed=fuzz_seed(77))
     w = engine.witness(tip2.data, tip2.off, tip2.lens, tip2.cids)
     st = oracle.store(tip2.data, tip2.off, tip2.lens, tip2.cids)
     gs, ghas, gm, gids = w.scan_events(tip2.receipts_root, tip2.topic0, tip2.topic1, actor=tip2.filter_actor)
@@ -224,7 +226,7 @@ def test_tipsets_with_more_than_sixteen_parent_blocks(engine, oracle, P):
     Expected blocks per epoch: 5; 17 or more happen (Poisson tail ~ 2e-5 per epoch), so the engine's table holds 32
     (IPCFP_MAX_PARENTS; round 3: 16 and IPCFP_E_UNSUPPORTED beyond)."""
     import ipc_filecoin_proofs_amd as ipcfp
-    tp = Tipset(n_receipts=700, n_parents=P, n_planted=5, variety=1, max_events=4, dup_permille=40, seed=80 + P)
+    tp = Tipset(n_receipts=700, n_parents=P, n_planted=5, variety=1, max_events=4, dup_permille=40, seed=fuzz_seed(80 + P))
     w = engine.witness(tp.data, tp.off, tp.lens, tp.cids)
     st = oracle.store(tp.data, tp.off, tp.lens, tp.cids)
     gs, gc = w.exec_order(tp.parent_cids)
@@ -482,8 +484,8 @@ def test_bundle_with_two_tipset_pairs_at_size(engine, oracle, fast):
     route — 120 k claims, interleaved pair by pair, liars of several kinds in both halves, every status against the
     multi-threaded oracle, with the fast route enabled (it must decline) and disabled."""
     import ipc_filecoin_proofs_amd as ipcfp
-    tips = [Tipset(n_receipts=60_000, n_parents=3, dup_permille=30, n_planted=20, variety=1, max_events=4, seed=901),
-            Tipset(n_receipts=60_000, n_parents=5, dup_permille=10, n_planted=20, variety=1, max_events=3, seed=902)]
+    tips = [Tipset(n_receipts=60_000, n_parents=3, dup_permille=30, n_planted=20, variety=1, max_events=4, seed=fuzz_seed(901)),
+            Tipset(n_receipts=60_000, n_parents=5, dup_permille=10, n_planted=20, variety=1, max_events=3, seed=fuzz_seed(902))]
     packs = [packed_for(t) for t in tips]
     data = np.concatenate([t.data for t in tips])
     off = np.concatenate([tips[0].off, tips[1].off + np.uint64(tips[0].data.size)])
@@ -618,6 +620,6 @@ def test_verify_and_scan_in_one_call_equals_the_two_calls(tip, engine, oracle):
     s, want = both_ways(tip, (tip.data, tip.off[idx], tip.lens[idx], tip.cids[idx]), hint, 1)
     assert s == 65 and (want >= 64).all()
     # deep events AMTs: the table leaves them to the walkers, the riding scan hands over to the ordinary one
-    tip2 = Tipset(n_receipts=300, n_planted=6, variety=1, max_events=40, events_bit_width=2, seed=77)
+    tip2 = Tipset(n_receipts=300, n_planted=6, variety=1, max_events=40, events_bit_width=2, seed=fuzz_seed(77))
     s, _ = both_ways(tip2, (tip2.data, tip2.off, tip2.lens, tip2.cids), (tip2.topic0, tip2.topic1, tip2.filter_actor), 1)
     assert s == 1

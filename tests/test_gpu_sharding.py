@@ -4,6 +4,8 @@ unsharded engine's, bit for bit, and the oracle's.  The RCCL path is exercised w
 run-time binding of librccl, ncclCommInitRank, ncclAllGather on the engine's stream)."""
 import numpy as np
 import pytest
+
+from conftest import fuzz_seed
 import torch
 
 import ipc_filecoin_proofs_amd as ipcfp
@@ -51,7 +53,7 @@ def run_shards(engine, tip, G, ts, cl, blob, comm=None, tamper=None):
 @pytest.fixture(scope="module")
 def tip():
     return Tipset(n_receipts=40_000, n_parents=4, dup_permille=30, n_planted=40, max_events=4, no_events_permille=50,
-                  variety=1, seed=77)
+                  variety=1, seed=fuzz_seed(77))
 
 
 @pytest.fixture(scope="module")

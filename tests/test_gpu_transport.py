@@ -6,6 +6,8 @@
 Reference: src/proofs/common/bundle.rs:10-45 (blocks and event_proofs of a bundle), src/proofs/events/bundle.rs:5-23."""
 import numpy as np
 import pytest
+
+from conftest import fuzz_seed
 import torch
 
 import claims
@@ -19,7 +21,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def tip():
     return Tipset(n_receipts=6000, n_parents=4, dup_permille=30, n_planted=12, max_events=4, no_events_permille=50,
-                  variety=1, seed=404)
+                  variety=1, seed=fuzz_seed(404))
 
 
 @pytest.fixture(scope="module")
