@@ -1182,7 +1182,8 @@ def tipset_kernels(tip, kern, steps, n_claims, claim_bytes, bracketed_ms):
         "tipset_prologue": (None, "latency", "latency (5 headers, 10 TxMeta/AMT roots: a dependent chain of ~4 block reads)",
                             "k_tipset_prepare, k_enum_roots", "a few KB"),
         "amt_walk": (float(st["message_amt_bytes"] + st["receipts_amt_bytes"]) + 8.0 * n_msgs + 16.0 * n_receipts, "hbm",
-                     "latency (3 dependent levels, then leaves)", "k_dense_level, k_dense_link_leaves, k_dense_leaves",
+                     "latency (the narrow levels in one single-workgroup launch, 3 dependent levels, then leaves)",
+                     "k_dense_top, k_dense_level, k_dense_link_leaves, k_dense_leaves",
                      "message AMTs + receipts AMT read once; 8 B per message key and 16 B per receipt leaf written"),
         "exec_order": (28.0 * n_msgs, "hbm", "latency (hash-table insert, scan, scatter)",
                        "k_exec_insert_flags, k_exec_flag_sums, k_scan_tiles_u64, k_exec_apply_finish",

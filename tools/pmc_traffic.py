@@ -16,6 +16,7 @@ KERNELS = [
     ("k_index_insert", "cid_index", "rand16"),              # coalesced CID words + one random 8-byte slot per lane
     ("k_tipset_prepare", "tipset_prologue", "lane_seq"),
     ("k_enum_roots", "tipset_prologue", "lane_seq"),
+    ("k_dense_top", "amt_walk", "lane_seq"),                # the narrow levels at the top, one workgroup
     ("k_dense_level", "amt_walk", "lane_seq"),              # one AMT node per lane, parsed front to back
     ("k_dense_link_leaves", "amt_walk", "lane_seq"),
     ("k_dense_leaves", "amt_walk", "lane_seq"),
