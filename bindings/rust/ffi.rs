@@ -46,6 +46,8 @@ pub const IPCFP_CID_SLOT: usize = 40;
 pub const IPCFP_MAX_PARENTS: usize = 32;
 /// == `IPCFP_ABI_VERSION` of include/ipcfp.h: the struct layouts below are this version's (2: IPCFP_MAX_PARENTS 16 -> 32)
 pub const IPCFP_ABI_VERSION: c_int = 2;
+pub const IPCFP_SCAN_PHASE_RECEIPTS: u32 = 1;
+pub const IPCFP_SCAN_PHASE_EVENTS: u32 = 2;
 pub const IPCFP_ST_TRUE: u8 = 1;
 pub const IPCFP_ST_FALSE_FILTER: u8 = 17;
 /// `ipcfp_check_event_fn` of the header: the host predicate of ipcfp_verify_event_proofs_with
@@ -230,8 +232,18 @@ impl Engine {
 impl Drop for Engine { fn drop(&mut self) { unsafe { ipcfp_ctx_destroy(self.ctx) } } }
 impl Drop for Witness<'_> { fn drop(&mut self) { unsafe { ipcfp_witness_destroy(*self.w.borrow()) } } }
 
+/// The scan status of ONE tipset from its receipt-range shards' `(status, phase)` pairs in range order (a multi-GPU host:
+/// INTEGRATION.md "Multi-GPU").  The unsharded scan enumerates every receipt before it opens an events AMT, so the first
+/// shard with an Err of the receipts phase decides, and only without one the first shard with any Err.
+pub fn merge_scan_status(per_shard: &[(u8, u32)]) -> u8 {
+    per_shard.iter().find(|(st, ph)| *st != 1 && *ph == IPCFP_SCAN_PHASE_RECEIPTS).or_else(|| per_shard.iter().find(|(st, _)| *st != 1)).map(|(st, _)| *st).unwrap_or(1)
+}
+
 impl Witness<'_> {
     fn raw(&self) -> *mut ipcfp_witness_t { *self.w.borrow() }
+
+    /// where the Err of the last scan on this witness arose (0: it returned TRUE; IPCFP_SCAN_PHASE_RECEIPTS / _EVENTS)
+    pub fn last_scan_phase(&self) -> u32 { unsafe { ipcfp_witness_last_scan_phase(self.raw()) as u32 } }
 
     /// K1: Blake2b-256 of every block against its CID — the check `MemoryBlockstore` never makes
     pub fn verify_cids(&self) -> Result<u64> {

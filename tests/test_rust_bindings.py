@@ -59,7 +59,7 @@ def test_rust_constants_follow_the_header():
     version, and every binding compares versions before its first call."""
     header = open(os.path.join(ROOT, "include", "ipcfp.h")).read()
     text = open(os.path.join(RUST, "ffi.rs"), "rb").read().decode("utf-8", "replace")
-    for name in ("IPCFP_ABI_VERSION", "IPCFP_MAX_PARENTS", "IPCFP_CID_SLOT"):
+    for name in ("IPCFP_ABI_VERSION", "IPCFP_MAX_PARENTS", "IPCFP_CID_SLOT", "IPCFP_SCAN_PHASE_RECEIPTS", "IPCFP_SCAN_PHASE_EVENTS"):
         h = int(re.search(r"#define %s (\d+)" % name, header).group(1))
         r = int(re.search(r"pub const %s: \w+ = (\d+);" % name, text).group(1))
         assert h == r, name
