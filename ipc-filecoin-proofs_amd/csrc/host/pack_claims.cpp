@@ -8,6 +8,7 @@
 // the very same string arrays, which makes it a pointer compare), then lowered in parallel by contiguous
 // ranges, each range into its own blob; the blobs are concatenated and the offsets rebased.
 #include "pack_claims.h"
+#include "parallel.h"
 
 #include <algorithm>
 #include <cstring>
@@ -148,13 +149,9 @@ int pack_event_claims_host(const ipcfp_event_proof_t* proofs, uint64_t n, Packed
             out.claims[i].context = ctx_keep;
         }
     };
-    if (n_threads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto& th : pool) th.join();
+    if (!run_parts(n_threads, work)) {  // (host/parallel.h: a part that ran out of memory is an error code, not a terminate)
+        err = "out of memory while lowering the claims";
+        return IPCFP_E_NOMEM;
     }
     // ---- pass 3: one blob, offsets rebased ----
     uint64_t total = 0;
@@ -268,15 +265,7 @@ int ipcfp_pack_storage_proofs(const ipcfp_storage_proof_t* proofs, uint64_t n, i
         const uint64_t lo = n * t / n_threads, hi = n * (t + 1) / n_threads;
         for (uint64_t i = lo; i < hi; ++i) ipcfp::lower_storage_one(proofs[i], out[i]);
     };
-    if (n_threads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto& th : pool) th.join();
-    }
-    return IPCFP_OK;
+    return ipcfp::run_parts(n_threads, work) ? IPCFP_OK : IPCFP_E_NOMEM;
 }
 
 }  // extern "C"

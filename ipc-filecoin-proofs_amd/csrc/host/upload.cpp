@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../common.h"
+#include "parallel.h"
 
 namespace ipcfp {
 
@@ -97,10 +98,7 @@ int upload(ipcfp_ctx* ctx, void* dst_d, const void* src, size_t bytes, hipStream
             r->recorded[slot] = true;
         }
     };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
+    if (!run_parts(T, work)) failed = 1;  // (host/parallel.h: a thread that cannot be made does not throw across the ABI)
     if (failed) return set_error(ctx, IPCFP_E_HIP, "staged upload of %zu bytes failed: %s", bytes, hipGetErrorString(hipGetLastError()));
     return IPCFP_OK;
 }

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../common.h"
+#include "parallel.h"
 #include "../kernels/launch.h"
 #include "exec_state.h"
 
@@ -190,7 +191,7 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
     uint64_t payload = 0;
     {
         const unsigned T = n >= (1u << 18) ? 4u : 1u;
-        std::vector<uint64_t> sum(T, 0), bad(T, ~0ull);
+        uint64_t sum[4] = {0, 0, 0, 0}, bad[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         auto part = [&](unsigned t) {
             const uint64_t lo = n * t / T, hi = n * (t + 1) / T;
             uint64_t acc = 0;
@@ -203,10 +204,7 @@ int ipcfp_witness_create(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint64_t nbytes
             }
             sum[t] = acc;
         };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < T; ++t) pool.emplace_back(part, t);
-        part(0);
-        for (auto& th : pool) th.join();
+        (void)run_parts(T, part);  // (host/parallel.h: nothing is thrown across the ABI; `part` itself allocates nothing)
         for (unsigned t = 0; t < T; ++t) {
             if (bad[t] != ~0ull) {
                 const uint64_t i = bad[t];  // (the first offender: the parts are in index order)
