@@ -101,6 +101,9 @@ pub struct ipcfp_storage_proof_t {
                                               pub actor_state: [u8; 40], pub storage_root: [u8; 40], pub slot: [u8; 32],
                                               pub value: [u8; 32], pub flags: u32, pub reserved: u32 }
 #[repr(C)] pub struct ipcfp_storage_proof_spec_t { pub actor_id: u64, pub slot: [u8; 32] }
+#[repr(C)] #[derive(Clone, Copy, Default, Debug)]
+pub struct ipcfp_shard_pull_stats_t { pub rounds: u32, pub blocks: u32, pub table_bytes: u64, pub block_bytes: u64, pub payload_bytes: u64,
+                                      pub tables_ms: f64, pub pull_ms: f64, pub create_ms: f64 }
 #[repr(C)] pub struct ipcfp_event_proof_spec_t { pub event_signature: *const c_char, pub topic_1: *const c_char,
                                                  pub actor_id_filter: u64, pub has_actor_id_filter: u8 }
 
@@ -146,6 +149,106 @@ pub fn trust_pod(p: &TrustPolicy) -> ipcfp_trust_policy_t {
     }
 }
 
+// ---- the bundle in transport form; a rank's shard -----------------------------------------------------------------------
+/// `Vec<ProofBlock>` (src/proofs/common/bundle.rs:10-15) as the tables of `ipcfp_witness_create_packed` /
+/// `ipcfp_witness_create_shard_pull`: blocks back to back, lengths, 32-byte digests + the chain's CID prefix, escapes for
+/// every other CID form.  `register = true` maps `bytes` for device reads (`ipcfp_host_register`; undone on drop): what a
+/// self-planned shard needs — an ingest buffer is registered once, when it is made, not per call.
+pub struct PackedBundle { pub bytes: Vec<u8>, pub len: Vec<u32>, pub digests: Vec<u8>, pub esc_index: Vec<u32>, pub esc_cids: Vec<u8>,
+                          registered: bool }
+impl PackedBundle {
+    pub const STD: [u8; 6] = [0x01, 0x71, 0xa0, 0xe4, 0x02, 0x20];  // CIDv1, dag-cbor, blake2b-256, 32-byte digest
+    pub fn new(blocks: &[ProofBlock], register: bool) -> Result<Self> {
+        let (mut bytes, mut len, mut digests) = (Vec::new(), Vec::new(), Vec::new());
+        let (mut esc_index, mut esc_cids) = (Vec::<u32>::new(), Vec::<u8>::new());
+        for (i, b) in blocks.iter().enumerate() {
+            len.push(u32::try_from(b.data.len())?);
+            bytes.extend_from_slice(&b.data);
+            let slot = cid_slot(&b.cid)?;
+            if slot[..6] == Self::STD && slot[38..] == [0, 0] {
+                digests.extend_from_slice(&slot[6..38]);
+            } else {
+                digests.extend_from_slice(&[0u8; 32]);
+                esc_index.push(i as u32);
+                esc_cids.extend_from_slice(&slot);
+            }
+        }
+        let mut t = Self { bytes, len, digests, esc_index, esc_cids, registered: false };
+        if register && !t.bytes.is_empty() {
+            match unsafe { ipcfp_host_register(t.bytes.as_mut_ptr() as *mut std::ffi::c_void, t.bytes.len() as u64) } {
+                0 => t.registered = true,
+                rc => return Err(anyhow!("ipcfp_host_register: {rc}")),
+            }
+        }
+        Ok(t)
+    }
+}
+impl Drop for PackedBundle {
+    fn drop(&mut self) { if self.registered { unsafe { ipcfp_host_unregister(self.bytes.as_mut_ptr() as *mut std::ffi::c_void); } } }
+}
+
+/// Rank `shard`'s part of one tipset: the witness of the receipts `receipts` (of `n_receipts`), and what the pull moved.
+pub struct WitnessShard<'e> { pub witness: Witness<'e>, pub receipts: std::ops::Range<u64>, pub n_receipts: u64, pub n_shards: u32,
+                              pub shard: u32, pub stats: ipcfp_shard_pull_stats_t }
+
+/// The event proofs of a bundle lowered ONCE to the binary claims every rank slices (`ipcfp_pack_event_proofs`): the
+/// reference's strings parsed (CIDs, hex) exactly as `verify_event_proof` would (src/proofs/events/verifier.rs:93-181).
+pub struct PackedEvents { p: *mut ipcfp_packed_events_t }
+impl PackedEvents {
+    pub fn new(proofs: &[EventProof]) -> Result<Self> {
+        let keep: Vec<_> = proofs.iter().map(CEventProof::new).collect();
+        let raw: Vec<ipcfp_event_proof_t> = keep.iter().map(|k| k.raw()).collect();
+        let mut p = std::ptr::null_mut();
+        match unsafe { ipcfp_pack_event_proofs(raw.as_ptr(), raw.len() as u64, &mut p) } { 0 => Ok(Self { p }), rc => Err(anyhow!("ipcfp_pack_event_proofs: {rc}")) }
+    }
+    pub fn len(&self) -> usize { let mut n = 0u64; unsafe { ipcfp_packed_events_claims(self.p, &mut n) }; n as usize }
+    pub fn is_empty(&self) -> bool { self.len() == 0 }
+}
+impl Drop for PackedEvents { fn drop(&mut self) { unsafe { ipcfp_packed_events_destroy(self.p) } } }
+
+impl WitnessShard<'_> {
+    /// `verify_event_proof` (src/proofs/events/verifier.rs:51-74) for THIS rank's share of the batch: the proofs whose
+    /// `exec_index` lies in `self.receipts` (the last rank also takes everything beyond the last receipt, so that every
+    /// proof has one owner), found by two binary searches in `events` — which must be in `exec_index` order, the order
+    /// `generate_event_proof` emits (src/proofs/events/generator.rs:242-301); the device checks it and the call is an
+    /// `Err` otherwise.  Returns the index of the first proof verified and the verdicts from there on.  A multi-GPU host
+    /// gathers every rank's `(first, statuses)` (one all-gather of status bytes) and only THEN applies the reference's
+    /// "first Err aborts" rule over the whole batch: `merge_event_statuses`.
+    pub fn verify_event_proof_range(&self, events: &PackedEvents, trust: &ipcfp_trust_policy_t,
+                                    filter: Option<&ipcfp_event_filter_t>) -> Result<(usize, Vec<u8>)> {
+        let (mut nt, mut n, mut bl) = (0u32, 0u64, 0u64);
+        let (ts, cl, blob) = unsafe { (ipcfp_packed_events_tipsets(events.p, &mut nt), ipcfp_packed_events_claims(events.p, &mut n),
+                                       ipcfp_packed_events_blob(events.p, &mut bl)) };
+        let mut st = vec![0u8; (n as usize).max(1)];
+        let (mut first, mut count) = (0u64, 0u64);
+        let w = &self.witness;
+        let rc = unsafe { ipcfp_verify_event_claims_range(w.eng.ctx, w.raw(), ts, nt, cl, n, blob, bl, self.receipts.start, self.receipts.end,
+                                                          (self.shard + 1 == self.n_shards) as c_int, trust,
+                                                          filter.map_or(std::ptr::null(), |f| f as *const _), &mut first, &mut count,
+                                                          st.as_mut_ptr()) };
+        if rc != 0 { return Err(w.eng.err("ipcfp_verify_event_claims_range", rc)); }
+        st.truncate(count as usize);
+        Ok((first as usize, st))
+    }
+}
+
+/// The verdicts of a whole batch from every rank's `(first, statuses)`: the reference's `Result<Vec<bool>>` — the Err of
+/// the LOWEST proof index aborts (src/proofs/events/verifier.rs:62-71), whichever rank met it.
+pub fn merge_event_statuses(n_proofs: usize, per_rank: &[(usize, Vec<u8>)]) -> Result<Vec<bool>> {
+    let mut all = vec![0u8; n_proofs];
+    let mut seen = vec![false; n_proofs];
+    for (first, st) in per_rank {
+        for (k, s) in st.iter().enumerate() {
+            let i = first + k;
+            if i >= n_proofs || seen[i] { return Err(anyhow!("merge_event_statuses: proof {i} has no single owner")); }
+            all[i] = *s;
+            seen[i] = true;
+        }
+    }
+    if let Some(i) = seen.iter().position(|s| !*s) { return Err(anyhow!("merge_event_statuses: proof {i} was verified by no rank")); }
+    statuses_to_result(&all)
+}
+
 // ---- engine / witness -------------------------------------------------------------------------------------------------
 pub struct Engine { ctx: *mut ipcfp_ctx_t }
 /// The HBM-resident witness store.  `&self` methods with interior state, like the trait it implements
@@ -170,27 +273,38 @@ impl Engine {
     /// (`ipcfp_witness_create_packed`): lengths instead of offsets, 32-byte digests + the chain's CID prefix instead of
     /// 40-byte slots, and the few CIDs of another form as escapes.
     pub fn load_witness_store(&self, blocks: &[ProofBlock]) -> Result<Witness<'_>> {
-        const STD: [u8; 6] = [0x01, 0x71, 0xa0, 0xe4, 0x02, 0x20];  // CIDv1, dag-cbor, blake2b-256, 32-byte digest
-        let (mut bytes, mut len, mut digests) = (Vec::new(), Vec::new(), Vec::new());
-        let (mut esc_index, mut esc_cids) = (Vec::<u32>::new(), Vec::<u8>::new());
-        for (i, b) in blocks.iter().enumerate() {
-            len.push(u32::try_from(b.data.len())?);
-            bytes.extend_from_slice(&b.data);
-            let slot = cid_slot(&b.cid)?;
-            if slot[..6] == STD && slot[38..] == [0, 0] {
-                digests.extend_from_slice(&slot[6..38]);
-            } else {
-                digests.extend_from_slice(&[0u8; 32]);
-                esc_index.push(i as u32);
-                esc_cids.extend_from_slice(&slot);
-            }
-        }
+        let t = PackedBundle::new(blocks, false)?;
         let mut w = std::ptr::null_mut();
-        let rc = unsafe { ipcfp_witness_create_packed(self.ctx, bytes.as_ptr(), bytes.len() as u64, len.as_ptr(), digests.as_ptr(),
-                                                      blocks.len() as u64, STD.as_ptr(), STD.len() as u32, esc_index.as_ptr(),
-                                                      esc_cids.as_ptr(), esc_index.len() as u64, &mut w) };
+        let rc = unsafe { ipcfp_witness_create_packed(self.ctx, t.bytes.as_ptr(), t.bytes.len() as u64, t.len.as_ptr(), t.digests.as_ptr(),
+                                                      t.len.len() as u64, PackedBundle::STD.as_ptr(), PackedBundle::STD.len() as u32,
+                                                      t.esc_index.as_ptr(), t.esc_cids.as_ptr(), t.esc_index.len() as u64, &mut w) };
         if rc != 0 { return Err(self.err("ipcfp_witness_create_packed", rc)); }
         Ok(Witness { eng: self, w: RefCell::new(w) })
+    }
+
+    /// MULTI-GPU, rank `shard` of `n_shards` (one process per GPU; INTEGRATION.md "Multi-GPU"): the receipt-range shard
+    /// of ONE tipset, built by the device straight out of the bundle in THIS host's memory — no rank holds the whole
+    /// witness, nobody plans for anybody (`ipcfp_witness_create_shard_pull`).  Cuts the sequential loops of
+    /// src/proofs/verifier.rs:19-28,49-54 and src/proofs/events/verifier.rs:62-71 by receipt index.
+    /// `Ok(None)`: the child header or the receipts root is not in the bundle — there is no range to cut by, verify on
+    /// the whole bundle (`load_witness_store`).
+    pub fn shard_pull<'e>(&'e self, bundle: &PackedBundle, parent_cids: &[Cid], child_cid: &Cid, n_shards: u32, shard: u32)
+                          -> Result<Option<WitnessShard<'e>>> {
+        if !bundle.registered { return Err(anyhow!("shard_pull: the bundle's bytes must be device-readable (PackedBundle::new(blocks, true))")); }
+        let mut pc = Vec::new();
+        for c in parent_cids { pc.extend_from_slice(&cid_slot(c)?); }
+        let child = cid_slot(child_cid)?;
+        let (mut st, mut lo, mut hi, mut n_receipts) = (0u8, 0u64, 0u64, 0u64);
+        let mut stats = ipcfp_shard_pull_stats_t::default();
+        let mut w = std::ptr::null_mut();
+        let rc = unsafe { ipcfp_witness_create_shard_pull(self.ctx, bundle.bytes.as_ptr(), bundle.bytes.len() as u64, bundle.len.as_ptr(),
+                                                          bundle.digests.as_ptr(), bundle.len.len() as u64, PackedBundle::STD.as_ptr(),
+                                                          PackedBundle::STD.len() as u32, bundle.esc_index.as_ptr(), bundle.esc_cids.as_ptr(),
+                                                          bundle.esc_index.len() as u64, pc.as_ptr(), parent_cids.len() as u32, child.as_ptr(),
+                                                          n_shards, shard, &mut st, &mut lo, &mut hi, &mut n_receipts, &mut stats, &mut w) };
+        if rc != 0 { return Err(self.err("ipcfp_witness_create_shard_pull", rc)); }
+        if st != IPCFP_ST_TRUE || w.is_null() { return Ok(None); }
+        Ok(Some(WitnessShard { witness: Witness { eng: self, w: RefCell::new(w) }, receipts: lo..hi, n_receipts, n_shards, shard, stats }))
     }
 
     /// `create_event_filter(event_sig, subnet_id)` (src/proofs/events/verifier.rs:28-39) as the POD the device applies

@@ -633,8 +633,10 @@ int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
  * the claims with exec_index >= receipt_hi are this rank's too (every claim has one owner: ipcfp_route_event_claims).
  *   *first_out, *count_out   the records verified are claims[*first_out .. *first_out + *count_out)
  *   status                   receives *count_out bytes (room for n)
- * IPCFP_E_INVALID when the batch is visibly out of order at the slice's ends; a batch in another order goes through
- * ipcfp_route_event_claims.                                                                                          */
+ * IPCFP_E_INVALID when the batch is not in exec_index order: at the slice's ends (seen on the host), or anywhere INSIDE
+ * the slice — a record below its predecessor or outside the rank's range — which the device checks where the records are
+ * anyway (no verdicts are returned then: the binary searches may have routed claims to the wrong rank).  A batch in another
+ * order goes through ipcfp_route_event_claims.                                                                       */
 int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_tipset_ref_t* tipsets,
                                     uint32_t n_tipsets, const ipcfp_event_claim_t* claims, uint64_t n, const uint8_t* blob,
                                     uint64_t blob_len, uint64_t receipt_lo, uint64_t receipt_hi, int last_shard,

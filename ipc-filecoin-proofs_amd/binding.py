@@ -136,8 +136,7 @@ CLAIM_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), (
                         ("event_index", np.uint64), ("emitter", np.uint64), ("message_cid", np.uint8, (CID_SLOT,)),
                         ("tipset", np.uint32), ("flags", np.uint32), ("n_topics", np.uint32),
                         ("topics_off", np.uint32), ("data_off", np.uint32), ("data_len", np.uint32)])
-# event claims in transport form (include/ipcfp.h ipcfp_event_claim_compact_t / ipcfp_event_claim_group_t)
-ABI_VERSION = 2
+ABI_VERSION = 2  # == IPCFP_ABI_VERSION of include/ipcfp.h (tests/test_abi_symbols.py holds the three together)
 SCAN_PHASE_RECEIPTS, SCAN_PHASE_EVENTS = 1, 2
 
 
@@ -151,7 +150,10 @@ def merge_scan_status(per_shard):
     for st, _ in per_shard:
         if st != 1:
             return st
-    return 1  # == IPCFP_ABI_VERSION of include/ipcfp.h (tests/test_abi_symbols.py holds the three together)
+    return 1
+
+
+# event claims in transport form (include/ipcfp.h ipcfp_event_claim_compact_t / ipcfp_event_claim_group_t)
 COMPACT_DTYPE = np.dtype([("emitter", np.uint64), ("exec_index", np.uint32), ("event_index", np.uint32),
                           ("message_digest", np.uint8, (32,)), ("data_len", np.uint16), ("n_topics", np.uint8),
                           ("topic_flags", np.uint8), ("flags", np.uint8), ("group", np.uint8), ("reserved", np.uint16)])

@@ -121,6 +121,10 @@ struct ipcfp_ctx {
         uint64_t base = 0, blob_len = 0;
         uint64_t full_len = 0;       // the whole batch's blob (what a record may point into at all)
         uint32_t* miss_d = nullptr;  // set to 1 when a record lies inside the batch's blob but outside the uploaded window (nullable)
+        // ipcfp_verify_event_claims_range: the slice was found by binary search in a batch the caller PROMISED to be in
+        // exec_index order; the promise is checked where the records are anyway (nullable: no check)
+        uint32_t* order_d = nullptr;  // set to 1 when a record's exec_index is below its predecessor's or outside [key_lo, key_hi)
+        uint64_t key_lo = 0, key_hi = ~0ull;
     } claims_rebase;
     // --- the mailbox: a page of COHERENT pinned host memory a kernel writes while the stream keeps going (device →
     // host without a synchronisation; kernels/amt_enum.hip k_enum_roots, host/verify_fast.cpp) ---
@@ -312,6 +316,20 @@ struct ProfileScope {
 };
 
 // A device allocation owned by the engine.
+// Error paths that leave a function while ANOTHER stream (or rounds queued ahead of the host) may still touch pooled
+// scratch: the guard drains that stream before the DevBufs declared BEFORE it go back to the pool (declare it after
+// them: destructors run in reverse order).  Disarmed on the ordinary path, where an event wait orders the reuse.
+struct StreamDrainGuard {
+    hipStream_t stream;
+    bool armed = false;
+    explicit StreamDrainGuard(hipStream_t s) : stream(s) {}
+    StreamDrainGuard(const StreamDrainGuard&) = delete;
+    StreamDrainGuard& operator=(const StreamDrainGuard&) = delete;
+    ~StreamDrainGuard() {
+        if (armed) (void)hipStreamSynchronize(stream);
+    }
+};
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;

@@ -26,7 +26,7 @@ int claims_ready(ipcfp_ctx* ctx) {
         ipcfp_ctx::ClaimsRebase& rb = ctx->claims_rebase;
         rb.pending = false;
         if (rc) return rc;
-        rc = launch_rebase_claims(ctx, rb.claims_d, rb.n, rb.base, rb.blob_len, rb.full_len, rb.miss_d);
+        rc = launch_rebase_claims(ctx, rb.claims_d, rb.n, rb.base, rb.blob_len, rb.full_len, rb.miss_d, rb.order_d, rb.key_lo, rb.key_hi);
     }
     ipcfp_ctx::ClaimsExpand& x = ctx->claims_expand;
     if (!x.pending) return rc;

@@ -69,7 +69,7 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     const auto t_start = std::chrono::steady_clock::now();
     const uint32_t N = uint32_t(n);
     // ---- the bundle's tables: lengths, digests → offsets in the host buffer, 40-byte CID slots, the index over them ----
-    DevBuf<uint32_t> glen, esc_i, slots, resident, pulled, copy_len;
+    DevBuf<uint32_t> glen, esc_i, slots, resident, pulled, copy_len, role;
     DevBuf<uint64_t> goff, scan_scratch, stage_off, copy_src, copy_dst;
     DevBuf<uint8_t> dig, esc_c, gcids, stage;
     DevBuf<PullItem> fa, fb;
@@ -115,6 +115,8 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     const uint32_t fcap = N + 1024u;                          // items of one frontier (tree positions of one level)
     const uint64_t stage_cap = nbytes + 128ull * N + 256ull;  // every block of the bundle on lines of its own: the upper bound
     IPCFP_HIP(ctx, resident.alloc(words));
+    IPCFP_HIP(ctx, role.alloc(N));
+    IPCFP_HIP(ctx, hipMemsetAsync(role.p, 0, size_t(N) * 4, ctx->stream));
     IPCFP_HIP(ctx, stage_off.alloc(N));
     IPCFP_HIP(ctx, pulled.alloc(N));
     IPCFP_HIP(ctx, copy_src.alloc(fcap));
@@ -161,7 +163,11 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     seeds.child = key_from_slot(child_cid40);
     seeds.n_parents = n_parents;
     for (uint32_t k = 0; k < n_parents; ++k) seeds.parents[k] = key_from_slot(parent_cids40 + size_t(k) * IPCFP_CID_SLOT);
-    rc = launch_pull_seed(ctx, view, seeds, PullFrontier{fa.p, fcap}, ctl.p);
+    // rounds are queued ahead of the host's reading: whatever way this function is left from here on, the stream is drained
+    // before the buffers above go back to the pool (the ordinary path has synchronised by then and pays nothing)
+    StreamDrainGuard drain(ctx->stream);
+    drain.armed = true;
+    rc = launch_pull_seed(ctx, view, seeds, PullFrontier{fa.p, fcap, role.p}, ctl.p);
     if (rc) return rc;
     // ---- rounds.  Every kernel takes the frontier's true size from the device, so rounds are queued AHEAD of the host's
     // knowledge (two deep): the queue never runs dry between two rounds — a submission to an idle queue is picked up
@@ -173,7 +179,7 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     auto queue_round = [&](uint32_t hint) -> int {
         const unsigned long long seq = ++ctx->mailbox_seq;
         const uint32_t k = queued++;
-        const PullFrontier cur{(k & 1u) ? fa.p : fb.p, fcap}, next{(k & 1u) ? fb.p : fa.p, fcap};
+        const PullFrontier cur{(k & 1u) ? fa.p : fb.p, fcap, role.p}, next{(k & 1u) ? fb.p : fa.p, fcap, role.p};
         return launch_pull_round(ctx, view, bytes_dev, t, cur, k ? hint : 0u, next, ctl.p, n_shards, shard, ctx->mailbox_dev, seq);
     };
     auto wait_round = [&](unsigned long long seq, uint32_t& n_next, uint32_t& overflow) -> int {
@@ -227,6 +233,7 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     PullCtl h{};
     IPCFP_HIP(ctx, d2h_small(ctx, &h, ctl.p, sizeof h, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+    drain.armed = false;  // every queued round has run
     const auto t_pulled = std::chrono::steady_clock::now();
     if (stats) {
         stats->rounds = rounds;

@@ -590,8 +590,10 @@ int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const 
         DevBuf<EventClaimPacked> cd;
         DevBuf<uint8_t> bd, sd;
         DevBuf<unsigned long long> win_d;
-        DevBuf<uint32_t> miss_d;
+        DevBuf<uint32_t> miss_d, order_d;
         IPCFP_HIP(ctx, cd.alloc(m));
+        IPCFP_HIP(ctx, order_d.alloc(1));
+        IPCFP_HIP(ctx, hipMemsetAsync(order_d.p, 0, 4, ctx->stream));
         IPCFP_HIP(ctx, sd.alloc(m));
         uint64_t o0 = ~0ull, o1 = 0;
         int rc = IPCFP_OK;
@@ -643,6 +645,9 @@ int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const 
         ctx->claims_rebase.blob_len = wlen;
         ctx->claims_rebase.full_len = blob_len;
         ctx->claims_rebase.miss_d = guessed ? miss_d.p : nullptr;
+        ctx->claims_rebase.order_d = order_d.p;
+        ctx->claims_rebase.key_lo = receipt_lo;
+        ctx->claims_rebase.key_hi = last_shard ? ~0ull : receipt_hi;
         rc = verify_packed(ctx, w, tcs, cd.p, uint32_t(m), bd.p, wlen, trust, filter, sd.p);
         {
             const int rc_up = upload_task_wait(ctx);
@@ -656,11 +661,14 @@ int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const 
             (void)hipStreamSynchronize(ctx->stream);
             return rc;
         }
-        uint32_t miss = 0;
+        uint32_t miss = 0, disorder = 0;
         if (guessed) IPCFP_HIP(ctx, d2h_small(ctx, &miss, miss_d.p, 4, ctx->stream));
+        IPCFP_HIP(ctx, d2h_small(ctx, &disorder, order_d.p, 4, ctx->stream));
         IPCFP_HIP(ctx, hipMemcpyAsync(status, sd.p, m, hipMemcpyDeviceToHost, ctx->stream));
         IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
         *missed = miss != 0;
+        if (disorder)  // (checked over the whole slice on the device, where the records are: the binary searches above trusted it)
+            return set_error(ctx, IPCFP_E_INVALID, "the claim batch is not in exec_index order (ipcfp_route_event_claims takes any order)");
         return IPCFP_OK;
     };
     static const bool allow_guess = [] {

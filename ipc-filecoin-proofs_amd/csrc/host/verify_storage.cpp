@@ -95,7 +95,11 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     // stream has just been drained, so nothing there is still writing the table, and the runs' typed decodes below — one lane
     // per run, 157 wavefronts — fill the chip no better than the outline's single-wavefront workgroups do: side by side)
     const bool aux = n_long && ctx->stream_aux != ctx->stream && ctx->aux_event;
+    // (declared BEFORE the aux-stream launches and AFTER table / long_list / long_count: an early return below drains the
+    // aux stream before those buffers go back to the pool — ADVICE r5)
+    StreamDrainGuard aux_guard(ctx->stream_aux);
     if (n_long) {
+        aux_guard.armed = aux;
         hipStream_t s = aux ? ctx->stream_aux : ctx->stream;
         rc = launch_hamt_outline_list(ctx, s, w, table.p, long_list.p, long_count.p, n_long);
         if (!rc) rc = launch_hamt_node_table_rest(ctx, s, w, long_list.p, long_count.p, n_long, HK_ACTOR_STATE | HK_VEC_U8, table.p);
@@ -109,6 +113,7 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     rc = launch_storage_run_facts(ctx, w, claims_d, runs.p, uint32_t(n_runs));
     if (rc) return rc;
     if (aux) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));  // the table is whole from here on
+    aux_guard.armed = false;  // the main stream is ordered behind the aux kernels now: pool reuse on it is safe
     rc = launch_storage_run_actors_table(ctx, w, table.p, claims_d, runs.p, uint32_t(n_runs), kUndecided);
     if (rc) return rc;
     rc = launch_storage_run_actors_lane(ctx, w, claims_d, runs.p, uint32_t(n_runs), kUndecided);

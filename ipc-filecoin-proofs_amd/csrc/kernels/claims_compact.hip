@@ -102,11 +102,17 @@ __global__ __launch_bounds__(256) void k_compact_expand(const ClaimCompact* __re
 // or data do not lie inside that window is marked out of range (ERR_BAD_CLAIM, never followed).
 // `miss` (nullable): the window was GUESSED (from the slice's ends, before the records were in HBM) — a record that lies inside
 // the batch's blob [0, full_len) but outside the window sets *miss, and the caller repeats the call with the exact window.
+// `order` (nullable): the slice came out of a binary search over a batch promised to be in exec_index order — a record below
+// its predecessor or outside [key_lo, key_hi) breaks the promise (the search may have routed claims to the wrong shard) and
+// sets *order; the caller returns IPCFP_E_INVALID instead of verdicts.  (exec_index is not rewritten here: the
+// neighbour's read races with nothing.)
 __global__ __launch_bounds__(256) void k_rebase_claims(EventClaimPacked* __restrict__ claims, uint32_t n, uint64_t base, uint64_t blob_len,
-                                                       uint64_t full_len, uint32_t* __restrict__ miss) {
+                                                       uint64_t full_len, uint32_t* __restrict__ miss, uint32_t* __restrict__ order,
+                                                       uint64_t key_lo, uint64_t key_hi) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     EventClaimPacked c = claims[i];
+    if (order && (c.exec_index < key_lo || c.exec_index >= key_hi || (i && claims[i - 1].exec_index > c.exec_index))) *order = 1u;
     const uint64_t t0 = c.topics_off, t1 = t0 + 33ull * c.n_topics, d0 = c.data_off, d1 = d0 + c.data_len;
     const bool t_ok = c.n_topics == 0 || (t0 >= base && t1 <= base + blob_len);
     const bool d_ok = c.data_len == 0 || (d0 >= base && d1 <= base + blob_len);
@@ -156,10 +162,11 @@ int launch_claims_window(ipcfp_ctx* ctx, const void* claims_d, uint32_t n, unsig
     return IPCFP_OK;
 }
 
-int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len, uint64_t full_len, uint32_t* miss_d) {
+int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len, uint64_t full_len, uint32_t* miss_d,
+                         uint32_t* order_d, uint64_t key_lo, uint64_t key_hi) {
     if (n == 0) return IPCFP_OK;
     hipLaunchKernelGGL(k_rebase_claims, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, static_cast<EventClaimPacked*>(claims_d), n, base,
-                       blob_len, full_len, miss_d);
+                       blob_len, full_len, miss_d, order_d, key_lo, key_hi);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -197,7 +197,7 @@ int launch_hamt_node_table_lane(ipcfp_ctx* ctx, const uint8_t* arena, const void
 int launch_hamt_node_table_rest(ipcfp_ctx* ctx, hipStream_t stream, const WitnessView& w, const uint32_t* work_d, const uint32_t* count_d,
                                 uint32_t bound, uint32_t kinds, void* recs_d);
 int launch_rebase_claims(ipcfp_ctx* ctx, void* claims_d, uint32_t n, uint64_t base, uint64_t blob_len, uint64_t full_len,
-                         uint32_t* miss_d);  // claims_compact.hip
+                         uint32_t* miss_d, uint32_t* order_d = nullptr, uint64_t key_lo = 0, uint64_t key_hi = ~0ull);  // claims_compact.hip
 // --- shard_pull.hip (shard_pull.h) --- a rank pulls its shard out of a bundle in host memory, level by level
 struct PullSeeds;
 struct PullFrontier;

@@ -28,6 +28,12 @@ struct PullItem {
 struct PullFrontier {
     PullItem* items;
     uint32_t cap;
+    // N words, zero at the start: the role (PullKind | height << 8 | 1 << 31) a block was first emitted in.  A block of a
+    // tree that is needed WHOLE (headers, TxMeta, message AMTs, events AMTs) links to the same children wherever it is
+    // reached from, so a second emission in the same role adds nothing to the closure and is dropped: identical receipts
+    // share one events root, and the bundle keeps one copy of it — without this the events-root level holds one item per
+    // RECEIPT while the frontier is sized by the bundle's BLOCKS.  Receipts-AMT nodes carry a base and are never dropped.
+    uint32_t* role;
 };
 
 struct PullCtl {

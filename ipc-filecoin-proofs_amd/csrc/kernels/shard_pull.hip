@@ -36,8 +36,12 @@ namespace {
 __device__ __forceinline__ void pull_emit(const PullFrontier& next, PullCtl* ctl, uint32_t id, uint32_t kind, uint32_t height,
                                           uint64_t base) {
     if (id == kNoBlock) return;
+    if (kind != PK_RCPT_NODE && kind != PK_RCPT_ROOT) {
+        const uint32_t sig = kind | (height << 8) | 0x80000000u;
+        if (atomicCAS(&next.role[id], 0u, sig) == sig) return;  // emitted in this role before: same children, nothing new
+    }
     const uint32_t at = atomicAdd(&ctl->n_next, 1u);
-    if (at >= next.cap) {
+    if (at >= next.cap) {  // (n_next runs on past cap; k_pull_round_end never hands such a count to a reader)
         atomicOr(&ctl->overflow, 1u);
         return;
     }
@@ -125,7 +129,8 @@ __global__ void k_pull_seed(WitnessView w, PullSeeds seeds, PullFrontier first, 
 // this round's copy list; the three counters are advanced once per wavefront (every lane of the chip on one address of
 // the L2 was 787 µs in another kernel of this library: profiles/r04_experiments.md).
 __global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, PullTables t, PullCtl* __restrict__ ctl) {
-    const uint32_t n_items = ctl->n_cur;
+    if (ctl->overflow) return;  // a buffer was outgrown: the rounds queued ahead do nothing, the host reports it
+    const uint32_t n_items = min(ctl->n_cur, cur.cap);
     const uint32_t lane = threadIdx.x & 63u;
     // (whole wavefronts stride through the frontier: the shuffles below need all 64 lanes in every pass)
     for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; i0 < n_items; i0 += gridDim.x * blockDim.x) {
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(256) void k_pull_claim(PullFrontier cur, PullTables
 __global__ __launch_bounds__(256) void k_pull_copy(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
                                                    const uint32_t* __restrict__ len, const uint64_t* __restrict__ dst_off,
                                                    const PullCtl* __restrict__ ctl, uint8_t* __restrict__ dst) {
+    if (ctl->overflow) return;
     const uint32_t n = ctl->n_copy;
     const uint32_t sub = threadIdx.x & 31;
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -309,15 +315,19 @@ __device__ __forceinline__ void pull_expand_item(const WitnessView& w, const Pul
 
 __global__ __launch_bounds__(256) void k_pull_expand(WitnessView w, PullFrontier cur, PullFrontier next, PullCtl* __restrict__ ctl,
                                                      uint32_t n_shards, uint32_t shard) {
-    const uint32_t n_items = ctl->n_cur;
+    if (ctl->overflow) return;
+    const uint32_t n_items = min(ctl->n_cur, cur.cap);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x)
         pull_expand_item(w, cur.items[i], next, ctl, n_shards, shard);
 }
 
 // between two rounds: the next frontier's size goes to the host (mailbox), the round counters start again
-__global__ void k_pull_round_end(PullCtl* __restrict__ ctl, unsigned long long* __restrict__ mailbox, unsigned long long seq) {
+__global__ void k_pull_round_end(PullCtl* __restrict__ ctl, uint32_t cap, unsigned long long* __restrict__ mailbox,
+                                 unsigned long long seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t n_next = ctl->n_next;
+    // an outgrown frontier ends the walk HERE: no later round reads past `cap` items (pull_emit counts on beyond it), and
+    // the host, which has rounds queued ahead of what it has read, is told through the mailbox's overflow word
+    const uint32_t n_next = ctl->overflow ? 0u : min(ctl->n_next, cap);
     ctl->n_cur = n_next;
     ctl->n_next = 0;
     ctl->n_copy = 0;
@@ -348,7 +358,7 @@ int launch_pull_round(ipcfp_ctx* ctx, const WitnessView& w, const uint8_t* host_
                            t.copy_dst, ctl_d, t.stage);
         hipLaunchKernelGGL(k_pull_expand, dim3(wgs), dim3(256), 0, ctx->stream, w, cur, next, ctl_d, n_shards, shard);
     }
-    hipLaunchKernelGGL(k_pull_round_end, dim3(1), dim3(64), 0, ctx->stream, ctl_d, mailbox_dev, seq);
+    hipLaunchKernelGGL(k_pull_round_end, dim3(1), dim3(64), 0, ctx->stream, ctl_d, next.cap, mailbox_dev, seq);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

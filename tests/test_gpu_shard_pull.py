@@ -200,3 +200,131 @@ def test_pull_refuses_a_buffer_the_device_cannot_read(engine, tip):
             engine.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, 2, 0)
     finally:
         ipcfp.host_unregister(pk.data)
+
+
+# ---- the frontier's capacity is the documented defence against hostile DAGs, and the frontier counts tree
+# POSITIONS while its capacity is sized by the bundle's BLOCKS ----
+def _receipt_event_links(data: np.ndarray):
+    """offsets of the 38 CID bytes of every `Receipt [0, h'', gas, link]` in the witness bytes (the synthetic writer's form)"""
+    import re
+
+    pat = re.compile(rb"\x84\x00\x40(?:\x1a.{4}|\x19.{2}|\x18.|[\x00-\x17])\xd8\x2a\x58\x27\x00", re.S)
+    return [m.end() for m in pat.finditer(data.tobytes())]
+
+
+def test_receipts_that_share_one_events_root(engine, oracle):
+    """Identical events ⇒ identical events root; a bundle keeps ONE copy of it.  The events-root level of the walk then has
+    one position per receipt (20 000) in a bundle of far fewer blocks: emitted once, expanded once, and the shard is what
+    the planner over the whole witness makes — not `E_UNSUPPORTED: not a tree of this bundle`."""
+    t = Tipset(n_receipts=20_000, n_parents=2, n_planted=10, max_events=3, no_events_permille=0, variety=0, seed=91)
+    data = t.data.copy()
+    at = _receipt_event_links(data)
+    assert len(at) == 20_000
+    shared = data[at[0]: at[0] + 38].copy()
+    for a in at:
+        data[a: a + 38] = shared
+    with engine.witness(data, t.off, t.lens, t.cids) as full:
+        st, lo, hi, nr, ids = full.shard_plan_tipset(t.parent_cids, t.child_cid, 1, 0)
+        assert st == 1 and nr == 20_000
+    sub = ipcfp.witness_cut_host(data, t.off, t.lens, t.cids, ids)
+    assert len(sub[2]) + 1024 < 20_000          # fewer blocks (+ the frontier's slack) than receipts
+    pk = ipcfp.PackedWitnessTables(*sub)
+    ipcfp.host_register(pk.data)
+    try:
+        with engine.witness(*sub) as full:
+            want_scan = full.scan_events(t.receipts_root, t.topic0, t.topic1, actor=t.filter_actor, want_touched=False)
+            has_all = np.zeros(20_000, dtype=np.uint8)
+            for G in (1, 2, 5):
+                for r in range(G):
+                    st, lo, hi, nr, ids = full.shard_plan_tipset(t.parent_cids, t.child_cid, G, r)
+                    pst, w, plo, phi, pn, stats = engine.witness_shard_pull(pk, t.parent_cids, t.child_cid, G, r)
+                    assert pst == st == 1 and (plo, phi, pn) == (lo, hi, nr) and w.block_count == len(ids)
+                    has, _ = w.has([bytes(sub[3][i]) for i in ids[:: max(1, len(ids) // 2000)]])
+                    assert has.all()
+                    sst, shas, sm, _ = w.scan_events(t.receipts_root, t.topic0, t.topic1, actor=t.filter_actor, want_touched=False)
+                    assert sst == 1
+                    if G == 5:
+                        has_all[lo:hi] = shas
+                    w.close()
+            assert want_scan[0] == 1 and np.array_equal(has_all, want_scan[1])
+        ost = oracle.store(*sub)
+        os_, ohas, _, _ = ost.scan_events(t.receipts_root, t.topic0, t.topic1, actor=t.filter_actor)
+        ost.close()
+        assert os_ == 1 and np.array_equal(ohas, has_all)
+    finally:
+        ipcfp.host_unregister(pk.data)
+
+
+def test_a_dag_that_outgrows_the_frontier_is_refused_not_followed(engine, tip):
+    """Three receipts-AMT nodes whose eight links all name the next one (A → B → C → A: nothing re-hashes a witness block, so
+    a bundle may say so) under a root of height 7: 8^k tree positions at level k from a handful of blocks.  The walk must stop
+    at the frontier's capacity — `IPCFP_E_UNSUPPORTED`, no read or write past the buffers, rounds queued ahead of the host
+    included — and the engine must be whole afterwards."""
+    from pyamt import array, bstr, link, uint
+
+    small = Tipset(n_receipts=300, n_parents=2, n_planted=3, max_events=2, variety=0, seed=92)
+    at = _receipt_event_links(small.data)
+    victims = [small.find_block(small.data[a: a + 38].tobytes()) for a in (at[0], at[100], at[200])]
+    assert len(set(victims)) == 3 and min(victims) >= 0
+    cid = [small.cids[v, :38].tobytes() for v in victims]
+
+    def node(child):
+        return array([bstr(b"\xff"), array([link(child)] * 8), array([])])
+
+    new = {victims[0]: node(cid[1]), victims[1]: node(cid[2]), victims[2]: node(cid[0]),
+           small.find_block(small.receipts_root): array([uint(7), uint(8 ** 8), node(cid[0])])}
+    chunks, off, lens = [small.data], small.off.copy(), small.lens.copy()
+    end = int(small.data.size)
+    for i, b in new.items():
+        chunks.append(np.frombuffer(b, dtype=np.uint8))
+        off[i], lens[i] = end, len(b)
+        end += len(b)
+    data = np.concatenate(chunks)
+    # (transport form wants the blocks back to back: cut "all of them" in table order)
+    sub = ipcfp.witness_cut_host(data, off, lens, small.cids, np.arange(small.n_blocks, dtype=np.uint32))
+    pk = ipcfp.PackedWitnessTables(*sub)
+    ipcfp.host_register(pk.data)
+    try:
+        for G, r in ((1, 0), (2, 1)):
+            with pytest.raises(ipcfp.EngineError, match="outgrew"):
+                engine.witness_shard_pull(pk, small.parent_cids, small.child_cid, G, r)
+    finally:
+        ipcfp.host_unregister(pk.data)
+    # the context is unharmed: an honest pull right after
+    pk2 = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
+    ipcfp.host_register(pk2.data)
+    try:
+        pst, w, lo, hi, nr, stats = engine.witness_shard_pull(pk2, tip.parent_cids, tip.child_cid, 2, 1)
+        assert pst == 1 and nr == 40_000 and (lo, hi) == (20_000, 40_000)
+        _, n_bad = w.verify_cids()
+        assert n_bad == 0
+        w.close()
+    finally:
+        ipcfp.host_unregister(pk2.data)
+
+
+def test_claim_range_refuses_a_batch_that_is_out_of_order_in_the_middle(engine, tip, bundle, claims_packed):
+    """ipcfp_verify_event_claims_range finds its slice by binary search; a batch whose order breaks INSIDE the slice (the
+    ends still look sorted) would route claims to the wrong shard silently.  The order is checked on the device, over the
+    whole slice, where the records are anyway: IPCFP_E_INVALID."""
+    ts, cl, blob, blob_len = claims_packed
+    order = np.argsort(cl["exec_index"], kind="stable")
+    cs = cl[order].copy()
+    pst, w, lo, hi, nr, stats = engine.witness_shard_pull(bundle, tip.parent_cids, tip.child_cid, 2, 0)
+    assert pst == 1
+    try:
+        a, st = w.verify_event_claims_range(ts, cs, blob, blob_len, lo, hi, False)
+        assert len(st) > 1000
+        bad = cs.copy()
+        mid = a + len(st) // 2
+        bad["exec_index"][mid] = bad["exec_index"][mid + 40]      # one record ahead of its place: ends untouched
+        with pytest.raises(ipcfp.EngineError, match="exec_index order"):
+            w.verify_event_claims_range(ts, bad, blob, blob_len, lo, hi, False)
+        bad = cs.copy()
+        bad["exec_index"][mid] = hi + 5                            # a record of the OTHER shard inside this slice
+        with pytest.raises(ipcfp.EngineError, match="exec_index order"):
+            w.verify_event_claims_range(ts, bad, blob, blob_len, lo, hi, False)
+        a2, st2 = w.verify_event_claims_range(ts, cs, blob, blob_len, lo, hi, False)   # and the honest batch again
+        assert a2 == a and np.array_equal(st, st2)
+    finally:
+        w.close()
