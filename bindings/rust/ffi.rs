@@ -44,8 +44,9 @@ use crate::proofs::trust::TrustPolicy;
 // ---- PODs of include/ipcfp.h --------------------------------------------------------------------------------------
 pub const IPCFP_CID_SLOT: usize = 40;
 pub const IPCFP_MAX_PARENTS: usize = 32;
-/// == `IPCFP_ABI_VERSION` of include/ipcfp.h: the struct layouts below are this version's (2: IPCFP_MAX_PARENTS 16 -> 32)
-pub const IPCFP_ABI_VERSION: c_int = 2;
+/// == `IPCFP_ABI_VERSION` of include/ipcfp.h: the struct layouts below are this version's (2: IPCFP_MAX_PARENTS 16 -> 32;
+/// 3: `ipcfp_tipset_ref_t.more_parents`, long CIDs cross folded)
+pub const IPCFP_ABI_VERSION: c_int = 3;
 pub const IPCFP_SCAN_PHASE_RECEIPTS: u32 = 1;
 pub const IPCFP_SCAN_PHASE_EVENTS: u32 = 2;
 pub const IPCFP_ST_TRUE: u8 = 1;
@@ -89,7 +90,9 @@ pub struct ipcfp_storage_proof_t {
                                                                          pub storage_root: [u8; 40], pub value: [u8; 32],
                                                                          pub status: u32, pub reserved: u32 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct ipcfp_trust_policy_t { pub kind: c_int, pub ec_chain_empty: c_int, pub min_epoch: i64, pub max_epoch: i64 }
-#[repr(C)] pub struct ipcfp_tipset_ref_t { pub flags: u32, pub n_parents: u32, pub child: [u8; 40], pub parents: [[u8; 40]; IPCFP_MAX_PARENTS] }
+/// `more_parents`: the slots of parents[IPCFP_MAX_PARENTS ..] of a tipset key wider than the inline form (host memory, valid for the call)
+#[repr(C)] pub struct ipcfp_tipset_ref_t { pub flags: u32, pub n_parents: u32, pub child: [u8; 40], pub parents: [[u8; 40]; IPCFP_MAX_PARENTS],
+                                           pub more_parents: *const u8 }
 #[repr(C)] pub struct ipcfp_event_claim_t { pub parent_epoch: i64, pub child_epoch: i64, pub exec_index: u64, pub event_index: u64,
                                             pub emitter: u64, pub message_cid: [u8; 40], pub tipset: u32, pub flags: u32,
                                             pub n_topics: u32, pub topics_off: u32, pub data_off: u32, pub data_len: u32 }
@@ -115,15 +118,21 @@ fn c_string(s: &str) -> CString {
     CString::new(bytes).expect("no interior NUL left")
 }
 
+/// A `Cid` as its 40-byte ABI slot: zero padded, or — longer than the slot (a 64-byte digest) — FOLDED to
+/// `ff | len | blake2b-256(bytes)` by `ipcfp_cid_to_slot` (include/ipcfp.h "CIDs"); the device folds the long links it
+/// reads out of blocks the same way, so such a CID is found and compared like any other.
 fn cid_slot(c: &Cid) -> Result<[u8; 40]> {
     let b = c.to_bytes();
-    if b.len() > IPCFP_CID_SLOT { return Err(anyhow!("CID longer than {IPCFP_CID_SLOT} bytes: {c}")); }
     let mut slot = [0u8; 40];
-    slot[..b.len()].copy_from_slice(&b);
-    Ok(slot)
+    match unsafe { ipcfp_cid_to_slot(b.as_ptr(), b.len() as u32, slot.as_mut_ptr()) } {
+        n if n > 0 => Ok(slot),
+        rc => Err(anyhow!("ipcfp_cid_to_slot({c}): {rc}")),
+    }
 }
 
 fn cid_from_slot(slot: &[u8; 40]) -> Result<Cid> {
+    // (a CID longer than the slot comes back as its fold: its bytes stand in the block that holds it — include/ipcfp.h "CIDs")
+    if slot[0] == 0xff { return Err(anyhow!("a CID of {} bytes came back folded; read it from its block", slot[1])); }
     // a binary CID is self-delimiting: Cid::read_bytes stops after the multihash
     Ok(Cid::read_bytes(&slot[..])?)
 }

@@ -34,8 +34,10 @@ extern "C" {
 #endif
 
 /* Bumped whenever the layout of a public struct or the meaning of an argument changes; a binding compares it with
- * ipcfp_abi_version() before its first call.  2: IPCFP_MAX_PARENTS 16 -> 32 (sizeof(ipcfp_tipset_ref_t) 648 -> 1288). */
-#define IPCFP_ABI_VERSION 2
+ * ipcfp_abi_version() before its first call.  2: IPCFP_MAX_PARENTS 16 -> 32 (sizeof(ipcfp_tipset_ref_t) 648 -> 1328).
+ * 3: ipcfp_tipset_ref_t.more_parents (tipset keys of ANY length: 1328 -> 1336); a CID longer than the slot crosses the ABI
+ * FOLDED (ipcfp_cid_to_slot) instead of being refused.                                                                */
+#define IPCFP_ABI_VERSION 3
 
 /* ---- return codes ------------------------------------------------------- */
 #define IPCFP_OK 0
@@ -43,7 +45,7 @@ extern "C" {
 #define IPCFP_E_NO_DEVICE (-2)   /* no gfx950 device / HIP runtime unusable           */
 #define IPCFP_E_HIP (-3)         /* a HIP call failed; see ipcfp_last_error()         */
 #define IPCFP_E_NOMEM (-4)       /* host or device allocation failed                  */
-#define IPCFP_E_UNSUPPORTED (-5) /* e.g. a witness CID longer than IPCFP_CID_SLOT     */
+#define IPCFP_E_UNSUPPORTED (-5) /* e.g. more than 2^32-2 blocks, a claim blob over 3.75 GB */
 #define IPCFP_E_PARSE (-6)       /* a CID / hex string could not be parsed (host side)*/
 
 /* ---- CIDs --------------------------------------------------------------- */
@@ -51,9 +53,18 @@ extern "C" {
  * The Filecoin chain CID (CIDv1, dag-cbor 0x71, blake2b-256 0xb220, 32-byte
  * digest) is 38 bytes: 01 71 a0 e4 02 20 ‖ digest.  A binary CID is
  * self-delimiting, so zero padding is unambiguous.  Replaces `cid::Cid` values
- * (src/proofs/common/bundle.rs:12, src/proofs/common/witness.rs:60-72). */
+ * (src/proofs/common/bundle.rs:12, src/proofs/common/witness.rs:60-72).
+ * A CID of MORE than 40 bytes (a 64-byte digest: `cid` 0.11 takes multihashes of up to 64 bytes, so
+ * `Cid::try_from` / serde accept it and src/proofs/common/witness.rs:60-72 stores a block under it) crosses FOLDED:
+ *     ff | len | blake2b-256(the CID's bytes) | 00 …            (34 bytes; ipcfp_cid_to_slot)
+ * 0xff starts no CID (a CIDv1 starts 01, a CIDv0 12 20), so a fold equals no short CID; two folds are equal iff the
+ * CIDs are, short of a blake2b-256 collision — the assumption every chain CID rests on already.  The device folds a
+ * long link it reads out of a block the same way, so long CIDs are found, compared and deduplicated like any other.
+ * Where a CID comes BACK across the ABI in a slot (ipcfp_exec_order, the generator's message CIDs, touched sets) a long
+ * one comes back as its fold: the caller that needs its bytes reads them from the block they stand in.           */
 #define IPCFP_CID_SLOT 40
 #define IPCFP_CID_BLAKE2B_LEN 38
+#define IPCFP_CID_MAX_LEN 104 /* 1 + 9 + 9 + 1 + 64 rounded up: the longest binary CID `cid` 0.11 parses */
 
 /* ---- per-item status bytes ---------------------------------------------- */
 typedef uint8_t ipcfp_status_t;
@@ -106,11 +117,14 @@ enum {
  *   up to and including the first "/ipfs/" is dropped; a 46-character "Qm…" is a CIDv0 (base58btc); else multibase,
  *   case-strict — b (base32 lower), B (base32 upper), f / F (base16 lower / upper), z (base58btc).  The other
  *   multibase alphabets (k, m, u, …) are an ENGINE LIMIT: such a string is reported like an unparsable one.  Returns
- *   the CID's byte length (written zero-padded into the 40-byte slot), IPCFP_E_PARSE if the parse is Err, or
- *   IPCFP_E_UNSUPPORTED for a valid CID longer than the slot.
+ *   the CID's byte length — the CID written zero-padded into the 40-byte slot, or FOLDED when it is longer than the slot
+ *   (see "CIDs" above) — or IPCFP_E_PARSE if the parse is Err.
+ * ipcfp_cid_to_slot: a binary CID of any length → its slot (zero padded, or folded); returns the CID's length,
+ *   IPCFP_E_PARSE when the bytes are not exactly one well-formed CID.
  * ipcfp_cid_to_string: `Cid::to_string()` — "b" + base32-lower for CIDv1, base58btc for CIDv0; returns
  *   the string length (excluding NUL) or IPCFP_E_INVALID if cap is too small / the bytes are not a CID. */
 int ipcfp_cid_from_string(const char* s, uint8_t out40[IPCFP_CID_SLOT]);
+int ipcfp_cid_to_slot(const uint8_t* cid, uint32_t len, uint8_t out40[IPCFP_CID_SLOT]);
 int ipcfp_cid_to_string(const uint8_t* cid, uint32_t len, char* out, uint32_t cap);
 
 /* ---- context ------------------------------------------------------------ */
@@ -518,7 +532,13 @@ int ipcfp_verify_storage_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcf
  * already holds binary CIDs (or verifies the same bundle repeatedly) can build them itself and keep
  * them in HBM.  Semantics are identical: the flags record what `Cid::try_from(str)?` and the
  * hex compares of the reference would have observed for the original strings.               */
-#define IPCFP_MAX_PARENTS 32 /* parent blocks per tipset key (engine limit; expected 5 per epoch, P(> 32) < 1e-15) */
+/* Parent blocks a tipset key holds INLINE (expected 5 per epoch; 17 happens every few weeks).  A longer key — the
+ * reference takes any (src/proofs/events/verifier.rs:147-181, src/proofs/events/utils.rs:16-30) — carries the rest behind
+ * `more_parents`; such a tipset is verified by the general route (one workgroup per parent block, the level-by-level
+ * enumerator) instead of the single-launch prologue and the dense walk, with the same verdicts.  Up to
+ * IPCFP_MAX_PARENTS_WIDE parents (the enumeration's error word orders 2^16 sequence numbers). */
+#define IPCFP_MAX_PARENTS 32
+#define IPCFP_MAX_PARENTS_WIDE 16000
 
 #define IPCFP_TIPSET_PARENTS_PARSED 1u /* every parent_tipset_cids[i] parses (events/verifier.rs:130) */
 #define IPCFP_TIPSET_CHILD_PARSED 2u   /* child_block_cid parses (:131)                               */
@@ -526,7 +546,9 @@ typedef struct ipcfp_tipset_ref {
     uint32_t flags;
     uint32_t n_parents;
     uint8_t child[IPCFP_CID_SLOT];
-    uint8_t parents[IPCFP_MAX_PARENTS][IPCFP_CID_SLOT];
+    uint8_t parents[IPCFP_MAX_PARENTS][IPCFP_CID_SLOT]; /* the first min(n_parents, IPCFP_MAX_PARENTS) */
+    const uint8_t* more_parents; /* n_parents > IPCFP_MAX_PARENTS: parents[IPCFP_MAX_PARENTS ..] as 40-byte slots in HOST
+                                    memory, valid for the call; ignored (may be NULL) otherwise */
 } ipcfp_tipset_ref_t;
 
 #define IPCFP_CLAIM_MSG_PARSED 1u     /* message_cid parses (events/verifier.rs:193)                   */

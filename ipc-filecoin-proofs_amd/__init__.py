@@ -33,6 +33,9 @@ from .binding import (  # noqa: F401
     pack_cids,
     CLAIM_DTYPE,
     TIPSET_DTYPE,
+    TipsetRefs,
+    cid_slot,
+    cid_slots,
     LOC_DTYPE,
     MATCH_DTYPE,
     witness_cut_host,

@@ -54,6 +54,9 @@ __all__ = [
     "pack_cids",
     "CLAIM_DTYPE",
     "TIPSET_DTYPE",
+    "TipsetRefs",
+    "cid_slot",
+    "cid_slots",
     "LOC_DTYPE",
     "MATCH_DTYPE",
 ]
@@ -130,13 +133,41 @@ class ST:
 VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "vec_u8": 4, "any": 5}
 LOC_DTYPE = np.dtype([("block", np.uint32), ("off", np.uint32), ("len", np.uint32)])
 MAX_PARENTS = 32
+# (`more_parents`: host address of the slots of parents[MAX_PARENTS ..] when n_parents > MAX_PARENTS — TipsetRefs keeps them alive)
 TIPSET_DTYPE = np.dtype([("flags", np.uint32), ("n_parents", np.uint32), ("child", np.uint8, (CID_SLOT,)),
-                         ("parents", np.uint8, (MAX_PARENTS, CID_SLOT))])
+                         ("parents", np.uint8, (MAX_PARENTS, CID_SLOT)), ("more_parents", np.uint64)])
+
+
+class TipsetRefs(np.ndarray):
+    """ipcfp_tipset_ref_t[] that owns the arrays its `more_parents` pointers name (tipset keys of more than MAX_PARENTS blocks)."""
+
+    def __array_finalize__(self, obj):
+        self._keep = getattr(obj, "_keep", [])
+
+
+def cid_slot(cid: bytes) -> np.ndarray:
+    """A binary CID of any length as its 40-byte slot: zero padded, or — longer than the slot — FOLDED
+    (ff | len | blake2b-256(cid); include/ipcfp.h "CIDs", ipcfp_cid_to_slot)."""
+    out = np.zeros(CID_SLOT, dtype=np.uint8)
+    raw = np.frombuffer(bytes(cid), dtype=np.uint8)
+    rc = load_library().ipcfp_cid_to_slot(_p(raw), len(raw), _p(out))
+    if rc < 0:
+        raise EngineError(f"cid_slot: not a CID ({rc})")
+    return out
+
+
+def cid_slots(cids) -> np.ndarray:
+    """[binary CID, …] → u8[n, 40] (each through cid_slot)."""
+    out = np.zeros((len(cids), CID_SLOT), dtype=np.uint8)
+    for i, c in enumerate(cids):
+        c = bytes(c)
+        out[i] = cid_slot(c) if len(c) > CID_SLOT else np.frombuffer(c.ljust(CID_SLOT, b"\0"), dtype=np.uint8)
+    return out
 CLAIM_DTYPE = np.dtype([("parent_epoch", np.int64), ("child_epoch", np.int64), ("exec_index", np.uint64),
                         ("event_index", np.uint64), ("emitter", np.uint64), ("message_cid", np.uint8, (CID_SLOT,)),
                         ("tipset", np.uint32), ("flags", np.uint32), ("n_topics", np.uint32),
                         ("topics_off", np.uint32), ("data_off", np.uint32), ("data_len", np.uint32)])
-ABI_VERSION = 2  # == IPCFP_ABI_VERSION of include/ipcfp.h (tests/test_abi_symbols.py holds the three together)
+ABI_VERSION = 3  # == IPCFP_ABI_VERSION of include/ipcfp.h (tests/test_abi_symbols.py holds the three together)
 SCAN_PHASE_RECEIPTS, SCAN_PHASE_EVENTS = 1, 2
 
 
@@ -292,6 +323,7 @@ def load_library() -> C.CDLL:
         "ipcfp_witness_last_scan_phase": (i32, [vp]),
         "ipcfp_verify_storage_claims_device": (i32, [vp, vp, vp, u64, vp, vp]),
         "ipcfp_cid_from_string": (i32, [C.c_char_p, vp]),
+        "ipcfp_cid_to_slot": (i32, [vp, C.c_uint32, vp]),
         "ipcfp_cid_to_string": (i32, [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]),
         "ipcfp_create_event_filter": (i32, [vp, C.c_char_p, C.c_char_p, vp]),
         "ipcfp_verify_storage_proofs": (i32, [vp, vp, vp, u64, vp, vp]),
@@ -469,7 +501,7 @@ class Engine:
         Returns (status, Witness | None, receipt_lo, receipt_hi, n_receipts, stats dict)."""
         pk = packed
         pc = pack_cids(parent_cids)
-        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        child = cid_slots([child_cid])[0].copy()
         st = np.zeros(1, dtype=np.uint8)
         lo, hi, nr = C.c_uint64(), C.c_uint64(), C.c_uint64()
         stats = ShardPullStats()
@@ -656,12 +688,16 @@ def pack_event_claims(parent_cids, child_cid, parent_epoch, child_epoch, exec_in
     ipcfp_event_claim_t[n], blob).  topics: u8[n, 4, 32]; data: u8[n, dmax].  All flags are set: binary
     inputs correspond to strings that parsed."""
     n = len(exec_index)
-    ts = np.zeros(1, dtype=TIPSET_DTYPE)
+    ts = np.zeros(1, dtype=TIPSET_DTYPE).view(TipsetRefs)
     ts["flags"] = 3
     ts["n_parents"] = len(parent_cids)
-    ts["child"][0, : len(child_cid)] = np.frombuffer(bytes(child_cid), dtype=np.uint8)
-    for k, c in enumerate(parent_cids):
-        ts["parents"][0, k, : len(c)] = np.frombuffer(bytes(c), dtype=np.uint8)
+    ts["child"][0] = cid_slots([child_cid])[0]
+    slots = cid_slots(parent_cids)
+    ts["parents"][0, : min(len(slots), MAX_PARENTS)] = slots[:MAX_PARENTS]
+    if len(slots) > MAX_PARENTS:  # a tipset key wider than the inline form: the rest behind `more_parents`
+        more = np.ascontiguousarray(slots[MAX_PARENTS:])
+        ts._keep = [more]
+        ts["more_parents"] = more.ctypes.data
     cl = np.zeros(n, dtype=CLAIM_DTYPE)
     cl["parent_epoch"] = parent_epoch
     cl["child_epoch"] = child_epoch
@@ -723,8 +759,8 @@ def pack_storage_claims(child_cid, state_root, child_epoch, actor_id, actor_stat
     cl = np.zeros(n, dtype=SCLAIM_DTYPE)
     cl["child_epoch"] = child_epoch
     cl["actor_id"] = actor_id
-    cl["child"][:, : len(child_cid)] = np.frombuffer(bytes(child_cid), dtype=np.uint8)
-    cl["state_root"][:, : len(state_root)] = np.frombuffer(bytes(state_root), dtype=np.uint8)
+    cl["child"][:] = cid_slots([child_cid])[0]
+    cl["state_root"][:] = cid_slots([state_root])[0]
     cl["actor_state"] = actor_state40
     cl["storage_root"] = storage_root40
     cl["slot"] = slot32
@@ -747,12 +783,8 @@ def cid_to_string(cid: bytes):
 
 
 def pack_cids(cids) -> np.ndarray:
-    out = np.zeros((len(cids), CID_SLOT), dtype=np.uint8)
-    for i, c in enumerate(cids):
-        if len(c) > CID_SLOT:
-            raise EngineError(f"CID {i} is {len(c)} bytes; the ABI slot is {CID_SLOT}")
-        out[i, : len(c)] = np.frombuffer(c, dtype=np.uint8)
-    return out
+    """[binary CID, …] → u8[n, 40]: zero padded; a CID longer than the slot folded (cid_slot)."""
+    return cid_slots(cids)
 
 
 def pack_event_proofs(claims_arr, n: int):
@@ -775,7 +807,15 @@ def pack_event_proofs(claims_arr, n: int):
             buf = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr)
             return np.frombuffer(buf, dtype=dtype).copy()
 
-        return view(pt, nt.value, TIPSET_DTYPE), view(pc, nc.value, CLAIM_DTYPE), view(pb, nb.value, np.uint8)
+        ts = view(pt, nt.value, TIPSET_DTYPE).view(TipsetRefs)
+        ts._keep = []
+        for k in range(len(ts)):  # a key wider than the inline form: its tail is the handle's — copied before the handle goes
+            extra = int(ts["n_parents"][k]) - MAX_PARENTS
+            if extra > 0:
+                more = view(int(ts["more_parents"][k]), extra * CID_SLOT, np.uint8)
+                ts._keep.append(more)
+                ts["more_parents"][k] = more.ctypes.data
+        return ts, view(pc, nc.value, CLAIM_DTYPE), view(pb, nb.value, np.uint8)
     finally:
         lib.ipcfp_packed_events_destroy(h)
 
@@ -917,7 +957,7 @@ class Witness:
         n = len(idx)
         st = np.zeros(n, dtype=np.uint8)
         loc = np.zeros(n, dtype=LOC_DTYPE)
-        root = np.frombuffer(bytes(root_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        root = cid_slots([root_cid])[0].copy()
         self.eng._check(self.lib.ipcfp_amt_get(self.eng.h, self.h, _p(root), version, VALUE_KINDS[kind], _p(idx), n,
                                                _p(st), _p(loc)), "amt_get")
         return st, loc
@@ -932,7 +972,7 @@ class Witness:
         kb = np.frombuffer(b"".join(keys), dtype=np.uint8).copy() if n and kl.sum() else np.zeros(1, np.uint8)
         st = np.zeros(n, dtype=np.uint8)
         loc = np.zeros(n, dtype=LOC_DTYPE)
-        root = np.frombuffer(bytes(root_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        root = cid_slots([root_cid])[0].copy()
         self.eng._check(self.lib.ipcfp_hamt_get(self.eng.h, self.h, _p(root), bit_width, VALUE_KINDS[kind], _p(kb),
                                                 _p(ko), _p(kl), n, _p(st), _p(loc)), "hamt_get")
         return st, loc
@@ -940,7 +980,7 @@ class Witness:
     def hamt_get_device(self, root_cid: bytes, bit_width: int, kind: str, keys_ptr: int, key_off_ptr: int, key_len_ptr: int,
                         n: int, status_ptr: int, loc_ptr: int = 0):
         """K7 with every buffer resident in HBM; asynchronous (eng.sync() completes it)."""
-        root = np.frombuffer(bytes(root_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        root = cid_slots([root_cid])[0].copy()
         self.eng._check(self.lib.ipcfp_hamt_get_device(self.eng.h, self.h, _p(root), bit_width, VALUE_KINDS[kind], keys_ptr,
                                                        key_off_ptr, key_len_ptr, int(n), status_ptr, loc_ptr or None),
                         "hamt_get_device")
@@ -948,8 +988,7 @@ class Witness:
     def exec_order(self, parent_cids, cap=None):
         """reconstruct_execution_order → (status, cids u8[count, 40])."""
         pc = np.zeros((max(len(parent_cids), 1), CID_SLOT), dtype=np.uint8)
-        for i, c in enumerate(parent_cids):
-            pc[i, : len(c)] = np.frombuffer(bytes(c), dtype=np.uint8)
+        pc[: len(parent_cids)] = cid_slots(parent_cids)
         st = np.zeros(1, dtype=np.uint8)
         cnt = C.c_uint64()
         # first call: count only
@@ -1016,7 +1055,7 @@ class Witness:
     def scan_events_device(self, receipts_root: bytes, topic0: bytes, topic1: bytes, actor, has_ptr: int, cap_receipts: int,
                            matches_ptr: int = 0, cap_matches: int = 0, summary_ptr: int = 0):
         """K6 with device outputs (has-match map / match records stay in HBM).  → (status, n_receipts, n_matches)"""
-        root = np.frombuffer(bytes(receipts_root).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        root = cid_slots([receipts_root])[0].copy()
         filt = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
         st = np.zeros(1, dtype=np.uint8)
         nr, nm = C.c_uint64(), C.c_uint64()
@@ -1032,7 +1071,7 @@ class Witness:
         """generate_event_proof over this witness as the blockstore.  Returns
         (status, matches structured[n], message_cids u8[n,40], witness block ids u32[m] in `Cid: Ord` order)."""
         pc = pack_cids(parent_cids)
-        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        child = cid_slots([child_cid])[0].copy()
         filt = np.frombuffer(bytes(topic0) + bytes(topic1), dtype=np.uint8).copy()
         st = np.zeros(1, dtype=np.uint8)
         npf, nb = C.c_uint64(), C.c_uint64()
@@ -1051,7 +1090,7 @@ class Witness:
     def generate_storage_proofs(self, child_cid: bytes, actor_ids, slots32):
         """generate_storage_proof for n (actor_id, slot) specs.  Returns (records GEN_STORAGE_DTYPE[n],
         witness block ids of the union in `Cid: Ord` order)."""
-        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        child = cid_slots([child_cid])[0].copy()
         ids_in = np.ascontiguousarray(actor_ids, dtype=np.uint64)
         slots = np.ascontiguousarray(slots32, dtype=np.uint8).reshape(-1, 32)
         n = len(ids_in)
@@ -1084,7 +1123,7 @@ class Witness:
         """Blocks of this (whole-tipset) witness that `shard` of `n_shards` needs.  Returns
         (status, receipt_lo, receipt_hi, n_receipts, block ids u32[] ascending)."""
         pc = pack_cids(parent_cids)
-        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        child = cid_slots([child_cid])[0].copy()
         st = np.zeros(1, dtype=np.uint8)
         lo, hi, nr, nb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         ids = np.zeros(max(self.n, 1), dtype=np.uint32)
@@ -1096,7 +1135,7 @@ class Witness:
     def shard_plan_tipset_all(self, parent_cids, child_cid: bytes, n_shards: int):
         """Every shard's plan in one call.  Returns (status, n_receipts, receipt_bounds u64[G+1], [ids of shard 0, …])."""
         pc = pack_cids(parent_cids)
-        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        child = cid_slots([child_cid])[0].copy()
         st = np.zeros(1, dtype=np.uint8)
         nr, nids = C.c_uint64(), C.c_uint64()
         bounds = np.zeros(n_shards + 1, dtype=np.uint64)
@@ -1138,7 +1177,7 @@ class Witness:
 
     def get(self, cid: bytes):
         """Blockstore::get → bytes, or None."""
-        c = np.frombuffer(bytes(cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        c = cid_slots([cid])[0].copy()
         ln, found = C.c_uint64(), C.c_int()
         self.eng._check(self.lib.ipcfp_witness_get(self.eng.h, self.h, _p(c), None, 0, C.byref(ln), C.byref(found)), "witness_get")
         if not found.value:
@@ -1204,7 +1243,7 @@ class Witness:
         → dict(storage GEN_STORAGE_DTYPE[], event_status, matches, message_cids, match_spec, block_ids (Cid order),
                first_error | None)"""
         pc = pack_cids(parent_cids)
-        child = np.frombuffer(bytes(child_cid).ljust(CID_SLOT, b"\0"), dtype=np.uint8).copy()
+        child = cid_slots([child_cid])[0].copy()
         ss = np.zeros(len(storage_specs), dtype=STORAGE_SPEC_DTYPE)
         for i, (a, slot) in enumerate(storage_specs):
             ss["actor_id"][i] = a

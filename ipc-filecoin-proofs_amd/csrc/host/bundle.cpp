@@ -373,8 +373,6 @@ int ipcfp_bundle_parse_json(ipcfp_ctx_t* ctx, const char* json, uint64_t len, ui
         // serde reads `cid` and `data` in text order, block by block: report the earlier block
         const unsigned long long b64_blk = bad[0], cid_blk = bad[1] == none ? none : bad[1] >> 2;
         if (cid_blk != none && cid_blk <= b64_blk) {
-            if ((bad[1] & 3) == 2)
-                return set_error(ctx, IPCFP_E_UNSUPPORTED, "bundle JSON: blocks[%llu].cid is longer than 40 bytes", cid_blk);
             return set_error(ctx, IPCFP_E_PARSE, "bundle JSON: blocks[%llu].cid is not a CID byte array", cid_blk);
         }
         if (b64_blk != none)

@@ -91,6 +91,77 @@ bool hex_decode(const char* s, size_t n, std::vector<uint8_t>& out) {
     return true;
 }
 
+// ---- Blake2b-256 on the host (RFC 7693; digest length 32, no key): only for folding CIDs longer than the ABI slot ----
+namespace {
+inline uint64_t rotr64(uint64_t x, unsigned n) { return (x >> n) | (x << (64 - n)); }
+const uint64_t kB2bIV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                            0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+const uint8_t kB2bSigma[12][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+void b2b_compress(uint64_t h[8], const uint8_t block[128], uint64_t t, bool last) {
+    uint64_t m[16], v[16];
+    for (int i = 0; i < 16; ++i) {
+        m[i] = 0;
+        for (int b = 0; b < 8; ++b) m[i] |= uint64_t(block[8 * i + b]) << (8 * b);
+    }
+    for (int i = 0; i < 8; ++i) {
+        v[i] = h[i];
+        v[8 + i] = kB2bIV[i];
+    }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+    auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+        v[a] = v[a] + v[b] + x; v[d] = rotr64(v[d] ^ v[a], 32);
+        v[c] = v[c] + v[d];     v[b] = rotr64(v[b] ^ v[c], 24);
+        v[a] = v[a] + v[b] + y; v[d] = rotr64(v[d] ^ v[a], 16);
+        v[c] = v[c] + v[d];     v[b] = rotr64(v[b] ^ v[c], 63);
+    };
+    for (int r = 0; r < 12; ++r) {
+        const uint8_t* s = kB2bSigma[r];
+        G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+        G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+        G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+        G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[8 + i];
+}
+}  // namespace
+
+void blake2b256_host(const uint8_t* data, size_t len, uint8_t out32[32]) {
+    uint64_t h[8];
+    for (int i = 0; i < 8; ++i) h[i] = kB2bIV[i];
+    h[0] ^= 0x01010020ULL;  // digest length 32, no key, fanout 1, depth 1
+    size_t done = 0;
+    uint8_t block[128];
+    for (;;) {
+        const size_t left = len - done;
+        const bool last = left <= 128;
+        const size_t take = last ? left : 128;
+        std::memset(block, 0, sizeof block);
+        if (take) std::memcpy(block, data + done, take);
+        done += take;
+        b2b_compress(h, block, uint64_t(done), last);
+        if (last) break;
+    }
+    for (int i = 0; i < 32; ++i) out32[i] = uint8_t(h[i >> 3] >> (8 * (i & 7)));
+}
+
+void cid_to_slot(const uint8_t* cid, size_t len, uint8_t slot40[40]) {
+    std::memset(slot40, 0, 40);
+    if (len <= 40) {
+        if (len) std::memcpy(slot40, cid, len);
+        return;
+    }
+    slot40[0] = 0xff;
+    slot40[1] = uint8_t(len);
+    blake2b256_host(cid, len, slot40 + 2);
+}
+
 bool cid_binary_ok(const uint8_t* p, size_t n) {
     if (n == 34 && p[0] == 0x12 && p[1] == 0x20) return true;
     size_t pos = 0;

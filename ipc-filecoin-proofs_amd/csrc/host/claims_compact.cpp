@@ -13,6 +13,7 @@
 #include "../kernels/launch.h"
 #include "../kernels/tipset_ctx.h"
 #include "exec_state.h"
+#include "tipset_wide.h"
 
 namespace ipcfp {
 
@@ -132,14 +133,9 @@ int ipcfp_verify_event_claims_compact(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, cons
     if (n == 0) return IPCFP_OK;
     IPCFP_ENTER(ctx);
     std::vector<TipsetCtxDev> tcs(n_tipsets);
-    for (uint32_t k = 0; k < n_tipsets; ++k) {
-        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
-        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
-        tcs[k].flags = tipsets[k].flags;
-        tcs[k].n_parents = tipsets[k].n_parents;
-        std::memcpy(tcs[k].child.w, tipsets[k].child, IPCFP_CID_SLOT);
-        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) std::memcpy(tcs[k].parents[j].w, tipsets[k].parents[j], IPCFP_CID_SLOT);
-    }
+    WideParents wide;
+    for (uint32_t k = 0; k < n_tipsets; ++k)
+        if (int rc_t = tipset_inputs(ctx, tipsets[k], tcs[k], wide)) return rc_t;
     const uint64_t cap_blob = cblob_len + 8 * n + 64;
     DevBuf<uint8_t> cc, cb, bd, sd;
     DevBuf<EventClaimPacked> cd;

@@ -19,6 +19,7 @@
 #include "../kernels/claims_dev.h"
 #include "../kernels/launch.h"
 #include "exec_state.h"
+#include "tipset_wide.h"
 
 using namespace ipcfp;
 
@@ -134,7 +135,6 @@ int ipcfp_generate_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
     if (!ctx || !w || w->ctx != ctx || !child_cid40 || !filter || !status_out || !n_proofs || !n_blocks ||
         (n_parents && !parent_cids40))
         return IPCFP_E_INVALID;
-    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
     IPCFP_ENTER(ctx);
     *n_proofs = *n_blocks = 0;
     *status_out = IPCFP_ST_ERR;
@@ -149,11 +149,8 @@ int ipcfp_generate_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
 
     // Step 1 (generator.rs:89-95): child header → receipts root.  The context kernel also loads parent 0.
     TipsetCtxDev tc;
-    std::memset(&tc, 0, sizeof tc);
-    tc.flags = TC_PARENTS_PARSED | TC_CHILD_PARSED;
-    tc.n_parents = n_parents;
-    tc.child = key_from_slot(child_cid40);
-    for (uint32_t k = 0; k < n_parents; ++k) tc.parents[k] = key_from_slot(parent_cids40 + size_t(k) * IPCFP_CID_SLOT);
+    WideParents wide;
+    if (int rc_t = tipset_inputs_list(ctx, TC_PARENTS_PARSED | TC_CHILD_PARSED, parent_cids40, n_parents, child_cid40, tc, wide)) return rc_t;
     DevBuf<TipsetCtxDev> tc_d;
     IPCFP_HIP(ctx, tc_d.alloc(1));
     IPCFP_HIP(ctx, hipMemcpyAsync(tc_d.p, &tc, sizeof tc, hipMemcpyHostToDevice, ctx->stream));
@@ -210,7 +207,7 @@ int ipcfp_generate_event_proofs(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
     }
     // base witness (generator.rs:97-112): parents, child, receipts root (TxMeta CIDs were marked by the traversal)
     std::vector<CidKey> base;
-    for (uint32_t k = 0; k < n_parents; ++k) base.push_back(tc.parents[k]);
+    tipset_parent_keys(tc, wide, base);
     base.push_back(tc.child);
     base.push_back(tc.receipts_root);
     DevBuf<CidKey> base_d;

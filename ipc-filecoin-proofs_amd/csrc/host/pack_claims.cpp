@@ -66,6 +66,7 @@ void lower_one(const ipcfp_event_proof_t& p, EventClaimPacked& c, std::vector<ui
 
 int pack_event_claims_host(const ipcfp_event_proof_t* proofs, uint64_t n, PackedEvents& out, std::string& err) {
     out.tipsets.clear();
+    out.more_parents.clear();
     out.claims.assign(n, EventClaimPacked{});
     out.blob.clear();
     // ---- pass 1 (sequential): tipset contexts ----
@@ -97,20 +98,27 @@ int pack_event_claims_host(const ipcfp_event_proof_t* proofs, uint64_t n, Packed
             put_str(p.child_block_cid);
             auto it = ctx_index.find(key);
             if (it == ctx_index.end()) {
-                if (p.n_parent_tipset_cids > uint32_t(IPCFP_MAX_PARENTS)) {
+                if (p.n_parent_tipset_cids > uint32_t(IPCFP_MAX_PARENTS_WIDE)) {
                     err = "proof " + std::to_string(i) + " names " + std::to_string(p.n_parent_tipset_cids) +
-                          " parent blocks (engine limit " + std::to_string(uint32_t(IPCFP_MAX_PARENTS)) + ")";
+                          " parent blocks (engine limit " + std::to_string(uint32_t(IPCFP_MAX_PARENTS_WIDE)) + ")";
                     return IPCFP_E_UNSUPPORTED;
                 }
                 ipcfp_tipset_ref_t tr;
                 std::memset(&tr, 0, sizeof tr);
                 tr.n_parents = p.n_parent_tipset_cids;
+                uint8_t* more = nullptr;  // a key wider than the inline form keeps its tail in the handle
+                if (tr.n_parents > uint32_t(IPCFP_MAX_PARENTS)) {
+                    out.more_parents.emplace_back(new std::vector<uint8_t>(size_t(tr.n_parents - IPCFP_MAX_PARENTS) * IPCFP_CID_SLOT));
+                    more = out.more_parents.back()->data();
+                    tr.more_parents = more;
+                }
                 bool all = true;
                 for (uint32_t k = 0; k < tr.n_parents; ++k) {
                     bool parsed, canon;
                     CidKey key40;
                     parse_cid_claim(p.parent_tipset_cids ? p.parent_tipset_cids[k] : nullptr, key40, parsed, canon);
-                    std::memcpy(tr.parents[k], key40.w, IPCFP_CID_SLOT);
+                    std::memcpy(k < uint32_t(IPCFP_MAX_PARENTS) ? tr.parents[k] : more + size_t(k - IPCFP_MAX_PARENTS) * IPCFP_CID_SLOT, key40.w,
+                                IPCFP_CID_SLOT);
                     all = all && parsed;
                 }
                 if (all) tr.flags |= TC_PARENTS_PARSED;

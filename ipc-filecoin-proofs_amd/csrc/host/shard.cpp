@@ -24,6 +24,7 @@
 #include "../kernels/types_dev.h"
 #include "../kernels/launch.h"
 #include "exec_state.h"
+#include "tipset_wide.h"
 
 using namespace ipcfp;
 
@@ -108,11 +109,8 @@ void ipcfp_shard_range(uint64_t n, uint32_t n_shards, uint32_t shard, uint64_t* 
 // *status_out != TRUE: the traversal failed there and nothing else is valid.
 static int plan_replicated(ipcfp_ctx* ctx, const WitnessView& rec, const uint8_t* parent_cids40, uint32_t n_parents,
                            const uint8_t* child_cid40, TipsetCtxDev& tc, uint64_t& count, ipcfp_status_t* status_out) {
-    std::memset(&tc, 0, sizeof tc);
-    tc.flags = TC_PARENTS_PARSED | TC_CHILD_PARSED;
-    tc.n_parents = n_parents;
-    tc.child = key_from_slot(child_cid40);
-    for (uint32_t k = 0; k < n_parents; ++k) tc.parents[k] = key_from_slot(parent_cids40 + size_t(k) * IPCFP_CID_SLOT);
+    WideParents wide;  // (a tipset key wider than the inline form: alive until every kernel below has run)
+    if (int rc_t = tipset_inputs_list(ctx, TC_PARENTS_PARSED | TC_CHILD_PARSED, parent_cids40, n_parents, child_cid40, tc, wide)) return rc_t;
     DevBuf<TipsetCtxDev> tc_d;
     IPCFP_HIP(ctx, tc_d.alloc(1));
     IPCFP_HIP(ctx, hipMemcpyAsync(tc_d.p, &tc, sizeof tc, hipMemcpyHostToDevice, ctx->stream));
@@ -146,7 +144,7 @@ static int plan_replicated(ipcfp_ctx* ctx, const WitnessView& rec, const uint8_t
     count = info[2];
     // the tipset pair itself
     std::vector<CidKey> base;
-    for (uint32_t k = 0; k < n_parents; ++k) base.push_back(tc.parents[k]);
+    tipset_parent_keys(tc, wide, base);
     base.push_back(tc.child);
     base.push_back(tc.receipts_root);
     DevBuf<CidKey> base_d;
@@ -169,7 +167,6 @@ int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
     if (!ctx || !w || w->ctx != ctx || !child_cid40 || !status_out || !receipt_lo || !receipt_hi || !n_blocks ||
         (n_parents && !parent_cids40) || n_shards == 0 || shard >= n_shards)
         return IPCFP_E_INVALID;
-    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
     IPCFP_ENTER(ctx);
     *n_blocks = 0;
     *receipt_lo = *receipt_hi = 0;
@@ -218,7 +215,6 @@ int ipcfp_shard_plan_tipset_all(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
     if (!ctx || !w || w->ctx != ctx || !child_cid40 || !status_out || !receipt_bounds || !shard_off || !n_ids ||
         (n_parents && !parent_cids40) || n_shards == 0 || n_shards > IPCFP_MAX_SHARDS)
         return IPCFP_E_INVALID;
-    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
     IPCFP_ENTER(ctx);
     *n_ids = 0;
     if (n_receipts) *n_receipts = 0;

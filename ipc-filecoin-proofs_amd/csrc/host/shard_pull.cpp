@@ -13,6 +13,7 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <vector>
 
 #include "../common.h"
 #include "../kernels/launch.h"
@@ -57,7 +58,7 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     if (prefix_len > 8 || (prefix_len && !cid_prefix)) return set_error(ctx, IPCFP_E_INVALID, "CID prefix longer than 8 bytes");
     if (n_esc && (!esc_index || !esc_cids40)) return set_error(ctx, IPCFP_E_INVALID, "null escape table");
     if (n >= 0xffffffffull || n_esc > n) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 blocks");
-    if (n_parents > IPCFP_MAX_PARENTS) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", unsigned(IPCFP_MAX_PARENTS));
+    if (n_parents > IPCFP_MAX_PARENTS_WIDE) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", unsigned(IPCFP_MAX_PARENTS_WIDE));
     if (!ctx->mailbox) return set_error(ctx, IPCFP_E_UNSUPPORTED, "the context has no mailbox page (IPCFP_MAILBOX=0)");
     IPCFP_ENTER(ctx);
     // the device reads the blocks itself: the buffer must be mapped for it (hipHostMalloc / hipHostRegister / ipcfp_host_register)
@@ -162,7 +163,16 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     std::memset(&seeds, 0, sizeof seeds);
     seeds.child = key_from_slot(child_cid40);
     seeds.n_parents = n_parents;
-    for (uint32_t k = 0; k < n_parents; ++k) seeds.parents[k] = key_from_slot(parent_cids40 + size_t(k) * IPCFP_CID_SLOT);
+    for (uint32_t k = 0; k < n_parents && k < IPCFP_MAX_PARENTS; ++k) seeds.parents[k] = key_from_slot(parent_cids40 + size_t(k) * IPCFP_CID_SLOT);
+    DevBuf<CidKey> seeds_wide;  // a tipset key wider than the inline form: every key in HBM
+    std::vector<CidKey> seeds_wide_h;
+    if (n_parents > IPCFP_MAX_PARENTS) {
+        seeds_wide_h.resize(n_parents);
+        for (uint32_t k = 0; k < n_parents; ++k) seeds_wide_h[k] = key_from_slot(parent_cids40 + size_t(k) * IPCFP_CID_SLOT);
+        IPCFP_HIP(ctx, seeds_wide.alloc(n_parents));
+        IPCFP_HIP(ctx, hipMemcpyAsync(seeds_wide.p, seeds_wide_h.data(), size_t(n_parents) * sizeof(CidKey), hipMemcpyHostToDevice, ctx->stream));
+        seeds.parents_wide = seeds_wide.p;
+    }
     // rounds are queued ahead of the host's reading: whatever way this function is left from here on, the stream is drained
     // before the buffers above go back to the pool (the ordinary path has synchronised by then and pays nothing)
     StreamDrainGuard drain(ctx->stream);

@@ -21,6 +21,7 @@
 #include "../kernels/launch.h"
 #include "cidstr.h"
 #include "exec_state.h"
+#include "tipset_wide.h"
 #include "pack_claims.h"
 
 using namespace ipcfp;
@@ -44,7 +45,7 @@ int build_exec_order(ipcfp_ctx* ctx, const WitnessView& view, const TipsetCtxDev
     if (!prepared) {
         rc = exec_state_prepare(ctx, ex, n_parents);
         if (rc) return rc;
-        rc = launch_exec_roots(ctx, view, ctx_d, ex.roots.p, ex.err.p, verify_txmeta);
+        rc = launch_exec_roots(ctx, view, ctx_d, ex.roots.p, ex.err.p, verify_txmeta, n_parents);
         if (rc) return rc;
     }
     AmtEnumResult en;
@@ -131,12 +132,22 @@ int verify_packed(ipcfp_ctx* ctx, ipcfp_witness* w, std::vector<TipsetCtxDev>& t
         jobs[k].roots = execs[k]->roots.p;
         jobs[k].err = execs[k]->err.p;
     }
-    DevBuf<PrepareJob> jobs_d;  // (a handful of jobs travel as a kernel argument instead)
-    if (jobs.size() > kInlineJobs) {
-        IPCFP_HIP(ctx, jobs_d.alloc(jobs.size()));
-        IPCFP_HIP(ctx, h2d_small(ctx, jobs_d.p, jobs.data(), jobs.size() * sizeof(PrepareJob), ctx->stream));
+    // (a context whose tipset key is wider than the inline form has a prologue launch of its own: tipset_wide.h)
+    std::vector<PrepareJob> narrow;
+    for (size_t k = 0; k < tcs.size(); ++k) {
+        if (!tipset_is_wide(tcs[k].n_parents)) {
+            narrow.push_back(jobs[k]);
+            continue;
+        }
+        rc = launch_tipset_prepare_wide(ctx, view, &jobs[k], tcs[k].n_parents);
+        if (rc) return rc;
     }
-    rc = launch_tipset_prepare(ctx, view, jobs.data(), jobs_d.p, uint32_t(jobs.size()),
+    DevBuf<PrepareJob> jobs_d;  // (a handful of jobs travel as a kernel argument instead)
+    if (narrow.size() > kInlineJobs) {
+        IPCFP_HIP(ctx, jobs_d.alloc(narrow.size()));
+        IPCFP_HIP(ctx, h2d_small(ctx, jobs_d.p, narrow.data(), narrow.size() * sizeof(PrepareJob), ctx->stream));
+    }
+    rc = launch_tipset_prepare(ctx, view, narrow.data(), jobs_d.p, uint32_t(narrow.size()),
                                /*need_general=*/uint64_t(w->max_block_len) + 32u > uint64_t(kPrologueStageChunks) * 16u);
     if (rc) return rc;
     // the header facts come back with the first synchronisation below (the enumerator's), not one of their own
@@ -339,13 +350,9 @@ static int verify_event_proofs_impl(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const 
     std::vector<EventClaimPacked>& packed = pk.claims;
     std::vector<uint8_t>& blob = pk.blob;
     std::vector<TipsetCtxDev> tcs(pk.tipsets.size());
-    for (size_t k = 0; k < tcs.size(); ++k) {
-        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
-        tcs[k].flags = pk.tipsets[k].flags;
-        tcs[k].n_parents = pk.tipsets[k].n_parents;
-        tcs[k].child = key_from_slot(pk.tipsets[k].child);
-        for (uint32_t j = 0; j < pk.tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(pk.tipsets[k].parents[j]);
-    }
+    WideParents wide;
+    for (size_t k = 0; k < tcs.size(); ++k)
+        if (int rc_t = tipset_inputs(ctx, pk.tipsets[k], tcs[k], wide)) return rc_t;
 
     // ---- upload, then the shared device path ----
     DevBuf<EventClaimPacked> cd;
@@ -375,14 +382,9 @@ int ipcfp_verify_event_claims_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const
     if (n == 0) return IPCFP_OK;
     IPCFP_ENTER(ctx);
     std::vector<TipsetCtxDev> tcs(n_tipsets);
-    for (uint32_t k = 0; k < n_tipsets; ++k) {
-        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
-        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
-        tcs[k].flags = tipsets[k].flags;
-        tcs[k].n_parents = tipsets[k].n_parents;
-        tcs[k].child = key_from_slot(tipsets[k].child);
-        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
-    }
+    WideParents wide;
+    for (uint32_t k = 0; k < n_tipsets; ++k)
+        if (int rc_t = tipset_inputs(ctx, tipsets[k], tcs[k], wide)) return rc_t;
     int rc = verify_packed(ctx, w, tcs, static_cast<const EventClaimPacked*>(claims_d), uint32_t(n),
                            static_cast<const uint8_t*>(blob_d), blob_len, trust, filter, static_cast<uint8_t*>(status_d));
     if (rc) return rc;
@@ -408,14 +410,9 @@ int ipcfp_verify_and_scan_device(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipc
     *scan_status = IPCFP_ST_ERR;
     *n_receipts = *n_matches = 0;
     std::vector<TipsetCtxDev> tcs(n_tipsets);
-    for (uint32_t k = 0; k < n_tipsets; ++k) {
-        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
-        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
-        tcs[k].flags = tipsets[k].flags;
-        tcs[k].n_parents = tipsets[k].n_parents;
-        tcs[k].child = key_from_slot(tipsets[k].child);
-        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
-    }
+    WideParents wide;
+    for (uint32_t k = 0; k < n_tipsets; ++k)
+        if (int rc_t = tipset_inputs(ctx, tipsets[k], tcs[k], wide)) return rc_t;
     ScanRide ride;
     ride.filter = *scan_filter;
     ride.has_actor = has_actor;
@@ -480,14 +477,9 @@ int ipcfp_verify_event_claims(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const ipcfp_
     if (n == 0) return IPCFP_OK;
     IPCFP_ENTER(ctx);
     std::vector<TipsetCtxDev> tcs(n_tipsets);
-    for (uint32_t k = 0; k < n_tipsets; ++k) {
-        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
-        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
-        tcs[k].flags = tipsets[k].flags;
-        tcs[k].n_parents = tipsets[k].n_parents;
-        tcs[k].child = key_from_slot(tipsets[k].child);
-        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
-    }
+    WideParents wide;
+    for (uint32_t k = 0; k < n_tipsets; ++k)
+        if (int rc_t = tipset_inputs(ctx, tipsets[k], tcs[k], wide)) return rc_t;
     DevBuf<EventClaimPacked> cd;
     DevBuf<uint8_t> bd, sd;
     IPCFP_HIP(ctx, cd.alloc(n));
@@ -556,14 +548,9 @@ int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const 
         return set_error(ctx, IPCFP_E_INVALID, "the claim batch is not in exec_index order (ipcfp_route_event_claims takes any order)");
     IPCFP_ENTER(ctx);
     std::vector<TipsetCtxDev> tcs(n_tipsets);
-    for (uint32_t k = 0; k < n_tipsets; ++k) {
-        if (tipsets[k].n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "too many parent blocks");
-        std::memset(&tcs[k], 0, sizeof(TipsetCtxDev));
-        tcs[k].flags = tipsets[k].flags;
-        tcs[k].n_parents = tipsets[k].n_parents;
-        tcs[k].child = key_from_slot(tipsets[k].child);
-        for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) tcs[k].parents[j] = key_from_slot(tipsets[k].parents[j]);
-    }
+    WideParents wide;
+    for (uint32_t k = 0; k < n_tipsets; ++k)
+        if (int rc_t = tipset_inputs(ctx, tipsets[k], tcs[k], wide)) return rc_t;
     // Two ways to the window of the blob the slice points into.
     //   guessed   from the slice's two ends on the host (a bundle's blob is written in claim order: the first records'
     //             smallest offset, the last records' largest end) — records AND window then cross PCIe on a thread of their
@@ -690,13 +677,10 @@ int ipcfp_verify_event_claims_range(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const 
 int ipcfp_exec_order(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
                      ipcfp_status_t* status_out, uint8_t* out_cids40, uint64_t cap, uint64_t* count) {
     if (!ctx || !w || w->ctx != ctx || !status_out || !count || (n_parents && !parent_cids40)) return IPCFP_E_INVALID;
-    if (n_parents > kMaxParents) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than %u parent blocks", kMaxParents);
     IPCFP_ENTER(ctx);
     TipsetCtxDev tc;
-    std::memset(&tc, 0, sizeof tc);
-    tc.n_parents = n_parents;
-    tc.flags = TC_PARENTS_PARSED | TC_CHILD_PARSED;
-    for (uint32_t k = 0; k < n_parents; ++k) tc.parents[k] = key_from_slot(parent_cids40 + IPCFP_CID_SLOT * k);
+    WideParents wide;
+    if (int rc_t = tipset_inputs_list(ctx, TC_PARENTS_PARSED | TC_CHILD_PARSED, parent_cids40, n_parents, nullptr, tc, wide)) return rc_t;
     DevBuf<TipsetCtxDev> tc_d;
     IPCFP_HIP(ctx, tc_d.alloc(1));
     IPCFP_HIP(ctx, hipMemcpyAsync(tc_d.p, &tc, sizeof tc, hipMemcpyHostToDevice, ctx->stream));

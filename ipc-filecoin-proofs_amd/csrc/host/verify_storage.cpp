@@ -21,8 +21,8 @@ namespace ipcfp {
 CidKey key_from_slot(const uint8_t* slot40);
 
 // Parse a CID string into a witness key.  `parsed`: Cid::try_from succeeded.  `canonical`: the
-// string equals Cid::to_string() of what it parses to.  CIDs longer than the 40-byte slot parse
-// fine but can never be witness keys: they get the impossible key.
+// string equals Cid::to_string() of what it parses to.  A CID longer than the 40-byte slot becomes its fold
+// (cidstr.h cid_to_slot), the key the device makes of the same CID when it reads it out of a block.
 void parse_cid_claim(const char* s, CidKey& key, bool& parsed, bool& canonical) {
     std::vector<uint8_t> bin;
     parsed = cid_from_string(s, bin);
@@ -30,11 +30,9 @@ void parse_cid_claim(const char* s, CidKey& key, bool& parsed, bool& canonical) 
     for (auto& w : key.w) w = ~0ULL;
     if (!parsed) return;
     canonical = cid_to_string(bin.data(), bin.size()) == s;
-    if (bin.size() <= IPCFP_CID_SLOT) {
-        uint8_t slot[IPCFP_CID_SLOT] = {0};
-        std::memcpy(slot, bin.data(), bin.size());
-        std::memcpy(key.w, slot, IPCFP_CID_SLOT);
-    }
+    uint8_t slot[IPCFP_CID_SLOT];
+    cid_to_slot(bin.data(), bin.size(), slot);
+    std::memcpy(key.w, slot, IPCFP_CID_SLOT);
 }
 
 static const ipcfp_trust_policy_t kAcceptAll = {0, 0, 0, 0};
@@ -198,10 +196,15 @@ int ipcfp_cid_from_string(const char* s, uint8_t out40[IPCFP_CID_SLOT]) {
     if (!s || !out40) return IPCFP_E_INVALID;
     std::vector<uint8_t> bin;
     if (!cid_from_string(s, bin)) return IPCFP_E_PARSE;
-    if (bin.size() > IPCFP_CID_SLOT) return IPCFP_E_UNSUPPORTED;
-    std::memset(out40, 0, IPCFP_CID_SLOT);
-    std::memcpy(out40, bin.data(), bin.size());
+    cid_to_slot(bin.data(), bin.size(), out40);
     return int(bin.size());
+}
+
+int ipcfp_cid_to_slot(const uint8_t* cid, uint32_t len, uint8_t out40[IPCFP_CID_SLOT]) {
+    if (!cid || !out40) return IPCFP_E_INVALID;
+    if (!cid_binary_ok(cid, len)) return IPCFP_E_PARSE;
+    cid_to_slot(cid, len, out40);
+    return int(len);
 }
 
 int ipcfp_cid_to_string(const uint8_t* cid, uint32_t len, char* out, uint32_t cap) {

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../common.h"
+#include "blake2b_dev.h"
 #include "launch.h"
 
 namespace ipcfp {
@@ -210,13 +211,21 @@ __global__ __launch_bounds__(256) void k_parse_cid_arrays(const uint8_t* __restr
                 count - pos != size)
                 err = 1;
         }
-        if (!err && count > IPCFP_CID_SLOT) err = 2;
     }
     if (err) {
         atomicMin(first_bad, ((unsigned long long)t << 2) | err);
         return;
     }
     uint8_t* out = cids + size_t(t) * IPCFP_CID_SLOT;
+    if (count > IPCFP_CID_SLOT) {  // longer than the slot: the fold ff | len | blake2b-256(cid) (include/ipcfp.h "CIDs")
+        uint64_t d[4];
+        blake2b256_small(cid, count, d);
+        out[0] = 0xff;
+        out[1] = uint8_t(count);
+        for (uint32_t i = 0; i < 32; ++i) out[2 + i] = uint8_t(d[i >> 3] >> (8u * (i & 7u)));
+        for (uint32_t i = 34; i < IPCFP_CID_SLOT; ++i) out[i] = 0;
+        return;
+    }
     for (uint32_t i = 0; i < IPCFP_CID_SLOT; ++i) out[i] = i < count ? cid[i] : 0;
 }
 

@@ -21,6 +21,7 @@
 #include <cstdint>
 
 #include "ipcfp.h"
+#include "blake2b_dev.h"
 #include "witness_dev.h"
 
 namespace ipcfp {
@@ -97,6 +98,29 @@ typedef unsigned long long rd_chunk_t __attribute__((ext_vector_type(2)));  // o
 #error "IPCFP_RD_RING is a mode of the LDS reader"
 #endif
 constexpr uint32_t kRdRingLost = 0xfdu;  // not an ipcfp_status_t
+
+// A CID LONGER than the 40-byte slot as a witness key: the fold  ff | len | blake2b-256(the CID's bytes) | 00 …  of
+// include/ipcfp.h ("CIDs").  The reference stores and finds blocks under CIDs of any length
+// (src/proofs/common/witness.rs:60-72: `Cid::try_from`, digests of up to 64 bytes) and compares message CIDs of any length
+// (src/proofs/events/utils.rs:76-90, src/proofs/events/verifier.rs:193-201); folded, a long CID is found, compared and
+// deduplicated through the same five words as a short one.  m[]: the CID's bytes as little-endian words, zero padded
+// (len ≤ 128: one compression).  NOT inlined: one copy of the compression per kernel, however many readers it has, and no
+// live ranges of its 16 + 16 words in the callers' fast paths (no Filecoin chain has such a CID).
+static __device__ __noinline__ CidKey long_cid_fold(const uint64_t* __restrict__ m, uint32_t len) {
+    uint64_t h[8];
+    b2b::init256(h);
+    uint64_t mm[16];
+#pragma unroll
+    for (int w = 0; w < 16; ++w) mm[w] = m[w];
+    b2b::compress<0>(h, mm, uint64_t(len), true);
+    CidKey k;
+    k.w[0] = 0xffULL | (uint64_t(len & 0xffu) << 8) | (h[0] << 16);
+    k.w[1] = (h[0] >> 48) | (h[1] << 16);
+    k.w[2] = (h[1] >> 48) | (h[2] << 16);
+    k.w[3] = (h[2] >> 48) | (h[3] << 16);
+    k.w[4] = h[3] >> 48;
+    return k;
+}
 
 struct Rd {
     const IPCFP_RD_AS uint8_t* p;
@@ -409,6 +433,28 @@ struct Rd {
         }
         return k;
     }
+    // … and of a CID of 41 .. IPCFP_CID_MAX_LEN bytes: its fold (long_cid_fold above)
+    __device__ __forceinline__ CidKey key_long(uint32_t off, uint32_t len) {
+        uint64_t m[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t lo = 8u * w;
+            uint64_t v = 0;
+            if (lo < len) {
+                v = peek64(off + lo);
+                const uint32_t valid = len - lo;
+                if (valid < 8) v &= (1ULL << (8u * valid)) - 1ULL;
+            }
+            m[w] = v;
+        }
+        return long_cid_fold(m, len);
+    }
+    // the CID bytes [off, off+len) of a link that read_link accepted, as a witness key
+    __device__ __forceinline__ CidKey key_any(uint32_t off, uint32_t len) {
+        if (len <= 40u) return key_at(off, len);
+        if (len > 128u) return CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};  // (cid_ok admits no such CID)
+        return key_long(off, len);
+    }
     // 32 bytes at `off` equal to q[0..32)?  (q: any alignment)
     __device__ __forceinline__ bool equal32(uint32_t off, const uint8_t* q) {
         uint64_t diff = 0;
@@ -660,18 +706,12 @@ struct Rd {
         off = bo + 1;
         len = bl - 1;
     }
-    // the link as a witness key (CIDs longer than the 40-byte slot cannot be witness keys:
-    // they are still VALID links, but can never be found → the caller sees kNoBlock)
+    // the link as a witness key (a CID longer than the 40-byte slot: its fold — key_long)
     __device__ __forceinline__ bool read_link_key(CidKey& key) {
         uint32_t off, len;
         read_link(off, len);
         if (err) return false;
-        if (len > 40) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) key.w[j] = ~0ULL;  // not a possible key (slot bytes 38..39 are zero)
-            return true;
-        }
-        key = key_at(off, len);
+        key = key_any(off, len);
         return true;
     }
 

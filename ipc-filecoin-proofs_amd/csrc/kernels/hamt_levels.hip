@@ -22,6 +22,9 @@
 // outcome never depends on this path: it only ever answers what the walk would answer.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "../common.h"
 #include "launch.h"
 #include "hamt_outline.h"
@@ -34,8 +37,17 @@ struct HamtLevels {
     uint32_t* hash;       // n × 8      SHA-256 of the key, eight big-endian words
     HamtNodeRec* recs;    // n_blocks   indexed by block id; valid where `claimed` says so and the level has been parsed
     uint32_t* claimed;    // ⌈n_blocks / 32⌉ bits: the block is (or was) on a work list
-    uint32_t* work[2];    // work lists of even / odd levels (capacity: min(n, n_blocks))
-    uint32_t* count;      // entries of level l's list (one counter per level)
+    // Work lists of even / odd levels (capacity of each: min(n, n_blocks)), in TWO size classes when `split`: class 0 the
+    // nodes of the small-stage parse instance (len + 24 ≤ kCoopSmallStage), class 1 everything longer.  Round 5 kept one list
+    // per level and let both parse instances walk all of it, each skipping the other's nodes: at the bucket level the small
+    // instance read 29.5 k entries and lengths to find nothing, at the overflow level the big one did (≈ 60 µs of a 520 µs
+    // call: profiles/r05_experiments.md).  The claimant knows the block, so it files it where its parser will look.
+    uint32_t* work[2][2];
+    uint32_t* count;      // entries of level l's lists: count[2 l + class] (two counters per level)
+    uint32_t split;       // 1: lists by size class (the 32-lane parse of the state tree); 0: everything in class 0
+    uint32_t plain_list;  // 1: ONE list work[0][0] / count[0] whatever the level and class (launch_hamt_outline_list)
+    uint32_t cap;         // capacity of every list
+    uint32_t* top_overflow;  // set when a fused top level's list was full (k_hamt_lv_advance_top then leaves everything to the walker)
     HamtEntryTab* etabs;  // entry tables of the visited nodes that hold entries (`etab_cap` of them; null: none kept)
     uint32_t* etab_of;    // n_blocks: 1 + the node's table, 0: none (written for every node the 32-lane parse takes)
     uint32_t etab_cap;
@@ -62,7 +74,8 @@ __device__ __forceinline__ uint32_t witness_find_quiet(const WitnessView& w, con
 // out on the way: a workgroup-wide set in LDS lets one lane per distinct block through, and the lanes of a wavefront that
 // win their block append with one counter update between them.
 constexpr uint32_t kClaimSet = 512;  // LDS slots per 256-thread workgroup (a power of two ≥ 2 × the workgroup)
-__device__ __forceinline__ void hamt_claim(const HamtLevels& L, uint32_t block, uint32_t level, bool want, uint32_t* set) {
+__device__ __forceinline__ uint32_t hamt_size_class(const WitnessView& w, const HamtLevels& L, uint32_t block);
+__device__ __forceinline__ void hamt_claim(const WitnessView& w, const HamtLevels& L, uint32_t block, uint32_t level, bool want, uint32_t* set) {
     for (uint32_t i = threadIdx.x; i < kClaimSet; i += blockDim.x) set[i] = kNoBlock;
     __syncthreads();
     bool first = false;
@@ -85,14 +98,17 @@ __device__ __forceinline__ void hamt_claim(const HamtLevels& L, uint32_t block, 
         // (a stale miss of the plain look only costs the atomic)
         won = !(__builtin_nontemporal_load(word) & bit) && !(atomicOr(word, bit) & bit);
     }
-    const uint64_t winners = __ballot(won);
-    if (won) {
-        const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cls = won ? hamt_size_class(w, L, block) : 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t c = 0; c < 2u; ++c) {  // (one counter update per wavefront and class)
+        const uint64_t winners = __ballot(won && cls == c);
+        if (!winners) continue;
         const uint32_t leader = uint32_t(__ffsll((long long)winners)) - 1u;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(L.count + level, uint32_t(__popcll(winners)));
+        if (lane == leader) base = atomicAdd(L.count + 2u * level + c, uint32_t(__popcll(winners)));
         base = __shfl(base, leader, 64);
-        L.work[level & 1u][base + uint32_t(__popcll(winners & ((1ull << lane) - 1ull)))] = block;
+        if (won && cls == c) L.work[level & 1u][c][base + uint32_t(__popcll(winners & ((1ull << lane) - 1ull)))] = block;
     }
 }
 
@@ -105,10 +121,11 @@ __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey roo
         // hipMemsetAsync of this unaligned range is three fill kernels of the runtime, ≈ 25 µs in front of a 0.6 ms call.
         const uint32_t rb0 = witness_find(w, root);
         const uint32_t stride = gridDim.x * blockDim.x, n_count = uint32_t(L.claimed - L.count);
+        const uint32_t rcls = rb0 != kNoBlock ? hamt_size_class(w, L, rb0) : 0u;
         for (uint32_t j = t; j < n_clear; j += stride) {
             uint32_t v = 0;
             if (rb0 != kNoBlock) {
-                if (j == 0u) v = 1u;                                           // count[0]: the root is level 0's work list
+                if (j == rcls) v = 1u;                                         // count[0 + class]: the root is level 0's work list
                 else if (j == n_count + (rb0 >> 5)) v = 1u << (rb0 & 31u);    // … and claimed
             }
             L.count[j] = v;
@@ -124,14 +141,17 @@ __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey roo
     L.cur[t] = rb;
     status[t] = uint8_t(rb == kNoBlock ? uint32_t(IPCFP_ST_ERR_MISSING_BLOCK) : kStPending);
     if (loc) loc[t] = ValueLoc{kNoBlock, 0, 0};
-    if (t == 0 && rb != kNoBlock) L.work[0][0] = rb;
+    if (t == 0 && rb != kNoBlock) {
+        L.work[0][hamt_size_class(w, L, rb)][0] = rb;
+        L.recs[rb].status = 0;  // (until a parse of THIS call says otherwise: the fused top launches one instance only)
+    }
 }
 
 // lane = one node of level `level`'s work list
 __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_lv_parse(WitnessView w, HamtLevels L, uint32_t level, int vkind) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.count[level]) return;
-    const uint32_t block = L.work[level & 1u][i];
+    if (i >= L.count[2u * level]) return;
+    const uint32_t block = L.work[level & 1u][0][i];
     HamtNodeRec* out = L.recs + block;
     Rd r = open_block(w, block);
     uint32_t status = 0, std_links = 0, np32 = 0;
@@ -207,6 +227,10 @@ constexpr uint32_t kCoopLanes = 32, kCoopNodes = 2, kCoopParallelMin = 2048, kCo
 // length / offset → the node) and what hides them is the number of wavefronts in flight — everything else to the one with
 // the 6.9 KB stage.  Each skips the other's nodes.
 constexpr uint32_t kCoopBigStage = 6912, kCoopBigEntries = 96, kCoopSmallStage = 1536, kCoopSmallEntries = 24;
+
+__device__ __forceinline__ uint32_t hamt_size_class(const WitnessView& w, const HamtLevels& L, uint32_t block) {
+    return L.split && w.len[block] + 24u > kCoopSmallStage ? 1u : 0u;
+}
 
 // the 8 bytes at S[p, p + 8) as a little-endian word (one aligned two-word LDS read)
 __device__ __forceinline__ uint64_t lds_peek64(const uint8_t* S, uint32_t p) {
@@ -288,8 +312,14 @@ __device__ __forceinline__ bool lds_address_ok(const uint8_t* S, uint32_t off, u
     return false;
 }
 
+// One wavefront's pair of nodes: entries 2 · pair and 2 · pair + 1 of the level's list of this instance's size class
+// (`n_list` entries).  `emit_children` (the fused top levels): a node of links alone also FILES the blocks behind its links
+// as the next level's work — every child, not only the ones a query will step to: the top of a state tree is 1 + 32 + 1 024
+// link nodes that 66 k queries visit all of anyway, and listing them here takes the advance kernel (and its 66 k claims on
+// 32 blocks) out of every top level.  A record is a pure function of its block: parsing a node no query visits changes nothing.
 template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL>
-__global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level) {
+__device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, const HamtLevels& L, uint32_t level, uint32_t pair,
+                                                      uint32_t n_list, uint32_t emit_children) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kCoopNodes][kCoopStage];
     __shared__ uint16_t s_ptr[kCoopNodes][kHamtTablePointers];   // pointer starts
     __shared__ uint16_t s_val[kCoopNodes][kCoopMaxEntries];      // per bucket entry: where its ActorState (0x85) starts
@@ -301,11 +331,13 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     __shared__ uint32_t s_np[kCoopNodes], s_ne[kCoopNodes], s_links[kCoopNodes], s_lall[kCoopNodes], s_slot[kCoopNodes];
     __shared__ uint64_t s_bf[kCoopNodes];
     const uint32_t lane = threadIdx.x & 63u, g = lane / kCoopLanes, sub = lane % kCoopLanes;
-    const uint32_t i = blockIdx.x * kCoopNodes + g;
-    const bool listed = i < L.count[level];
-    const uint32_t block = listed ? L.work[level & 1u][i] : 0u;
+    const uint32_t i = pair * kCoopNodes + g;
+    const uint32_t cls = L.plain_list || SMALL ? 0u : 1u;
+    const bool listed = i < n_list;
+    const uint32_t block = listed ? L.work[L.plain_list ? 0u : (level & 1u)][cls][i] : 0u;
     const uint32_t len = listed ? w.len[block] : 0u;
-    const bool have = listed && (len + 24u <= kCoopSmallStage) == SMALL;  // (the other instance's node otherwise)
+    // (a split list holds this instance's nodes only; an unsplit one — the outline over a plain list — is the big instance's)
+    const bool have = listed && (L.split ? true : (len + 24u <= kCoopSmallStage) == SMALL);
     const bool staged = have && len >= 3u && len + 24u <= kCoopStage;
     uint8_t* S = stage[g];
     if (staged) {
@@ -487,8 +519,8 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         // 270 µs where the level's parse takes 70 (profiles/r04_experiments.md).
         uint32_t slot = 0;
         if (node_ok && s_ne[g] != 0u) {
-            uint32_t base = 0;
-            for (uint32_t l = 0; l < level; ++l) base += L.count[l];
+            uint32_t base = 0;  // (the lists of the earlier levels, both classes; this level's class 0 in front of its class 1)
+            for (uint32_t l = 0; l < 2u * level + cls; ++l) base += L.count[l];
             slot = base + i < L.etab_cap ? base + i + 1u : 0u;
         }
         s_slot[g] = slot;
@@ -526,8 +558,8 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     // node's few links lead to overflow nodes a handful of its queries follow: resolving all of them here cost the bucket
     // level's parse 28 µs (two more dependent reads in every wavefront) to save its advance nothing.
     const bool resolve = node_ok && L.child != nullptr && s_ne[g] == 0u;
+    uint32_t c = kNoBlock;
     if (resolve) {  // lane p: the block behind pointer p (the 38 CID bytes of a standard link start 5 bytes in)
-        uint32_t c = kNoBlock;
         if (sub < np && ((s_links[g] >> sub) & 1u)) {
             const uint32_t at = uint32_t(s_ptr[g][sub]) + 5u;
             CidKey key;
@@ -537,6 +569,26 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
             c = witness_find_quiet(w, key);
         }
         L.child[size_t(block) * kHamtTablePointers + sub] = c;
+    }
+    if (emit_children) {  // (uniform over the launch; the lanes that are still here vote)
+        const bool em = resolve && c != kNoBlock;
+        const uint32_t ccls = em ? hamt_size_class(w, L, c) : 0u;
+        // a child the fused top's parse (the small-stage instance alone) will not take must not keep a record of another call
+        if (em && ccls == 1u) L.recs[c].status = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+            const uint64_t votes = __ballot(em && ccls == k);
+            if (!votes) continue;
+            const uint32_t leader = uint32_t(__ffsll((long long)votes)) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(L.count + 2u * (level + 1u) + k, uint32_t(__popcll(votes)));
+            base = __shfl(base, leader, 64);
+            if (em && ccls == k) {
+                const uint32_t at = base + uint32_t(__popcll(votes & ((1ull << lane) - 1ull)));
+                if (at < L.cap) L.work[(level + 1u) & 1u][k][at] = c;
+                else *L.top_overflow = 1u;
+            }
+        }
     }
     if (sub == 0) {
         out->status = uint8_t(node_ok ? 1u : 0u);  // 0: not tabulated — the walker decides
@@ -548,20 +600,32 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
     }
 }
 
-// lane = query: one level down
-__global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLevels L, uint32_t level, uint32_t bit_width, int vkind,
-                                                         const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
-                                                         const uint32_t* __restrict__ key_len, uint32_t n,
-                                                         uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
-    __shared__ uint32_t s_claims[kClaimSet];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t block = t < n ? L.cur[t] : kNoBlock;
-    const bool live = block != kNoBlock;  // (else: settled, left to the walker, or beyond the batch — still a party to the workgroup's claims)
-    const HamtNodeRec* rec = L.recs + (live ? block : 0u);
-    const uint32_t etab = live && L.etab_of ? L.etab_of[block] : 0u;
-    uint32_t st = kStPending, next = kNoBlock;
-    ValueLoc hit{kNoBlock, 0, 0};
-    if (live) do {
+// A level's list of one size class, two nodes per wavefront, COUNT-DRIVEN: the grid is what the chip holds of this
+// instance and strides over the list, so a list that turned out empty costs a launch of workgroups that read one word
+// (round 5 sized every launch by the level's upper bound: 32 k workgroups to find an empty list).
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL>
+__global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level, uint32_t emit_children) {
+    const uint32_t n_raw = L.count[L.plain_list ? 0u : 2u * level + (SMALL ? 0u : 1u)];
+    const uint32_t n_list = !L.plain_list && n_raw > L.cap ? L.cap : n_raw;
+    for (uint32_t pair = blockIdx.x; pair * kCoopNodes < n_list; pair += gridDim.x) {
+        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, SMALL>(w, L, level, pair, n_list, emit_children);
+        __syncthreads();  // (the pair's LDS is the next pair's)
+    }
+}
+
+// One query one level down from `block` (a node whose record is THIS call's).  → st (kStPending: not settled here),
+// next (the node it stands on afterwards, or kNoBlock), hit (the value, when st is TRUE), via_child (the step took a link the
+// parse had resolved: HamtLevels::child).
+__device__ __forceinline__ void hamt_advance_step(const WitnessView& w, const HamtLevels& L, uint32_t level, uint32_t bit_width, int vkind,
+                                                  const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
+                                                  const uint32_t* __restrict__ key_len, uint32_t t, uint32_t block, uint32_t& st,
+                                                  uint32_t& next, ValueLoc& hit, bool& via_child) {
+    const HamtNodeRec* rec = L.recs + block;
+    const uint32_t etab = L.etab_of ? L.etab_of[block] : 0u;
+    st = kStPending;
+    next = kNoBlock;
+    via_child = false;
+    do {
         const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);  // status | kinds_ok << 8 | np << 16
         if ((head & 0xffu) != 1u) break;  // not tabulated: the walker decides (from the root)
         const uint32_t np = (head >> 16) & 0xffu;
@@ -619,6 +683,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
         bool is_link = true;
         if (((rec->std_links >> rank) & 1u) && (head & (1u << 24))) {  // resolved by the parse: one word
             next = L.child[size_t(block) * kHamtTablePointers + rank];
+            via_child = true;
             if (next == kNoBlock) st = IPCFP_ST_ERR_MISSING_BLOCK;
             else if (w.touched) atomicOr(&w.touched[next >> 5], 1u << (next & 31));  // (what witness_find records)
             break;
@@ -635,7 +700,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
                 uint32_t o, l;
                 r.read_link(o, l);
                 if (!r.ok()) break;  // (cannot happen: the node was validated) → the walker
-                link = l <= 40 ? r.key_at(o, l) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                link = r.key_any(o, l);
             } else {
                 // a bucket `[[key, value]…]` of a validated node: find the key
                 is_link = false;
@@ -665,7 +730,22 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
             if (next == kNoBlock) st = IPCFP_ST_ERR_MISSING_BLOCK;
         }
     } while (false);
-    hamt_claim(L, next, level + 1u, next != kNoBlock, s_claims);  // (the ONE place: every lane of the workgroup comes through here)
+}
+
+// lane = query: one level down
+__global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLevels L, uint32_t level, uint32_t bit_width, int vkind,
+                                                         const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
+                                                         const uint32_t* __restrict__ key_len, uint32_t n,
+                                                         uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+    __shared__ uint32_t s_claims[kClaimSet];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t block = t < n ? L.cur[t] : kNoBlock;
+    const bool live = block != kNoBlock;  // (else: settled, left to the walker, or beyond the batch — still a party to the workgroup's claims)
+    uint32_t st = kStPending, next = kNoBlock;
+    ValueLoc hit{kNoBlock, 0, 0};
+    bool via_child = false;
+    if (live) hamt_advance_step(w, L, level, bit_width, vkind, keys, key_off, key_len, t, block, st, next, hit, via_child);
+    hamt_claim(w, L, next, level + 1u, next != kNoBlock, s_claims);  // (the ONE place: every lane of the workgroup comes through here)
     if (!live) return;
     if (next != kNoBlock) {
         L.cur[t] = next;
@@ -678,10 +758,51 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance(WitnessView w, HamtLeve
     }
 }
 
-// Scratch of one call: [cur n | hash 8n | work0 cap | work1 cap | count (levels + 1) | claimed words] u32 + the record table.
+// lane = query: the `top` FUSED levels in one go.  Their nodes were listed by the parse itself (hamt_parse_actor_pair
+// emit_children), level after level, so every record on the way down is this call's as long as each step takes a link the
+// parse resolved; a step that goes another way (a bucket node this high, a link in another spelling) ends the query's part
+// here and the walker takes it from the root.  The node a query stands on after the last fused level is claimed for level
+// `top`'s lists — from there on the batch advances level by level as before.
+__global__ __launch_bounds__(256) void k_hamt_lv_advance_top(WitnessView w, HamtLevels L, uint32_t top, uint32_t bit_width, int vkind,
+                                                             const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
+                                                             const uint32_t* __restrict__ key_len, uint32_t n,
+                                                             uint8_t* __restrict__ status, ValueLoc* __restrict__ loc) {
+    __shared__ uint32_t s_claims[kClaimSet];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t block = t < n ? L.cur[t] : kNoBlock;
+    const bool live = block != kNoBlock && *L.top_overflow == 0u;  // (a full list: nothing of the top is trusted, the walker decides)
+    uint32_t st = kStPending, next = kNoBlock;
+    ValueLoc hit{kNoBlock, 0, 0};
+    if (live)
+        for (uint32_t lv = 0; lv < top; ++lv) {
+            bool via_child = false;
+            hamt_advance_step(w, L, lv, bit_width, vkind, keys, key_off, key_len, t, block, st, next, hit, via_child);
+            if (next == kNoBlock) break;  // settled, or left pending
+            if (lv + 1u == top) break;    // stands on a node of level `top`: claimed below
+            if (!via_child) {             // the child was not listed by the parse: its record is not this call's
+                next = kNoBlock;
+                st = kStPending;
+                break;
+            }
+            block = next;
+        }
+    hamt_claim(w, L, next, top, next != kNoBlock, s_claims);
+    if (t >= n || L.cur[t] == kNoBlock) return;
+    if (next != kNoBlock) {
+        L.cur[t] = next;
+        return;
+    }
+    L.cur[t] = kNoBlock;
+    if (st != kStPending) {
+        status[t] = uint8_t(st);
+        if (loc && st == IPCFP_ST_TRUE) loc[t] = hit;
+    }
+}
+
+// Scratch of one call: [cur n | hash 8n | 4 work lists of cap | count 2 (levels + 2) | claimed words | 8 spare] u32 + child table + etab_of.
 size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels) {
     const size_t cap = n < n_blocks ? n : n_blocks;
-    return size_t(n) * 9 + cap * 2 + (levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
+    return size_t(n) * 9 + cap * 4 + 2 * size_t(levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
 }
 
 // The 32-lane outline over ANY list of blocks (not a level of a walk): every block of `work_d[0 .. *count_d)` whose length
@@ -694,12 +815,13 @@ int launch_hamt_outline_list(ipcfp_ctx* ctx, hipStream_t stream, const WitnessVi
     if (bound == 0) return IPCFP_OK;
     HamtLevels L{};
     L.recs = static_cast<HamtNodeRec*>(recs_d);
-    L.work[0] = work_d;
-    L.work[1] = work_d;
+    L.work[0][0] = work_d;
     L.count = count_d;
+    L.plain_list = 1u;
+    L.cap = bound;
     static_assert(kHamtOutlineMinLen + 24u > kCoopSmallStage, "every listed block is the big-stage instance's");
-    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(div_up(bound, kCoopNodes)), dim3(64), 0, stream, w, L,
-                       0u);
+    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(std::min(div_up(bound, kCoopNodes), 4096u)), dim3(64), 0,
+                       stream, w, L, 0u, 0u);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
@@ -711,36 +833,66 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     if (n == 0) return IPCFP_OK;
     const uint32_t cap = n < w.n ? n : w.n;
     const uint32_t words = div_up(w.n, 32);
-    HamtLevels L;
+    const bool actor = vkind == VK_ACTOR_STATE && coop;
+    HamtLevels L{};
     L.cur = scratch_d;
     L.hash = scratch_d + size_t(n);
-    L.work[0] = scratch_d + size_t(n) * 9;
-    L.work[1] = L.work[0] + cap;
-    L.count = L.work[1] + cap;
-    L.claimed = L.count + (levels + 2);
-    L.child = vkind == VK_ACTOR_STATE && coop ? L.claimed + words + 8 : nullptr;  // (the 32-lane parse fills it)
+    L.work[0][0] = scratch_d + size_t(n) * 9;
+    L.work[0][1] = L.work[0][0] + cap;
+    L.work[1][0] = L.work[0][1] + cap;
+    L.work[1][1] = L.work[1][0] + cap;
+    L.count = L.work[1][1] + cap;
+    L.claimed = L.count + 2 * (levels + 2);
+    L.split = actor ? 1u : 0u;
+    L.cap = cap;
+    L.top_overflow = L.claimed + words;  // (the first of the eight spare words behind the bitmap: cleared with it)
+    L.child = actor ? L.claimed + words + 8 : nullptr;  // (the 32-lane parse fills it)
     const bool tabs = L.child != nullptr && etabs_d != nullptr && etab_cap != 0;
     L.etab_of = tabs ? L.claimed + words + 8 + size_t(w.n) * kHamtTablePointers : nullptr;
     L.etabs = tabs ? static_cast<HamtEntryTab*>(etabs_d) : nullptr;
     L.etab_cap = tabs ? etab_cap : 0u;
     L.recs = static_cast<HamtNodeRec*>(recs_d);
-    // counters and bitmap are contiguous: cleared by the first launch
+    // counters, bitmap and the spare words are contiguous: cleared by the first launch
     ValueLoc* loc = static_cast<ValueLoc*>(loc_d);
     hipLaunchKernelGGL(k_hamt_lv_start, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, root, L, keys_d, key_off_d, key_len_d,
-                       n, status_d, loc, levels + 2u + words);
-    for (uint32_t lv = 0; lv < levels; ++lv) {
-        // level l holds at most min(n, 2^(bit_width · l)) distinct nodes
-        uint64_t fan = 1;
+                       n, status_d, loc, 2u * (levels + 2u) + words + 8u);
+    // The FUSED TOP (round 6).  The upper levels of a big tree are a handful of link nodes every query passes: level l holds
+    // at most 32^l of them.  Round 5 ran a parse / parse / advance triple per level there — 130 µs for 1 + 32 + 1 024 nodes
+    // of a 4 M-actor tree, the advance kernels being 66 k queries claiming the same few blocks.  Now the parse lists a link
+    // node's children itself (level after level, the small-stage instance alone: a link node is 1.4 KB) and ONE advance
+    // launch takes every query down all of them.  How many levels: all but the last three the call queues (the bucket level
+    // and two of overflow nodes), at most three, and only while a level's worst case fits a list.
+    static const int top_env = [] { const char* e = std::getenv("IPCFP_HAMT_TOP"); return e ? std::atoi(e) : -1; }();
+    uint32_t top = 0;
+    if (actor && levels >= 4 && bit_width == 5 && top_env != 0) {
+        top = std::min(levels - 3u, 3u);
+        if (top_env > 0) top = std::min(uint32_t(top_env), levels - 1u);
+        while (top > 0 && (1ull << (bit_width * (top - 1u))) > cap) --top;
+    }
+    auto parse_grid = [&](uint32_t lv, uint32_t per_cu) {
+        uint64_t fan = 1;  // level l holds at most min(n, 2^(bit_width · l)) distinct nodes
         for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
         const uint32_t bound = fan < cap ? uint32_t(fan) : cap;
-        if (vkind == VK_ACTOR_STATE && coop) {
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(div_up(bound, kCoopNodes)), dim3(64), 0,
-                               ctx->stream, w, L, lv);
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(div_up(bound, kCoopNodes)), dim3(64), 0,
-                               ctx->stream, w, L, lv);
-        }
-        else
+        return std::min(div_up(bound, kCoopNodes), 256u * per_cu);  // (what the chip holds; the kernel strides)
+    };
+    for (uint32_t lv = 0; lv < top; ++lv)
+        hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(parse_grid(lv, 32)), dim3(64), 0, ctx->stream, w,
+                           L, lv, lv + 1u < top ? 1u : 0u);
+    if (top)
+        hipLaunchKernelGGL(k_hamt_lv_advance_top, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, L, top, bit_width, vkind, keys_d, key_off_d,
+                           key_len_d, n, status_d, loc);
+    for (uint32_t lv = top; lv < levels; ++lv) {
+        if (actor) {
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(parse_grid(lv, 32)), dim3(64), 0,
+                               ctx->stream, w, L, lv, 0u);
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(parse_grid(lv, 10)), dim3(64), 0,
+                               ctx->stream, w, L, lv, 0u);
+        } else {
+            uint64_t fan = 1;
+            for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
+            const uint32_t bound = fan < cap ? uint32_t(fan) : cap;
             hipLaunchKernelGGL(k_hamt_lv_parse, dim3(div_up(bound, 256)), dim3(256), 0, ctx->stream, w, L, lv, vkind);
+        }
         hipLaunchKernelGGL(k_hamt_lv_advance, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, L, lv, bit_width, vkind, keys_d,
                            key_off_d, key_len_d, n, status_d, loc);
     }

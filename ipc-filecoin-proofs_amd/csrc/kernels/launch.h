@@ -115,7 +115,9 @@ int launch_tipset_prepare(ipcfp_ctx* ctx, const WitnessView& w, const void* jobs
                           uint32_t* anomaly = nullptr, bool defer_rehash = false,  // defer_rehash: see tipset_ctx.h txmeta_block
                           const void* inline_inputs = nullptr);  // host TipsetInputs of the one context: sent as a kernel argument
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
-                      unsigned long long* err_d, int verify_txmeta = 1);
+                      unsigned long long* err_d, int verify_txmeta = 1, uint32_t n_parents = 0);
+// the whole prologue of ONE context with a tipset key wider than the inline form (job: host PrepareJob)
+int launch_tipset_prepare_wide(ipcfp_ctx* ctx, const WitnessView& w, const void* job, uint32_t n_parents);
 int launch_exec_dedup(ipcfp_ctx* ctx, const WitnessView& w, const LeafRef* leaves_d, uint32_t n, CidKey* keys_d,
                       unsigned long long* slots_d, uint32_t mask, uint32_t* first_d);
 int launch_exec_compact(ipcfp_ctx* ctx, const CidKey* keys_d, uint32_t n, const uint32_t* first_d,

@@ -52,6 +52,7 @@ struct PullSeeds {
     CidKey child;
     CidKey parents[IPCFP_MAX_PARENTS];
     uint32_t n_parents;
+    const CidKey* parents_wide;  // n_parents > IPCFP_MAX_PARENTS: ALL the keys, in HBM (else null)
 };
 
 struct PullTables {

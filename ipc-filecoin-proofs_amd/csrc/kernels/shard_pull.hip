@@ -119,10 +119,12 @@ __device__ __forceinline__ void expand_receipts_node(const WitnessView& w, Rd& r
 
 // the tipset key → the first frontier
 __global__ void k_pull_seed(WitnessView w, PullSeeds seeds, PullFrontier first, PullCtl* __restrict__ ctl) {
-    const uint32_t t = threadIdx.x;
-    if (blockIdx.x != 0 || t > seeds.n_parents) return;
-    const bool child = t == seeds.n_parents;
-    pull_emit(first, ctl, witness_find(w, child ? seeds.child : seeds.parents[t]), child ? PK_HDR_CHILD : PK_HDR_PARENT, 0, 0);
+    if (blockIdx.x != 0) return;
+    for (uint32_t t = threadIdx.x; t <= seeds.n_parents; t += blockDim.x) {
+        const bool child = t == seeds.n_parents;
+        const CidKey key = child ? seeds.child : (seeds.parents_wide ? seeds.parents_wide[t] : seeds.parents[t < IPCFP_MAX_PARENTS ? t : 0u]);
+        pull_emit(first, ctl, witness_find(w, key), child ? PK_HDR_CHILD : PK_HDR_PARENT, 0, 0);
+    }
 }
 
 // CLAIM: lane = frontier item.  A block nobody has claimed yet gets the next lines of the staging arena and an entry of

@@ -41,6 +41,11 @@ struct TipsetCtxDev {
     // roots_slot with `defer_rehash`); 0: nothing to re-hash (checked inline, or never reached) — so that a context
     // taken from zeroed memory needs no initialisation.
     uint32_t txmeta_block[IPCFP_MAX_PARENTS];
+    // A tipset key of MORE than IPCFP_MAX_PARENTS blocks (the reference takes any: src/proofs/events/verifier.rs:147-181,
+    // src/proofs/events/utils.rs:16-30): ALL n_parents keys in HBM, read through tipset_parent(); null for the keys every
+    // chain has, whose parents travel inline (and as kernel arguments: TipsetInputs).  A wide context never takes the
+    // single-launch prologue or the dense walk — host/tipset_wide.h.
+    const CidKey* parents_wide;
     // execution order (filled by the host after the enumeration)
     uint32_t exec_status;      // TRUE or the first ERR_* of reconstruct_execution_order
     uint32_t exec_mask;        // hash-table size - 1
@@ -60,6 +65,11 @@ struct TipsetCtxDev {
 };
 
 static_assert(sizeof(TipsetInputs) == 8 + 40 * (1 + IPCFP_MAX_PARENTS), "TipsetInputs is the head of TipsetCtxDev");
+
+// parent block b of a context's tipset key (b < n_parents)
+__device__ __forceinline__ CidKey tipset_parent(const TipsetCtxDev& c, uint32_t b) {
+    return c.parents_wide ? c.parents_wide[b] : c.parents[b < IPCFP_MAX_PARENTS ? b : 0u];
+}
 
 // what k_ctx_finish (verify_events.hip) writes into a context on the device
 struct CtxFinish {

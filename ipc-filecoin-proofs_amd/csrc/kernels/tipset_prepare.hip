@@ -237,8 +237,8 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, const TipsetInp
                     // only ever adds an error.  A launch of its own on the aux stream does it (amt_enum.hip k_txmeta_rehash), joined
                     // at the end of the call; a mismatch reaches the same error word with the same sequence number.
                     c.txmeta_block[b] = tb + 1u;
-                    bls.root = l0 <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
-                    secp.root = l1 <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                    bls.root = r.key_any(o0, l0);
+                    secp.root = r.key_any(o1, l1);
                     bls.skip = secp.skip = 0;
                 } else {
                     // put_cbor(&(bls_root, secp_root), Blake2b256): canonical re-encoding, hashed (:65-72)
@@ -266,8 +266,8 @@ __device__ __forceinline__ void roots_slot(const WitnessView& w, const TipsetInp
                     if (!cid_equal(re, tx)) {  // (the verify path always checks: reconstruct_execution_order)
                         fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
                     } else {
-                        bls.root = lens[0] <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
-                        secp.root = lens[1] <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        bls.root = r.key_any(o0, l0);
+                        secp.root = r.key_any(o1, l1);
                         bls.skip = secp.skip = 0;
                     }
                 }

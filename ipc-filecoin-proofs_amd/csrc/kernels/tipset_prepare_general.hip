@@ -58,7 +58,7 @@ __device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtx
                             for (uint32_t i = 0; i < c.n_parents && same; ++i) {
                                 CidKey k;
                                 q.read_link_key(k);
-                                same = q.ok() && cid_equal(k, c.parents[i]);
+                                same = q.ok() && cid_equal(k, tipset_parent(c, i));
                             }
                         }
                         match = same ? 1u : 0u;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void ctx_headers_body(const WitnessView& w, TipsetCtx
         uint32_t status = IPCFP_ST_ERR_BAD_CLAIM;
         long long height = 0;
         if (parsed && c.n_parents > 0) {  // parent_cids[0] (:171-174)
-            const uint32_t pb = witness_find(w, c.parents[0]);
+            const uint32_t pb = witness_find(w, tipset_parent(c, 0));
             if (pb == kNoBlock) {
                 status = IPCFP_ST_ERR_MISSING_BLOCK;
             } else {
@@ -128,7 +128,7 @@ __device__ __forceinline__ void exec_roots_body(const WitnessView& w, const Tips
     bool have_tx[1];
     {
         have_tx[0] = false;
-        const uint32_t hb = witness_find(w, ctx->parents[b]);
+        const uint32_t hb = witness_find(w, tipset_parent(*ctx, b));
         if (hb == kNoBlock) {
             if (lead) fail(b, IPCFP_ST_ERR_MISSING_BLOCK);
         } else {
@@ -191,8 +191,8 @@ __device__ __forceinline__ void exec_roots_body(const WitnessView& w, const Tips
                     if (verify_txmeta && !cid_equal(re, tx[0])) {
                         fail(seq, IPCFP_ST_ERR_TXMETA_MISMATCH);
                     } else {
-                        bls.root = lens[0] <= 40 ? r.key_at(o0, l0) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
-                        secp.root = lens[1] <= 40 ? r.key_at(o1, l1) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                        bls.root = r.key_any(o0, l0);
+                        secp.root = r.key_any(o1, l1);
                         bls.skip = secp.skip = 0;
                     }
                 }
@@ -221,6 +221,21 @@ __global__ __launch_bounds__(64) void k_tipset_prepare_general(WitnessView w, Pr
     if (!((jb.ctx->prologue_general >> slot) & 1ull)) return;
     if (slot < 2) ctx_headers_body(w, *jb.ctx, slot == 0, lds, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
     else if (jb.roots) exec_roots_body(w, jb.ctx, jb.roots, jb.err, 1, slot - 2, lds);
+}
+
+// The whole prologue of ONE context whose tipset key is wider than the inline form (TipsetCtxDev::parents_wide): workgroups
+// 0 / 1 the header facts (child header with the receipts root as the enumeration's extra spec, first parent header),
+// workgroup 2 + b parent block b's header → TxMeta → re-hash → message-AMT roots.  General reader throughout.
+__global__ __launch_bounds__(64) void k_tipset_prepare_wide(WitnessView w, PrepareJob jb) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kHeaderLds];
+    if (blockIdx.x < 2) ctx_headers_body(w, *jb.ctx, blockIdx.x == 0, lds, jb.roots ? jb.roots + 2u * jb.ctx->n_parents : nullptr);
+    else if (jb.roots) exec_roots_body(w, jb.ctx, jb.roots, jb.err, 1, blockIdx.x - 2u, lds);
+}
+
+int launch_tipset_prepare_wide(ipcfp_ctx* ctx, const WitnessView& w, const void* job, uint32_t n_parents) {
+    hipLaunchKernelGGL(k_tipset_prepare_wide, dim3(2u + n_parents), dim3(64), 0, ctx->stream, w, *static_cast<const PrepareJob*>(job));
+    IPCFP_HIP(ctx, hipGetLastError());
+    return IPCFP_OK;
 }
 
 void launch_tipset_prepare_lds(hipStream_t stream, const WitnessView& w, const PrepareJobs& jobs, uint32_t n_jobs,
@@ -256,12 +271,13 @@ int launch_ctx_headers(ipcfp_ctx* ctx, const WitnessView& w, TipsetCtxDev* ctxs_
 }
 
 int launch_exec_roots(ipcfp_ctx* ctx, const WitnessView& w, const TipsetCtxDev* ctx_d, AmtRootSpec* roots_d,
-                      unsigned long long* err_d, int verify_txmeta) {
+                      unsigned long long* err_d, int verify_txmeta, uint32_t n_parents) {
     const unsigned long long none = kNoEnumError;
     IPCFP_HIP(ctx, hipMemsetAsync(err_d, 0xff, 8, ctx->stream));  // kNoEnumError
     (void)none;
-    hipLaunchKernelGGL(k_exec_roots, dim3(IPCFP_MAX_PARENTS), dim3(64), 0, ctx->stream, w, ctx_d, roots_d, err_d,
-                       verify_txmeta);
+    // (one workgroup per parent block; the grid of the inline form is fixed so that the host need not know the count)
+    hipLaunchKernelGGL(k_exec_roots, dim3(n_parents > IPCFP_MAX_PARENTS ? n_parents : IPCFP_MAX_PARENTS), dim3(64), 0, ctx->stream, w, ctx_d,
+                       roots_d, err_d, verify_txmeta);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -222,8 +222,7 @@ __device__ __forceinline__ uint32_t amt_get(const WitnessView& w, const AmtRootI
         }
         if (height == 0) return IPCFP_ST_ERR_DECODE;  // link node at height 0
         if (sub64 >= nd.width || !nd.bit(uint32_t(sub64))) return IPCFP_ST_NOT_FOUND;
-        const CidKey key = nd.want_len <= 40 ? r.key_at(nd.want_off, nd.want_len)
-                                             : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+        const CidKey key = r.key_any(nd.want_off, nd.want_len);
         const uint32_t child = witness_find(w, key);
         if (child == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
         block = child;
@@ -342,8 +341,7 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
             loc = hit;
             return IPCFP_ST_TRUE;
         }
-        const CidKey ck = link_len <= 40 ? r.key_at(link_off, link_len)
-                                         : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+        const CidKey ck = r.key_any(link_off, link_len);
         block = witness_find(w, ck);
         if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
     }
@@ -394,7 +392,7 @@ __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const H
                 uint32_t o, l;
                 r.read_link(o, l);
                 if (!r.ok()) return kTablePunt;  // (cannot happen: the table validated it)
-                link = l <= 40 ? r.key_at(o, l) : CidKey{{~0ULL, ~0ULL, ~0ULL, ~0ULL, ~0ULL}};
+                link = r.key_any(o, l);
             } else {
                 // a bucket: `[[key, value]…]`, validated; find the key, skip the values
                 const uint64_t nkv = r.read_array();

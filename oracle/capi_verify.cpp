@@ -111,6 +111,22 @@ void* orc_store_create_mt(const uint8_t* bytes, const uint64_t* off, const uint3
     load_store(s->bs, bytes, off, len, cids40, n, threads);
     return s;
 }
+// The store keyed by CIDs of ANY length (the 40-byte slot tables above cannot name a CID with a 64-byte digest):
+// block i's CID is cid_bytes[cid_off[i] .. cid_off[i] + cid_len[i]).  `load_witness_store` takes whatever `Cid` the
+// bundle holds (src/proofs/events/verifier.rs:79-89, src/proofs/common/witness.rs:60-72).  The as-written baseline's
+// per-proof rebuild (mode 0) is not available on such a store.
+void* orc_store_create_var(const uint8_t* bytes, const uint64_t* off, const uint32_t* len, const uint8_t* cid_bytes,
+                           const uint64_t* cid_off, const uint32_t* cid_len, uint64_t n) {
+    auto* s = new Store();
+    s->bytes = bytes; s->off = off; s->len = len; s->cids40 = nullptr; s->n = 0;
+    s->bs.reshard(1);
+    s->bs.shards[0].reserve(size_t(n) * 2);
+    for (uint64_t i = 0; i < n; ++i) {
+        Cid c{Bytes(cid_bytes + cid_off[i], cid_bytes + cid_off[i] + cid_len[i])};
+        s->bs.put_keyed(c, bytes + off[i], len[i]);
+    }
+    return s;
+}
 void orc_store_destroy(void* s) { delete static_cast<Store*>(s); }
 uint64_t orc_store_size(void* s) { return static_cast<Store*>(s)->bs.size(); }
 int orc_num_procs(void) { return omp_get_num_procs(); }
@@ -241,11 +257,13 @@ void orc_verify_event_claims_packed(void* store, const ipcfp_tipset_ref_t* tipse
     };
     std::vector<Ts> ts(n_tipsets);
     for (uint32_t k = 0; k < n_tipsets; ++k) {
-        ts[k].ok = tipsets[k].flags == 3u && tipsets[k].n_parents <= IPCFP_MAX_PARENTS;
+        ts[k].ok = tipsets[k].flags == 3u && (tipsets[k].n_parents <= IPCFP_MAX_PARENTS || tipsets[k].more_parents != nullptr);
         if (!ts[k].ok) continue;
         std::vector<Cid> parents;
         for (uint32_t j = 0; j < tipsets[k].n_parents; ++j) {
-            const uint8_t* slot = tipsets[k].parents[j];
+            // (a tipset key wider than the inline form keeps its tail behind more_parents: include/ipcfp.h)
+            const uint8_t* slot = j < IPCFP_MAX_PARENTS ? tipsets[k].parents[j]
+                                                        : tipsets[k].more_parents + size_t(j - IPCFP_MAX_PARENTS) * IPCFP_CID_SLOT;
             parents.push_back(Cid{Bytes(slot, slot + cid_slot_len(slot))});
             ts[k].parents.push_back(cid_to_string(parents.back()));
         }

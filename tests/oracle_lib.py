@@ -37,6 +37,8 @@ class Oracle:
         lib.orc_cid_for_block.argtypes = [C.c_char_p, u64, vp]
         lib.orc_store_create.restype = vp
         lib.orc_store_create.argtypes = [vp, vp, vp, vp, u64]
+        lib.orc_store_create_var.restype = vp
+        lib.orc_store_create_var.argtypes = [vp, vp, vp, vp, vp, vp, u64]
         lib.orc_store_create_mt.restype = vp
         lib.orc_store_create_mt.argtypes = [vp, vp, vp, vp, u64, C.c_int]
         lib.orc_store_size.restype = u64
@@ -112,6 +114,11 @@ class Oracle:
         """threads=1: the reference's sequential load_witness_store; 0 = every processor (baseline B2 all-cores)"""
         return OracleStore(self, data, off, lens, cids40, threads)
 
+    def store_var(self, data, off, lens, cids):
+        """The store keyed by CIDs of ANY length (`cids`: list of bytes) — a CID with a 64-byte digest does not fit the
+        40-byte slots of `store`."""
+        return OracleStore(self, data, off, lens, None, var_cids=cids)
+
     def num_procs(self) -> int:
         return int(self.lib.orc_num_procs())
 
@@ -148,12 +155,21 @@ VALUE_KINDS = {"cid": 0, "receipt": 1, "stamped_event": 2, "actor_state": 3, "ve
 class OracleStore:
     """MemoryBlockstore over a witness table (keeps the arrays alive)."""
 
-    def __init__(self, orc: Oracle, data, off, lens, cids40, threads=1):
+    def __init__(self, orc: Oracle, data, off, lens, cids40, threads=1, var_cids=None):
         self.orc = orc
         self.lib = orc.lib
         self.data = np.ascontiguousarray(data, dtype=np.uint8)
         self.off = np.ascontiguousarray(off, dtype=np.uint64)
         self.lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        if var_cids is not None:
+            self.cid_len = np.array([len(c) for c in var_cids], dtype=np.uint32)
+            self.cid_off = np.zeros(len(var_cids), dtype=np.uint64)
+            if len(var_cids):
+                self.cid_off[1:] = np.cumsum(self.cid_len[:-1], dtype=np.uint64)
+            self.cid_bytes = np.frombuffer(b"".join(bytes(c) for c in var_cids) + b"\0", dtype=np.uint8).copy()
+            self.h = self.lib.orc_store_create_var(_p(self.data), _p(self.off), _p(self.lens), _p(self.cid_bytes), _p(self.cid_off),
+                                                   _p(self.cid_len), len(self.off))
+            return
         self.cids = np.ascontiguousarray(cids40, dtype=np.uint8).reshape(-1, 40)
         if threads == 1:
             self.h = self.lib.orc_store_create(_p(self.data), _p(self.off), _p(self.lens), _p(self.cids), len(self.off))
