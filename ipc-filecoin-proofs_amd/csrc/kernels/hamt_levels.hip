@@ -42,7 +42,12 @@ struct HamtLevels {
     // per level and let both parse instances walk all of it, each skipping the other's nodes: at the bucket level the small
     // instance read 29.5 k entries and lengths to find nothing, at the overflow level the big one did (≈ 60 µs of a 520 µs
     // call: profiles/r05_experiments.md).  The claimant knows the block, so it files it where its parser will look.
-    uint32_t* work[2][2];
+    // An entry is {block, length, arena offset}: whoever files a block knows it (the claimant has just probed the index for
+    // it) and reads its length for the size class anyway — so the parse's wavefront starts staging after ONE dependent read
+    // (its list entry) instead of three (entry → length / offset → bytes): a level's parse is a few thousand wavefronts whose
+    // time is that chain.
+    uint4* work[2][2];    // .x block, .y length, .z / .w arena offset (low / high word)
+    const uint32_t* plain;  // plain_list: the one list, block ids only
     uint32_t* count;      // entries of level l's lists: count[2 l + class] (two counters per level)
     uint32_t split;       // 1: lists by size class (the 32-lane parse of the state tree); 0: everything in class 0
     uint32_t plain_list;  // 1: ONE list work[0][0] / count[0] whatever the level and class (launch_hamt_outline_list)
@@ -73,8 +78,15 @@ __device__ __forceinline__ uint32_t witness_find_quiet(const WitnessView& w, con
 // same few words of the L2, and every appended block one more atomic on the level's ONE counter — so claims are thinned
 // out on the way: a workgroup-wide set in LDS lets one lane per distinct block through, and the lanes of a wavefront that
 // win their block append with one counter update between them.
+constexpr uint32_t kCoopBigStage = 6912, kCoopBigEntries = 96, kCoopSmallStage = 1536, kCoopSmallEntries = 24;
+__device__ __forceinline__ uint32_t hamt_size_class(const WitnessView& w, const HamtLevels& L, uint32_t block) {
+    return L.split && w.len[block] + 24u > kCoopSmallStage ? 1u : 0u;
+}
+__device__ __forceinline__ uint4 hamt_work_entry(const WitnessView& w, uint32_t block, uint32_t len) {
+    const uint64_t off = w.off[block];
+    return make_uint4(block, len, uint32_t(off), uint32_t(off >> 32));
+}
 constexpr uint32_t kClaimSet = 512;  // LDS slots per 256-thread workgroup (a power of two ≥ 2 × the workgroup)
-__device__ __forceinline__ uint32_t hamt_size_class(const WitnessView& w, const HamtLevels& L, uint32_t block);
 __device__ __forceinline__ void hamt_claim(const WitnessView& w, const HamtLevels& L, uint32_t block, uint32_t level, bool want, uint32_t* set) {
     for (uint32_t i = threadIdx.x; i < kClaimSet; i += blockDim.x) set[i] = kNoBlock;
     __syncthreads();
@@ -98,7 +110,8 @@ __device__ __forceinline__ void hamt_claim(const WitnessView& w, const HamtLevel
         // (a stale miss of the plain look only costs the atomic)
         won = !(__builtin_nontemporal_load(word) & bit) && !(atomicOr(word, bit) & bit);
     }
-    const uint32_t cls = won ? hamt_size_class(w, L, block) : 0u;
+    const uint32_t blen = won ? w.len[block] : 0u;
+    const uint32_t cls = won && L.split && blen + 24u > kCoopSmallStage ? 1u : 0u;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (uint32_t c = 0; c < 2u; ++c) {  // (one counter update per wavefront and class)
@@ -108,7 +121,7 @@ __device__ __forceinline__ void hamt_claim(const WitnessView& w, const HamtLevel
         uint32_t base = 0;
         if (lane == leader) base = atomicAdd(L.count + 2u * level + c, uint32_t(__popcll(winners)));
         base = __shfl(base, leader, 64);
-        if (won && cls == c) L.work[level & 1u][c][base + uint32_t(__popcll(winners & ((1ull << lane) - 1ull)))] = block;
+        if (won && cls == c) L.work[level & 1u][c][base + uint32_t(__popcll(winners & ((1ull << lane) - 1ull)))] = hamt_work_entry(w, block, blen);
     }
 }
 
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey roo
     status[t] = uint8_t(rb == kNoBlock ? uint32_t(IPCFP_ST_ERR_MISSING_BLOCK) : kStPending);
     if (loc) loc[t] = ValueLoc{kNoBlock, 0, 0};
     if (t == 0 && rb != kNoBlock) {
-        L.work[0][hamt_size_class(w, L, rb)][0] = rb;
+        L.work[0][hamt_size_class(w, L, rb)][0] = hamt_work_entry(w, rb, w.len[rb]);
         L.recs[rb].status = 0;  // (until a parse of THIS call says otherwise: the fused top launches one instance only)
     }
 }
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey roo
 __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_lv_parse(WitnessView w, HamtLevels L, uint32_t level, int vkind) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.count[2u * level]) return;
-    const uint32_t block = L.work[level & 1u][0][i];
+    const uint32_t block = L.work[level & 1u][0][i].x;
     HamtNodeRec* out = L.recs + block;
     Rd r = open_block(w, block);
     uint32_t status = 0, std_links = 0, np32 = 0;
@@ -226,11 +239,8 @@ constexpr uint32_t kCoopLanes = 32, kCoopNodes = 2, kCoopParallelMin = 2048, kCo
 // so that a CU keeps 32 of them resident instead of 9: such a wavefront's time is three dependent random reads (work list →
 // length / offset → the node) and what hides them is the number of wavefronts in flight — everything else to the one with
 // the 6.9 KB stage.  Each skips the other's nodes.
-constexpr uint32_t kCoopBigStage = 6912, kCoopBigEntries = 96, kCoopSmallStage = 1536, kCoopSmallEntries = 24;
+// (kCoopBigStage / kCoopBigEntries / kCoopSmallStage / kCoopSmallEntries: defined above hamt_claim, which files by them)
 
-__device__ __forceinline__ uint32_t hamt_size_class(const WitnessView& w, const HamtLevels& L, uint32_t block) {
-    return L.split && w.len[block] + 24u > kCoopSmallStage ? 1u : 0u;
-}
 
 // the 8 bytes at S[p, p + 8) as a little-endian word (one aligned two-word LDS read)
 __device__ __forceinline__ uint64_t lds_peek64(const uint8_t* S, uint32_t p) {
@@ -319,7 +329,7 @@ __device__ __forceinline__ bool lds_address_ok(const uint8_t* S, uint32_t off, u
 // 32 blocks) out of every top level.  A record is a pure function of its block: parsing a node no query visits changes nothing.
 template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL>
 __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, const HamtLevels& L, uint32_t level, uint32_t pair,
-                                                      uint32_t n_list, uint32_t emit_children) {
+                                                      uint32_t n_list, uint32_t emit_children, uint32_t slot_base) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kCoopNodes][kCoopStage];
     __shared__ uint16_t s_ptr[kCoopNodes][kHamtTablePointers];   // pointer starts
     __shared__ uint16_t s_val[kCoopNodes][kCoopMaxEntries];      // per bucket entry: where its ActorState (0x85) starts
@@ -334,14 +344,22 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     const uint32_t i = pair * kCoopNodes + g;
     const uint32_t cls = L.plain_list || SMALL ? 0u : 1u;
     const bool listed = i < n_list;
-    const uint32_t block = listed ? L.work[L.plain_list ? 0u : (level & 1u)][cls][i] : 0u;
-    const uint32_t len = listed ? w.len[block] : 0u;
+    uint4 we = make_uint4(0, 0, 0, 0);
+    if (listed) {
+        if (L.plain_list) {
+            const uint32_t b = L.plain[i];
+            we = hamt_work_entry(w, b, w.len[b]);
+        } else {
+            we = L.work[level & 1u][cls][i];
+        }
+    }
+    const uint32_t block = we.x, len = we.y;
     // (a split list holds this instance's nodes only; an unsplit one — the outline over a plain list — is the big instance's)
     const bool have = listed && (L.split ? true : (len + 24u <= kCoopSmallStage) == SMALL);
     const bool staged = have && len >= 3u && len + 24u <= kCoopStage;
     uint8_t* S = stage[g];
     if (staged) {
-        const uint4* src = reinterpret_cast<const uint4*>(w.arena + w.off[block]);  // line-aligned, padded to a line
+        const uint4* src = reinterpret_cast<const uint4*>(w.arena + (uint64_t(we.z) | (uint64_t(we.w) << 32)));  // line-aligned, padded to a line
         uint4* dst = reinterpret_cast<uint4*>(S);
         const uint32_t chunks = (len + 15u) >> 4;
         for (uint32_t c = sub; c < chunks; c += kCoopLanes) dst[c] = src[c];
@@ -519,9 +537,10 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
         // 270 µs where the level's parse takes 70 (profiles/r04_experiments.md).
         uint32_t slot = 0;
         if (node_ok && s_ne[g] != 0u) {
-            uint32_t base = 0;  // (the lists of the earlier levels, both classes; this level's class 0 in front of its class 1)
-            for (uint32_t l = 0; l < 2u * level + cls; ++l) base += L.count[l];
-            slot = base + i < L.etab_cap ? base + i + 1u : 0u;
+            // (`slot_base`: the lists of the earlier levels, both classes, and this level's class 0 in front of its class 1 —
+            // summed once per workgroup, by all lanes at once, while the node is being staged: as a loop of dependent
+            // reads by lane 0 here it stood in every wavefront's critical path)
+            slot = slot_base + i < L.etab_cap ? slot_base + i + 1u : 0u;
         }
         s_slot[g] = slot;
         L.etab_of[block] = slot;
@@ -572,7 +591,8 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     }
     if (emit_children) {  // (uniform over the launch; the lanes that are still here vote)
         const bool em = resolve && c != kNoBlock;
-        const uint32_t ccls = em ? hamt_size_class(w, L, c) : 0u;
+        const uint32_t clen = em ? w.len[c] : 0u;
+        const uint32_t ccls = em && L.split && clen + 24u > kCoopSmallStage ? 1u : 0u;
         // a child the fused top's parse (the small-stage instance alone) will not take must not keep a record of another call
         if (em && ccls == 1u) L.recs[c].status = 0;
 #pragma unroll
@@ -585,7 +605,7 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
             base = __shfl(base, leader, 64);
             if (em && ccls == k) {
                 const uint32_t at = base + uint32_t(__popcll(votes & ((1ull << lane) - 1ull)));
-                if (at < L.cap) L.work[(level + 1u) & 1u][k][at] = c;
+                if (at < L.cap) L.work[(level + 1u) & 1u][k][at] = hamt_work_entry(w, c, clen);
                 else *L.top_overflow = 1u;
             }
         }
@@ -607,8 +627,15 @@ template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL>
 __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level, uint32_t emit_children) {
     const uint32_t n_raw = L.count[L.plain_list ? 0u : 2u * level + (SMALL ? 0u : 1u)];
     const uint32_t n_list = !L.plain_list && n_raw > L.cap ? L.cap : n_raw;
+    uint32_t slot_base = 0;
+    if (L.etab_of && !L.plain_list) {  // lane l: the count of list l in front of this one (2 · levels + 1 < 64 lists)
+        const uint32_t before = 2u * level + (SMALL ? 0u : 1u);
+        slot_base = threadIdx.x < before ? L.count[threadIdx.x] : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) slot_base += __shfl_xor(slot_base, d, 64);
+    }
     for (uint32_t pair = blockIdx.x; pair * kCoopNodes < n_list; pair += gridDim.x) {
-        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, SMALL>(w, L, level, pair, n_list, emit_children);
+        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, SMALL>(w, L, level, pair, n_list, emit_children, slot_base);
         __syncthreads();  // (the pair's LDS is the next pair's)
     }
 }
@@ -626,7 +653,10 @@ __device__ __forceinline__ void hamt_advance_step(const WitnessView& w, const Ha
     next = kNoBlock;
     via_child = false;
     do {
-        const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);  // status | kinds_ok << 8 | np << 16
+        // status | kinds_ok << 8 | np << 16 | pad << 24, std_links, bitfield: the record's first 16 bytes in ONE read (three
+        // reads at three points of the control flow were three round trips of the query's chain)
+        const uint4 rec_head = *reinterpret_cast<const uint4*>(rec);
+        const uint32_t head = rec_head.x;
         if ((head & 0xffu) != 1u) break;  // not tabulated: the walker decides (from the root)
         const uint32_t np = (head >> 16) & 0xffu;
         const uint32_t consumed = level * bit_width;
@@ -638,7 +668,7 @@ __device__ __forceinline__ void hamt_advance_step(const WitnessView& w, const Ha
         const uint4 h0 = hp[0], h1 = hp[1];
         const uint32_t h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         const uint32_t idx = sha256::take_bits(h, consumed, bit_width);
-        const uint64_t bf = rec->bitfield;
+        const uint64_t bf = uint64_t(rec_head.z) | (uint64_t(rec_head.w) << 32);
         if (idx >= 64u || !((bf >> idx) & 1ull)) {
             st = IPCFP_ST_NOT_FOUND;
             break;
@@ -681,14 +711,14 @@ __device__ __forceinline__ void hamt_advance_step(const WitnessView& w, const Ha
         const uint32_t off = rec->ptr_off[rank];
         CidKey link;
         bool is_link = true;
-        if (((rec->std_links >> rank) & 1u) && (head & (1u << 24))) {  // resolved by the parse: one word
+        if (((rec_head.y >> rank) & 1u) && (head & (1u << 24))) {  // resolved by the parse: one word
             next = L.child[size_t(block) * kHamtTablePointers + rank];
             via_child = true;
             if (next == kNoBlock) st = IPCFP_ST_ERR_MISSING_BLOCK;
             else if (w.touched) atomicOr(&w.touched[next >> 5], 1u << (next & 31));  // (what witness_find records)
             break;
         }
-        if ((rec->std_links >> rank) & 1u) {
+        if ((rec_head.y >> rank) & 1u) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) __builtin_memcpy(&link.w[j], g + off + 5 + 8 * j, 8);  // unaligned 8-byte loads
             link.w[4] &= (1ull << 48) - 1ull;
@@ -799,10 +829,10 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance_top(WitnessView w, Hamt
     }
 }
 
-// Scratch of one call: [cur n | hash 8n | 4 work lists of cap | count 2 (levels + 2) | claimed words | 8 spare] u32 + child table + etab_of.
+// Scratch of one call: [cur n | hash 8n | 4 work lists of cap 16-byte entries | count 2 (levels + 2) | claimed words | 8 spare] u32 + child table + etab_of.
 size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels) {
     const size_t cap = n < n_blocks ? n : n_blocks;
-    return size_t(n) * 9 + cap * 4 + 2 * size_t(levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
+    return size_t(n) * 9 + 4 + cap * 16 + 2 * size_t(levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
 }
 
 // The 32-lane outline over ANY list of blocks (not a level of a walk): every block of `work_d[0 .. *count_d)` whose length
@@ -815,12 +845,12 @@ int launch_hamt_outline_list(ipcfp_ctx* ctx, hipStream_t stream, const WitnessVi
     if (bound == 0) return IPCFP_OK;
     HamtLevels L{};
     L.recs = static_cast<HamtNodeRec*>(recs_d);
-    L.work[0][0] = work_d;
+    L.plain = work_d;
     L.count = count_d;
     L.plain_list = 1u;
     L.cap = bound;
     static_assert(kHamtOutlineMinLen + 24u > kCoopSmallStage, "every listed block is the big-stage instance's");
-    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(std::min(div_up(bound, kCoopNodes), 4096u)), dim3(64), 0,
+    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(std::min(div_up(bound, kCoopNodes), 32768u)), dim3(64), 0,
                        stream, w, L, 0u, 0u);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
@@ -837,11 +867,11 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     HamtLevels L{};
     L.cur = scratch_d;
     L.hash = scratch_d + size_t(n);
-    L.work[0][0] = scratch_d + size_t(n) * 9;
+    L.work[0][0] = reinterpret_cast<uint4*>(scratch_d + ((size_t(n) * 9 + 3) & ~size_t(3)));  // (16-byte entries: scratch_d is hipMalloc'd)
     L.work[0][1] = L.work[0][0] + cap;
     L.work[1][0] = L.work[0][1] + cap;
     L.work[1][1] = L.work[1][0] + cap;
-    L.count = L.work[1][1] + cap;
+    L.count = reinterpret_cast<uint32_t*>(L.work[1][1] + cap);
     L.claimed = L.count + 2 * (levels + 2);
     L.split = actor ? 1u : 0u;
     L.cap = cap;
@@ -873,7 +903,11 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
         uint64_t fan = 1;  // level l holds at most min(n, 2^(bit_width · l)) distinct nodes
         for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
         const uint32_t bound = fan < cap ? uint32_t(fan) : cap;
-        return std::min(div_up(bound, kCoopNodes), 256u * per_cu);  // (what the chip holds; the kernel strides)
+        (void)per_cu;
+        // One workgroup per pair up to a cap the loop covers: the dispatcher backfills workgroups as they retire and so
+        // balances nodes of unequal length; a grid of "what the chip holds" striding over the list was 255 µs for the
+        // bucket level against 173 (profiles/r06_experiments.md).  An empty list is one word read per workgroup.
+        return std::min(div_up(bound, kCoopNodes), 32768u);
     };
     for (uint32_t lv = 0; lv < top; ++lv)
         hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(parse_grid(lv, 32)), dim3(64), 0, ctx->stream, w,
@@ -881,8 +915,20 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     if (top)
         hipLaunchKernelGGL(k_hamt_lv_advance_top, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, L, top, bit_width, vkind, keys_d, key_off_d,
                            key_len_d, n, status_d, loc);
+    // Below the fused top the SHORT nodes (the overflow nodes under full buckets) keep the 32-lane form, two nodes per
+    // wavefront.  IPCFP_HAMT_SMALL_LANE=1 (A/B): one lane each with the line-staged reader (hamt_table_lane.hip) — measured
+    // and off: 182 µs for the overflow level against ≈ 100, and its nodes have no entry table, so the advance behind it
+    // walks the bucket with the reader (42 µs against 12): profiles/r06_experiments.md.
+    static const bool small_lane = [] { const char* e = std::getenv("IPCFP_HAMT_SMALL_LANE"); return e && std::atoi(e) == 1; }();
     for (uint32_t lv = top; lv < levels; ++lv) {
         if (actor) {
+            if (small_lane && lv >= top && top > 0) {
+                uint64_t fan = 1;
+                for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
+                const int rc = launch_hamt_lv_parse_lane(ctx, w, L.work[lv & 1u][0], L.count + 2u * lv, cap, fan < cap ? uint32_t(fan) : cap,
+                                                         HK_ACTOR_STATE, recs_d, L.etab_of);
+                if (rc) return rc;
+            } else
             hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(parse_grid(lv, 32)), dim3(64), 0,
                                ctx->stream, w, L, lv, 0u);
             hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(parse_grid(lv, 10)), dim3(64), 0,

@@ -48,6 +48,9 @@ int launch_hamt_get(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, ui
                     uint8_t* status_d, void* loc_d, int pending_only = 0);
 // --- hamt_levels.hip --- K7 level by level: every visited node decoded once; what it leaves kStPending is the walker's
 size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels);
+// one lane per SHORT node of a level's work list (hamt_table_lane.hip; list entries {block, length, offset lo, offset hi})
+int launch_hamt_lv_parse_lane(ipcfp_ctx* ctx, const WitnessView& w, const void* list_d, const uint32_t* count_d, uint32_t cap, uint32_t bound,
+                              uint32_t kind_bit, void* recs_d, uint32_t* etab_of_d);
 int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& root, uint32_t bit_width, int vkind,
                            const uint8_t* keys_d, const uint32_t* key_off_d, const uint32_t* key_len_d, uint32_t n,
                            uint8_t* status_d, void* loc_d, uint32_t levels, uint32_t* scratch_d, void* recs_d, bool coop = true,
