@@ -972,7 +972,21 @@ def shard_projection(args, eng, torch, dev, tip, ts, cl, blob, blob_len, w_full,
             if not np.array_equal(status, status_full) or not np.array_equal(has, has_full):
                 raise SystemExit("bench self-check failed: the merged verdicts of %d shards differ from the unsharded run" % G)
             t3_max, t2_max = max(p["T3_ms_per_step"] for p in per), max(p["T2_ms"] for p in per)
+            # The same T2 under the OTHER host ceiling: G ranks reading one host's memory at the rate that host measurably
+            # delivers (`host_memory_read_GBps`: CPU threads under the container's quota — a lower bound of its DMA paths)
+            # instead of every link at the rate one link reaches alone.  Neither is measured with G links at once.
+            host_gbps = max(out["host_memory_read_GBps"].values())
+            t2_host = 0.0
+            for p in per:
+                link_ms = p["pull"]["tables_ms"] + p["pull"]["pull_ms"]
+                shared_ms = G * (p["pull"]["table_bytes"] + p["pull"]["block_bytes"]) / (host_gbps * 1e9) * 1e3
+                t2_host = max(t2_host, p["T2_ms"] - link_ms + max(link_ms, shared_ms))
+            replicated = int(per[0]["pull"]["table_bytes"] + tip.stats["message_amt_bytes"])
             out["shards"][str(G)] = {
+                "T2_ms_if_host_memory_bound": round(t2_host, 3),
+                "projected_speedup_T2_if_host_memory_bound": round(t2_ms_1 / t2_host, 3) if t2_ms_1 else None,
+                "host_GBps_assumed": host_gbps,
+                "pcie_bytes_identical_on_every_rank": replicated,  # the bundle's tables + the message AMTs (the execution order is global)
                 "allgather_bytes_per_rank": layout.bytes_per_rank,
                 "T3_ms_max_over_shards": t3_max, "T2_ms_max_over_shards": t2_max,
                 "projected_speedup_T3": round(t3_ms_1 / t3_max, 3), "projected_speedup_T2": round(t2_ms_1 / t2_max, 3) if t2_ms_1 else None,
@@ -991,8 +1005,10 @@ def shard_projection(args, eng, torch, dev, tip, ts, cl, blob, blob_len, w_full,
                    "all-gather of `allgather_bytes_per_rank` per rank (latency-bound; not measurable on one GPU).  The projection "
                    "assumes each rank's PCIe link reads host memory at the rate one link does alone: G x 50 GB/s of host DRAM reads "
                    "(`host_memory_read_GBps` is what the host's memory system delivers to CPU threads under the quota — a lower "
-                   "bound of what its DMA paths can).  T3 divides only as far as the replicated execution order lets it: five "
-                   "parents' message AMTs are walked on every rank.")
+                   "bound of what its DMA paths can); `T2_ms_if_host_memory_bound` is the same T2 with the G pulls sharing THAT rate "
+                   "instead.  `pcie_bytes_identical_on_every_rank` (tables + message AMTs) cross PCIe G times in this flow; pulling 1/G "
+                   "each and all-gathering the blocks over xGMI is costed in DESIGN.md §13, not built.  T3 divides only as far as the "
+                   "replicated execution order lets it: five parents' message AMTs are walked on every rank.")
     return out
 
 

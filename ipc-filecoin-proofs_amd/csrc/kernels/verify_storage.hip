@@ -204,32 +204,6 @@ __global__ __launch_bounds__(256) void k_storage_run_actors_table(WitnessView w,
     runs[i].actor_state = actor_state;
 }
 
-// left_pad_32 (src/proofs/common/evm.rs:91-100) of a serde Vec<u8> (a CBOR array of u8, type-checked by the table) as four
-// little-endian words: byte i of the padded value = word i/8, bits 8·(i%8)…
-__device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
-    out[0] = out[1] = out[2] = out[3] = 0;
-    const uint64_t n = v.read_array();
-    auto put = [&](uint64_t i, uint32_t x) {
-        if (n >= 32 && i < n - 32) return;
-        const uint32_t j = n >= 32 ? uint32_t(i - (n - 32)) : uint32_t(32 - n + i);
-        const uint64_t b = uint64_t(x & 0xffu) << (8u * (j & 7u));
-        const uint32_t k = j >> 3;
-        out[0] |= k == 0 ? b : 0ull;
-        out[1] |= k == 1 ? b : 0ull;
-        out[2] |= k == 2 ? b : 0ull;
-        out[3] |= k == 3 ? b : 0ull;
-    };
-    uint64_t i = 0;
-    while (i < n && v.ok() && v.pos + 8u <= v.n) {  // eight bytes per fetch (cbor_dev.h vec_u8_step)
-        const uint64_t w = v.peek64(v.pos);
-        uint32_t used = 0, x;
-        while (i < n && vec_u8_step(w, used, x)) put(i++, x);
-        v.pos += used;
-        if (i < n && used <= 6u) put(i++, uint32_t(v.read_uint()));
-    }
-    for (; i < n && v.ok(); ++i) put(i, uint32_t(v.read_uint()));
-}
-
 // verify_storage_proof, steps 2-6 in the reference's order of checks (src/proofs/storage/verifier.rs:24-63), one claim per
 // lane: everything its run shares comes from the run's record, `read_storage_slot`'s HAMT get (storage/decode.rs:79-96)
 // walks the node table.  A claim it cannot settle (an inline small-map layout, a block the table does not cover) is left
@@ -295,14 +269,11 @@ __global__ __launch_bounds__(256) void k_verify_storage_table(WitnessView w, con
         if (run.root_kind != 3) break;  // an inline small map (A1-A3): the one-lane kernel searches it
         uint64_t padded[4] = {0, 0, 0, 0};
         ValueLoc loc;
-        const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, slot, 32, loc);  // decode.rs:79-96
+        // (the value of the entry that matches is padded where the bucket search stands on it: one pass over its elements
+        // instead of a typed skip there and a second walk here)
+        const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, slot, 32, loc, padded);  // decode.rs:79-96
         if (hs == kTablePunt) break;
-        if (hs != IPCFP_ST_NOT_FOUND) {  // unwrap_or_default(): a missing key means zero
-            if (hs != IPCFP_ST_TRUE) { st = hs; break; }
-            Rd v;
-            v.init(w.arena + w.off[loc.block] + loc.off, loc.len);
-            left_pad_32_words(v, padded);
-        }
+        if (hs != IPCFP_ST_NOT_FOUND && hs != IPCFP_ST_TRUE) { st = hs; break; }  // (NOT_FOUND: unwrap_or_default() — zero)
         if (!(flags & SC_VALUE_MATCHABLE)) { st = IPCFP_ST_FALSE_VALUE; break; }  // can never equal "0x" + 64 hex digits
         const uint64_t diff = (padded[0] ^ cv[0]) | (padded[1] ^ cv[1]) | (padded[2] ^ cv[2]) | (padded[3] ^ cv[3]);
         st = diff == 0 ? IPCFP_ST_TRUE : IPCFP_ST_FALSE_VALUE;                                            // :169
