@@ -19,7 +19,6 @@ using namespace ipcfp;
 namespace ipcfp {
 
 CidKey key_from_slot(const uint8_t* slot40);
-int launch_storage_run_matches(ipcfp_ctx* ctx, const void* claims_d, void* runs_d, uint32_t n_runs);  // kernels/verify_storage.hip
 
 // Parse a CID string into a witness key.  `parsed`: Cid::try_from succeeded.  `canonical`: the
 // string equals Cid::to_string() of what it parses to.  A CID longer than the 40-byte slot becomes its fold
@@ -116,8 +115,6 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     rc = launch_storage_run_actors_table(ctx, w, table.p, claims_d, runs.p, uint32_t(n_runs), kUndecided);
     if (rc) return rc;
     rc = launch_storage_run_actors_lane(ctx, w, claims_d, runs.p, uint32_t(n_runs), kUndecided);
-    if (rc) return rc;
-    rc = launch_storage_run_matches(ctx, claims_d, runs.p, uint32_t(n_runs));
     if (rc) return rc;
     rc = launch_verify_storage_table(ctx, w, table.p, claims_d, n, run_of.p, runs.p, trust, kUndecided, status_d);
     if (rc) return rc;

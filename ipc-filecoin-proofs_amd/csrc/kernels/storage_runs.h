@@ -28,14 +28,7 @@ struct StorageRun {
     CidKey contract_state;       // EvmState.contract_state
     CidKey hamt_root;
     uint32_t hamt_bw;
-    // What the run's claims ask about its CIDs, answered ONCE for the run (its claims agree on the three CIDs by definition):
-    // SRM_STATE_ROOT  child_hdr.parent_state_root == the claimed parent_state_root   (storage/verifier.rs:110)
-    // SRM_ACTOR_STATE ActorState.state == the claimed actor_state_cid               (:126)
-    // SRM_STORAGE_ROOT EvmState.contract_state == the claimed storage_root          (:144)
-    // so that a claim's lane reads its own flags, epoch, slot and value — 76 of the record's 248 bytes — and none of the
-    // four 40-byte CIDs (k_storage_run_matches; round 5 compared them per claim: 2.57 M × three strided 40-byte reads).
-    uint32_t match;
+    uint32_t pad;
 };
-enum : uint32_t { SRM_STATE_ROOT = 1u, SRM_ACTOR_STATE = 2u, SRM_STORAGE_ROOT = 4u };
 
 }  // namespace ipcfp

@@ -8,8 +8,6 @@
 // which line decided.
 #include <hip/hip_runtime.h>
 
-#include <cstddef>
-
 #include <cstdlib>
 
 #include "../common.h"
@@ -204,77 +202,77 @@ __global__ __launch_bounds__(256) void k_storage_run_actors_table(WitnessView w,
     runs[i].actor_state = actor_state;
 }
 
+// left_pad_32 (src/proofs/common/evm.rs:91-100) of a serde Vec<u8> (a CBOR array of u8, type-checked by the table) as four
+// little-endian words: byte i of the padded value = word i/8, bits 8·(i%8)…
+__device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    const uint64_t n = v.read_array();
+    auto put = [&](uint64_t i, uint32_t x) {
+        if (n >= 32 && i < n - 32) return;
+        const uint32_t j = n >= 32 ? uint32_t(i - (n - 32)) : uint32_t(32 - n + i);
+        const uint64_t b = uint64_t(x & 0xffu) << (8u * (j & 7u));
+        const uint32_t k = j >> 3;
+        out[0] |= k == 0 ? b : 0ull;
+        out[1] |= k == 1 ? b : 0ull;
+        out[2] |= k == 2 ? b : 0ull;
+        out[3] |= k == 3 ? b : 0ull;
+    };
+    uint64_t i = 0;
+    while (i < n && v.ok() && v.pos + 8u <= v.n) {  // eight bytes per fetch (cbor_dev.h vec_u8_step)
+        const uint64_t w = v.peek64(v.pos);
+        uint32_t used = 0, x;
+        while (i < n && vec_u8_step(w, used, x)) put(i++, x);
+        v.pos += used;
+        if (i < n && used <= 6u) put(i++, uint32_t(v.read_uint()));
+    }
+    for (; i < n && v.ok(); ++i) put(i, uint32_t(v.read_uint()));
+}
+
 // verify_storage_proof, steps 2-6 in the reference's order of checks (src/proofs/storage/verifier.rs:24-63), one claim per
 // lane: everything its run shares comes from the run's record, `read_storage_slot`'s HAMT get (storage/decode.rs:79-96)
 // walks the node table.  A claim it cannot settle (an inline small-map layout, a block the table does not cover) is left
 // kStPending for k_verify_storage.
-// the three CID comparisons of a run, once per run (storage_runs.h StorageRun::match): after every run-level kernel
-__global__ __launch_bounds__(256) void k_storage_run_matches(const StorageClaimPacked* __restrict__ claims, StorageRun* __restrict__ runs,
-                                                             uint32_t n_runs) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_runs) return;
-    const StorageRun& run = runs[i];
-    const StorageClaimPacked& c = claims[run.first_claim];
-    uint32_t m = 0;
-    if (cid_equal(run.parent_state_root, c.state_root)) m |= SRM_STATE_ROOT;
-    if (cid_equal(run.actor_state, c.actor_state)) m |= SRM_ACTOR_STATE;
-    if (cid_equal(run.contract_state, c.storage_root)) m |= SRM_STORAGE_ROOT;
-    runs[i].match = m;
-}
-
 __global__ __launch_bounds__(256) void k_verify_storage_table(WitnessView w, const HamtNodeRec* __restrict__ table,
                                                               const StorageClaimPacked* __restrict__ claims, uint32_t n,
                                                               const uint32_t* __restrict__ run_of, const StorageRun* __restrict__ runs,
                                                               ipcfp_trust_policy_t trust, uint32_t undecided, uint8_t* __restrict__ status) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    // A claim's lane reads what is ITS OWN — flags, epoch, slot, value: ten 8-byte words of the 248-byte record — up front and
-    // side by side; the CIDs are the run's business (run.match).  Round 5 read the record field by field where the checks
-    // wanted it, the slot byte by byte for SHA-256 and again per bucket entry: ≈ 30 strided loads of 64 lines each per
-    // wavefront, 0.99 ms for 2.57 M claims (profiles/r05_storage_kernel_stats.txt).
-    const uint64_t* cw = reinterpret_cast<const uint64_t*>(claims + t);  // (the record is 31 words; 8-byte aligned)
-    const long long child_epoch = (long long)cw[0];
-    uint64_t sk[4], cv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sk[i] = cw[22 + i];  // slot  at byte 176
-        cv[i] = cw[26 + i];  // value at byte 208
-    }
-    const uint32_t flags = uint32_t(cw[30]);  // flags at byte 240
-    static_assert(offsetof(StorageClaimPacked, slot) == 176 && offsetof(StorageClaimPacked, value) == 208 &&
-                      offsetof(StorageClaimPacked, flags) == 240 && offsetof(StorageClaimPacked, child_epoch) == 0, "claim layout");
-    uint8_t slot[32];
-    __builtin_memcpy(slot, sk, 32);
+    const StorageClaimPacked& c = claims[t];
     const StorageRun& run = runs[run_of[t]];
-    const uint32_t match = run.match;
+    const uint32_t flags = c.flags;
     uint32_t st = kStPending;
     do {
         // Step 2: verify_trust_anchor (storage/verifier.rs:81-92)
         if (!(flags & SC_CHILD_PARSED)) { st = IPCFP_ST_ERR_BAD_CLAIM; break; }                           // :85
-        if (!trusted(trust, child_epoch)) { st = IPCFP_ST_FALSE_UNTRUSTED_CHILD; break; }                 // :87
+        if (!trusted(trust, c.child_epoch)) { st = IPCFP_ST_FALSE_UNTRUSTED_CHILD; break; }               // :87
         // Step 3: verify_parent_state_root (:95-111)
         if (run.hdr_status != IPCFP_ST_TRUE) { st = run.hdr_status; break; }                              // :101-107
-        if (!((flags & SC_STATE_ROOT_CANON) && (match & SRM_STATE_ROOT))) { st = IPCFP_ST_FALSE_STATE_ROOT; break; }  // :110
+        if (!((flags & SC_STATE_ROOT_CANON) && cid_equal(run.parent_state_root, c.state_root))) { st = IPCFP_ST_FALSE_STATE_ROOT; break; }  // :110
         // Step 4: verify_actor_state (:114-127)
         if (run.sr_status != IPCFP_ST_TRUE) { st = run.sr_status; break; }                                // decode.rs:23-26
         if (run.actor_status == undecided) break;                                                         // (pending)
         if (run.actor_status != IPCFP_ST_TRUE) { st = run.actor_status; break; }                          // :122
-        if (!((flags & SC_ACTOR_STATE_CANON) && (match & SRM_ACTOR_STATE))) { st = IPCFP_ST_FALSE_ACTOR_STATE; break; }  // :126
+        if (!((flags & SC_ACTOR_STATE_CANON) && cid_equal(run.actor_state, c.actor_state))) { st = IPCFP_ST_FALSE_ACTOR_STATE; break; }  // :126
         // Step 5: verify_storage_root (:130-145)
         if (run.evm_status != IPCFP_ST_TRUE) { st = run.evm_status; break; }                              // :136-141
-        if (!((flags & SC_STORAGE_ROOT_CANON) && (match & SRM_STORAGE_ROOT))) { st = IPCFP_ST_FALSE_STORAGE_ROOT; break; }  // :144
+        if (!((flags & SC_STORAGE_ROOT_CANON) && cid_equal(run.contract_state, c.storage_root))) { st = IPCFP_ST_FALSE_STORAGE_ROOT; break; }  // :144
         // Step 6: verify_storage_value (:148-170)
         if (!(flags & SC_SLOT_PARSED)) { st = IPCFP_ST_ERR_BAD_CLAIM; break; }                            // :155-157
         if (run.root_kind == 4) { st = IPCFP_ST_ERR_MISSING_BLOCK; break; }                               // decode.rs:41-43
         if (run.root_kind != 3) break;  // an inline small map (A1-A3): the one-lane kernel searches it
         uint64_t padded[4] = {0, 0, 0, 0};
         ValueLoc loc;
-        // (the value of the entry that matches is padded where the bucket search stands on it: one pass over its elements
-        // instead of a typed skip there and a second walk here)
-        const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, slot, 32, loc, padded);  // decode.rs:79-96
+        const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, c.slot, 32, loc);  // decode.rs:79-96
         if (hs == kTablePunt) break;
-        if (hs != IPCFP_ST_NOT_FOUND && hs != IPCFP_ST_TRUE) { st = hs; break; }  // (NOT_FOUND: unwrap_or_default() — zero)
+        if (hs != IPCFP_ST_NOT_FOUND) {  // unwrap_or_default(): a missing key means zero
+            if (hs != IPCFP_ST_TRUE) { st = hs; break; }
+            Rd v;
+            v.init(w.arena + w.off[loc.block] + loc.off, loc.len);
+            left_pad_32_words(v, padded);
+        }
         if (!(flags & SC_VALUE_MATCHABLE)) { st = IPCFP_ST_FALSE_VALUE; break; }  // can never equal "0x" + 64 hex digits
+        const uint64_t* cv = reinterpret_cast<const uint64_t*>(c.value);
         const uint64_t diff = (padded[0] ^ cv[0]) | (padded[1] ^ cv[1]) | (padded[2] ^ cv[2]) | (padded[3] ^ cv[3]);
         st = diff == 0 ? IPCFP_ST_TRUE : IPCFP_ST_FALSE_VALUE;                                            // :169
     } while (false);
@@ -287,13 +285,6 @@ int launch_storage_run_actors_table(ipcfp_ctx* ctx, const WitnessView& w, const 
     hipLaunchKernelGGL(k_storage_run_actors_table, dim3(div_up(n_runs, 256)), dim3(256), 0, ctx->stream, w,
                        static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageClaimPacked*>(claims_d),
                        static_cast<StorageRun*>(runs_d), n_runs, undecided);
-    IPCFP_HIP(ctx, hipGetLastError());
-    return IPCFP_OK;
-}
-int launch_storage_run_matches(ipcfp_ctx* ctx, const void* claims_d, void* runs_d, uint32_t n_runs) {
-    if (n_runs == 0) return IPCFP_OK;
-    hipLaunchKernelGGL(k_storage_run_matches, dim3(div_up(n_runs, 256)), dim3(256), 0, ctx->stream,
-                       static_cast<const StorageClaimPacked*>(claims_d), static_cast<StorageRun*>(runs_d), n_runs);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -353,38 +353,9 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
 // ---------------------------------------------------------------------------
 constexpr uint32_t kTablePunt = 0xfdu;  // not an ipcfp_status_t
 
-// left_pad_32 (src/proofs/common/evm.rs:91-100) of a serde Vec<u8> (a CBOR array of u8, type-checked by the table) as four
-// little-endian words: byte i of the padded value = word i/8, bits 8·(i%8)…
-__device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
-    out[0] = out[1] = out[2] = out[3] = 0;
-    const uint64_t n = v.read_array();
-    auto put = [&](uint64_t i, uint32_t x) {
-        if (n >= 32 && i < n - 32) return;
-        const uint32_t j = n >= 32 ? uint32_t(i - (n - 32)) : uint32_t(32 - n + i);
-        const uint64_t b = uint64_t(x & 0xffu) << (8u * (j & 7u));
-        const uint32_t k = j >> 3;
-        out[0] |= k == 0 ? b : 0ull;
-        out[1] |= k == 1 ? b : 0ull;
-        out[2] |= k == 2 ? b : 0ull;
-        out[3] |= k == 3 ? b : 0ull;
-    };
-    uint64_t i = 0;
-    while (i < n && v.ok() && v.pos + 8u <= v.n) {  // eight bytes per fetch (cbor_dev.h vec_u8_step)
-        const uint64_t w = v.peek64(v.pos);
-        uint32_t used = 0, x;
-        while (i < n && vec_u8_step(w, used, x)) put(i++, x);
-        v.pos += used;
-        if (i < n && used <= 6u) put(i++, uint32_t(v.read_uint()));
-    }
-    for (; i < n && v.ok(); ++i) put(i, uint32_t(v.read_uint()));
-}
-
-
 __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const HamtNodeRec* __restrict__ table, const CidKey& root,
                                                    uint32_t bit_width, uint32_t kbit, const uint8_t* key, uint32_t key_len,
-                                                   ValueLoc& loc, uint64_t* vec32_padded = nullptr) {
-    // `vec32_padded` (HK_VEC_U8 only): four words that receive left_pad_32 of the value found (they keep their content —
-    // the caller's zeros — when the key is absent)
+                                                   ValueLoc& loc) {
     if (bit_width < 1 || bit_width > 8) return IPCFP_ST_ERR_DECODE;
     uint32_t h[8];
     sha256::hash_bytes(key, key_len, h);
@@ -434,8 +405,7 @@ __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const H
                     // Behind the key: the value, which the table has type-checked as `kbit`'s kind — so the typed walk
                     // reaches its end, in a fraction of the generic skip's instructions (a Vec<u8> of 32 elements is 33 item
                     // headers the generic way, ≈ 2 k instructions per entry per claim, and eight-byte steps the typed way).
-                    if (kbit == HK_VEC_U8 && eq && vec32_padded) left_pad_32_words(r, vec32_padded);  // (the walk that is wanted anyway)
-                    else if (kbit == HK_VEC_U8) check_vec_u8(r);
+                    if (kbit == HK_VEC_U8) check_vec_u8(r);
                     else if (kbit == HK_ACTOR_STATE) check_actor_state(r);
                     else r.skip();
                     if (eq && r.ok()) {

@@ -9,7 +9,7 @@ for r in $(seq 1 "$rounds"); do
     name=${v%%:*}; envs=""
     [ "$v" != "$name" ] && envs=$(echo "${v#*:}" | tr ',' ' ')
     ( env $envs timeout 120 python bench.py --steps ${AB_STEPS:-30} --warmup 5 --plain --no-cpu-baseline --no-sub-records --t2-reps 0 ) > "$out/ab_${name}_$r.log" 2>&1
-    ms=$(grep -o '"ms_per_step": [0-9.]*' "$out/ab_${name}_$r.log" | head -1)
+    ms=$(grep -o '"ms_per_step": *[0-9.]*' "$out/ab_${name}_$r.log" | head -1)
     echo "AB round $r $name [$envs] $ms $(grep -c Traceback "$out/ab_${name}_$r.log") errors"
   done
 done
