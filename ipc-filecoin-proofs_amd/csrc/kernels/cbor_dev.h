@@ -21,7 +21,6 @@
 #include <cstdint>
 
 #include "ipcfp.h"
-#include "blake2b_dev.h"
 #include "witness_dev.h"
 
 namespace ipcfp {
@@ -104,15 +103,58 @@ constexpr uint32_t kRdRingLost = 0xfdu;  // not an ipcfp_status_t
 // (src/proofs/common/witness.rs:60-72: `Cid::try_from`, digests of up to 64 bytes) and compares message CIDs of any length
 // (src/proofs/events/utils.rs:76-90, src/proofs/events/verifier.rs:193-201); folded, a long CID is found, compared and
 // deduplicated through the same five words as a short one.  m[]: the CID's bytes as little-endian words, zero padded
-// (len ≤ 128: one compression).  NOT inlined: one copy of the compression per kernel, however many readers it has, and no
-// live ranges of its 16 + 16 words in the callers' fast paths (no Filecoin chain has such a CID).
-static __device__ __noinline__ CidKey long_cid_fold(const uint64_t* __restrict__ m, uint32_t len) {
-    uint64_t h[8];
-    b2b::init256(h);
-    uint64_t mm[16];
-#pragma unroll
-    for (int w = 0; w < 16; ++w) mm[w] = m[w];
-    b2b::compress<0>(h, mm, uint64_t(len), true);
+// (len ≤ 128: one compression).  NOT inlined: one copy per kernel, however many readers it has (no Filecoin chain has such a CID).
+static __device__ __noinline__ CidKey long_cid_fold(const uint64_t* __restrict__ m_in, uint32_t len) {
+    // A ROLLED Blake2b-256 compression with its state in arrays that are indexed at run time — i.e. in scratch memory, on
+    // purpose: this is the coldest path of the library, and a kernel's register allocation is the maximum over everything
+    // it can call.  The unrolled compression of blake2b_dev.h here cost every caller ≈ 100 VGPRs whether or not it ever met
+    // a long link (k_receipt_events 31 → 100, k_hamt_lv_advance 57 → 100, k_verify_storage_table 83 → 108: one wavefront
+    // per SIMD less in each; profiles/r06_experiments.md); this form needs about two dozen.
+    const uint64_t iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                            0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    // sigma rows as sixteen nibbles each, entry 0 in the low nibble (RFC 7693 §2.7; rounds 10, 11 repeat rows 0, 1)
+    const uint64_t sigma[12] = {0xfedcba9876543210ULL, 0x357b20c16df984aeULL, 0x491763eadf250c8bULL, 0x8f04a562ebcd1397ULL,
+                                0xd386cb1efa427509ULL, 0x91ef57d438b0a6c2ULL, 0xb8293670a4def15cULL, 0xa2684f05931ce7bdULL,
+                                0x5a417d2c803b9ef6ULL, 0x0dc3e9bf5167482aULL, 0xfedcba9876543210ULL, 0x357b20c16df984aeULL};
+    uint64_t v[16], m[16];
+#pragma nounroll
+    for (uint32_t i = 0; i < 16; ++i) m[i] = m_in[i];
+#pragma nounroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        v[i] = iv[i];
+        v[8 + i] = iv[i];
+    }
+    v[0] ^= 0x01010020ULL;  // digest length 32, no key, fanout 1, depth 1
+    v[12] ^= uint64_t(len);  // t0 = bytes compressed; one block: the last
+    v[14] = ~v[14];
+    auto rotr = [](uint64_t x, uint32_t n) { return (x >> n) | (x << (64u - n)); };
+#pragma nounroll
+    for (uint32_t r = 0; r < 12; ++r) {
+        const uint64_t sg = sigma[r];
+#pragma nounroll
+        for (uint32_t g = 0; g < 8; ++g) {
+            const uint32_t i = g & 3u, diag = g >> 2;  // columns, then diagonals
+            const uint32_t a = i, b = 4u + ((i + diag) & 3u), c = 8u + ((i + 2u * diag) & 3u), d = 12u + ((i + 3u * diag) & 3u);
+            const uint64_t x = m[(sg >> (8u * g)) & 15u], y = m[(sg >> (8u * g + 4u)) & 15u];
+            uint64_t va = v[a], vb = v[b], vc = v[c], vd = v[d];
+            va = va + vb + x;
+            vd = rotr(vd ^ va, 32);
+            vc = vc + vd;
+            vb = rotr(vb ^ vc, 24);
+            va = va + vb + y;
+            vd = rotr(vd ^ va, 16);
+            vc = vc + vd;
+            vb = rotr(vb ^ vc, 63);
+            v[a] = va;
+            v[b] = vb;
+            v[c] = vc;
+            v[d] = vd;
+        }
+    }
+    uint64_t h[4];
+#pragma nounroll
+    for (uint32_t i = 0; i < 4; ++i) h[i] = iv[i] ^ v[i] ^ v[8 + i];
+    h[0] ^= 0x01010020ULL;
     CidKey k;
     k.w[0] = 0xffULL | (uint64_t(len & 0xffu) << 8) | (h[0] << 16);
     k.w[1] = (h[0] >> 48) | (h[1] << 16);

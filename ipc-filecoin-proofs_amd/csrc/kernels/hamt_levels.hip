@@ -327,9 +327,9 @@ __device__ __forceinline__ bool lds_address_ok(const uint8_t* S, uint32_t off, u
 // as the next level's work — every child, not only the ones a query will step to: the top of a state tree is 1 + 32 + 1 024
 // link nodes that 66 k queries visit all of anyway, and listing them here takes the advance kernel (and its 66 k claims on
 // 32 blocks) out of every top level.  A record is a pure function of its block: parsing a node no query visits changes nothing.
-template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL>
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL, bool EMIT>
 __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, const HamtLevels& L, uint32_t level, uint32_t pair,
-                                                      uint32_t n_list, uint32_t emit_children, uint32_t slot_base) {
+                                                      uint32_t n_list, uint32_t slot_base) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kCoopNodes][kCoopStage];
     __shared__ uint16_t s_ptr[kCoopNodes][kHamtTablePointers];   // pointer starts
     __shared__ uint16_t s_val[kCoopNodes][kCoopMaxEntries];      // per bucket entry: where its ActorState (0x85) starts
@@ -589,7 +589,7 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
         }
         L.child[size_t(block) * kHamtTablePointers + sub] = c;
     }
-    if (emit_children) {  // (uniform over the launch; the lanes that are still here vote)
+    if (EMIT) {  // (an instance of its own — the fused top's: the other launches do not carry this code; the lanes still here vote)
         const bool em = resolve && c != kNoBlock;
         const uint32_t clen = em ? w.len[c] : 0u;
         const uint32_t ccls = em && L.split && clen + 24u > kCoopSmallStage ? 1u : 0u;
@@ -623,8 +623,11 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
 // A level's list of one size class, two nodes per wavefront, COUNT-DRIVEN: the grid is what the chip holds of this
 // instance and strides over the list, so a list that turned out empty costs a launch of workgroups that read one word
 // (round 5 sized every launch by the level's upper bound: 32 k workgroups to find an empty list).
-template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL>
-__global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level, uint32_t emit_children) {
+// (EMIT: hamt_parse_actor_pair's child listing, the fused top's instance.  The short-node instance asks for FOUR wavefronts
+// per SIMD, what round 5's form reached at 99 VGPRs: with the listing code and the count-driven loop the
+// allocator otherwise took 152 and one wavefront per SIMD less, 85 → 100 µs for the overflow level.)
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL, bool EMIT>
+__global__ __launch_bounds__(64, SMALL ? 5 : 3) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level) {
     const uint32_t n_raw = L.count[L.plain_list ? 0u : 2u * level + (SMALL ? 0u : 1u)];
     const uint32_t n_list = !L.plain_list && n_raw > L.cap ? L.cap : n_raw;
     uint32_t slot_base = 0;
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(64) void k_hamt_lv_parse_actor(WitnessView w, HamtL
         for (int d = 32; d >= 1; d >>= 1) slot_base += __shfl_xor(slot_base, d, 64);
     }
     for (uint32_t pair = blockIdx.x; pair * kCoopNodes < n_list; pair += gridDim.x) {
-        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, SMALL>(w, L, level, pair, n_list, emit_children, slot_base);
+        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, SMALL, EMIT>(w, L, level, pair, n_list, slot_base);
         __syncthreads();  // (the pair's LDS is the next pair's)
     }
 }
@@ -850,8 +853,8 @@ int launch_hamt_outline_list(ipcfp_ctx* ctx, hipStream_t stream, const WitnessVi
     L.plain_list = 1u;
     L.cap = bound;
     static_assert(kHamtOutlineMinLen + 24u > kCoopSmallStage, "every listed block is the big-stage instance's");
-    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(std::min(div_up(bound, kCoopNodes), 32768u)), dim3(64), 0,
-                       stream, w, L, 0u, 0u);
+    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false, false>), dim3(std::min(div_up(bound, kCoopNodes), 32768u)), dim3(64), 0,
+                       stream, w, L, 0u);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
@@ -909,9 +912,14 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
         // bucket level against 173 (profiles/r06_experiments.md).  An empty list is one word read per workgroup.
         return std::min(div_up(bound, kCoopNodes), 32768u);
     };
-    for (uint32_t lv = 0; lv < top; ++lv)
-        hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(parse_grid(lv, 32)), dim3(64), 0, ctx->stream, w,
-                           L, lv, lv + 1u < top ? 1u : 0u);
+    for (uint32_t lv = 0; lv < top; ++lv) {
+        if (lv + 1u < top)
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true, true>), dim3(parse_grid(lv, 32)), dim3(64), 0,
+                               ctx->stream, w, L, lv);
+        else
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true, false>), dim3(parse_grid(lv, 32)), dim3(64), 0,
+                               ctx->stream, w, L, lv);
+    }
     if (top)
         hipLaunchKernelGGL(k_hamt_lv_advance_top, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, L, top, bit_width, vkind, keys_d, key_off_d,
                            key_len_d, n, status_d, loc);
@@ -929,10 +937,10 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
                                                          HK_ACTOR_STATE, recs_d, L.etab_of);
                 if (rc) return rc;
             } else
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true>), dim3(parse_grid(lv, 32)), dim3(64), 0,
-                               ctx->stream, w, L, lv, 0u);
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false>), dim3(parse_grid(lv, 10)), dim3(64), 0,
-                               ctx->stream, w, L, lv, 0u);
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true, false>), dim3(parse_grid(lv, 32)), dim3(64), 0,
+                               ctx->stream, w, L, lv);
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false, false>), dim3(parse_grid(lv, 10)), dim3(64), 0,
+                               ctx->stream, w, L, lv);
         } else {
             uint64_t fan = 1;
             for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
