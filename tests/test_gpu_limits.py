@@ -321,3 +321,108 @@ def test_wide_tipset_shards_planned_and_pulled(engine, oracle, P):
         ost.close()
     finally:
         ipcfp.host_unregister(pk.data)
+
+
+# ---- differential fuzz at the former limits: random corruptions of a witness that HOLDS long CIDs and of one whose
+# tipset key is wide — the fold must agree with the true bytes on every error path too (a corrupted long link is another
+# long link, or no link at all) ----
+def _mutate(blocks, rng, n_flips):
+    out = list(blocks)
+    touched = []
+    for _ in range(n_flips):
+        b = int(rng.integers(0, len(out)))
+        if not out[b]:
+            continue
+        buf = bytearray(out[b])
+        pos = int(rng.integers(0, len(buf)))
+        mode = int(rng.integers(0, 4))
+        if mode == 0:
+            buf[pos] ^= 1 << int(rng.integers(0, 8))
+        elif mode == 1:
+            buf[pos] = int(rng.integers(0, 256))
+        elif mode == 2:
+            buf[pos] = [0x80, 0x9F, 0xFF, 0xD8, 0x5F, 0xF6, 0x00, 0x1B][int(rng.integers(0, 8))]
+        else:
+            buf[pos] = (buf[pos] + 1) & 0xFF
+        out[b] = bytes(buf)
+        touched.append(b)
+    return out, touched
+
+
+def test_fuzz_of_a_witness_with_long_cids(engine, oracle, long_tip):
+    from conftest import fuzz_seed
+
+    tip, rw = long_tip
+    rng = np.random.default_rng(fuzz_seed(20260930))
+    slots = ipcfp.cid_slots(rw.cids)
+    ec = claims.EventClaims(tip, indices=np.arange(0, 300))
+    for k in range(ec.n):
+        ec.set_str(k, "child_block_cid", rw.s(tip.child_cid))
+        ec.set_str(k, "message_cid", rw.s(tip.exec_order[int(tip.claim_exec[k])]))
+    sc = claims.StorageClaims(tip)
+    for k in range(sc.n):
+        sc.set_str(k, "child_block_cid", rw.s(tip.child_cid))
+    # the blocks whose bytes hold long links are hit on purpose half of the time
+    hot = [i for i, b in enumerate(rw.blocks) if bytes.fromhex("d82a584700") in b]
+    assert len(hot) >= 4
+    n_err = 0
+    for it in range(120):
+        blocks, touched = _mutate(rw.blocks, rng, 1 + it % 3)
+        if it % 2:
+            b = hot[int(rng.integers(0, len(hot)))]
+            buf = bytearray(blocks[b])
+            at = buf.find(bytes.fromhex("d82a584700")) + int(rng.integers(0, 76))   # inside the long link
+            buf[at] ^= 1 << int(rng.integers(0, 8))
+            blocks[b] = bytes(buf)
+            touched.append(b)
+        lens = np.array([len(b) for b in blocks], dtype=np.uint32)
+        off = np.zeros(len(lens), dtype=np.uint64)
+        off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        data = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()
+        ost = oracle.store_var(data, off, lens, rw.cids)
+        want_e = ost.verify_event_proofs(ec, mode=1)
+        want_s = ost.verify_storage_proofs(sc, mode=1)
+        with engine.witness(data, off, lens, slots) as w:
+            got_e = w.verify_event_proofs(ec.arr, ec.n)
+            got_s = w.verify_storage_proofs(sc.arr, sc.n)
+        ost.close()
+        ctx = f"round {it}, blocks {touched}"
+        assert np.array_equal(got_e, want_e), ("events", ctx, np.nonzero(got_e != want_e)[0][:5], got_e[got_e != want_e][:5], want_e[got_e != want_e][:5])
+        assert np.array_equal(got_s, want_s), ("storage", ctx, np.nonzero(got_s != want_s)[0][:5], got_s[got_s != want_s][:5], want_s[got_s != want_s][:5])
+        n_err += int((want_e >= 64).any()) + int((want_s >= 64).any())
+    assert n_err > 5
+
+
+def test_fuzz_of_a_wide_tipset(engine, oracle):
+    from conftest import fuzz_seed
+
+    tp = Tipset(n_receipts=300, n_parents=40, n_planted=4, variety=1, max_events=3, dup_permille=80, seed=fuzz_seed(0x71DE))
+    rng = np.random.default_rng(fuzz_seed(20260931))
+    blocks = [tp.block(i) for i in range(tp.n_blocks)]
+    headers = [tp.find_block(c) for c in tp.parent_cids] + [tp.find_block(tp.child_cid)]
+    ec = claims.EventClaims(tp, indices=np.arange(0, 200))
+    n_err = 0
+    for it in range(80):
+        mut, touched = _mutate(blocks, rng, 1 + it % 3)
+        if it % 2:   # a parent header, the child header or a TxMeta on purpose
+            b = headers[int(rng.integers(0, len(headers)))]
+            buf = bytearray(mut[b])
+            buf[int(rng.integers(0, len(buf)))] ^= 1 << int(rng.integers(0, 8))
+            mut[b] = bytes(buf)
+            touched.append(b)
+        lens = np.array([len(b) for b in mut], dtype=np.uint32)
+        off = np.zeros(len(lens), dtype=np.uint64)
+        off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        data = np.frombuffer(b"".join(mut), dtype=np.uint8).copy()
+        ost = oracle.store(data, off, lens, tp.cids)
+        want = ost.verify_event_proofs(ec, mode=1)
+        o, oc = ost.exec_order(tp.parent_cids)
+        with engine.witness(data, off, lens, tp.cids) as w:
+            got = w.verify_event_proofs(ec.arr, ec.n)
+            g, gc = w.exec_order(tp.parent_cids)
+        ost.close()
+        ctx = f"round {it}, blocks {touched}"
+        assert np.array_equal(got, want), ("events", ctx, np.nonzero(got != want)[0][:5], got[got != want][:5], want[got != want][:5])
+        assert g == o and np.array_equal(gc, oc), ("exec_order", ctx, g, o)
+        n_err += int((want >= 64).any())
+    assert n_err > 5
