@@ -232,7 +232,10 @@ __device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
 // lane: everything its run shares comes from the run's record, `read_storage_slot`'s HAMT get (storage/decode.rs:79-96)
 // walks the node table.  A claim it cannot settle (an inline small-map layout, a block the table does not cover) is left
 // kStPending for k_verify_storage.
-__global__ __launch_bounds__(256) void k_verify_storage_table(WitnessView w, const HamtNodeRec* __restrict__ table,
+// (Seven wavefronts per SIMD asked of the allocator: 72 VGPRs and 48 more bytes of scratch against its own 83 and five.  The
+// kernel is a long instruction stream with 116 loads per wavefront that depend on each other; more wavefronts in flight
+// were 2.13 → 2.02 ms for configs[4]'s call — 6: 2.05, 8: 2.03; profiles/r06_experiments.md.)
+__global__ __launch_bounds__(256, 7) void k_verify_storage_table(WitnessView w, const HamtNodeRec* __restrict__ table,
                                                               const StorageClaimPacked* __restrict__ claims, uint32_t n,
                                                               const uint32_t* __restrict__ run_of, const StorageRun* __restrict__ runs,
                                                               ipcfp_trust_policy_t trust, uint32_t undecided, uint8_t* __restrict__ status) {
