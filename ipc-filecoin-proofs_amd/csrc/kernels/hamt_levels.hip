@@ -46,9 +46,9 @@ struct HamtLevels {
     // it) and reads its length for the size class anyway — so the parse's wavefront starts staging after ONE dependent read
     // (its list entry) instead of three (entry → length / offset → bytes): a level's parse is a few thousand wavefronts whose
     // time is that chain.
-    uint4* work[2][2];    // .x block, .y length, .z / .w arena offset (low / high word)
+    uint4* work[2][3];    // [level parity][size class]; .x block, .y length, .z / .w arena offset (low / high word)
     const uint32_t* plain;  // plain_list: the one list, block ids only
-    uint32_t* count;      // entries of level l's lists: count[2 l + class] (two counters per level)
+    uint32_t* count;      // entries of level l's lists: count[3 l + class] (kHamtClasses counters per level)
     uint32_t split;       // 1: lists by size class (the 32-lane parse of the state tree); 0: everything in class 0
     uint32_t plain_list;  // 1: ONE list work[0][0] / count[0] whatever the level and class (launch_hamt_outline_list)
     uint32_t cap;         // capacity of every list
@@ -79,8 +79,17 @@ __device__ __forceinline__ uint32_t witness_find_quiet(const WitnessView& w, con
 // out on the way: a workgroup-wide set in LDS lets one lane per distinct block through, and the lanes of a wavefront that
 // win their block append with one counter update between them.
 constexpr uint32_t kCoopBigStage = 6912, kCoopBigEntries = 96, kCoopSmallStage = 1536, kCoopSmallEntries = 24;
+// … and a THIRD size class between them (round 6): nine of ten bucket nodes of a 4 M-actor tree are 2-4 KB, and an instance
+// whose stage is sized for them keeps 14 wavefronts on a CU where the 6.9 KB one keeps 9.  Round 5 measured such an instance
+// beside the big one on two streams and dropped it (158 vs 173 µs, the extra launches and the fork cost more); with a list
+// per class and count-driven launches an instance costs its own nodes and ≈ 4 µs when it has none.
+constexpr uint32_t kCoopMidStage = 4352, kCoopMidEntries = 64;
+constexpr uint32_t kHamtClasses = 3;
+__device__ __forceinline__ uint32_t hamt_class_of_len(uint32_t len) {
+    return len + 24u <= kCoopSmallStage ? 0u : (len + 24u <= kCoopMidStage ? 1u : 2u);
+}
 __device__ __forceinline__ uint32_t hamt_size_class(const WitnessView& w, const HamtLevels& L, uint32_t block) {
-    return L.split && w.len[block] + 24u > kCoopSmallStage ? 1u : 0u;
+    return L.split ? hamt_class_of_len(w.len[block]) : 0u;
 }
 __device__ __forceinline__ uint4 hamt_work_entry(const WitnessView& w, uint32_t block, uint32_t len) {
     const uint64_t off = w.off[block];
@@ -111,15 +120,15 @@ __device__ __forceinline__ void hamt_claim(const WitnessView& w, const HamtLevel
         won = !(__builtin_nontemporal_load(word) & bit) && !(atomicOr(word, bit) & bit);
     }
     const uint32_t blen = won ? w.len[block] : 0u;
-    const uint32_t cls = won && L.split && blen + 24u > kCoopSmallStage ? 1u : 0u;
+    const uint32_t cls = won && L.split ? hamt_class_of_len(blen) : 0u;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (uint32_t c = 0; c < 2u; ++c) {  // (one counter update per wavefront and class)
+    for (uint32_t c = 0; c < kHamtClasses; ++c) {  // (one counter update per wavefront and class)
         const uint64_t winners = __ballot(won && cls == c);
         if (!winners) continue;
         const uint32_t leader = uint32_t(__ffsll((long long)winners)) - 1u;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(L.count + 2u * level + c, uint32_t(__popcll(winners)));
+        if (lane == leader) base = atomicAdd(L.count + kHamtClasses * level + c, uint32_t(__popcll(winners)));
         base = __shfl(base, leader, 64);
         if (won && cls == c) L.work[level & 1u][c][base + uint32_t(__popcll(winners & ((1ull << lane) - 1ull)))] = hamt_work_entry(w, block, blen);
     }
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_start(WitnessView w, CidKey roo
 // lane = one node of level `level`'s work list
 __global__ __launch_bounds__(256, IPCFP_WALK_WAVES) void k_hamt_lv_parse(WitnessView w, HamtLevels L, uint32_t level, int vkind) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.count[2u * level]) return;
+    if (i >= L.count[kHamtClasses * level]) return;
     const uint32_t block = L.work[level & 1u][0][i].x;
     HamtNodeRec* out = L.recs + block;
     Rd r = open_block(w, block);
@@ -327,7 +336,7 @@ __device__ __forceinline__ bool lds_address_ok(const uint8_t* S, uint32_t off, u
 // as the next level's work — every child, not only the ones a query will step to: the top of a state tree is 1 + 32 + 1 024
 // link nodes that 66 k queries visit all of anyway, and listing them here takes the advance kernel (and its 66 k claims on
 // 32 blocks) out of every top level.  A record is a pure function of its block: parsing a node no query visits changes nothing.
-template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL, bool EMIT>
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, uint32_t CLS, bool EMIT>
 __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, const HamtLevels& L, uint32_t level, uint32_t pair,
                                                       uint32_t n_list, uint32_t slot_base) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kCoopNodes][kCoopStage];
@@ -342,7 +351,8 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     __shared__ uint64_t s_bf[kCoopNodes];
     const uint32_t lane = threadIdx.x & 63u, g = lane / kCoopLanes, sub = lane % kCoopLanes;
     const uint32_t i = pair * kCoopNodes + g;
-    const uint32_t cls = L.plain_list || SMALL ? 0u : 1u;
+    constexpr bool SMALL = CLS == 0u;
+    const uint32_t cls = L.plain_list ? 0u : CLS;
     const bool listed = i < n_list;
     uint4 we = make_uint4(0, 0, 0, 0);
     if (listed) {
@@ -355,7 +365,7 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     }
     const uint32_t block = we.x, len = we.y;
     // (a split list holds this instance's nodes only; an unsplit one — the outline over a plain list — is the big instance's)
-    const bool have = listed && (L.split ? true : (len + 24u <= kCoopSmallStage) == SMALL);
+    const bool have = listed && (L.split ? true : (len + 24u <= kCoopSmallStage) == SMALL);  // (unsplit: small or not small)
     const bool staged = have && len >= 3u && len + 24u <= kCoopStage;
     uint8_t* S = stage[g];
     if (staged) {
@@ -592,16 +602,16 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     if (EMIT) {  // (an instance of its own — the fused top's: the other launches do not carry this code; the lanes still here vote)
         const bool em = resolve && c != kNoBlock;
         const uint32_t clen = em ? w.len[c] : 0u;
-        const uint32_t ccls = em && L.split && clen + 24u > kCoopSmallStage ? 1u : 0u;
+        const uint32_t ccls = em && L.split ? hamt_class_of_len(clen) : 0u;
         // a child the fused top's parse (the small-stage instance alone) will not take must not keep a record of another call
-        if (em && ccls == 1u) L.recs[c].status = 0;
+        if (em && ccls != 0u) L.recs[c].status = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 2u; ++k) {
+        for (uint32_t k = 0; k < kHamtClasses; ++k) {
             const uint64_t votes = __ballot(em && ccls == k);
             if (!votes) continue;
             const uint32_t leader = uint32_t(__ffsll((long long)votes)) - 1u;
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(L.count + 2u * (level + 1u) + k, uint32_t(__popcll(votes)));
+            if (lane == leader) base = atomicAdd(L.count + kHamtClasses * (level + 1u) + k, uint32_t(__popcll(votes)));
             base = __shfl(base, leader, 64);
             if (em && ccls == k) {
                 const uint32_t at = base + uint32_t(__popcll(votes & ((1ull << lane) - 1ull)));
@@ -626,19 +636,19 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
 // (EMIT: hamt_parse_actor_pair's child listing, the fused top's instance.  The short-node instance asks for FOUR wavefronts
 // per SIMD, what round 5's form reached at 99 VGPRs: with the listing code and the count-driven loop the
 // allocator otherwise took 152 and one wavefront per SIMD less, 85 → 100 µs for the overflow level.)
-template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, bool SMALL, bool EMIT>
-__global__ __launch_bounds__(64, SMALL ? 5 : 3) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level) {
-    const uint32_t n_raw = L.count[L.plain_list ? 0u : 2u * level + (SMALL ? 0u : 1u)];
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, uint32_t CLS, bool EMIT>
+__global__ __launch_bounds__(64, CLS == 0u ? 5 : (CLS == 1u ? 4 : 3)) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level) {
+    const uint32_t n_raw = L.count[L.plain_list ? 0u : kHamtClasses * level + CLS];
     const uint32_t n_list = !L.plain_list && n_raw > L.cap ? L.cap : n_raw;
     uint32_t slot_base = 0;
     if (L.etab_of && !L.plain_list) {  // lane l: the count of list l in front of this one (2 · levels + 1 < 64 lists)
-        const uint32_t before = 2u * level + (SMALL ? 0u : 1u);
+        const uint32_t before = kHamtClasses * level + CLS;
         slot_base = threadIdx.x < before ? L.count[threadIdx.x] : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) slot_base += __shfl_xor(slot_base, d, 64);
     }
     for (uint32_t pair = blockIdx.x; pair * kCoopNodes < n_list; pair += gridDim.x) {
-        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, SMALL, EMIT>(w, L, level, pair, n_list, slot_base);
+        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, CLS, EMIT>(w, L, level, pair, n_list, slot_base);
         __syncthreads();  // (the pair's LDS is the next pair's)
     }
 }
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(256) void k_hamt_lv_advance_top(WitnessView w, Hamt
 // Scratch of one call: [cur n | hash 8n | 4 work lists of cap 16-byte entries | count 2 (levels + 2) | claimed words | 8 spare] u32 + child table + etab_of.
 size_t hamt_levels_scratch_words(uint32_t n, uint32_t n_blocks, uint32_t levels) {
     const size_t cap = n < n_blocks ? n : n_blocks;
-    return size_t(n) * 9 + 4 + cap * 16 + 2 * size_t(levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
+    return size_t(n) * 9 + 4 + cap * 24 + 3 * size_t(levels + 2) + div_up(n_blocks, 32) + 8 + size_t(n_blocks) * kHamtTablePointers + size_t(n_blocks);
 }
 
 // The 32-lane outline over ANY list of blocks (not a level of a walk): every block of `work_d[0 .. *count_d)` whose length
@@ -853,7 +863,7 @@ int launch_hamt_outline_list(ipcfp_ctx* ctx, hipStream_t stream, const WitnessVi
     L.plain_list = 1u;
     L.cap = bound;
     static_assert(kHamtOutlineMinLen + 24u > kCoopSmallStage, "every listed block is the big-stage instance's");
-    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false, false>), dim3(std::min(div_up(bound, kCoopNodes), 32768u)), dim3(64), 0,
+    hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, 2u, false>), dim3(std::min(div_up(bound, kCoopNodes), 32768u)), dim3(64), 0,
                        stream, w, L, 0u);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
@@ -871,11 +881,9 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     L.cur = scratch_d;
     L.hash = scratch_d + size_t(n);
     L.work[0][0] = reinterpret_cast<uint4*>(scratch_d + ((size_t(n) * 9 + 3) & ~size_t(3)));  // (16-byte entries: scratch_d is hipMalloc'd)
-    L.work[0][1] = L.work[0][0] + cap;
-    L.work[1][0] = L.work[0][1] + cap;
-    L.work[1][1] = L.work[1][0] + cap;
-    L.count = reinterpret_cast<uint32_t*>(L.work[1][1] + cap);
-    L.claimed = L.count + 2 * (levels + 2);
+    for (uint32_t k = 1; k < 2u * kHamtClasses; ++k) L.work[k / kHamtClasses][k % kHamtClasses] = L.work[0][0] + size_t(k) * cap;
+    L.count = reinterpret_cast<uint32_t*>(L.work[0][0] + size_t(2u * kHamtClasses) * cap);
+    L.claimed = L.count + kHamtClasses * (levels + 2);
     L.split = actor ? 1u : 0u;
     L.cap = cap;
     L.top_overflow = L.claimed + words;  // (the first of the eight spare words behind the bitmap: cleared with it)
@@ -888,7 +896,7 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     // counters, bitmap and the spare words are contiguous: cleared by the first launch
     ValueLoc* loc = static_cast<ValueLoc*>(loc_d);
     hipLaunchKernelGGL(k_hamt_lv_start, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w, root, L, keys_d, key_off_d, key_len_d,
-                       n, status_d, loc, 2u * (levels + 2u) + words + 8u);
+                       n, status_d, loc, kHamtClasses * (levels + 2u) + words + 8u);
     // The FUSED TOP (round 6).  The upper levels of a big tree are a handful of link nodes every query passes: level l holds
     // at most 32^l of them.  Round 5 ran a parse / parse / advance triple per level there — 130 µs for 1 + 32 + 1 024 nodes
     // of a 4 M-actor tree, the advance kernels being 66 k queries claiming the same few blocks.  Now the parse lists a link
@@ -914,10 +922,10 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     };
     for (uint32_t lv = 0; lv < top; ++lv) {
         if (lv + 1u < top)
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true, true>), dim3(parse_grid(lv, 32)), dim3(64), 0,
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, 0u, true>), dim3(parse_grid(lv, 32)), dim3(64), 0,
                                ctx->stream, w, L, lv);
         else
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true, false>), dim3(parse_grid(lv, 32)), dim3(64), 0,
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, 0u, false>), dim3(parse_grid(lv, 32)), dim3(64), 0,
                                ctx->stream, w, L, lv);
     }
     if (top)
@@ -930,17 +938,28 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
     static const bool small_lane = [] { const char* e = std::getenv("IPCFP_HAMT_SMALL_LANE"); return e && std::atoi(e) == 1; }();
     for (uint32_t lv = top; lv < levels; ++lv) {
         if (actor) {
-            if (small_lane && lv >= top && top > 0) {
+            // Which class a level's nodes fall into is the tree's business, but the odds are known: the first level below
+            // the fused top of a big tree is the BUCKET level (2-8 KB nodes), the levels under it hold the short overflow
+            // nodes.  The unlikely class gets a narrow grid — the kernel strides, so a surprise costs time, not results — and
+            // an empty list then costs ≈ 4 µs instead of ≈ 9 (32 k workgroups that read one word each).
+            const bool bucket_level = top > 0 && lv == top;
+            const uint32_t narrow = 1024u;
+            const uint32_t g_small = top > 0 && bucket_level ? std::min(parse_grid(lv, 32), narrow) : parse_grid(lv, 32);
+            const uint32_t g_long = top > 0 && !bucket_level ? std::min(parse_grid(lv, 14), narrow) : parse_grid(lv, 14);
+            if (small_lane && top > 0) {
                 uint64_t fan = 1;
                 for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
-                const int rc = launch_hamt_lv_parse_lane(ctx, w, L.work[lv & 1u][0], L.count + 2u * lv, cap, fan < cap ? uint32_t(fan) : cap,
+                const int rc = launch_hamt_lv_parse_lane(ctx, w, L.work[lv & 1u][0], L.count + kHamtClasses * lv, cap, fan < cap ? uint32_t(fan) : cap,
                                                          HK_ACTOR_STATE, recs_d, L.etab_of);
                 if (rc) return rc;
-            } else
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, true, false>), dim3(parse_grid(lv, 32)), dim3(64), 0,
-                               ctx->stream, w, L, lv);
-            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, false, false>), dim3(parse_grid(lv, 10)), dim3(64), 0,
-                               ctx->stream, w, L, lv);
+            } else {
+                hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, 0u, false>), dim3(g_small), dim3(64), 0, ctx->stream,
+                                   w, L, lv);
+            }
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopMidStage, kCoopMidEntries, 1u, false>), dim3(g_long), dim3(64), 0, ctx->stream, w, L,
+                               lv);
+            hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopBigStage, kCoopBigEntries, 2u, false>), dim3(g_long), dim3(64), 0, ctx->stream, w, L,
+                               lv);
         } else {
             uint64_t fan = 1;
             for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
