@@ -60,6 +60,17 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     DevBuf<uint32_t> long_list, long_count;
     IPCFP_HIP(ctx, table.alloc(wit->n));
     static const bool ring = [] { const char* e = std::getenv("IPCFP_HAMT_TABLE_FORM"); return e && e[0] == 'r'; }();
+    // Round 6: the node table (0.6 ms of one-lane parses, latency-bound) and the runs' boundary pass (0.18 ms of streaming
+    // 248-byte records, bandwidth-bound) need nothing of each other: the table goes to the AUX stream, its 32-lane outline
+    // of the long blocks — whose grid wants the list's size, i.e. the call's one synchronisation — to the K1 stream beside it,
+    // and the main stream runs flags → scan → heads → typed decodes meanwhile and joins both before the first kernel that
+    // reads a record.  IPCFP_STORAGE_SIDE=0: everything on the main stream in round 5's order.
+    static const bool side_env = [] { const char* e = std::getenv("IPCFP_STORAGE_SIDE"); return !(e && std::atoi(e) == 0); }();
+    const bool side = side_env && !ring && ctx->stream_aux != ctx->stream && ctx->aux_event && ctx->main_event;
+    const bool side2 = side && ctx->stream_k1 != ctx->stream && ctx->stream_k1 != ctx->stream_aux;
+    // (declared AFTER table / long_list / long_count: an early return drains the side streams before those buffers go back
+    // to the pool — ADVICE r5)
+    StreamDrainGuard aux_guard(ctx->stream_aux), k1_guard(ctx->stream_k1);
     int rc = IPCFP_OK;
     if (ring) {  // (round 3's form, for A/B runs: eight lanes per block with the ring reader, every block)
         rc = launch_hamt_node_table(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
@@ -70,7 +81,17 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
         IPCFP_HIP(ctx, hipMemsetAsync(long_count.p, 0, 4, ctx->stream));
         rc = launch_hamt_list_long(ctx, wit->k1_meta.p, uint32_t(wit->n), long_list.p, long_count.p);
         // … everything shorter: one block per lane, line-staged reader
-        if (!rc) rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+        if (!rc && side) {
+            IPCFP_HIP(ctx, hipEventRecord(ctx->main_event, ctx->stream));  // (everything that made the witness and took `table` from the pool is behind this)
+            IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->main_event, 0));
+            aux_guard.armed = true;
+            hipStream_t saved = ctx->stream;
+            ctx->stream = ctx->stream_aux;  // (the launcher queues on the context's stream)
+            rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+            ctx->stream = saved;
+        } else if (!rc) {
+            rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+        }
     }
     if (rc) return rc;
     DevBuf<uint32_t> flag, pos, run_of;
@@ -89,29 +110,39 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     IPCFP_HIP(ctx, d2h_small(ctx, &n_runs, total_d.p, 8, ctx->stream));
     if (!ring) IPCFP_HIP(ctx, d2h_small(ctx, &n_long, long_count.p, 4, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    // (behind the one synchronisation the call has anyway — the grid is the list's size — and on the aux stream: the main
-    // stream has just been drained, so nothing there is still writing the table, and the runs' typed decodes below — one lane
-    // per run, 157 wavefronts — fill the chip no better than the outline's single-wavefront workgroups do: side by side)
-    const bool aux = n_long && ctx->stream_aux != ctx->stream && ctx->aux_event;
-    // (declared BEFORE the aux-stream launches and AFTER table / long_list / long_count: an early return below drains the
-    // aux stream before those buffers go back to the pool — ADVICE r5)
-    StreamDrainGuard aux_guard(ctx->stream_aux);
+    // the outline of the long blocks (its grid is the list's size): beside the lane kernel when that runs on the aux stream,
+    // else on the aux stream beside the runs' typed decodes (round 5)
+    hipEvent_t outline_event = nullptr;
     if (n_long) {
-        aux_guard.armed = aux;
-        hipStream_t s = aux ? ctx->stream_aux : ctx->stream;
+        hipStream_t s = ctx->stream;
+        if (side2) {
+            s = ctx->stream_k1;
+            k1_guard.armed = true;
+            IPCFP_HIP(ctx, hipStreamWaitEvent(s, ctx->main_event, 0));
+        } else if (ctx->stream_aux != ctx->stream && ctx->aux_event) {
+            s = ctx->stream_aux;
+            aux_guard.armed = true;
+        }
         rc = launch_hamt_outline_list(ctx, s, w, table.p, long_list.p, long_count.p, n_long);
         if (!rc) rc = launch_hamt_node_table_rest(ctx, s, w, long_list.p, long_count.p, n_long, HK_ACTOR_STATE | HK_VEC_U8, table.p);
         if (rc) return rc;
-        if (aux) IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream_aux));
+        if (s == ctx->stream_k1) {
+            if (!ctx->k1_gate_event) IPCFP_HIP(ctx, hipEventCreateWithFlags(&ctx->k1_gate_event, hipEventDisableTiming));
+            outline_event = ctx->k1_gate_event;
+            IPCFP_HIP(ctx, hipEventRecord(outline_event, s));
+        }
     }
+    if (aux_guard.armed) IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream_aux));
     DevBuf<StorageRun> runs;
     IPCFP_HIP(ctx, runs.alloc(n_runs));
     rc = launch_storage_run_heads(ctx, flag.p, pos.p, n, run_of.p, runs.p);
     if (rc) return rc;
     rc = launch_storage_run_facts(ctx, w, claims_d, runs.p, uint32_t(n_runs));
     if (rc) return rc;
-    if (aux) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));  // the table is whole from here on
-    aux_guard.armed = false;  // the main stream is ordered behind the aux kernels now: pool reuse on it is safe
+    // the table is whole from here on
+    if (aux_guard.armed) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
+    if (outline_event) IPCFP_HIP(ctx, hipStreamWaitEvent(ctx->stream, outline_event, 0));
+    aux_guard.armed = k1_guard.armed = false;  // the main stream is ordered behind the side kernels now: pool reuse on it is safe
     rc = launch_storage_run_actors_table(ctx, w, table.p, claims_d, runs.p, uint32_t(n_runs), kUndecided);
     if (rc) return rc;
     rc = launch_storage_run_actors_lane(ctx, w, claims_d, runs.p, uint32_t(n_runs), kUndecided);
