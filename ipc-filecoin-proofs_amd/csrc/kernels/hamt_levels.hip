@@ -336,21 +336,28 @@ __device__ __forceinline__ bool lds_address_ok(const uint8_t* S, uint32_t off, u
 // as the next level's work — every child, not only the ones a query will step to: the top of a state tree is 1 + 32 + 1 024
 // link nodes that 66 k queries visit all of anyway, and listing them here takes the advance kernel (and its 66 k claims on
 // 32 blocks) out of every top level.  A record is a pure function of its block: parsing a node no query visits changes nothing.
-template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, uint32_t CLS, bool EMIT>
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, uint32_t CLS, bool EMIT, uint32_t LANES>
 __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, const HamtLevels& L, uint32_t level, uint32_t pair,
                                                       uint32_t n_list, uint32_t slot_base) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kCoopNodes][kCoopStage];
-    __shared__ uint16_t s_ptr[kCoopNodes][kHamtTablePointers];   // pointer starts
-    __shared__ uint16_t s_val[kCoopNodes][kCoopMaxEntries];      // per bucket entry: where its ActorState (0x85) starts
-    __shared__ uint16_t s_l2[kCoopNodes][kCoopMaxEntries];       // … its second link (`state`) …
-    __shared__ uint16_t s_adr[kCoopNodes][kCoopMaxEntries];      // … and its delegated_address item
-    __shared__ uint16_t s_end[kCoopNodes][kCoopMaxEntries];      // … and where the entry ends (the parallel outline's tiling check)
-    __shared__ uint8_t s_gn[kCoopNodes][kCoopMaxEntries + 4], s_gc[kCoopNodes][kCoopMaxEntries + 4], s_gb[kCoopNodes][kCoopMaxEntries + 4];
-    __shared__ uint8_t s_klen[kCoopNodes][kCoopMaxEntries + 4], s_first[kCoopNodes][kHamtTablePointers];  // (the entry table's extras)
-    __shared__ uint32_t s_np[kCoopNodes], s_ne[kCoopNodes], s_links[kCoopNodes], s_lall[kCoopNodes], s_slot[kCoopNodes];
-    __shared__ uint64_t s_bf[kCoopNodes];
-    const uint32_t lane = threadIdx.x & 63u, g = lane / kCoopLanes, sub = lane % kCoopLanes;
-    const uint32_t i = pair * kCoopNodes + g;
+    // LANES lanes per node, 64 / LANES nodes per wavefront.  32: the form the outline's parallel phases were written for.  8
+    // (round 6, the SHORT nodes below the fused top): an overflow node is ≈ 500 bytes and five entries that one lane reads
+    // front to back out of LDS — with 32 lanes on it, 31 wait; eight groups of eight read eight nodes side by side.
+    static_assert(LANES == 32u || LANES == 8u, "group size");
+    static_assert(!EMIT || LANES == 32u, "the fused top lists one child per lane");
+    constexpr uint32_t NODES = 64u / LANES;
+    constexpr uint64_t GMASK = (1ull << LANES) - 1ull;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[NODES][kCoopStage];
+    __shared__ uint16_t s_ptr[NODES][kHamtTablePointers];   // pointer starts
+    __shared__ uint16_t s_val[NODES][kCoopMaxEntries];      // per bucket entry: where its ActorState (0x85) starts
+    __shared__ uint16_t s_l2[NODES][kCoopMaxEntries];       // … its second link (`state`) …
+    __shared__ uint16_t s_adr[NODES][kCoopMaxEntries];      // … and its delegated_address item
+    __shared__ uint16_t s_end[NODES][kCoopMaxEntries];      // … and where the entry ends (the parallel outline's tiling check)
+    __shared__ uint8_t s_gn[NODES][kCoopMaxEntries + 4], s_gc[NODES][kCoopMaxEntries + 4], s_gb[NODES][kCoopMaxEntries + 4];
+    __shared__ uint8_t s_klen[NODES][kCoopMaxEntries + 4], s_first[NODES][kHamtTablePointers];  // (the entry table's extras)
+    __shared__ uint32_t s_np[NODES], s_ne[NODES], s_links[NODES], s_lall[NODES], s_slot[NODES];
+    __shared__ uint64_t s_bf[NODES];
+    const uint32_t lane = threadIdx.x & 63u, g = lane / LANES, sub = lane % LANES;
+    const uint32_t i = pair * NODES + g;
     constexpr bool SMALL = CLS == 0u;
     const uint32_t cls = L.plain_list ? 0u : CLS;
     const bool listed = i < n_list;
@@ -372,7 +379,7 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
         const uint4* src = reinterpret_cast<const uint4*>(w.arena + (uint64_t(we.z) | (uint64_t(we.w) << 32)));  // line-aligned, padded to a line
         uint4* dst = reinterpret_cast<uint4*>(S);
         const uint32_t chunks = (len + 15u) >> 4;
-        for (uint32_t c = sub; c < chunks; c += kCoopLanes) dst[c] = src[c];
+        for (uint32_t c = sub; c < chunks; c += LANES) dst[c] = src[c];
     }
     if (sub == 0) {
         s_np[g] = 0xffffffffu;  // "no outline"
@@ -386,26 +393,26 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     // Mid-sized nodes whose first pointer is a BUCKET (the overflow nodes under a full bucket: 4-20 entries) also gain a little
     // (a level of them: 115 µs front to back, 90 µs in parallel); which route reads a node never changes its record.
     const outline::Header hd = staged ? outline::header(S, len) : outline::Header{false, 0, 0, 0};
-    const bool wide = staged && hd.ok && (len >= kCoopParallelMin || (len >= kCoopParallelMinBuckets && hd.pos0 < len && S[hd.pos0] != 0xd8u));
+    const bool wide = LANES == 32u && staged && hd.ok && (len >= kCoopParallelMin || (len >= kCoopParallelMinBuckets && hd.pos0 < len && S[hd.pos0] != 0xd8u));
     bool fast_ok = false;
     if (__ballot(wide) != 0ull) {  // (wave-uniform: a wavefront of two small nodes skips the phases altogether)
     uint32_t cnt = 0, a_from = 0, a_to = 0;
     uint64_t packed = 0;  // the lane's first four anchors (one pass); more than four: the group scans again, writing
     if (wide && hd.ok) {
-        const uint32_t span = (((len + kCoopLanes - 1u) / kCoopLanes) + 7u) & ~7u;  // a lane's share of the node, whole words
+        const uint32_t span = (((len + LANES - 1u) / LANES) + 7u) & ~7u;  // a lane's share of the node, whole words
         const uint32_t scan_end = len >= 2u ? len - 2u : 0u;
         a_from = sub * span > hd.pos0 ? sub * span : hd.pos0;
         a_to = (sub + 1u) * span < scan_end ? (sub + 1u) * span : scan_end;
         if (a_from < a_to) cnt = outline::scan_anchors_packed(S, a_from, a_to, packed);
     }
-    const bool crowded = ((__ballot(cnt > 4u) >> (g * kCoopLanes)) & 0xffffffffull) != 0ull;
+    const bool crowded = ((__ballot(cnt > 4u) >> (g * LANES)) & GMASK) != 0ull;
     uint32_t incl = cnt;
 #pragma unroll
-    for (uint32_t d = 1; d < kCoopLanes; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, kCoopLanes);
+    for (uint32_t d = 1; d < LANES; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, LANES);
         if (sub >= d) incl += up;
     }
-    const uint32_t na = __shfl(incl, kCoopLanes - 1u, kCoopLanes);  // anchors of the node
+    const uint32_t na = __shfl(incl, LANES - 1u, LANES);  // anchors of the node
     const bool fast = wide && hd.ok && na <= kCoopMaxEntries;
     if (fast && cnt) {
         if (crowded) (void)outline::scan_anchors<true>(S, a_from, a_to, s_val[g] + (incl - cnt), cnt);
@@ -420,15 +427,15 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     // tile the node below, so an entry that is wrongly dropped, or a stray anchor that does parse, sends the node to the
     // sequential reader.
     uint32_t ne_kept = 0;
-    for (uint32_t r = 0; r * kCoopLanes < (fast ? na : 0u); ++r) {
-        const uint32_t e = r * kCoopLanes + sub;
+    for (uint32_t r = 0; r * LANES < (fast ? na : 0u); ++r) {
+        const uint32_t e = r * LANES + sub;
         uint32_t a = 0, l2 = 0, adr = 0, end = 0;
         bool keep = false;
         if (e < na) {
             a = s_val[g][e];
             keep = outline::entry_forward(S, a, len, l2, adr, end);
         }
-        const uint32_t kept = uint32_t((__ballot(keep) >> (g * kCoopLanes)) & 0xffffffffull);
+        const uint32_t kept = uint32_t((__ballot(keep) >> (g * LANES)) & GMASK);
         __syncthreads();  // (every anchor of this round has been read: the kept ones move down)
         if (keep) {
             const uint32_t at = ne_kept + uint32_t(__popc(kept & ((1u << sub) - 1u)));
@@ -441,7 +448,7 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     }
     __syncthreads();
     if (fast) {  // every gap: how many pointers start in it, the bucket header's count (the tail is gap `na`)
-        for (uint32_t e = sub; e <= ne_kept; e += kCoopLanes) {
+        for (uint32_t e = sub; e <= ne_kept; e += LANES) {
             uint32_t n_ptr = 0, count = 0, kl = 0;
             const uint32_t from = e ? uint32_t(s_end[g][e - 1u]) : hd.pos0, target = e < ne_kept ? uint32_t(s_val[g][e]) : len;
             const bool ok = outline::gap_walk(S, from, target, len, e == ne_kept, e == 0u, n_ptr, count, nullptr, 0u, nullptr, &kl);
@@ -454,25 +461,25 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     __syncthreads();
     if (fast) {  // pointer numbers: a running sum over the gaps; the buckets' counts must hop from header to header
         uint32_t carry = 0;
-        for (uint32_t r = 0; r * kCoopLanes <= ne_kept; ++r) {
-            const uint32_t e = r * kCoopLanes + sub;
+        for (uint32_t r = 0; r * LANES <= ne_kept; ++r) {
+            const uint32_t e = r * LANES + sub;
             const uint32_t v = e <= ne_kept ? uint32_t(s_gn[g][e]) : 0u;
             uint32_t run = v;
 #pragma unroll
-            for (uint32_t d = 1; d < kCoopLanes; d <<= 1) {
-                const uint32_t up = __shfl_up(run, d, kCoopLanes);
+            for (uint32_t d = 1; d < LANES; d <<= 1) {
+                const uint32_t up = __shfl_up(run, d, LANES);
                 if (sub >= d) run += up;
             }
             if (e <= ne_kept) s_gb[g][e] = uint8_t(carry + run - v);
-            carry += __shfl(run, kCoopLanes - 1u, kCoopLanes);
+            carry += __shfl(run, LANES - 1u, LANES);
         }
         okl = okl && carry == hd.np;
-        for (uint32_t e = sub; e < ne_kept; e += kCoopLanes) okl = okl && outline::bucket_spans(s_gc[g], e, ne_kept);
+        for (uint32_t e = sub; e < ne_kept; e += LANES) okl = okl && outline::bucket_spans(s_gc[g], e, ne_kept);
     }
     __syncthreads();
     if (fast) {  // the same walk again, now writing where every pointer starts
         uint32_t lm = 0;
-        for (uint32_t e = sub; e <= ne_kept; e += kCoopLanes) {
+        for (uint32_t e = sub; e <= ne_kept; e += LANES) {
             uint32_t n_ptr = 0, count = 0;
             const uint32_t from = e ? uint32_t(s_end[g][e - 1u]) : hd.pos0, target = e < ne_kept ? uint32_t(s_val[g][e]) : len;
             const uint32_t gn = s_gn[g][e], gb = s_gb[g][e];
@@ -488,7 +495,7 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     }
     {   // every lane of the group content?  Then the outline stands; else lane 0 reads the node front to back
         const uint64_t votes = __ballot(fast && okl);
-        const uint64_t mine = 0xffffffffull << (g * kCoopLanes);
+        const uint64_t mine = GMASK << (g * LANES);
         fast_ok = (votes & mine) == mine;
         __syncthreads();
         if (fast_ok && sub == 0) {
@@ -520,13 +527,13 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     bool good = staged && np != 0xffffffffu;
     if (good) {
         const uint32_t links = s_links[g], ne = s_ne[g];
-        for (uint32_t p = sub; p < np; p += kCoopLanes)
+        for (uint32_t p = sub; p < np; p += LANES)
             if ((links >> p) & 1u) {
                 bool std_form = true;  // (a node already found bad is not used: its mask does not matter)
                 good = good && lds_link_ok(S, s_ptr[g][p], &std_form);
                 if (!std_form) atomicAnd(&s_links[g], ~(1u << p));  // (the record's mask names the STANDARD links only)
             }
-        for (uint32_t e = sub; e < ne; e += kCoopLanes) {
+        for (uint32_t e = sub; e < ne; e += LANES) {
             const uint32_t q = s_val[g][e];
             bool std_form;
             good = good && lds_link_ok(S, q + 1u, &std_form) && lds_link_ok(S, s_l2[g][e], &std_form);
@@ -539,7 +546,7 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     }
     // all thirty-two lanes of the group agree?
     const uint64_t votes = __ballot(good);
-    const uint64_t mine = 0xffffffffull << (g * kCoopLanes);
+    const uint64_t mine = GMASK << (g * LANES);
     const bool node_ok = (votes & mine) == mine;
     if (have && sub == 0 && L.etab_of) {  // a table for the node's entries, if it has any (and the pool reaches that far)
         // The node's place in the pool is its place in the call's work lists — the earlier levels' counts + its index —
@@ -560,15 +567,15 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     if (L.etab_of && s_slot[g]) {
         HamtEntryTab* T = L.etabs + (s_slot[g] - 1u);
         const uint32_t ne = s_ne[g], lall = s_lall[g];
-        for (uint32_t e = sub; e < ne; e += kCoopLanes) {
+        for (uint32_t e = sub; e < ne; e += LANES) {
             const uint32_t v = s_val[g][e], kl = s_klen[g][e];
             T->e[e] = HamtEntryTab::Entry{uint16_t(v - kl), uint16_t(v), uint16_t(uint32_t(s_end[g][e]) - v), uint8_t(kl), 0};
         }
-        {   // lane p: pointer p
-            const bool bucket = sub < np && !((lall >> sub) & 1u);
-            const uint32_t cnt = bucket ? uint32_t(S[s_ptr[g][sub]]) - 0x80u : 0u;
-            T->first[sub] = uint8_t(cnt ? s_first[g][sub] : 0u);
-            T->count[sub] = uint8_t(cnt);
+        for (uint32_t p = sub; p < kHamtTablePointers; p += LANES) {  // pointer p
+            const bool bucket = p < np && !((lall >> p) & 1u);
+            const uint32_t cnt = bucket ? uint32_t(S[s_ptr[g][p]]) - 0x80u : 0u;
+            T->first[p] = uint8_t(cnt ? s_first[g][p] : 0u);
+            T->count[p] = uint8_t(cnt);
         }
         if (sub == 0) {
             T->links = lall;
@@ -578,26 +585,29 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
     HamtNodeRec* out = L.recs + block;
     if (node_ok) {
         // offsets: sixteen dwords = thirty-two u16
-        if (sub < 16u) {
-            const uint32_t lo = 2u * sub < np ? s_ptr[g][2u * sub] : 0u, hi = 2u * sub + 1u < np ? s_ptr[g][2u * sub + 1u] : 0u;
-            reinterpret_cast<uint32_t*>(out->ptr_off)[sub] = lo | (hi << 16);
+        for (uint32_t q = sub; q < 16u; q += LANES) {
+            const uint32_t lo = 2u * q < np ? s_ptr[g][2u * q] : 0u, hi = 2u * q + 1u < np ? s_ptr[g][2u * q + 1u] : 0u;
+            reinterpret_cast<uint32_t*>(out->ptr_off)[q] = lo | (hi << 16);
         }
     }
     // Only for a node of links alone (the upper levels: every query that stands on it steps through one of them).  A bucket
     // node's few links lead to overflow nodes a handful of its queries follow: resolving all of them here cost the bucket
     // level's parse 28 µs (two more dependent reads in every wavefront) to save its advance nothing.
     const bool resolve = node_ok && L.child != nullptr && s_ne[g] == 0u;
-    uint32_t c = kNoBlock;
-    if (resolve) {  // lane p: the block behind pointer p (the 38 CID bytes of a standard link start 5 bytes in)
-        if (sub < np && ((s_links[g] >> sub) & 1u)) {
-            const uint32_t at = uint32_t(s_ptr[g][sub]) + 5u;
-            CidKey key;
+    uint32_t c = kNoBlock;  // (LANES == 32: the block behind the lane's own pointer, what EMIT lists)
+    if (resolve) {  // the block behind pointer p (the 38 CID bytes of a standard link start 5 bytes in)
+        for (uint32_t p = sub; p < kHamtTablePointers; p += LANES) {
+            c = kNoBlock;
+            if (p < np && ((s_links[g] >> p) & 1u)) {
+                const uint32_t at = uint32_t(s_ptr[g][p]) + 5u;
+                CidKey key;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) key.w[j] = lds_peek64(S, at + 8u * uint32_t(j));
-            key.w[4] &= (1ull << 48) - 1ull;
-            c = witness_find_quiet(w, key);
+                for (int j = 0; j < 5; ++j) key.w[j] = lds_peek64(S, at + 8u * uint32_t(j));
+                key.w[4] &= (1ull << 48) - 1ull;
+                c = witness_find_quiet(w, key);
+            }
+            L.child[size_t(block) * kHamtTablePointers + p] = c;
         }
-        L.child[size_t(block) * kHamtTablePointers + sub] = c;
     }
     if (EMIT) {  // (an instance of its own — the fused top's: the other launches do not carry this code; the lanes still here vote)
         const bool em = resolve && c != kNoBlock;
@@ -636,8 +646,9 @@ __device__ __forceinline__ void hamt_parse_actor_pair(const WitnessView& w, cons
 // (EMIT: hamt_parse_actor_pair's child listing, the fused top's instance.  The short-node instance asks for FOUR wavefronts
 // per SIMD, what round 5's form reached at 99 VGPRs: with the listing code and the count-driven loop the
 // allocator otherwise took 152 and one wavefront per SIMD less, 85 → 100 µs for the overflow level.)
-template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, uint32_t CLS, bool EMIT>
-__global__ __launch_bounds__(64, CLS == 0u ? 5 : (CLS == 1u ? 4 : 3)) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L, uint32_t level) {
+template <uint32_t kCoopStage, uint32_t kCoopMaxEntries, uint32_t CLS, bool EMIT, uint32_t LANES = kCoopLanes>
+__global__ __launch_bounds__(64, LANES != 32u ? 3 : (CLS == 0u ? 5 : (CLS == 1u ? 4 : 3))) void k_hamt_lv_parse_actor(WitnessView w, HamtLevels L,
+                                                                                                                    uint32_t level) {
     const uint32_t n_raw = L.count[L.plain_list ? 0u : kHamtClasses * level + CLS];
     const uint32_t n_list = !L.plain_list && n_raw > L.cap ? L.cap : n_raw;
     uint32_t slot_base = 0;
@@ -647,8 +658,8 @@ __global__ __launch_bounds__(64, CLS == 0u ? 5 : (CLS == 1u ? 4 : 3)) void k_ham
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) slot_base += __shfl_xor(slot_base, d, 64);
     }
-    for (uint32_t pair = blockIdx.x; pair * kCoopNodes < n_list; pair += gridDim.x) {
-        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, CLS, EMIT>(w, L, level, pair, n_list, slot_base);
+    for (uint32_t pair = blockIdx.x; pair * (64u / LANES) < n_list; pair += gridDim.x) {
+        hamt_parse_actor_pair<kCoopStage, kCoopMaxEntries, CLS, EMIT, LANES>(w, L, level, pair, n_list, slot_base);
         __syncthreads();  // (the pair's LDS is the next pair's)
     }
 }
@@ -910,7 +921,7 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
         if (top_env > 0) top = std::min(uint32_t(top_env), levels - 1u);
         while (top > 0 && (1ull << (bit_width * (top - 1u))) > cap) --top;
     }
-    auto parse_grid = [&](uint32_t lv, uint32_t per_cu) {
+    auto parse_grid = [&](uint32_t lv, uint32_t per_cu, uint32_t nodes_per_wg = kCoopNodes) {
         uint64_t fan = 1;  // level l holds at most min(n, 2^(bit_width · l)) distinct nodes
         for (uint32_t k = 0; k < lv && fan < cap; ++k) fan <<= bit_width;
         const uint32_t bound = fan < cap ? uint32_t(fan) : cap;
@@ -918,7 +929,7 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
         // One workgroup per pair up to a cap the loop covers: the dispatcher backfills workgroups as they retire and so
         // balances nodes of unequal length; a grid of "what the chip holds" striding over the list was 255 µs for the
         // bucket level against 173 (profiles/r06_experiments.md).  An empty list is one word read per workgroup.
-        return std::min(div_up(bound, kCoopNodes), 32768u);
+        return std::min(div_up(bound, nodes_per_wg), 32768u);
     };
     for (uint32_t lv = 0; lv < top; ++lv) {
         if (lv + 1u < top)
@@ -944,7 +955,10 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
             // an empty list then costs ≈ 4 µs instead of ≈ 9 (32 k workgroups that read one word each).
             const bool bucket_level = top > 0 && lv == top;
             const uint32_t narrow = 1024u;
-            const uint32_t g_small = top > 0 && bucket_level ? std::min(parse_grid(lv, 32), narrow) : parse_grid(lv, 32);
+            static const bool small8 = [] { const char* e = std::getenv("IPCFP_HAMT_SMALL8"); return !(e && std::atoi(e) == 0); }();
+            const bool eight = small8 && top > 0;  // (eight lanes per short node below a fused top: hamt_parse_actor_pair LANES)
+            const uint32_t g_small = top > 0 && bucket_level ? std::min(parse_grid(lv, 32, eight ? 8u : kCoopNodes), narrow)
+                                                             : parse_grid(lv, 32, eight ? 8u : kCoopNodes);
             const uint32_t g_long = top > 0 && !bucket_level ? std::min(parse_grid(lv, 14), narrow) : parse_grid(lv, 14);
             if (small_lane && top > 0) {
                 uint64_t fan = 1;
@@ -952,6 +966,9 @@ int launch_hamt_get_levels(ipcfp_ctx* ctx, const WitnessView& w, const CidKey& r
                 const int rc = launch_hamt_lv_parse_lane(ctx, w, L.work[lv & 1u][0], L.count + kHamtClasses * lv, cap, fan < cap ? uint32_t(fan) : cap,
                                                          HK_ACTOR_STATE, recs_d, L.etab_of);
                 if (rc) return rc;
+            } else if (eight) {
+                hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, 0u, false, 8u>), dim3(g_small), dim3(64), 0,
+                                   ctx->stream, w, L, lv);
             } else {
                 hipLaunchKernelGGL((k_hamt_lv_parse_actor<kCoopSmallStage, kCoopSmallEntries, 0u, false>), dim3(g_small), dim3(64), 0, ctx->stream,
                                    w, L, lv);
