@@ -32,12 +32,16 @@ if [ -z "$SKIP_WORKLOAD_PMC" ]; then
   if [ -n "$TRAFFIC_INTO_PROFILES" ] && [ -s "$out/traffic_workloads.json" ] && [ "$rnd" != 0 ]; then cp "$out/traffic_workloads.json" "profiles/r$(printf %02d "$rnd")_traffic_workloads.json"; fi
 fi
 # ---- 2 ----
+# (the line on stdout is the driver's compact record; the whole report is bench_detail.json, rewritten by every invocation)
 ( time timeout 400 python bench.py --steps 20 --warmup 5 ) > "$out/bench.log" 2>&1; json_line "$out/bench.log" > "$out/bench.json"; head -c 400 "$out/bench.json"; echo
-for wl in cid hamt storage; do ( timeout 200 python bench.py --workload $wl --steps 10 --warmup 3 ) > "$out/bench_$wl.log" 2>&1; json_line "$out/bench_$wl.log" > "$out/bench_$wl.json"; head -c 300 "$out/bench_$wl.json"; echo; done
+cp bench_detail.json "$out/bench_detail.json" 2>/dev/null
+for wl in cid hamt storage; do ( timeout 200 python bench.py --workload $wl --steps 10 --warmup 3 ) > "$out/bench_$wl.log" 2>&1; json_line "$out/bench_$wl.log" > "$out/bench_$wl.json"; cp bench_detail.json "$out/bench_detail_$wl.json" 2>/dev/null; head -c 300 "$out/bench_$wl.json"; echo; done
 ( timeout 200 python bench.py --steps 10 --warmup 3 --force-sharded ) > "$out/bench_sharded1.log" 2>&1; json_line "$out/bench_sharded1.log" > "$out/bench_sharded1.json"; head -c 300 "$out/bench_sharded1.json"; echo
 # ---- 3 ----
 bash tools/gpu_prof.sh "$out"
 bash tools/gpu_pmc.sh "$out" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
 bash tools/gpu_pmc.sh "$out" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_IFETCH GRBM_GUI_ACTIVE"
+# the L2's own view of the step: hits and misses per kernel, a pass of its own
+bash tools/gpu_pmc.sh "$out" "TCC_HIT_sum TCC_MISS_sum"
 # (4: configs[3] / [4] kernel stats + PMC are stage 1b's files)
 ls "$out"
