@@ -147,7 +147,12 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     if (rc) return rc;
     rc = launch_storage_run_actors_lane(ctx, w, claims_d, runs.p, uint32_t(n_runs), kUndecided);
     if (rc) return rc;
-    rc = launch_verify_storage_table(ctx, w, table.p, claims_d, n, run_of.p, runs.p, trust, kUndecided, status_d);
+    // the first step of the runs' storage gets, once per run (IPCFP_STORAGE_RUN_CHILDREN=0: every claim by itself)
+    static const bool run_children = [] { const char* e = std::getenv("IPCFP_STORAGE_RUN_CHILDREN"); return !(e && std::atoi(e) == 0); }();
+    DevBuf<uint32_t> root_children;
+    if (run_children && n_runs) IPCFP_HIP(ctx, root_children.alloc(size_t(n_runs) * 33u));
+    rc = launch_verify_storage_table(ctx, w, table.p, claims_d, n, run_of.p, runs.p, uint32_t(n_runs), root_children.p, trust, kUndecided,
+                                     status_d);
     if (rc) return rc;
     return launch_verify_storage_lanes(ctx, w, claims_d, n, trust, status_d, 1);
     // (the scratch buffers go back to the pool on return; reuse is ordered on the one stream)

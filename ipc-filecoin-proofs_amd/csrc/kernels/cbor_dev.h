@@ -964,6 +964,59 @@ __device__ __forceinline__ bool vec_u8_step(uint64_t w, uint32_t& used, uint32_t
     return false;
 }
 
+// Four elements of a serde Vec<u8> out of the eight bytes {hi, lo} at the reader's position (one or two bytes
+// each, so eight bytes always hold four): the elements packed big-endian into `cur` (first element highest), the bytes they
+// took added to `pos`.  `bad`: a byte that is neither 00..17 nor 18 where an element starts.  COUNT ≤ 4.
+template <int COUNT>
+__device__ __forceinline__ void vec_u8_take(uint32_t lo, uint32_t hi, uint32_t& cur, uint32_t& pos, uint32_t& bad) {
+#pragma unroll
+    for (int e = 0; e < COUNT; ++e) {
+        const uint32_t b = lo & 0xffu;
+        const bool two = b == 0x18u;
+        bad |= uint32_t(b > 0x18u);
+        const uint32_t x = two ? (lo >> 8) & 0xffu : b;
+        const uint32_t sh = two ? 16u : 8u;
+        lo = __builtin_amdgcn_alignbit(hi, lo, sh);
+        hi >>= sh;
+        cur = (cur << 8) | x;
+        pos += sh >> 3;
+    }
+}
+
+// A serde Vec<u8> in its usual spelling (`8n` | `98 nn`, then n elements of one or two bytes) at offset `at` of the reader's
+// item, four elements per fetch: → the offset behind it, or 0 when it is spelled some other way (or is no such thing): the
+// caller then reads it item by item.  The reader's position is left alone.
+__device__ __forceinline__ uint32_t vec_u8_end(Rd& r, uint32_t at) {
+    if (at >= r.n) return 0;
+    const uint64_t v8 = r.peek64(at);
+    const uint32_t hv = uint32_t(v8) & 0xffu;
+    uint32_t n;
+    if (hv >= 0x80u && hv < 0x98u) {
+        n = hv - 0x80u;
+        at += 1u;
+    } else if (hv == 0x98u) {
+        n = uint32_t(v8 >> 8) & 0xffu;
+        at += 2u;
+    } else {
+        return 0;
+    }
+    uint32_t cur = 0, bad = 0, q = n >> 2;
+    for (; q && at < r.n; --q) {
+        const uint64_t w8 = r.peek64(at);
+        vec_u8_take<4>(uint32_t(w8), uint32_t(w8 >> 32), cur, at, bad);
+    }
+    if (q) return 0;
+    const uint32_t rest = n & 3u;
+    if (rest) {
+        if (at >= r.n) return 0;
+        const uint64_t w8 = r.peek64(at);
+        if (rest == 1) vec_u8_take<1>(uint32_t(w8), uint32_t(w8 >> 32), cur, at, bad);
+        else if (rest == 2) vec_u8_take<2>(uint32_t(w8), uint32_t(w8 >> 32), cur, at, bad);
+        else vec_u8_take<3>(uint32_t(w8), uint32_t(w8 >> 32), cur, at, bad);
+    }
+    return bad || at > r.n || !r.ok() ? 0u : at;
+}
+
 __device__ __forceinline__ void check_vec_u8(Rd& r) {  // serde Vec<u8> = array of u8
     const uint64_t n = r.read_array();
     uint64_t i = 0;

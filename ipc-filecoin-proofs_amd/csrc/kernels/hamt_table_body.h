@@ -68,8 +68,29 @@ __device__ __forceinline__ void hamt_node_parse(Rd& r, uint32_t kinds, bool writ
                     (r.peek64(at + 8) & 0xffffffull) == 0x2002e4ull)
                     std_links |= 1u << p;
             } else if ((b0 >> 5) == 4) {
-                const uint64_t nkv = r.read_array();
+                uint64_t nkv;
+                if (b0 < 0x98u) {  // (the head of a short array is its one byte)
+                    nkv = b0 - 0x80u;
+                    r.pos += 1u;
+                } else {
+                    nkv = r.read_array();
+                }
                 for (uint64_t k = 0; k < nkv && r.ok(); ++k) {
+                    // A storage entry as every encoder writes it — `82 58 20 <32-byte slot>` and a Vec<u8> of one- and two-byte
+                    // elements — from two fetches and one more per four elements.  Item by item it is four heads and an element
+                    // loop, ≈ 2.7 k instructions, and one lane does that for the ≈ 8 entries of its node: 0.6 ms of configs[4]'s
+                    // call for k_hamt_node_table_lane (profiles/r06_experiments.md).  Anything else takes that way as before.
+                    if (kinds & HK_VEC_U8) {
+                        const uint32_t e0 = r.pos;
+                        if (e0 + 36u <= r.n && (r.peek64(e0) & 0xffffffull) == 0x205882ull) {
+                            const uint32_t end = vec_u8_end(r, e0 + 35u);
+                            if (end) {
+                                r.pos = end;
+                                kinds_ok &= HK_VEC_U8 | HK_ANY;
+                                continue;
+                            }
+                        }
+                    }
                     r.expect_array(2);
                     uint32_t ko, kl;
                     r.read_bytes(ko, kl);

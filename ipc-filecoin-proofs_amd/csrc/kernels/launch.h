@@ -75,8 +75,8 @@ int launch_storage_run_facts(ipcfp_ctx* ctx, const WitnessView& w, const void* c
 int launch_storage_run_actors_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, void* runs_d,
                                     uint32_t n_runs, uint32_t undecided);
 int launch_verify_storage_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, uint32_t n,
-                                const uint32_t* run_of_d, const void* runs_d, const ipcfp_trust_policy_t& trust, uint32_t undecided,
-                                uint8_t* status_d);
+                                const uint32_t* run_of_d, const void* runs_d, uint32_t n_runs, uint32_t* root_children_d,
+                                const ipcfp_trust_policy_t& trust, uint32_t undecided, uint8_t* status_d);
 int launch_storage_run_actors_lane(ipcfp_ctx* ctx, const WitnessView& w, const void* claims_d, void* runs_d, uint32_t n_runs,
                                    uint32_t undecided);
 int launch_verify_storage_lanes(ipcfp_ctx* ctx, const WitnessView& w, const StorageClaimPacked* claims_d, uint32_t n,

@@ -202,6 +202,38 @@ __global__ __launch_bounds__(256) void k_storage_run_actors_table(WitnessView w,
     runs[i].actor_state = actor_state;
 }
 
+// The first step of every storage get of a run, taken ONCE for the run (round 6): the storage root's block and the blocks
+// behind its 32 links.  A contract's 256 proofs all open the same root and follow one of its links: each claim read the
+// link's 38 bytes, probed the index and compared a CID — three dependent random reads of its ≈ eight — for an answer its
+// run's neighbours had found already.  32 lanes per run; kNoBlock where the table has no record of the root, the pointer is
+// not a standard link or the block is missing (the claim's own lane then takes the long way and gives the status).
+__global__ __launch_bounds__(256) void k_storage_run_children(WitnessView w, const HamtNodeRec* __restrict__ table,
+                                                              const StorageRun* __restrict__ runs, uint32_t n_runs,
+                                                              uint32_t* __restrict__ root_block, uint32_t* __restrict__ root_child) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 5, p = t & 31u;
+    if (i >= n_runs) return;
+    uint32_t rb = kNoBlock, child = kNoBlock;
+    if (runs[i].root_kind == 3) {
+        rb = witness_find(w, runs[i].hamt_root);  // (the 32 lanes of a run: the same probe, broadcast)
+        if (rb != kNoBlock) {
+            const HamtNodeRec* rec = table + rb;
+            const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);
+            if ((head & 0xffu) != 1u) {
+                rb = kNoBlock;  // not tabulated: nothing is known about its pointers
+            } else if (p < ((head >> 16) & 0xffu) && ((rec->std_links >> p) & 1u)) {
+                const uint8_t* g = w.arena + w.off[rb] + rec->ptr_off[p];
+                CidKey link;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) __builtin_memcpy(&link.w[j], g + 5 + 8 * j, 8);
+                link.w[4] &= (1ull << 48) - 1ull;
+                child = witness_find(w, link);
+            }
+        }
+    }
+    root_child[size_t(i) * 32u + p] = child;
+    if (p == 0) root_block[i] = rb;
+}
+
 // left_pad_32 (src/proofs/common/evm.rs:91-100) of a serde Vec<u8> (a CBOR array of u8, type-checked by the table) as four
 // little-endian words: byte i of the padded value = word i/8, bits 8·(i%8)…
 __device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
@@ -228,6 +260,50 @@ __device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
     for (; i < n && v.ok(); ++i) put(i, uint32_t(v.read_uint()));
 }
 
+// The same from plain 8-byte reads, for the usual spelling (`8n` | `98 nn`, elements of one or two bytes): the padded value is
+// what a 32-byte shift register holds after every element has been pushed in at its low end — the last 32 elements, zeros
+// above a shorter one — as eight big-endian limbs, L[0] the lowest.  false: another spelling, take the reader.
+__device__ __forceinline__ bool left_pad_32_raw(const uint8_t* __restrict__ p, uint32_t avail, uint32_t L[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) L[m] = 0;
+    const uint32_t hv = p[0];
+    uint32_t n, pos;
+    if (hv >= 0x80u && hv < 0x98u) {
+        n = hv - 0x80u;
+        pos = 1u;
+    } else if (hv == 0x98u) {
+        n = p[1];
+        pos = 2u;
+    } else {
+        return false;
+    }
+    uint32_t bad = 0;
+    uint32_t q = n >> 2;
+    for (; q && pos < avail; --q) {  // four elements per 8-byte read: one limb
+        const uint64_t w8 = raw_ld64(p + pos);
+        uint32_t cur = 0;
+        vec_u8_take<4>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+#pragma unroll
+        for (int m = 7; m > 0; --m) L[m] = L[m - 1];
+        L[0] = cur;
+    }
+    if (q) return false;
+    const uint32_t r = n & 3u;
+    if (r) {  // the last one to three: the register moves up by as many bytes
+        const uint64_t w8 = raw_ld64(p + pos);
+        uint32_t cur = 0;
+        if (r == 1) vec_u8_take<1>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        else if (r == 2) vec_u8_take<2>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        else vec_u8_take<3>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        const uint32_t down = 32u - 8u * r;
+#pragma unroll
+        for (int m = 7; m > 0; --m) L[m] = __builtin_amdgcn_alignbit(L[m], L[m - 1], down);  // (L[m] << 8r) | (L[m-1] >> (32 - 8r))
+        L[0] = (L[0] << (8u * r)) | cur;
+    }
+    if (bad || pos > avail) return false;
+    return true;
+}
+
 // verify_storage_proof, steps 2-6 in the reference's order of checks (src/proofs/storage/verifier.rs:24-63), one claim per
 // lane: everything its run shares comes from the run's record, `read_storage_slot`'s HAMT get (storage/decode.rs:79-96)
 // walks the node table.  A claim it cannot settle (an inline small-map layout, a block the table does not cover) is left
@@ -238,11 +314,13 @@ __device__ __forceinline__ void left_pad_32_words(Rd& v, uint64_t out[4]) {
 __global__ __launch_bounds__(256, 7) void k_verify_storage_table(WitnessView w, const HamtNodeRec* __restrict__ table,
                                                               const StorageClaimPacked* __restrict__ claims, uint32_t n,
                                                               const uint32_t* __restrict__ run_of, const StorageRun* __restrict__ runs,
+                                                              const uint32_t* __restrict__ root_block, const uint32_t* __restrict__ root_child,
                                                               ipcfp_trust_policy_t trust, uint32_t undecided, uint8_t* __restrict__ status) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const StorageClaimPacked& c = claims[t];
-    const StorageRun& run = runs[run_of[t]];
+    const uint32_t ri = run_of[t];
+    const StorageRun& run = runs[ri];
     const uint32_t flags = c.flags;
     uint32_t st = kStPending;
     do {
@@ -266,13 +344,22 @@ __global__ __launch_bounds__(256, 7) void k_verify_storage_table(WitnessView w, 
         if (run.root_kind != 3) break;  // an inline small map (A1-A3): the one-lane kernel searches it
         uint64_t padded[4] = {0, 0, 0, 0};
         ValueLoc loc;
-        const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, c.slot, 32, loc);  // decode.rs:79-96
+        const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, c.slot, 32, loc,  // decode.rs:79-96
+                                           root_block ? root_block[ri] : kNoBlock, root_child ? root_child + size_t(ri) * 32u : nullptr);
         if (hs == kTablePunt) break;
         if (hs != IPCFP_ST_NOT_FOUND) {  // unwrap_or_default(): a missing key means zero
             if (hs != IPCFP_ST_TRUE) { st = hs; break; }
-            Rd v;
-            v.init(w.arena + w.off[loc.block] + loc.off, loc.len);
-            left_pad_32_words(v, padded);
+            const uint8_t* vp = w.arena + w.off[loc.block] + loc.off;
+            uint32_t L[8];
+            if (left_pad_32_raw(vp, loc.len, L)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)  // byte i of the value: limb (31 - i) / 4, big-endian inside it
+                    padded[k] = uint64_t(__builtin_bswap32(L[7 - 2 * k])) | uint64_t(__builtin_bswap32(L[6 - 2 * k])) << 32;
+            } else {
+                Rd v;
+                v.init(vp, loc.len);
+                left_pad_32_words(v, padded);
+            }
         }
         if (!(flags & SC_VALUE_MATCHABLE)) { st = IPCFP_ST_FALSE_VALUE; break; }  // can never equal "0x" + 64 hex digits
         const uint64_t* cv = reinterpret_cast<const uint64_t*>(c.value);
@@ -291,12 +378,18 @@ int launch_storage_run_actors_table(ipcfp_ctx* ctx, const WitnessView& w, const 
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
+// root_children_d: n_runs × 33 words of scratch (block of every run's root, then 32 children per run), or null: every claim resolves its own
 int launch_verify_storage_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, uint32_t n,
-                                const uint32_t* run_of_d, const void* runs_d, const ipcfp_trust_policy_t& trust, uint32_t undecided,
-                                uint8_t* status_d) {
+                                const uint32_t* run_of_d, const void* runs_d, uint32_t n_runs, uint32_t* root_children_d,
+                                const ipcfp_trust_policy_t& trust, uint32_t undecided, uint8_t* status_d) {
+    uint32_t* root_block = root_children_d;
+    uint32_t* root_child = root_children_d ? root_children_d + n_runs : nullptr;
+    if (root_children_d && n_runs)
+        hipLaunchKernelGGL(k_storage_run_children, dim3(div_up(n_runs * 32u, 256)), dim3(256), 0, ctx->stream, w,
+                           static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageRun*>(runs_d), n_runs, root_block, root_child);
     hipLaunchKernelGGL(k_verify_storage_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w,
                        static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageClaimPacked*>(claims_d), n, run_of_d,
-                       static_cast<const StorageRun*>(runs_d), trust, undecided, status_d);
+                       static_cast<const StorageRun*>(runs_d), root_block, root_child, trust, undecided, status_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

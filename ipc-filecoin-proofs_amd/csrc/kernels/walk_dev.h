@@ -348,6 +348,68 @@ __device__ __forceinline__ uint32_t hamt_get(const WitnessView& w, const CidKey&
 }
 
 // ---------------------------------------------------------------------------
+// A bucket of a storage HAMT searched with plain 8-byte reads (round 6).  The node table has validated the node and
+// type-checked its values (kinds_ok): what is left for a claim is to find its 32-byte key among ≤ 3 entries spelled
+// `82 58 20 <key> <value>`, value = `8n` | `98 nn` and n elements of one or two bytes.  The windowed reader's item heads
+// (≈ 80 instructions each, four per entry) and the walk over the MATCHED value — which left_pad_32 walks again — were
+// 0.4 of configs[4]'s 0.88 ms kernel (profiles/r06_experiments.md).  Reads may run ≤ 8 bytes past the block: the arena has
+// blocks on 128-byte lines and 256 bytes of tail slack (witness.cpp kTailSlack).
+// 1: found, `vstart` = the value's offset in the block; 0: not in the bucket; 2: spelled some other way — take the reader.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t raw_ld64(const uint8_t* p) {
+    uint64_t x;
+    __builtin_memcpy(&x, p, 8);
+    return x;
+}
+
+__device__ __forceinline__ uint32_t bucket_find32_raw(const uint8_t* __restrict__ g, uint32_t blen, uint32_t off, const uint64_t kw[4],
+                                                      uint32_t& vstart) {
+    const uint32_t hb = g[off];
+    if (hb < 0x81u || hb > 0x83u) return 2;
+    const uint32_t nkv = hb - 0x80u;
+    uint32_t pos = off + 1u;
+    for (uint32_t k = 0; k < nkv; ++k) {
+        if (pos + 36u > blen) return 2;
+        if ((raw_ld64(g + pos) & 0xffffffull) != 0x205882ull) return 2;
+        const uint64_t diff = (raw_ld64(g + pos + 3) ^ kw[0]) | (raw_ld64(g + pos + 11) ^ kw[1]) | (raw_ld64(g + pos + 19) ^ kw[2]) |
+                              (raw_ld64(g + pos + 27) ^ kw[3]);
+        pos += 35u;
+        if (diff == 0) {
+            vstart = pos;
+            return 1;
+        }
+        if (k + 1u == nkv) break;
+        const uint32_t hv = g[pos];  // the value of another key: over it
+        uint32_t n;
+        if (hv >= 0x80u && hv < 0x98u) {
+            n = hv - 0x80u;
+            pos += 1u;
+        } else if (hv == 0x98u) {
+            n = g[pos + 1u];
+            pos += 2u;
+        } else {
+            return 2;
+        }
+        uint32_t cur = 0, bad = 0;
+        uint32_t q = n >> 2;
+        for (; q && pos < blen; --q) {
+            const uint64_t w8 = raw_ld64(g + pos);
+            vec_u8_take<4>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        }
+        if (q) return 2;
+        if (n & 3u) {
+            const uint64_t w8 = raw_ld64(g + pos);
+            const uint32_t r = n & 3u;
+            if (r == 1) vec_u8_take<1>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+            else if (r == 2) vec_u8_take<2>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+            else vec_u8_take<3>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        }
+        if (bad || pos > blen) return 2;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // HAMT get over the node table (hamt_table.h): same outcomes as hamt_get above, or kTablePunt when the walk meets a block
 // the table does not cover (the caller then walks).  `kbit`: the HK_* bit of the HAMT's value kind.
 // ---------------------------------------------------------------------------
@@ -355,12 +417,16 @@ constexpr uint32_t kTablePunt = 0xfdu;  // not an ipcfp_status_t
 
 __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const HamtNodeRec* __restrict__ table, const CidKey& root,
                                                    uint32_t bit_width, uint32_t kbit, const uint8_t* key, uint32_t key_len,
-                                                   ValueLoc& loc) {
+                                                   ValueLoc& loc, uint32_t root_block = kNoBlock,
+                                                   const uint32_t* __restrict__ root_children = nullptr) {
+    // `root_block` / `root_children` (optional): the root's block id and the blocks behind its pointers as SOMEBODY ELSE has
+    // already resolved them (kNoBlock where not: the link is then read and looked up here) — the 256 storage proofs of one
+    // contract all start at the same root and step through one of its 32 links (verify_storage.hip k_storage_run_children).
     if (bit_width < 1 || bit_width > 8) return IPCFP_ST_ERR_DECODE;
     uint32_t h[8];
     sha256::hash_bytes(key, key_len, h);
     uint32_t consumed = 0;
-    uint32_t block = witness_find(w, root);
+    uint32_t block = root_block != kNoBlock ? root_block : witness_find(w, root);
     if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
     for (;;) {
         const HamtNodeRec* rec = table + block;
@@ -376,6 +442,13 @@ __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const H
         if (idx >= 64u || !((bf >> idx) & 1ull)) return IPCFP_ST_NOT_FOUND;
         const uint32_t rank = uint32_t(__popcll(bf & ((1ull << idx) - 1ull)));
         if (rank >= np) return IPCFP_ST_ERR_DECODE;
+        if (root_children && consumed == bit_width && ((rec->std_links >> rank) & 1u)) {  // the root's link, resolved per run
+            const uint32_t cb = root_children[rank];
+            if (cb != kNoBlock) {
+                block = cb;
+                continue;
+            }
+        }
         const uint32_t off = rec->ptr_off[rank];
         const uint8_t* g = w.arena + w.off[block];
         CidKey link;
@@ -395,6 +468,20 @@ __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const H
                 link = r.key_any(o, l);
             } else {
                 // a bucket: `[[key, value]…]`, validated; find the key, skip the values
+                if (kbit == HK_VEC_U8 && key_len == 32) {  // a storage slot: plain reads first
+                    uint64_t kw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) kw[j] = raw_ld64(key + 8 * j);
+                    uint32_t vstart = 0;
+                    const uint32_t f = bucket_find32_raw(g, w.len[block], off, kw, vstart);
+                    if (f == 0) return IPCFP_ST_NOT_FOUND;
+                    if (f == 1) {
+                        loc.block = block;
+                        loc.off = vstart;
+                        loc.len = w.len[block] - vstart;  // (the value ends before the block does; its reader stops at its own end)
+                        return IPCFP_ST_TRUE;
+                    }
+                }
                 const uint64_t nkv = r.read_array();
                 for (uint64_t k = 0; k < nkv && r.ok(); ++k) {
                     r.expect_array(2);

@@ -185,3 +185,172 @@ def test_actor_state_spellings_and_flaws_every_route(engine, oracle, routed, fla
             gs, gl = w.hamt_get(root, 5, "actor_state", probe)
             assert np.array_equal(gs, os_), (name, flaw, np.nonzero(gs != os_)[0][:5], gs[gs != os_][:5], os_[gs != os_][:5])
             assert loc_bytes(data, off, gl) == ov, (name, flaw)
+
+
+# ---- storage values and keys in every spelling: the plain-read paths of round 6 against the item-by-item reader -----------
+
+def _head(b, p):
+    """CBOR item head at p → (major, argument, next position)"""
+    m, ai = b[p] >> 5, b[p] & 31
+    if ai < 24:
+        return m, ai, p + 1
+    nb = 1 << (ai - 24)
+    return m, int.from_bytes(b[p + 1: p + 1 + nb], "big"), p + 1 + nb
+
+
+def parse_storage_node(b):
+    """`[bitfield, [pointer…]]` with pointers = links or buckets of `[32-byte key, [u8…]]` → (bitfield bytes, pointers) with a
+    link as bytes and a bucket as [(key, [elements])]; None when the block is anything else."""
+    try:
+        m, a, p = _head(b, 0)
+        if (m, a) != (4, 2):
+            return None
+        m, a, p = _head(b, p)
+        if m != 2 or a > 8:
+            return None
+        bf, p = b[p: p + a], p + a
+        m, npt, p = _head(b, p)
+        if m != 4 or npt > 32:
+            return None
+        ptrs = []
+        for _ in range(npt):
+            if b[p] == 0xD8:
+                if b[p: p + 5] != b"\xd8\x2a\x58\x27\x00":
+                    return None
+                ptrs.append(bytes(b[p: p + 43]))
+                p += 43
+                continue
+            m, nkv, p = _head(b, p)
+            if m != 4:
+                return None
+            bucket = []
+            for _ in range(nkv):
+                m, a, p = _head(b, p)
+                if (m, a) != (4, 2):
+                    return None
+                m, kl, p = _head(b, p)
+                if m != 2 or kl != 32:
+                    return None
+                key, p = bytes(b[p: p + 32]), p + 32
+                m, n, p = _head(b, p)
+                if m != 4:
+                    return None
+                el = []
+                for _ in range(n):
+                    m, v, p = _head(b, p)
+                    if m != 0 or v > 255:
+                        return None
+                    el.append(v)
+                bucket.append((key, el))
+            ptrs.append(bucket)
+        return (bytes(bf), ptrs) if p == len(b) else None
+    except IndexError:
+        return None
+
+
+def wide_head(major, n, nbytes):
+    return bytes([(major << 5) | {1: 24, 2: 25, 4: 26}[nbytes]]) + int(n).to_bytes(nbytes, "big")
+
+
+def respell_entry(key, el, mode, rng):
+    """One bucket entry, its key and value spelled by `mode`; → (bytes, the elements a decoder reads or None if it must fail)"""
+    el = list(el)
+    khead, vhead, spell = None, None, {}
+    if mode == 1:
+        vhead = wide_head(4, len(el), 2)                       # 99 00 nn
+    elif mode == 2 and el:
+        spell[int(rng.integers(0, len(el)))] = 2                # one element as 19 00 xx
+    elif mode == 3 and el:
+        k = int(rng.integers(0, len(el)))
+        el[k] = int(rng.integers(0, 24))
+        spell[k] = 1                                            # a small element in two bytes (18 0x)
+    elif mode == 4:
+        el = el[: [0, 1, 2, 3, 5, 23, 24, 31][int(rng.integers(0, 8))]]   # shorter than a word: left-padded
+    elif mode == 5:
+        el = [int(x) for x in rng.integers(0, 256, int(rng.integers(1, 9)))] + el   # longer: the last 32 count
+    elif mode == 6:
+        khead = wide_head(2, 32, 2)                             # 59 00 20
+    elif mode == 7:
+        el = [24] * len(el)                                     # 18 18 18 18 …: headers and payloads look alike
+    elif mode == 8:
+        el[-1:] = [300]                                         # not a u8: the typed decode fails
+        spell[len(el) - 1] = 2
+    elif mode == 9 and el:
+        el = el[:-1] + [0x17, 0x18, 0x19][: 1 + int(rng.integers(0, 3))]  # the three kinds of first byte side by side
+    out = (khead or pyamt.head(2, 32)) + key + (vhead or pyamt.head(4, len(el)))
+    for k, v in enumerate(el):
+        out += wide_head(0, v, spell[k]) if k in spell else pyamt.uint(v)
+    return out, (None if mode == 8 else el)
+
+
+def left_pad_32(el):
+    b = bytes(el)
+    return b[-32:] if len(b) >= 32 else bytes(32 - len(b)) + b
+
+
+@pytest.mark.parametrize("slots", [40, 300])
+def test_storage_values_in_every_spelling_both_routes(engine, oracle, slots):
+    """Storage nodes rewritten in place (their CIDs kept: the store never re-hashes) so that keys and values come in every
+    spelling a decoder accepts — wide heads, wide and non-minimal elements, values shorter and longer than 32 elements, runs of
+    0x18 — and one it rejects.  The tabled route reads the usual spelling with plain 8-byte loads (walk_dev.h
+    bucket_find32_raw, verify_storage.hip left_pad_32_raw, cbor_dev.h vec_u8_end) and everything else item by item; the
+    one-lane route reads everything item by item: both must say what the oracle says, claim by claim."""
+    rng = np.random.default_rng(fuzz_seed(4242) + slots)
+    tip = Tipset(n_receipts=8, n_parents=1, n_actors=300, n_contracts=12, slots_per_contract=slots, storage_layout_mix=0,
+                 keep_full_state=1, seed=fuzz_seed(31) + slots)
+    blocks = [bytes(tip.data[int(o): int(o) + int(l)]) for o, l in zip(tip.off, tip.lens)]
+    modes = {}
+    new_value = {}   # slot → the elements its entry now holds (None: undecodable)
+    n_nodes = 0
+    for bi, b in enumerate(blocks):
+        node = parse_storage_node(b)
+        if node is None or not any(isinstance(p, list) and p for p in node[1]):
+            continue
+        n_nodes += 1
+        if n_nodes % 4 == 0:
+            continue  # every fourth node stays as written
+        ptrs = []
+        for p in node[1]:
+            if not isinstance(p, list):
+                ptrs.append(p)
+                continue
+            ents = []
+            for key, el in p:
+                mode = int(rng.integers(0, 10)) if rng.integers(0, 3) else 0
+                if mode == 8 and rng.integers(0, 16):
+                    mode = 0  # (a flawed value takes its whole node down: keep them rare)
+                if n_nodes == 2 and not ents and not any(isinstance(q, bytes) and q[:1] != b"\xd8" for q in ptrs):
+                    mode = 8  # … but have one
+                e, now = respell_entry(key, el, mode, rng)
+                ents.append(b"\x82" + e)
+                new_value[key, left_pad_32(el)] = now  # (contracts share slot numbers: an entry is its slot and what it held)
+                modes[key, left_pad_32(el)] = mode
+            bucket_head = wide_head(4, len(ents), 1) if rng.integers(0, 8) == 0 else pyamt.head(4, len(ents))
+            ptrs.append(bucket_head + b"".join(ents))
+        blocks[bi] = pyamt.head(4, 2) + pyamt.bstr(node[0]) + pyamt.head(4, len(ptrs)) + b"".join(ptrs)
+    assert n_nodes >= 12
+    lens = np.array([len(b) for b in blocks], dtype=tip.lens.dtype)
+    off = np.zeros(len(blocks), dtype=tip.off.dtype)
+    off[1:] = np.cumsum(lens)[:-1]
+    data = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy()
+    sc = claims.StorageClaims(tip)
+    n_set = 0
+    for k in range(sc.n):  # two claims of three follow their entry's new value: TRUE where the value still decodes
+        now = new_value.get((tip.sc_slot[k].tobytes(), tip.sc_value[k].tobytes()))
+        if now is not None and k % 3:
+            sc.set_str(k, "value", "0x" + left_pad_32(now).hex())
+            n_set += 1
+    st = oracle.store(data, off, lens, tip.cids)
+    want = st.verify_storage_proofs(sc, mode=1)
+    st.close()
+    for m in range(10):  # every decodable spelling verifies against the value it now spells
+        ks = [k for k in range(sc.n) if k % 3 and modes.get((tip.sc_slot[k].tobytes(), tip.sc_value[k].tobytes())) == m and want[k] < 64]
+        assert m == 8 or (len(ks) > 0 and (want[ks] == 1).all()), (m, len(ks), want[ks][:10])
+    assert (want == 1).sum() > sc.n // 4 and (want == 21).any() and (want >= 64).any(), np.unique(want, return_counts=True)
+    with engine.witness(data, off, lens, tip.cids) as w:
+        for table in (1, 0, -1):
+            engine.set_tuning("hamt_table", table)
+            got = w.verify_storage_proofs(sc.arr, sc.n)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (table, bad[:8], got[bad[:8]], want[bad[:8]])
+    engine.set_tuning("hamt_table", -1)
