@@ -72,8 +72,12 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     // to the pool — ADVICE r5)
     StreamDrainGuard aux_guard(ctx->stream_aux), k1_guard(ctx->stream_k1);
     int rc = IPCFP_OK;
+    static const uint32_t table_kinds = [] {  // IPCFP_TABLE_FAST=0: the node table reads every entry item by item (round 5's way)
+        const char* e = std::getenv("IPCFP_TABLE_FAST");
+        return HK_ACTOR_STATE | HK_VEC_U8 | (e && std::atoi(e) == 0 ? uint32_t(HK_ITEM_BY_ITEM) : 0u);
+    }();
     if (ring) {  // (round 3's form, for A/B runs: eight lanes per block with the ring reader, every block)
-        rc = launch_hamt_node_table(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+        rc = launch_hamt_node_table(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), table_kinds, table.p);
     } else {
         // the long blocks (4-5 KB state-tree nodes: the head of the schedule) as a work list for the 32-lane outline …
         IPCFP_HIP(ctx, long_list.alloc(wit->n));
@@ -87,10 +91,10 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
             aux_guard.armed = true;
             hipStream_t saved = ctx->stream;
             ctx->stream = ctx->stream_aux;  // (the launcher queues on the context's stream)
-            rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+            rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), table_kinds, table.p);
             ctx->stream = saved;
         } else if (!rc) {
-            rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), HK_ACTOR_STATE | HK_VEC_U8, table.p);
+            rc = launch_hamt_node_table_lane(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), table_kinds, table.p);
         }
     }
     if (rc) return rc;

@@ -271,6 +271,45 @@ struct Rd {
         }
         s.tag[lane] = line | (k < 4 ? 0ull : 4ull);
     }
+#if IPCFP_LINE_STAGE == 2
+    // ---- IPCFP_LINE_STAGE == 2: the slot is a WINDOW — the eight chunks from any 16-byte boundary on (tag = that address;
+    // chunk c sits in slot c mod 8) — and the parser says where it is about to read (ensure_span).  With line-aligned slots
+    // a lane meets the end of its line somewhere inside an element loop, and of the 64 lanes of a wavefront SOME lane does
+    // at nearly every fetch: a wavefront of k_hamt_node_table_lane made ≈ 80 refills per node, each a round trip to the L2
+    // with the other lanes waiting, and lived 260 µs whatever its instruction count was (profiles/r06_experiments.md).
+    // One call per pointer / per bucket entry takes all lanes' refills at the same place: ≈ 10 per node.
+    __device__ __attribute__((noinline)) static void stage_refill_window(unsigned long long a, uint32_t lane) {
+        StageLds& s = stage_lds();
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a);
+        const uint32_t k = uint32_t(a >> 4);
+        const ulonglong2 t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3], t4 = src[4], t5 = src[5], t6 = src[6], t7 = src[7];
+        s.chunk[(k + 0u) & 7u][lane] = t0;
+        s.chunk[(k + 1u) & 7u][lane] = t1;
+        s.chunk[(k + 2u) & 7u][lane] = t2;
+        s.chunk[(k + 3u) & 7u][lane] = t3;
+        s.chunk[(k + 4u) & 7u][lane] = t4;
+        s.chunk[(k + 5u) & 7u][lane] = t5;
+        s.chunk[(k + 6u) & 7u][lane] = t6;
+        s.chunk[(k + 7u) & 7u][lane] = t7;
+        s.tag[lane] = a;
+    }
+    __device__ __forceinline__ static ulonglong2 staged_chunk(const ulonglong2* addr) {
+        StageLds& s = stage_lds();
+        const uint32_t lane = threadIdx.x & 255u;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(addr);
+        if (a - s.tag[lane] >= 128ull) stage_refill_window(a, lane);  // (an invalid tag is ~0: a + 1)
+        return s.chunk[uint32_t(a >> 4) & 7u][lane];
+    }
+    // the next `span` bytes from the reader's position are about to be read: have them in the window (span ≤ 113)
+    __device__ __forceinline__ void ensure_span(uint32_t span) {
+        const uint32_t lane = threadIdx.x & 255u;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(base16 + ((pos + bias) >> 4));
+        const unsigned long long tag = stage_lds().tag[lane];
+        const unsigned long long end = reinterpret_cast<unsigned long long>(base16) + bias + pos + span;
+        if (pos < n && (a - tag >= 128ull || end > tag + 128ull)) stage_refill_window(a, lane);
+    }
+#else
+    __device__ __forceinline__ void ensure_span(uint32_t) {}
     __device__ __forceinline__ static ulonglong2 staged_chunk(const ulonglong2* addr) {
         StageLds& s = stage_lds();
         const uint32_t lane = threadIdx.x & 255u;
@@ -281,6 +320,7 @@ struct Rd {
         if ((tag & ~127ull) != line || k < uint32_t(tag & 7ull)) stage_refill(line, k, lane);
         return s.chunk[k][lane];
     }
+#endif
     __device__ __forceinline__ Win win() const { return Win{cwi, phi, lo, hi, ph, stage}; }
     __device__ __forceinline__ void keep(const Win& w) {
         cwi = w.cwi;

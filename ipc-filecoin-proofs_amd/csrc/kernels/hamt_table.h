@@ -26,7 +26,8 @@ constexpr uint32_t kHamtTablePointers = 32;
 // bucket nodes of a state tree — go to the 32-lane outline (hamt_levels.hip), shorter ones to one lane each; a long block
 // the outline does not take (it reads ActorState buckets only) gets its lane afterwards.
 constexpr uint32_t kHamtOutlineMinLen = 2048;
-enum : uint32_t { HK_ACTOR_STATE = 1u << 0, HK_VEC_U8 = 1u << 1, HK_ANY = 1u << 2 };
+enum : uint32_t { HK_ACTOR_STATE = 1u << 0, HK_VEC_U8 = 1u << 1, HK_ANY = 1u << 2,
+                  HK_ITEM_BY_ITEM = 1u << 6 };  // (a request to the node parse, not a kind: no plain-read entry path — A/B runs)
 
 struct HamtNodeRec {
     uint8_t status;      // 1: tabulated

@@ -41,7 +41,7 @@ __device__ __forceinline__ bool value_kinds(Rd& r, uint32_t want, uint32_t& ok_k
 __device__ __forceinline__ void hamt_node_parse(Rd& r, uint32_t kinds, bool writer, HamtNodeRec* __restrict__ out, uint32_t& status,
                                                 uint32_t& kinds_ok, uint32_t& std_links, uint32_t& np32, uint64_t& bf) {
     status = 0;
-    kinds_ok = kinds | HK_ANY;
+    kinds_ok = (kinds & (HK_ACTOR_STATE | HK_VEC_U8)) | HK_ANY;
     std_links = 0;
     np32 = 0;
     bf = 0;
@@ -56,6 +56,7 @@ __device__ __forceinline__ void hamt_node_parse(Rd& r, uint32_t kinds, bool writ
         np32 = uint32_t(np);
         bool fits = true;
         for (uint32_t p = 0; p < np32 && r.ok(); ++p) {
+            r.ensure_span(104);  // (a window-staged reader: the link, or the bucket's head and first entry, in one refill for all lanes)
             const uint32_t at = r.pos;
             fits = fits && at <= 0xffffu;
             if (writer) out->ptr_off[p] = uint16_t(at);
@@ -76,11 +77,12 @@ __device__ __forceinline__ void hamt_node_parse(Rd& r, uint32_t kinds, bool writ
                     nkv = r.read_array();
                 }
                 for (uint64_t k = 0; k < nkv && r.ok(); ++k) {
+                    if (k) r.ensure_span(104);
                     // A storage entry as every encoder writes it — `82 58 20 <32-byte slot>` and a Vec<u8> of one- and two-byte
                     // elements — from two fetches and one more per four elements.  Item by item it is four heads and an element
                     // loop, ≈ 2.7 k instructions, and one lane does that for the ≈ 8 entries of its node: 0.6 ms of configs[4]'s
                     // call for k_hamt_node_table_lane (profiles/r06_experiments.md).  Anything else takes that way as before.
-                    if (kinds & HK_VEC_U8) {
+                    if ((kinds & (HK_VEC_U8 | HK_ITEM_BY_ITEM)) == HK_VEC_U8) {
                         const uint32_t e0 = r.pos;
                         if (e0 + 36u <= r.n && (r.peek64(e0) & 0xffffffull) == 0x205882ull) {
                             const uint32_t end = vec_u8_end(r, e0 + 35u);

@@ -1,7 +1,9 @@
 // csrc/kernels/hamt_table_lane.hip — the HAMT node table (hamt_table.h), one block per LANE in arena order, the reader
-// staging each 128-byte line it touches in the lane's LDS slot (cbor_dev.h IPCFP_LINE_STAGE) — the form that won for the
+// staging the 128 bytes it is about to read in the lane's LDS slot (cbor_dev.h IPCFP_LINE_STAGE) — the form that won for the
 // block-order event parse (block_events.hip), against the eight-lanes-per-block ring reader of hamt_table.hip.
-#define IPCFP_LINE_STAGE 1
+#ifndef IPCFP_LINE_STAGE
+#define IPCFP_LINE_STAGE 2  // (a window the parse re-aims once per pointer and bucket entry: cbor_dev.h)
+#endif
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
