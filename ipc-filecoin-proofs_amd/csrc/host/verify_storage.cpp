@@ -154,7 +154,7 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     // the first step of the runs' storage gets, once per run (IPCFP_STORAGE_RUN_CHILDREN=0: every claim by itself)
     static const bool run_children = [] { const char* e = std::getenv("IPCFP_STORAGE_RUN_CHILDREN"); return !(e && std::atoi(e) == 0); }();
     DevBuf<uint32_t> root_children;
-    if (run_children && n_runs) IPCFP_HIP(ctx, root_children.alloc(size_t(n_runs) * 33u));
+    if (run_children && n_runs) IPCFP_HIP(ctx, root_children.alloc(size_t(n_runs) * 34u));
     rc = launch_verify_storage_table(ctx, w, table.p, claims_d, n, run_of.p, runs.p, uint32_t(n_runs), root_children.p, trust, kUndecided,
                                      status_d);
     if (rc) return rc;

@@ -105,6 +105,23 @@ __device__ __forceinline__ void hash_bytes(const uint8_t* __restrict__ p, uint32
     }
 }
 
+// SHA-256 of exactly 32 bytes held as four little-endian 64-bit words (byte i = word i/8, bits 8·(i%8)…): one compression
+// whose second half is the padding — no byte loads, no length logic.
+__device__ __forceinline__ void hash32_words(const uint64_t kw[4], uint32_t h[8]) {
+    init(h);
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w[2 * j] = __builtin_bswap32(uint32_t(kw[j]));
+        w[2 * j + 1] = __builtin_bswap32(uint32_t(kw[j] >> 32));
+    }
+    w[8] = 0x80000000u;
+#pragma unroll
+    for (int k = 9; k < 15; ++k) w[k] = 0;
+    w[15] = 256u;
+    compress(h, w);
+}
+
 // bits [bit_pos, bit_pos + width) of the digest, MSB first (HashBits::next).  width ≤ 8.
 __device__ __forceinline__ uint32_t take_bits(const uint32_t h[8], uint32_t bit_pos, uint32_t width) {
     // gather a 64-bit window starting at word bit_pos/32 without dynamic register indexing

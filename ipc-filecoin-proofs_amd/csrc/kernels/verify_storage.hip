@@ -16,6 +16,13 @@
 #include "storage_dev.h"
 #include "storage_runs.h"
 
+#ifndef IPCFP_VS_STAGE
+#define IPCFP_VS_STAGE 1
+#endif
+#ifndef IPCFP_VS_PRELOAD
+#define IPCFP_VS_PRELOAD 0  // (the slot and the value in registers from the start: 27-37 µs slower — spills)
+#endif
+
 namespace ipcfp {
 
 __device__ __forceinline__ bool trusted(const ipcfp_trust_policy_t& t, long long epoch) {
@@ -209,9 +216,19 @@ __global__ __launch_bounds__(256) void k_storage_run_actors_table(WitnessView w,
 // not a standard link or the block is missing (the claim's own lane then takes the long way and gives the status).
 __global__ __launch_bounds__(256) void k_storage_run_children(WitnessView w, const HamtNodeRec* __restrict__ table,
                                                               const StorageRun* __restrict__ runs, uint32_t n_runs,
-                                                              uint32_t* __restrict__ root_block, uint32_t* __restrict__ root_child) {
+                                                              const StorageClaimPacked* __restrict__ claims,
+                                                              uint32_t* __restrict__ root_block, uint32_t* __restrict__ run_match,
+                                                              uint32_t* __restrict__ root_child) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 5, p = t & 31u;
     if (i >= n_runs) return;
+    if (p == 1) {
+        // The three CID comparisons of steps 3-5 (storage/verifier.rs:110, :126, :144) are the same for every claim of a run — a
+        // run IS "same child, state root, actor, actor state, storage root" (same_run) — so they are made here, on the run's
+        // first claim; each claim still answers for its own strings' canonical form (flags).
+        const StorageClaimPacked& c = claims[runs[i].first_claim];
+        run_match[i] = (cid_equal(runs[i].parent_state_root, c.state_root) ? 1u : 0u) | (cid_equal(runs[i].actor_state, c.actor_state) ? 2u : 0u) |
+                       (cid_equal(runs[i].contract_state, c.storage_root) ? 4u : 0u);
+    }
     uint32_t rb = kNoBlock, child = kNoBlock;
     if (runs[i].root_kind == 3) {
         rb = witness_find(w, runs[i].hamt_root);  // (the 32 lanes of a run: the same probe, broadcast)
@@ -304,6 +321,60 @@ __device__ __forceinline__ bool left_pad_32_raw(const uint8_t* __restrict__ p, u
     return true;
 }
 
+// … and out of the lane's LDS slot, where the kernel has put the 72 bytes from the value's first byte on in ONE burst of
+// loads: the decode's fetches depend on each other (an element is one or two bytes), and on global memory each was a round
+// trip through an L2 that the kernel's own streaming turns over every few microseconds — lines came from memory two and
+// three times (FETCH_SIZE 3.2 GB for 1 GB of claims and witness; profiles/r06_experiments.md).  A value longer than the
+// stage holds (more than 32 two-byte elements) returns false like any unusual spelling.
+constexpr uint32_t kValueStageWords = 10;
+struct ValueStage {
+    uint64_t w[kValueStageWords + 1][256];  // [word][lane]: a wavefront reading the same word index is conflict-free
+};
+__device__ __forceinline__ uint64_t stage_ld64(const ValueStage& vs, uint32_t lane, uint32_t at) {
+    const uint32_t k = at >> 3, sh = (at & 7u) * 8u;
+    const uint64_t lo = vs.w[k][lane], hi = vs.w[k + 1u][lane];
+    return (lo >> sh) | ((hi << 1) << (63u - sh));
+}
+__device__ __forceinline__ bool left_pad_32_staged(const ValueStage& vs, uint32_t lane, uint32_t avail, uint32_t L[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) L[m] = 0;
+    const uint64_t h8 = vs.w[0][lane];
+    const uint32_t hv = uint32_t(h8) & 0xffu;
+    uint32_t n, pos;
+    if (hv >= 0x80u && hv < 0x98u) {
+        n = hv - 0x80u;
+        pos = 1u;
+    } else if (hv == 0x98u) {
+        n = uint32_t(h8 >> 8) & 0xffu;
+        pos = 2u;
+    } else {
+        return false;
+    }
+    if (n > 32u) return false;  // (≤ 2 + 64 bytes: inside the stage)
+    uint32_t bad = 0;
+    for (uint32_t q = n >> 2; q; --q) {  // four elements per 8 bytes: one limb
+        const uint64_t w8 = stage_ld64(vs, lane, pos);
+        uint32_t cur = 0;
+        vec_u8_take<4>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+#pragma unroll
+        for (int m = 7; m > 0; --m) L[m] = L[m - 1];
+        L[0] = cur;
+    }
+    const uint32_t r = n & 3u;
+    if (r) {  // the last one to three: the register moves up by as many bytes
+        const uint64_t w8 = stage_ld64(vs, lane, pos);
+        uint32_t cur = 0;
+        if (r == 1) vec_u8_take<1>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        else if (r == 2) vec_u8_take<2>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        else vec_u8_take<3>(uint32_t(w8), uint32_t(w8 >> 32), cur, pos, bad);
+        const uint32_t down = 32u - 8u * r;
+#pragma unroll
+        for (int m = 7; m > 0; --m) L[m] = __builtin_amdgcn_alignbit(L[m], L[m - 1], down);
+        L[0] = (L[0] << (8u * r)) | cur;
+    }
+    return !(bad || pos > avail);
+}
+
 // verify_storage_proof, steps 2-6 in the reference's order of checks (src/proofs/storage/verifier.rs:24-63), one claim per
 // lane: everything its run shares comes from the run's record, `read_storage_slot`'s HAMT get (storage/decode.rs:79-96)
 // walks the node table.  A claim it cannot settle (an inline small-map layout, a block the table does not cover) is left
@@ -314,44 +385,79 @@ __device__ __forceinline__ bool left_pad_32_raw(const uint8_t* __restrict__ p, u
 __global__ __launch_bounds__(256, 7) void k_verify_storage_table(WitnessView w, const HamtNodeRec* __restrict__ table,
                                                               const StorageClaimPacked* __restrict__ claims, uint32_t n,
                                                               const uint32_t* __restrict__ run_of, const StorageRun* __restrict__ runs,
-                                                              const uint32_t* __restrict__ root_block, const uint32_t* __restrict__ root_child,
-                                                              ipcfp_trust_policy_t trust, uint32_t undecided, uint8_t* __restrict__ status) {
+                                                              const uint32_t* __restrict__ root_block, const uint32_t* __restrict__ run_match,
+                                                              const uint32_t* __restrict__ root_child, ipcfp_trust_policy_t trust, uint32_t undecided, uint8_t* __restrict__ status) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+#if IPCFP_VS_STAGE
+    __shared__ ValueStage vstage;
+#endif
     const StorageClaimPacked& c = claims[t];
     const uint32_t ri = run_of[t];
     const StorageRun& run = runs[ri];
     const uint32_t flags = c.flags;
+    // everything of the claim that is used late — the slot (hash, bucket compare) and the value (the last compare) — now, with
+    // the lines that hold the CIDs: by the time the walk is done the L2 has long dropped them
+    uint64_t kw[4], cv[4];
+#if IPCFP_VS_PRELOAD
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        kw[j] = reinterpret_cast<const uint64_t*>(c.slot)[j];
+        cv[j] = reinterpret_cast<const uint64_t*>(c.value)[j];
+    }
+#endif
     uint32_t st = kStPending;
+    const uint32_t match = run_match ? run_match[ri] : 8u;  // (8: nobody has compared for the run)
     do {
         // Step 2: verify_trust_anchor (storage/verifier.rs:81-92)
         if (!(flags & SC_CHILD_PARSED)) { st = IPCFP_ST_ERR_BAD_CLAIM; break; }                           // :85
         if (!trusted(trust, c.child_epoch)) { st = IPCFP_ST_FALSE_UNTRUSTED_CHILD; break; }               // :87
         // Step 3: verify_parent_state_root (:95-111)
         if (run.hdr_status != IPCFP_ST_TRUE) { st = run.hdr_status; break; }                              // :101-107
-        if (!((flags & SC_STATE_ROOT_CANON) && cid_equal(run.parent_state_root, c.state_root))) { st = IPCFP_ST_FALSE_STATE_ROOT; break; }  // :110
+        if (!((flags & SC_STATE_ROOT_CANON) && (match & 8u ? cid_equal(run.parent_state_root, c.state_root) : (match & 1u) != 0u))) { st = IPCFP_ST_FALSE_STATE_ROOT; break; }  // :110
         // Step 4: verify_actor_state (:114-127)
         if (run.sr_status != IPCFP_ST_TRUE) { st = run.sr_status; break; }                                // decode.rs:23-26
         if (run.actor_status == undecided) break;                                                         // (pending)
         if (run.actor_status != IPCFP_ST_TRUE) { st = run.actor_status; break; }                          // :122
-        if (!((flags & SC_ACTOR_STATE_CANON) && cid_equal(run.actor_state, c.actor_state))) { st = IPCFP_ST_FALSE_ACTOR_STATE; break; }  // :126
+        if (!((flags & SC_ACTOR_STATE_CANON) && (match & 8u ? cid_equal(run.actor_state, c.actor_state) : (match & 2u) != 0u))) { st = IPCFP_ST_FALSE_ACTOR_STATE; break; }  // :126
         // Step 5: verify_storage_root (:130-145)
         if (run.evm_status != IPCFP_ST_TRUE) { st = run.evm_status; break; }                              // :136-141
-        if (!((flags & SC_STORAGE_ROOT_CANON) && cid_equal(run.contract_state, c.storage_root))) { st = IPCFP_ST_FALSE_STORAGE_ROOT; break; }  // :144
+        if (!((flags & SC_STORAGE_ROOT_CANON) && (match & 8u ? cid_equal(run.contract_state, c.storage_root) : (match & 4u) != 0u))) { st = IPCFP_ST_FALSE_STORAGE_ROOT; break; }  // :144
         // Step 6: verify_storage_value (:148-170)
         if (!(flags & SC_SLOT_PARSED)) { st = IPCFP_ST_ERR_BAD_CLAIM; break; }                            // :155-157
         if (run.root_kind == 4) { st = IPCFP_ST_ERR_MISSING_BLOCK; break; }                               // decode.rs:41-43
         if (run.root_kind != 3) break;  // an inline small map (A1-A3): the one-lane kernel searches it
         uint64_t padded[4] = {0, 0, 0, 0};
         ValueLoc loc;
+#if !IPCFP_VS_PRELOAD
+        {
+            const Raw16 a = raw_ld128(c.slot), b = raw_ld128(c.slot + 16);
+            kw[0] = a.lo, kw[1] = a.hi, kw[2] = b.lo, kw[3] = b.hi;
+        }
+#endif
         const uint32_t hs = table_hamt_get(w, table, run.hamt_root, run.hamt_bw, HK_VEC_U8, c.slot, 32, loc,  // decode.rs:79-96
-                                           root_block ? root_block[ri] : kNoBlock, root_child ? root_child + size_t(ri) * 32u : nullptr);
+                                           root_block ? root_block[ri] : kNoBlock, root_child ? root_child + size_t(ri) * 32u : nullptr, kw);
         if (hs == kTablePunt) break;
         if (hs != IPCFP_ST_NOT_FOUND) {  // unwrap_or_default(): a missing key means zero
             if (hs != IPCFP_ST_TRUE) { st = hs; break; }
             const uint8_t* vp = w.arena + w.off[loc.block] + loc.off;
             uint32_t L[8];
+#if IPCFP_VS_STAGE
+            {
+                Raw16 tw[kValueStageWords / 2];
+#pragma unroll
+                for (uint32_t j = 0; j < kValueStageWords / 2; ++j) tw[j] = raw_ld128(vp + 16u * j);  // (≤ 80 bytes past a block: the arena's slack)
+#pragma unroll
+                for (uint32_t j = 0; j < kValueStageWords / 2; ++j) {
+                    vstage.w[2 * j][threadIdx.x] = tw[j].lo;
+                    vstage.w[2 * j + 1][threadIdx.x] = tw[j].hi;
+                }
+                vstage.w[kValueStageWords][threadIdx.x] = 0;
+            }
+            if (left_pad_32_staged(vstage, threadIdx.x, loc.len, L) || left_pad_32_raw(vp, loc.len, L)) {
+#else
             if (left_pad_32_raw(vp, loc.len, L)) {
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k)  // byte i of the value: limb (31 - i) / 4, big-endian inside it
                     padded[k] = uint64_t(__builtin_bswap32(L[7 - 2 * k])) | uint64_t(__builtin_bswap32(L[6 - 2 * k])) << 32;
@@ -362,7 +468,12 @@ __global__ __launch_bounds__(256, 7) void k_verify_storage_table(WitnessView w, 
             }
         }
         if (!(flags & SC_VALUE_MATCHABLE)) { st = IPCFP_ST_FALSE_VALUE; break; }  // can never equal "0x" + 64 hex digits
-        const uint64_t* cv = reinterpret_cast<const uint64_t*>(c.value);
+#if !IPCFP_VS_PRELOAD
+        {
+            const Raw16 a = raw_ld128(c.value), b = raw_ld128(c.value + 16);
+            cv[0] = a.lo, cv[1] = a.hi, cv[2] = b.lo, cv[3] = b.hi;
+        }
+#endif
         const uint64_t diff = (padded[0] ^ cv[0]) | (padded[1] ^ cv[1]) | (padded[2] ^ cv[2]) | (padded[3] ^ cv[3]);
         st = diff == 0 ? IPCFP_ST_TRUE : IPCFP_ST_FALSE_VALUE;                                            // :169
     } while (false);
@@ -378,18 +489,20 @@ int launch_storage_run_actors_table(ipcfp_ctx* ctx, const WitnessView& w, const 
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }
-// root_children_d: n_runs × 33 words of scratch (block of every run's root, then 32 children per run), or null: every claim resolves its own
+// root_children_d: n_runs × 34 words of scratch (block of every run's root, the runs' CID matches, then 32 children per run), or null: every claim resolves its own
 int launch_verify_storage_table(ipcfp_ctx* ctx, const WitnessView& w, const void* table_d, const void* claims_d, uint32_t n,
                                 const uint32_t* run_of_d, const void* runs_d, uint32_t n_runs, uint32_t* root_children_d,
                                 const ipcfp_trust_policy_t& trust, uint32_t undecided, uint8_t* status_d) {
     uint32_t* root_block = root_children_d;
-    uint32_t* root_child = root_children_d ? root_children_d + n_runs : nullptr;
+    uint32_t* run_match = root_children_d ? root_children_d + n_runs : nullptr;
+    uint32_t* root_child = root_children_d ? root_children_d + 2 * size_t(n_runs) : nullptr;
     if (root_children_d && n_runs)
         hipLaunchKernelGGL(k_storage_run_children, dim3(div_up(n_runs * 32u, 256)), dim3(256), 0, ctx->stream, w,
-                           static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageRun*>(runs_d), n_runs, root_block, root_child);
+                           static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageRun*>(runs_d), n_runs,
+                           static_cast<const StorageClaimPacked*>(claims_d), root_block, run_match, root_child);
     hipLaunchKernelGGL(k_verify_storage_table, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, w,
                        static_cast<const HamtNodeRec*>(table_d), static_cast<const StorageClaimPacked*>(claims_d), n, run_of_d,
-                       static_cast<const StorageRun*>(runs_d), root_block, root_child, trust, undecided, status_d);
+                       static_cast<const StorageRun*>(runs_d), root_block, run_match, root_child, trust, undecided, status_d);
     IPCFP_HIP(ctx, hipGetLastError());
     return IPCFP_OK;
 }

@@ -362,17 +362,34 @@ __device__ __forceinline__ uint64_t raw_ld64(const uint8_t* p) {
     return x;
 }
 
+struct Raw16 {
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ Raw16 raw_ld128(const uint8_t* p) {
+    Raw16 x;
+    __builtin_memcpy(&x, p, 16);
+    return x;
+}
+
 __device__ __forceinline__ uint32_t bucket_find32_raw(const uint8_t* __restrict__ g, uint32_t blen, uint32_t off, const uint64_t kw[4],
                                                       uint32_t& vstart) {
-    const uint32_t hb = g[off];
-    if (hb < 0x81u || hb > 0x83u) return 2;
-    const uint32_t nkv = hb - 0x80u;
-    uint32_t pos = off + 1u;
-    for (uint32_t k = 0; k < nkv; ++k) {
+    // An entry's head and key are the 36 bytes from the byte BEFORE it on (the bucket's own head, for the first entry): three
+    // 16-byte reads.  What bounds this kernel is the number of load instructions whose 64 lanes go to 64 different lines —
+    // the CU's L1 looks up one line per clock, 112 such loads per wavefront were its 545 µs (profiles/r06_experiments.md) —
+    // so the same bytes in fewer, wider loads.
+    uint32_t nkv = 0, pos = off + 1u;
+    for (uint32_t k = 0; k == 0 || k < nkv; ++k) {
         if (pos + 36u > blen) return 2;
-        if ((raw_ld64(g + pos) & 0xffffffull) != 0x205882ull) return 2;
-        const uint64_t diff = (raw_ld64(g + pos + 3) ^ kw[0]) | (raw_ld64(g + pos + 11) ^ kw[1]) | (raw_ld64(g + pos + 19) ^ kw[2]) |
-                              (raw_ld64(g + pos + 27) ^ kw[3]);
+        const Raw16 a = raw_ld128(g + pos - 1u), b = raw_ld128(g + pos + 15u), c = raw_ld128(g + pos + 31u);
+        if (k == 0) {
+            const uint32_t hb = uint32_t(a.lo) & 0xffu;
+            if (hb < 0x81u || hb > 0x83u) return 2;
+            nkv = hb - 0x80u;
+        }
+        if ((uint32_t(a.lo >> 8) & 0xffffffu) != 0x205882u) return 2;
+        // key byte i = stream byte 4 + i: word j = the high half of stream word j and the low half of word j + 1
+        const uint64_t diff = (((a.lo >> 32) | (a.hi << 32)) ^ kw[0]) | (((a.hi >> 32) | (b.lo << 32)) ^ kw[1]) |
+                              (((b.lo >> 32) | (b.hi << 32)) ^ kw[2]) | (((b.hi >> 32) | (c.lo << 32)) ^ kw[3]);
         pos += 35u;
         if (diff == 0) {
             vstart = pos;
@@ -418,19 +435,25 @@ constexpr uint32_t kTablePunt = 0xfdu;  // not an ipcfp_status_t
 __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const HamtNodeRec* __restrict__ table, const CidKey& root,
                                                    uint32_t bit_width, uint32_t kbit, const uint8_t* key, uint32_t key_len,
                                                    ValueLoc& loc, uint32_t root_block = kNoBlock,
-                                                   const uint32_t* __restrict__ root_children = nullptr) {
+                                                   const uint32_t* __restrict__ root_children = nullptr,
+                                                   const uint64_t* key_words = nullptr) {
+    // `key_words` (optional, key_len == 32): the key's bytes as four little-endian words the caller holds in registers — the
+    // hash and the bucket's compare then read nothing of `key`.
     // `root_block` / `root_children` (optional): the root's block id and the blocks behind its pointers as SOMEBODY ELSE has
     // already resolved them (kNoBlock where not: the link is then read and looked up here) — the 256 storage proofs of one
     // contract all start at the same root and step through one of its 32 links (verify_storage.hip k_storage_run_children).
     if (bit_width < 1 || bit_width > 8) return IPCFP_ST_ERR_DECODE;
     uint32_t h[8];
-    sha256::hash_bytes(key, key_len, h);
+    if (key_words && key_len == 32) sha256::hash32_words(key_words, h);
+    else sha256::hash_bytes(key, key_len, h);
     uint32_t consumed = 0;
     uint32_t block = root_block != kNoBlock ? root_block : witness_find(w, root);
     if (block == kNoBlock) return IPCFP_ST_ERR_MISSING_BLOCK;
     for (;;) {
         const HamtNodeRec* rec = table + block;
-        const uint32_t head = *reinterpret_cast<const uint32_t*>(rec);  // status | kinds_ok << 8 | np << 16
+        const uint4 rh = *reinterpret_cast<const uint4*>(rec);  // the record's first 16 bytes in one read
+        const uint32_t head = rh.x;                              // status | kinds_ok << 8 | np << 16
+        const uint32_t rec_std_links = rh.y;
         if ((head & 0xffu) != 1u) return kTablePunt;
         if (!((head >> 8) & kbit)) return IPCFP_ST_ERR_DECODE;  // a value of another type in one of the node's buckets
         const uint32_t np = (head >> 16) & 0xffu;
@@ -438,11 +461,11 @@ __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const H
         if (consumed + bit_width > 256) return IPCFP_ST_ERR_MAX_DEPTH;
         const uint32_t idx = sha256::take_bits(h, consumed, bit_width);
         consumed += bit_width;
-        const uint64_t bf = rec->bitfield;
+        const uint64_t bf = uint64_t(rh.z) | (uint64_t(rh.w) << 32);
         if (idx >= 64u || !((bf >> idx) & 1ull)) return IPCFP_ST_NOT_FOUND;
         const uint32_t rank = uint32_t(__popcll(bf & ((1ull << idx) - 1ull)));
         if (rank >= np) return IPCFP_ST_ERR_DECODE;
-        if (root_children && consumed == bit_width && ((rec->std_links >> rank) & 1u)) {  // the root's link, resolved per run
+        if (root_children && consumed == bit_width && ((rec_std_links >> rank) & 1u)) {  // the root's link, resolved per run
             const uint32_t cb = root_children[rank];
             if (cb != kNoBlock) {
                 block = cb;
@@ -452,7 +475,7 @@ __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const H
         const uint32_t off = rec->ptr_off[rank];
         const uint8_t* g = w.arena + w.off[block];
         CidKey link;
-        if ((rec->std_links >> rank) & 1u) {
+        if ((rec_std_links >> rank) & 1u) {
             // the standard 43-byte link: its 38 CID bytes lie at off + 5
 #pragma unroll
             for (int j = 0; j < 5; ++j) __builtin_memcpy(&link.w[j], g + off + 5 + 8 * j, 8);  // unaligned 8-byte loads
@@ -471,7 +494,7 @@ __device__ __forceinline__ uint32_t table_hamt_get(const WitnessView& w, const H
                 if (kbit == HK_VEC_U8 && key_len == 32) {  // a storage slot: plain reads first
                     uint64_t kw[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) kw[j] = raw_ld64(key + 8 * j);
+                    for (int j = 0; j < 4; ++j) kw[j] = key_words ? key_words[j] : raw_ld64(key + 8 * j);
                     uint32_t vstart = 0;
                     const uint32_t f = bucket_find32_raw(g, w.len[block], off, kw, vstart);
                     if (f == 0) return IPCFP_ST_NOT_FOUND;
