@@ -76,6 +76,34 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
         const char* e = std::getenv("IPCFP_TABLE_FAST");
         return HK_ACTOR_STATE | HK_VEC_U8 | (e && std::atoi(e) == 0 ? uint32_t(HK_ITEM_BY_ITEM) : 0u);
     }();
+    // (IPCFP_STORAGE_EARLY_OUTLINE=1, measured and left off: see below)
+    static const bool early_env = [] { const char* e = std::getenv("IPCFP_STORAGE_EARLY_OUTLINE"); return e && std::atoi(e) == 1; }();
+    const bool early_outline = side2 && early_env;
+    uint32_t n_long = 0;
+    hipEvent_t outline_event = nullptr;
+    // the outline of the long blocks (its grid is the list's size): beside the lane kernel when that runs on the aux stream,
+    // else on the aux stream beside the runs' typed decodes (round 5)
+    auto queue_outline = [&]() -> int {
+        if (!n_long) return IPCFP_OK;
+        hipStream_t s = ctx->stream;
+        if (side2) {
+            s = ctx->stream_k1;
+            k1_guard.armed = true;
+            IPCFP_HIP(ctx, hipStreamWaitEvent(s, ctx->main_event, 0));
+        } else if (ctx->stream_aux != ctx->stream && ctx->aux_event) {
+            s = ctx->stream_aux;
+            aux_guard.armed = true;
+        }
+        int rc2 = launch_hamt_outline_list(ctx, s, w, table.p, long_list.p, long_count.p, n_long);
+        if (!rc2) rc2 = launch_hamt_node_table_rest(ctx, s, w, long_list.p, long_count.p, n_long, HK_ACTOR_STATE | HK_VEC_U8, table.p);
+        if (rc2) return rc2;
+        if (s == ctx->stream_k1) {
+            if (!ctx->k1_gate_event) IPCFP_HIP(ctx, hipEventCreateWithFlags(&ctx->k1_gate_event, hipEventDisableTiming));
+            outline_event = ctx->k1_gate_event;
+            IPCFP_HIP(ctx, hipEventRecord(outline_event, s));
+        }
+        return IPCFP_OK;
+    };
     if (ring) {  // (round 3's form, for A/B runs: eight lanes per block with the ring reader, every block)
         rc = launch_hamt_node_table(ctx, wit->arena.p, wit->k1_meta.p, uint32_t(wit->n), table_kinds, table.p);
     } else {
@@ -84,6 +112,17 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
         IPCFP_HIP(ctx, long_count.alloc(1));
         IPCFP_HIP(ctx, hipMemsetAsync(long_count.p, 0, 4, ctx->stream));
         rc = launch_hamt_list_long(ctx, wit->k1_meta.p, uint32_t(wit->n), long_list.p, long_count.p);
+        if (!rc && early_outline) {
+            // The outline's grid wants the list's size.  Read behind the runs' boundary pass (the call's one synchronisation) it
+            // starts 0.33 ms into the call and ends with the lane kernel; read HERE — a second synchronisation, of a stream
+            // that holds 7 µs of work — it starts with the call.  Measured: 1.40 ms against 1.21 (profiles/r06_experiments.md) —
+            // the synchronisation puts 60 µs in front of everything and the lane kernel, which the call waits for, shares the
+            // chip with the outline from its first workgroup (546 -> 694 µs).  Off.
+            IPCFP_HIP(ctx, d2h_small(ctx, &n_long, long_count.p, 4, ctx->stream));
+            IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
+            IPCFP_HIP(ctx, hipEventRecord(ctx->main_event, ctx->stream));
+            rc = queue_outline();
+        }
         // … everything shorter: one block per lane, line-staged reader
         if (!rc && side) {
             IPCFP_HIP(ctx, hipEventRecord(ctx->main_event, ctx->stream));  // (everything that made the witness and took `table` from the pool is behind this)
@@ -110,31 +149,12 @@ int launch_verify_storage(ipcfp_ctx* ctx, ipcfp_witness* wit, const StorageClaim
     rc = launch_scan_u32(ctx, flag.p, n, pos.p, total_d.p, scratch.p);
     if (rc) return rc;
     uint64_t n_runs = 0;
-    uint32_t n_long = 0;
     IPCFP_HIP(ctx, d2h_small(ctx, &n_runs, total_d.p, 8, ctx->stream));
-    if (!ring) IPCFP_HIP(ctx, d2h_small(ctx, &n_long, long_count.p, 4, ctx->stream));
+    if (!ring && !early_outline) IPCFP_HIP(ctx, d2h_small(ctx, &n_long, long_count.p, 4, ctx->stream));
     IPCFP_HIP(ctx, sync_stream(ctx, ctx->stream));
-    // the outline of the long blocks (its grid is the list's size): beside the lane kernel when that runs on the aux stream,
-    // else on the aux stream beside the runs' typed decodes (round 5)
-    hipEvent_t outline_event = nullptr;
-    if (n_long) {
-        hipStream_t s = ctx->stream;
-        if (side2) {
-            s = ctx->stream_k1;
-            k1_guard.armed = true;
-            IPCFP_HIP(ctx, hipStreamWaitEvent(s, ctx->main_event, 0));
-        } else if (ctx->stream_aux != ctx->stream && ctx->aux_event) {
-            s = ctx->stream_aux;
-            aux_guard.armed = true;
-        }
-        rc = launch_hamt_outline_list(ctx, s, w, table.p, long_list.p, long_count.p, n_long);
-        if (!rc) rc = launch_hamt_node_table_rest(ctx, s, w, long_list.p, long_count.p, n_long, HK_ACTOR_STATE | HK_VEC_U8, table.p);
+    if (!early_outline) {
+        rc = queue_outline();
         if (rc) return rc;
-        if (s == ctx->stream_k1) {
-            if (!ctx->k1_gate_event) IPCFP_HIP(ctx, hipEventCreateWithFlags(&ctx->k1_gate_event, hipEventDisableTiming));
-            outline_event = ctx->k1_gate_event;
-            IPCFP_HIP(ctx, hipEventRecord(outline_event, s));
-        }
     }
     if (aux_guard.armed) IPCFP_HIP(ctx, hipEventRecord(ctx->aux_event, ctx->stream_aux));
     DevBuf<StorageRun> runs;
