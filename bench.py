@@ -1561,7 +1561,7 @@ def run_hamt(args, eng, info, torch, ranks, state=None):
                                   "width 5; step = one ipcfp_hamt_get_device call (keys, statuses and locations resident in HBM, "
                                   "witness resident)%s" % (4_000_000, n, int((~present).sum()), _gather_line(world, width)),
                       "gets_per_gpu": m, "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
-           "roofline": {"bound": "hbm", "limiter": "latency + instruction issue", "kernel": "k_hamt_lv_start + per level k_hamt_lv_parse_actor (two instances) + k_hamt_lv_advance, k_hamt_get behind them (the K7 group: one HIP-event bracket)", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
+           "roofline": {"bound": "hbm", "limiter": "latency + instruction issue", "kernel": "k_hamt_lv_start + fused top (k_hamt_lv_advance_top) + per level k_hamt_lv_parse_actor (three size classes, 8 or 32 lanes per node) + k_hamt_lv_advance, k_hamt_get behind them (the K7 group: one HIP-event bracket)", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel_avg_ms": k_avg_ms, "launches": cnt, "algorithmic_bytes_per_launch": algo,
                         "bytes_basis": "SURVEY.md §8(d) cfg 4 (ii) WALK ONLY: 0.55 KB per get (4 B bitfield + 43 B link per level, <= 3 x 105 B bucket) — "
@@ -1644,7 +1644,7 @@ def run_storage(args, eng, info, torch, ranks, state=None):
                                   "(0.1 %% wrong), Keccak slot key + state-tree HAMT get + EVM state + storage HAMT get; "
                                   "step = one ipcfp_verify_storage_claims_device call, claims resident%s" % (n, _gather_line(world, width)),
                       "claims_per_gpu": m, "witness_blocks": T.n_blocks, "witness_bytes": T.stats["payload_bytes"], "device": info["name"]},
-           "roofline": {"bound": "hbm", "limiter": "latency", "kernel": "k_hamt_node_table_lane + k_hamt_lv_parse_actor (the per-call node table) + k_storage_run_* + k_verify_storage_table (the storage-proof group: one HIP-event bracket)", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
+           "roofline": {"bound": "hbm", "limiter": "valu (node table) + L1 line lookups of divergent loads (claim kernel)", "kernel": "k_hamt_node_table_lane + k_hamt_lv_parse_actor (the per-call node table, side streams) + k_storage_run_* + k_verify_storage_table (the storage-proof group: one HIP-event bracket)", "achieved": algo / (k_avg_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel_avg_ms": k_avg_ms, "launches": cnt, "algorithmic_bytes_per_launch": algo,
                         "bytes_basis": "SURVEY.md §8(d) cfg 5: unique witness bytes read once + 0.76 KB per proof (64 B Keccak input + walk bytes)"},
