@@ -299,7 +299,7 @@ def test_storage_values_in_every_spelling_both_routes(engine, oracle, slots):
     tip = Tipset(n_receipts=8, n_parents=1, n_actors=300, n_contracts=12, slots_per_contract=slots, storage_layout_mix=0,
                  keep_full_state=1, seed=fuzz_seed(31) + slots)
     blocks = [bytes(tip.data[int(o): int(o) + int(l)]) for o, l in zip(tip.off, tip.lens)]
-    modes = {}
+    modes, twice = {}, set()
     new_value = {}   # slot → the elements its entry now holds (None: undecodable)
     n_nodes = 0
     for bi, b in enumerate(blocks):
@@ -323,8 +323,14 @@ def test_storage_values_in_every_spelling_both_routes(engine, oracle, slots):
                     mode = 8  # … but have one
                 e, now = respell_entry(key, el, mode, rng)
                 ents.append(b"\x82" + e)
-                new_value[key, left_pad_32(el)] = now  # (contracts share slot numbers: an entry is its slot and what it held)
-                modes[key, left_pad_32(el)] = mode
+                ident = (key, left_pad_32(el))  # (contracts share slot numbers: an entry is its slot and what it held)
+                if ident in new_value or ident in twice:  # … and two contracts may hold the same value in the same slot
+                    twice.add(ident)
+                    new_value.pop(ident, None)
+                    modes.pop(ident, None)
+                else:
+                    new_value[ident] = now
+                    modes[ident] = mode
             bucket_head = wide_head(4, len(ents), 1) if rng.integers(0, 8) == 0 else pyamt.head(4, len(ents))
             ptrs.append(bucket_head + b"".join(ents))
         blocks[bi] = pyamt.head(4, 2) + pyamt.bstr(node[0]) + pyamt.head(4, len(ptrs)) + b"".join(ptrs)
