@@ -722,7 +722,11 @@ void ipcfp_shard_range(uint64_t n, uint32_t n_shards, uint32_t shard, uint64_t* 
  *                reconstruct_execution_order, src/proofs/events/utils.rs:16-30), the receipts-AMT root;
  *   this rank    the receipts-AMT nodes on the paths to its receipts and those receipts' events AMTs.
  *   *status_out  IPCFP_ST_TRUE, or the ERR_* the traversal met first (nothing else is then written)
- *   *n_receipts  (nullable) the receipts AMT's count;  block_ids: ascending ids, truncated to cap_blocks          */
+ *   *n_receipts  (nullable) the receipts AMT's count;  block_ids: ascending ids, truncated to cap_blocks
+ * The ranges are cut on the root's count, which `Amtv0::load` checks against nothing (a root that says 572 over 700
+ * receipts answers get(650)): whatever the tree holds beyond the count is the LAST shard's, as a claim beyond it is
+ * (ipcfp_route_event_claims) — its plan and ipcfp_witness_create_shard_pull's pull run to the end of the tree, and its
+ * witness is to be tagged [*receipt_lo, UINT64_MAX) (the pull does so itself).                                    */
 int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t* parent_cids40, uint32_t n_parents,
                             const uint8_t* child_cid40, uint32_t n_shards, uint32_t shard, ipcfp_status_t* status_out,
                             uint64_t* receipt_lo, uint64_t* receipt_hi, uint64_t* n_receipts, uint32_t* block_ids,
@@ -791,7 +795,8 @@ int ipcfp_witness_cut_host(const uint8_t* bytes, uint64_t nbytes, const uint64_t
 /* A new witness made of blocks block_ids[0..n) of `src` (device-side copy; block i of the new witness is block
  * block_ids[i] of src), tagged as the receipt-range shard [receipt_lo, receipt_hi): ipcfp_scan_events walks only
  * those receipts (receipt_has_match[i - receipt_lo] is receipt i) and ipcfp_verify_event_* resolves them by table.
- * Pass (0, UINT64_MAX) for an untagged subset (e.g. a block-range shard of a CID batch).                        */
+ * Pass (0, UINT64_MAX) for an untagged subset (e.g. a block-range shard of a CID batch), and UINT64_MAX as the LAST
+ * receipt-range shard's receipt_hi (see ipcfp_shard_plan_tipset).                                               */
 int ipcfp_witness_create_subset(ipcfp_ctx_t* ctx, ipcfp_witness_t* src, const uint32_t* block_ids, uint64_t n,
                                 uint64_t receipt_lo, uint64_t receipt_hi, ipcfp_witness_t** out);
 /* Tag / read the receipt range of a witness created by other means (drops its cached enumerations).             */

@@ -108,7 +108,8 @@ void ipcfp_shard_range(uint64_t n, uint32_t n_shards, uint32_t shard, uint64_t* 
 // headers, TxMeta, message AMTs (the execution order is global), then `Amtv0::load` of the receipts root for its count.
 // *status_out != TRUE: the traversal failed there and nothing else is valid.
 static int plan_replicated(ipcfp_ctx* ctx, const WitnessView& rec, const uint8_t* parent_cids40, uint32_t n_parents,
-                           const uint8_t* child_cid40, TipsetCtxDev& tc, uint64_t& count, ipcfp_status_t* status_out) {
+                           const uint8_t* child_cid40, TipsetCtxDev& tc, uint64_t& count, ipcfp_status_t* status_out,
+                           uint64_t* capacity = nullptr) {
     WideParents wide;  // (a tipset key wider than the inline form: alive until every kernel below has run)
     if (int rc_t = tipset_inputs_list(ctx, TC_PARENTS_PARSED | TC_CHILD_PARSED, parent_cids40, n_parents, child_cid40, tc, wide)) return rc_t;
     DevBuf<TipsetCtxDev> tc_d;
@@ -142,6 +143,10 @@ static int plan_replicated(ipcfp_ctx* ctx, const WitnessView& rec, const uint8_t
         return IPCFP_OK;
     }
     count = info[2];
+    if (capacity) {  // indices the tree can hold: 2^(bit width × (height + 1)), what `get` accepts whatever the count says
+        const uint64_t bits = info[3] * (info[1] + 1);
+        *capacity = bits >= 63 ? ~0ULL : (1ULL << bits);
+    }
     // the tipset pair itself
     std::vector<CidKey> base;
     tipset_parent_keys(tc, wide, base);
@@ -178,14 +183,22 @@ int ipcfp_shard_plan_tipset(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint8_t*
     IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, size_t(words + 1) * 4, ctx->stream));
     const WitnessView rec = witness_view(w, touched.p);
     TipsetCtxDev tc;
-    uint64_t count = 0;
-    int rc = plan_replicated(ctx, rec, parent_cids40, n_parents, child_cid40, tc, count, status_out);
+    uint64_t count = 0, capacity = 0;
+    int rc = plan_replicated(ctx, rec, parent_cids40, n_parents, child_cid40, tc, count, status_out, &capacity);
     if (rc || *status_out != IPCFP_ST_TRUE) return rc;
     *status_out = IPCFP_ST_ERR;
     uint64_t lo, hi;
     ipcfp_shard_range(count, n_shards, shard, &lo, &hi);
-    if (hi - lo >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "shard too large");
-    rc = launch_plan_receipts(ctx, rec, tc.receipts_root, lo, uint32_t(hi - lo));
+    // The LAST shard owns every index from its lo on — the root's count is checked by neither Amt::load nor get, and a claim
+    // beyond it is the last rank's (ipcfp_route_event_claims) — so its plan covers what the tree CAN hold, not what the
+    // count says (an index that is not there costs its lane the walk down to the first missing bitmap bit).
+    uint64_t hi_plan = hi;
+    if (shard + 1u == n_shards && capacity > hi) hi_plan = capacity;
+    if (hi_plan - lo >= 0xffffffffULL) {
+        if (hi - lo >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "shard too large");
+        hi_plan = lo + 0xfffffffeULL;
+    }
+    rc = launch_plan_receipts(ctx, rec, tc.receipts_root, lo, uint32_t(hi_plan - lo));
     if (rc) return rc;
     std::vector<uint32_t> bits(words + 1);
     IPCFP_HIP(ctx, hipMemcpyAsync(bits.data(), touched.p, size_t(words + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -227,16 +240,17 @@ int ipcfp_shard_plan_tipset_all(ipcfp_ctx_t* ctx, ipcfp_witness_t* w, const uint
     IPCFP_HIP(ctx, hipMemsetAsync(touched.p, 0, (size_t(words) * (n_shards + 1) + 1) * 4, ctx->stream));
     uint32_t* common_d = touched.p + size_t(words) * n_shards;
     TipsetCtxDev tc;
-    uint64_t count = 0;
-    int rc = plan_replicated(ctx, witness_view(w, common_d), parent_cids40, n_parents, child_cid40, tc, count, status_out);
+    uint64_t count = 0, capacity = 0;
+    int rc = plan_replicated(ctx, witness_view(w, common_d), parent_cids40, n_parents, child_cid40, tc, count, status_out, &capacity);
     if (rc || *status_out != IPCFP_ST_TRUE) return rc;
     *status_out = IPCFP_ST_ERR;
     if (count >= 0xffffffffULL) return set_error(ctx, IPCFP_E_UNSUPPORTED, "more than 2^32-2 receipts");
+    const uint64_t n_plan = capacity > count ? (capacity < 0xfffffffeULL ? capacity : 0xfffffffeULL) : count;  // (the last shard: to the tree's capacity)
     for (uint32_t s = 0; s < n_shards; ++s) ipcfp_shard_range(count, n_shards, s, &receipt_bounds[s], &receipt_bounds[s + 1]);
     DevBuf<uint64_t> bounds_d;
     IPCFP_HIP(ctx, bounds_d.alloc(n_shards + 1));
     IPCFP_HIP(ctx, hipMemcpyAsync(bounds_d.p, receipt_bounds, size_t(n_shards + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_plan_receipts_all(ctx, witness_view(w, touched.p), tc.receipts_root, uint32_t(count), bounds_d.p, n_shards, words);
+    rc = launch_plan_receipts_all(ctx, witness_view(w, touched.p), tc.receipts_root, uint32_t(n_plan), bounds_d.p, n_shards, words);
     if (rc) return rc;
     std::vector<uint32_t> bits(size_t(words) * (n_shards + 1));
     if (!bits.empty())

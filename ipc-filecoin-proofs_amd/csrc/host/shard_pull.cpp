@@ -266,7 +266,7 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
     w->n = np;
     w->nbytes = h.stage_used;  // (an upper bound: the lengths are not summed on the host)
     w->receipt_lo = h.lo;
-    w->receipt_hi = h.hi;
+    w->receipt_hi = shard + 1u == n_shards ? ~0ULL : h.hi;  // (the last shard enumerates what it holds: PullCtl::hi_walk)
     DevBuf<uint32_t> plen, bad;
     DevBuf<uint64_t> poff;
     DevBuf<uint8_t> pcids;

@@ -46,6 +46,12 @@ struct PullCtl {
     unsigned long long payload;  // bytes of the claimed blocks themselves (Σ len)
     unsigned long long lo, hi, n_receipts;
     uint32_t have_range;  // the receipts root was found and decoded: lo / hi / n_receipts are set
+    uint32_t pad;
+    // what the walk takes: hi, or — the LAST shard — everything from lo on.  The root's count is checked by neither
+    // `Amt::load` nor `get` (a root that says 572 over 700 receipts answers get(650)), and a claim beyond the count has an
+    // owner, the last rank: so the last rank holds whatever the tree has behind its lo, not what the count promises
+    // (tools/gpu_fuzz_seeds.sh seed 1010: one flipped bit of the count).
+    unsigned long long hi_walk;
 };
 
 struct PullSeeds {

@@ -295,11 +295,13 @@ __device__ __forceinline__ void pull_expand_item(const WitnessView& w, const Pul
             ctl->hi = hi;
             ctl->n_receipts = count;
             ctl->have_range = 1u;
-            expand_receipts_node(w, r, next, ctl, uint32_t(ht), 0, lo, hi);
+            const uint64_t hi_walk = shard + 1u == n_shards ? ~0ull : hi;
+            ctl->hi_walk = hi_walk;
+            expand_receipts_node(w, r, next, ctl, uint32_t(ht), 0, lo, hi_walk);
             return;
         }
         case PK_RCPT_NODE:
-            expand_receipts_node(w, r, next, ctl, height, it.base, ctl->lo, ctl->hi);
+            expand_receipts_node(w, r, next, ctl, height, it.base, ctl->lo, ctl->hi_walk);
             return;
         case PK_EV_ROOT: {  // Amt (v3) root [bit_width, height, count, node]: taller than a leaf ⇒ every node below it
             r.expect_array(4);

@@ -172,7 +172,9 @@ class TipsetShard:
         self.lo, self.hi = plan.range(shard)
         self.n_receipts_total, self.block_ids = plan.n_receipts, plan.block_ids[shard]
         self.witness = witness if witness is not None else eng.witness(*sub)
-        self.witness.set_receipt_range(self.lo, self.hi)
+        # (the last shard enumerates whatever the tree holds from its lo on: the root's count is not checked by Amt::load, and
+        # a claim beyond it is the last rank's)
+        self.witness.set_receipt_range(self.lo, self.hi if self.shard + 1 < self.n_shards else (1 << 64) - 1)
         self.receipts_root = bytes(receipts_root)
         self.parent_cids, self.child_cid = plan.parent_cids, plan.child_cid
         return self

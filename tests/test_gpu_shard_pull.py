@@ -49,7 +49,7 @@ def test_pulled_shard_holds_exactly_the_planned_blocks(engine, tip, bundle, G):
         for r in range(G):
             st, lo, hi, n_receipts, ids = full.shard_plan_tipset(tip.parent_cids, tip.child_cid, G, r)
             pst, w, plo, phi, pn, stats = engine.witness_shard_pull(bundle, tip.parent_cids, tip.child_cid, G, r)
-            assert st == pst == 1 and (lo, hi, n_receipts) == (plo, phi, pn) and w.receipt_range == (lo, hi)
+            assert st == pst == 1 and (lo, hi, n_receipts) == (plo, phi, pn) and w.receipt_range == (lo, hi if r + 1 < G else 2 ** 64 - 1)  # (the last shard: everything from lo on)
             assert w.block_count == len(ids) == stats["blocks"]
             has, _ = w.has([bytes(tip.cids[i]) for i in ids[:: max(1, len(ids) // 4000)]])
             assert has.all()
@@ -329,3 +329,60 @@ def test_claim_range_refuses_a_batch_that_is_out_of_order_in_the_middle(engine, 
         assert a2 == a and np.array_equal(st, st2)
     finally:
         w.close()
+
+
+def test_a_receipts_root_whose_count_lies_the_last_shard_owns_what_lies_beyond_it(engine):
+    """`Amtv0::load` checks the root's count against nothing and `get(i)` answers for any i the height allows, so a witness
+    whose receipts root says 572 over 700 receipts verifies every claim unsharded.  The ranges are cut on the count; whatever
+    lies beyond it is the LAST shard's (as a claim beyond the count is): its pull, its plan and its enumeration run to the
+    end of the tree.  Found by tools/gpu_fuzz_seeds.sh, seed 1010 (one flipped bit of the count)."""
+    tip = Tipset(n_receipts=700, n_parents=3, dup_permille=80, n_planted=9, variety=1, max_events=5, no_events_permille=60, seed=5151)
+    n_rcpt = tip.params["n_receipts"]
+    # the root block: [height, count, node] — find it by its CID
+    cids = [bytes(c) for c in tip.cids]
+    root = bytes(tip.receipts_root)
+    b = [c[: len(root)] for c in cids].index(root)
+    o = int(tip.off[b])
+    head = bytes(tip.data[o: o + 8])
+    assert head[0] == 0x83, head.hex()
+    data = tip.data.copy()
+    if head[2] == 0x19:      # a two-byte count: clear its second-highest bit (n → n - 128 for 700: 572)
+        assert int.from_bytes(head[3:5], "big") == n_rcpt
+        lie = n_rcpt - (1 << (n_rcpt.bit_length() - 3))
+        data[o + 3: o + 5] = np.frombuffer(lie.to_bytes(2, "big"), dtype=np.uint8)
+    else:
+        pytest.skip("the tipset's receipt count is not a two-byte integer")
+    ts, cl, blob, blob_len = ipcfp.pack_event_claims(
+        tip.parent_cids, tip.child_cid, tip.parent_epoch, tip.child_epoch, tip.claim_exec, tip.claim_event,
+        tip.claim_emitter, tip.exec_order[tip.claim_exec.astype(np.int64)], tip.claim_ntopics, tip.claim_topics,
+        tip.claim_datalen, tip.claim_data)
+    with engine.witness(data, tip.off, tip.lens, tip.cids) as w:
+        want = w.verify_event_claims(ts, cl, blob, blob_len)
+        ws, whas, wm, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
+        assert (want[cl["exec_index"] >= lie] == 1).any() and ws == 1
+        for G in (2, 3):
+            plans = [w.shard_plan_tipset(tip.parent_cids, tip.child_cid, G, r) for r in range(G)]
+            pk = ipcfp.PackedWitnessTables(data, tip.off, tip.lens, tip.cids)
+            ipcfp.host_register(pk.data)
+            try:
+                status = np.full(len(cl), 255, dtype=np.uint8)
+                has = np.zeros(n_rcpt, dtype=np.uint8)
+                n_matches = 0
+                for r in range(G):
+                    st, sw, lo, hi, nr, _ = engine.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, G, r)
+                    assert st == 1 and nr == lie and (lo, hi) == ipcfp.shard_range(lie, G, r)
+                    pst, plo, phi, pnr, pids = plans[r]
+                    assert pst == 1 and (plo, phi, pnr) == (lo, hi, nr)
+                    present, _ = sw.has([cids[i] for i in pids])
+                    assert present.all() and sw.block_count == len(pids), (G, r, sw.block_count, len(pids))
+                    pos, c_r, b_r, bl_r = ipcfp.route_event_claims(cl, blob, blob_len, lo, hi, r == G - 1)
+                    status[pos.astype(np.int64)] = sw.verify_event_claims(ts, c_r, b_r, bl_r)
+                    sst, shas, sm, _ = sw.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
+                    assert sst == 1
+                    has[lo: lo + len(shas)] = shas
+                    n_matches += len(sm)
+                    sw.close()
+            finally:
+                ipcfp.host_unregister(pk.data)
+            assert np.array_equal(status, want), (G, np.nonzero(status != want)[0][:6])
+            assert np.array_equal(has[: len(whas)], whas) and n_matches == len(wm), G
