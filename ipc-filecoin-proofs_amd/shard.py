@@ -202,7 +202,7 @@ class TipsetShard:
         if st != 1:
             raise B.EngineError(f"shard plan failed with status {st}")
         self.lo, self.hi, self.n_receipts_total, self.block_ids = lo, hi, n_receipts, ids
-        self.witness = full.subset(ids, lo, hi)
+        self.witness = full.subset(ids, lo, hi if self.shard + 1 < self.n_shards else (1 << 64) - 1)  # (the last shard: from_plan)
         self.receipts_root = bytes(receipts_root)
         self.parent_cids, self.child_cid = parent_cids, child_cid
 

@@ -375,8 +375,14 @@ def test_a_receipts_root_whose_count_lies_the_last_shard_owns_what_lies_beyond_i
                     assert pst == 1 and (plo, phi, pnr) == (lo, hi, nr)
                     present, _ = sw.has([cids[i] for i in pids])
                     assert present.all() and sw.block_count == len(pids), (G, r, sw.block_count, len(pids))
+                    # the planned shard (plan + device-side subset of the resident witness) answers as the pulled one does
+                    ps = shard.TipsetShard(engine, w, tip.parent_cids, tip.child_cid, tip.receipts_root, G, r)
+                    pc_r, pb_r, pbl_r = ps.route(ts, cl, blob, blob_len)
+                    planned_status = ps.witness.verify_event_claims(ts, pc_r, pb_r, pbl_r)
+                    ps.close()
                     pos, c_r, b_r, bl_r = ipcfp.route_event_claims(cl, blob, blob_len, lo, hi, r == G - 1)
                     status[pos.astype(np.int64)] = sw.verify_event_claims(ts, c_r, b_r, bl_r)
+                    assert np.array_equal(planned_status, status[pos.astype(np.int64)]), (G, r)
                     sst, shas, sm, _ = sw.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
                     assert sst == 1
                     has[lo: lo + len(shas)] = shas
