@@ -878,7 +878,7 @@ def shard_projection(args, eng, torch, dev, tip, ts, cl, blob, blob_len, w_full,
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
 
     # the bundle as a rank finds it: transport form in an ingest buffer that was registered when it was made
-    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
+    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids, ingest=True)
     t0 = time.perf_counter()
     ipcfp.host_register(pk.data)
     ipcfp.host_register(pk.digests)
@@ -1139,7 +1139,7 @@ def run_tipset_sharded(args, eng, info, torch, dist, world, rank, dev, ranks):
         tip.claim_datalen, tip.claim_data)
     # SELF-PLANNED: every rank is given the bundle in ITS host memory (transport form, an ingest buffer registered when it
     # was made) and the tipset key — nothing else; it finds and fetches its shard itself (ipcfp_witness_create_shard_pull)
-    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
+    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids, ingest=True)
     ipcfp.host_register(pk.data)
     ipcfp.host_register(pk.digests)
     sh = shard.TipsetShard.from_pull(eng, pk, tip.parent_cids, tip.child_cid, tip.receipts_root, world, rank)

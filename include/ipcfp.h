@@ -779,7 +779,12 @@ int ipcfp_witness_create_shard_pull(ipcfp_ctx_t* ctx, const uint8_t* bytes, uint
                                     uint32_t n_shards, uint32_t shard, ipcfp_status_t* status_out, uint64_t* receipt_lo,
                                     uint64_t* receipt_hi, uint64_t* n_receipts, ipcfp_shard_pull_stats_t* stats,
                                     ipcfp_witness_t** out);
-/* hipHostRegister / hipHostUnregister for hosts that do not link HIP themselves (a Rust caller's ingest buffer). */
+/* hipHostRegister / hipHostUnregister for hosts that do not link HIP themselves (a Rust caller's ingest buffer).
+ * The buffer must OWN its pages: `p` on a page boundary (IPCFP_E_INVALID otherwise) in a mapping of its own (mmap /
+ * posix_memalign of whole pages), never a slice of the heap and never memory that is also handed to the runtime as the
+ * pageable source of a copy.  Registration is by page: a page shared with another user (the runtime's own pin of a
+ * pageable source among them) loses its device mapping for that user when this one is unregistered, and a later,
+ * unrelated copy meets a GPU memory fault (seen in this repository's own suite: DESIGN.md §13).                     */
 int ipcfp_host_register(void* p, uint64_t bytes);
 int ipcfp_host_unregister(void* p);
 

@@ -17,6 +17,7 @@ __all__ = [
     "SCAN_PHASE_EVENTS",
     "merge_scan_status",
     "host_register",
+    "ingest_buffer",
     "host_unregister",
     "Engine",
     "EventProofSpec",
@@ -526,16 +527,36 @@ class ShardPullStats(C.Structure):  # == ipcfp_shard_pull_stats_t
                 ("payload_bytes", C.c_uint64), ("tables_ms", C.c_double), ("pull_ms", C.c_double), ("create_ms", C.c_double)]
 
 
+PAGE = 4096
+
+
+def ingest_buffer(nbytes: int) -> np.ndarray:
+    """A host byte buffer that OWNS its pages (an anonymous mapping: page-aligned, whole pages) — what an ingest buffer
+    handed to `host_register` has to be.  The array keeps the mapping alive."""
+    import mmap
+
+    # (private: a shared anonymous mapping is shmem-backed, which userptr registration may refuse)
+    m = mmap.mmap(-1, max((int(nbytes) + PAGE - 1) // PAGE * PAGE, PAGE), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    return np.frombuffer(m, dtype=np.uint8)[: int(nbytes)]
+
+
 def host_register(arr: np.ndarray):
     """Map a host array for device reads (ipcfp_host_register = hipHostRegister): what ipcfp_witness_create_shard_pull's
-    `bytes` must be.  An ingest buffer is registered once, when it is made."""
+    `bytes` must be.  An ingest buffer is registered once, when it is made — and it must own its pages (`ingest_buffer`,
+    `PackedWitnessTables(..., ingest=True)`): registration is by page, and a page shared with other host memory (a heap
+    allocation, or an array the runtime has also pinned as the pageable source of a copy) loses its device mapping for
+    that other user when this one is unregistered — a GPU memory fault in a later, unrelated copy."""
+    if arr.ctypes.data % PAGE:
+        raise EngineError("host_register: the buffer does not start on a page boundary (use ingest_buffer / PackedWitnessTables(..., ingest=True))")
     rc = load_library().ipcfp_host_register(_p(arr), arr.nbytes)
     if rc:
         raise EngineError(f"host_register: {load_library().ipcfp_strerror(rc).decode()}")
 
 
 def host_unregister(arr: np.ndarray):
-    load_library().ipcfp_host_unregister(_p(arr))
+    rc = load_library().ipcfp_host_unregister(_p(arr))
+    if rc:
+        raise EngineError(f"host_unregister: {load_library().ipcfp_strerror(rc).decode()}")
 
 
 STD_CID_PREFIX = bytes.fromhex("0171a0e40220")  # CIDv1, dag-cbor, blake2b-256, 32-byte digest
@@ -546,7 +567,9 @@ class PackedWitnessTables:
     table), one 32-byte digest per block + the CID prefix they share, and the blocks whose CID has another form as
     (index, 40-byte slot) escapes.  `h2d_bytes` is what crosses PCIe."""
 
-    def __init__(self, data, off, lens, cids40, prefix: bytes = STD_CID_PREFIX):
+    def __init__(self, data, off, lens, cids40, prefix: bytes = STD_CID_PREFIX, ingest: bool = False):
+        """ingest=True: `data` and `digests` are copied into buffers that own their pages (`ingest_buffer`), fit for
+        `host_register` — the form a rank's ingest path would receive a bundle in."""
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         cids40 = np.ascontiguousarray(cids40, dtype=np.uint8).reshape(-1, CID_SLOT)
@@ -569,6 +592,13 @@ class PackedWitnessTables:
             std &= (cids40[:, :pl] == self.prefix[None, :]).all(axis=1)
             std &= (cids40[:, pl + 32:] == 0).all(axis=1)
         self.digests = np.ascontiguousarray(cids40[:, pl: pl + 32])
+        if ingest:
+            own = ingest_buffer(self.data.size)
+            own[:] = self.data
+            self.data = own
+            own = ingest_buffer(self.digests.size).reshape(-1, 32)
+            own[:] = self.digests
+            self.digests = own
         self.esc_index = np.ascontiguousarray(np.nonzero(~std)[0].astype(np.uint32))
         self.esc_cids = np.ascontiguousarray(cids40[~std])
         self.h2d_bytes = int(self.data.size + self.lens.nbytes + self.digests.nbytes + self.esc_index.nbytes + self.esc_cids.nbytes)

@@ -66,7 +66,12 @@ hipError_t DevPool::take(void** out, size_t bytes, size_t* cap) {
 }
 
 void DevPool::give(void* p, size_t cap) {
-    constexpr size_t kMaxCached = size_t(16) << 30;  // 288 GB of HBM: keeping 16 GB of scratch warm is cheap
+    // 288 GB of HBM: keeping 16 GB of scratch warm is cheap.  IPCFP_POOL_CACHE_MB (debugging): 0 gives every buffer back to
+    // the runtime at once, so that a read past a buffer's end meets an unmapped page instead of a neighbour's slack.
+    static const size_t kMaxCached = [] {
+        const char* e = std::getenv("IPCFP_POOL_CACHE_MB");
+        return e ? size_t(std::strtoull(e, nullptr, 10)) << 20 : size_t(16) << 30;
+    }();
     if (cached_bytes + cap > kMaxCached) {
         (void)hipFree(p);
         return;

@@ -30,7 +30,7 @@ CidKey key_from_slot(const uint8_t* slot40);
 extern "C" {
 
 int ipcfp_host_register(void* p, uint64_t bytes) {
-    if (!p || !bytes) return IPCFP_E_INVALID;
+    if (!p || !bytes || (reinterpret_cast<uintptr_t>(p) & 4095u)) return IPCFP_E_INVALID;  // (a buffer that owns its pages: ipcfp.h)
     return hipHostRegister(p, size_t(bytes), hipHostRegisterDefault) == hipSuccess ? IPCFP_OK : IPCFP_E_HIP;
 }
 

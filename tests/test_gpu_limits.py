@@ -298,7 +298,7 @@ def test_wide_tipset_shards_planned_and_pulled(engine, oracle, P):
         tp.claim_emitter, tp.exec_order[tp.claim_exec.astype(np.int64)], tp.claim_ntopics, tp.claim_topics,
         tp.claim_datalen, tp.claim_data)
     cl["emitter"][7] ^= 1
-    pk = ipcfp.PackedWitnessTables(tp.data, tp.off, tp.lens, tp.cids)
+    pk = ipcfp.PackedWitnessTables(tp.data, tp.off, tp.lens, tp.cids, ingest=True)
     ipcfp.host_register(pk.data)
     try:
         with engine.witness(tp.data, tp.off, tp.lens, tp.cids) as full:

@@ -21,7 +21,7 @@ def tip():
 
 @pytest.fixture(scope="module")
 def bundle(tip):
-    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
+    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids, ingest=True)
     ipcfp.host_register(pk.data)   # an ingest buffer is registered once, when it is made
     yield pk
     ipcfp.host_unregister(pk.data)
@@ -157,7 +157,7 @@ def test_claim_slices_over_a_blob_in_another_order(engine, tip, claims_packed):
 def test_pull_of_tall_event_amts(engine):
     """Events AMTs of bit width 1 and height >= 8: every node of every tree of the rank's receipts is a level of its own."""
     tall = Tipset(n_receipts=60, n_planted=6, variety=1, max_events=700, events_bit_width=1, seed=79)
-    pk = ipcfp.PackedWitnessTables(tall.data, tall.off, tall.lens, tall.cids)
+    pk = ipcfp.PackedWitnessTables(tall.data, tall.off, tall.lens, tall.cids, ingest=True)
     ipcfp.host_register(pk.data)
     try:
         with engine.witness(tall.data, tall.off, tall.lens, tall.cids) as full:
@@ -179,7 +179,7 @@ def test_pull_without_a_receipts_root_has_no_range_to_cut_by(engine, tip):
         _, ids = w.has([tip.child_cid])
         keep[int(ids[0])] = False
     sub = ipcfp.witness_cut_host(tip.data, tip.off, tip.lens, tip.cids, np.nonzero(keep)[0].astype(np.uint32))
-    pk = ipcfp.PackedWitnessTables(*sub)
+    pk = ipcfp.PackedWitnessTables(*sub, ingest=True)
     ipcfp.host_register(pk.data)
     try:
         st, w, lo, hi, nr, stats = engine.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, 4, 2)
@@ -229,7 +229,7 @@ def test_receipts_that_share_one_events_root(engine, oracle):
         assert st == 1 and nr == 20_000
     sub = ipcfp.witness_cut_host(data, t.off, t.lens, t.cids, ids)
     assert len(sub[2]) + 1024 < len(at)         # fewer blocks (+ the frontier's slack) than receipts that share the root
-    pk = ipcfp.PackedWitnessTables(*sub)
+    pk = ipcfp.PackedWitnessTables(*sub, ingest=True)
     ipcfp.host_register(pk.data)
     try:
         with engine.witness(*sub) as full:
@@ -283,7 +283,7 @@ def test_a_dag_that_outgrows_the_frontier_is_refused_not_followed(engine, tip):
     data = np.concatenate(chunks)
     # (transport form wants the blocks back to back: cut "all of them" in table order)
     sub = ipcfp.witness_cut_host(data, off, lens, small.cids, np.arange(small.n_blocks, dtype=np.uint32))
-    pk = ipcfp.PackedWitnessTables(*sub)
+    pk = ipcfp.PackedWitnessTables(*sub, ingest=True)
     ipcfp.host_register(pk.data)
     try:
         for G, r in ((1, 0), (2, 1)):
@@ -292,7 +292,7 @@ def test_a_dag_that_outgrows_the_frontier_is_refused_not_followed(engine, tip):
     finally:
         ipcfp.host_unregister(pk.data)
     # the context is unharmed: an honest pull right after
-    pk2 = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids)
+    pk2 = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids, ingest=True)
     ipcfp.host_register(pk2.data)
     try:
         pst, w, lo, hi, nr, stats = engine.witness_shard_pull(pk2, tip.parent_cids, tip.child_cid, 2, 1)
@@ -362,7 +362,7 @@ def test_a_receipts_root_whose_count_lies_the_last_shard_owns_what_lies_beyond_i
         assert (want[cl["exec_index"] >= lie] == 1).any() and ws == 1
         for G in (2, 3):
             plans = [w.shard_plan_tipset(tip.parent_cids, tip.child_cid, G, r) for r in range(G)]
-            pk = ipcfp.PackedWitnessTables(data, tip.off, tip.lens, tip.cids)
+            pk = ipcfp.PackedWitnessTables(data, tip.off, tip.lens, tip.cids, ingest=True)
             ipcfp.host_register(pk.data)
             try:
                 status = np.full(len(cl), 255, dtype=np.uint8)

@@ -38,7 +38,7 @@ def test_pulled_shards_of_corrupted_witnesses_equal_the_unsharded_engine(tip, en
             ws, whas, wm, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
             G = 2 + it % 2
             plans = [w.shard_plan_tipset(tip.parent_cids, tip.child_cid, G, r) for r in range(G)]
-        pk = ipcfp.PackedWitnessTables(data, tip.off, tip.lens, tip.cids)
+        pk = ipcfp.PackedWitnessTables(data, tip.off, tip.lens, tip.cids, ingest=True)
         ipcfp.host_register(pk.data)
         try:
             status = np.full(len(cl), 255, dtype=np.uint8)
@@ -114,7 +114,7 @@ def test_a_receipts_error_in_a_high_shard_precedes_an_events_error_in_a_low_one(
     with engine.witness(data, tip.off, tip.lens, tip.cids) as w:
         ws, _, _, _ = w.scan_events(tip.receipts_root, tip.topic0, tip.topic1, actor=tip.filter_actor, want_touched=False)
         assert ws == 66 and w.last_scan_phase() == ipcfp.SCAN_PHASE_RECEIPTS
-    pk = ipcfp.PackedWitnessTables(data, tip.off, tip.lens, tip.cids)
+    pk = ipcfp.PackedWitnessTables(data, tip.off, tip.lens, tip.cids, ingest=True)
     ipcfp.host_register(pk.data)
     try:
         scans = []
