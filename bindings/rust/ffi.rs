@@ -163,7 +163,30 @@ pub fn trust_pod(p: &TrustPolicy) -> ipcfp_trust_policy_t {
 /// `ipcfp_witness_create_shard_pull`: blocks back to back, lengths, 32-byte digests + the chain's CID prefix, escapes for
 /// every other CID form.  `register = true` maps `bytes` for device reads (`ipcfp_host_register`; undone on drop): what a
 /// self-planned shard needs — an ingest buffer is registered once, when it is made, not per call.
-pub struct PackedBundle { pub bytes: Vec<u8>, pub len: Vec<u32>, pub digests: Vec<u8>, pub esc_index: Vec<u32>, pub esc_cids: Vec<u8>,
+/// A byte buffer that OWNS its pages (page-aligned, whole pages): what `ipcfp_host_register` takes (include/ipcfp.h — a
+/// slice of the heap shares its first and last page with other allocations, and registration is by page).
+pub struct PageBuf { ptr: *mut u8, len: usize, cap: usize }
+impl PageBuf {
+    const PAGE: usize = 4096;
+    pub fn from_slice(src: &[u8]) -> Self {
+        let cap = std::cmp::max((src.len() + Self::PAGE - 1) / Self::PAGE * Self::PAGE, Self::PAGE);
+        let layout = std::alloc::Layout::from_size_align(cap, Self::PAGE).expect("page layout");
+        let ptr = unsafe { std::alloc::alloc_zeroed(layout) };
+        if ptr.is_null() { std::alloc::handle_alloc_error(layout); }
+        unsafe { std::ptr::copy_nonoverlapping(src.as_ptr(), ptr, src.len()); }
+        Self { ptr, len: src.len(), cap }
+    }
+    pub fn as_ptr(&self) -> *const u8 { self.ptr }
+    pub fn as_mut_ptr(&mut self) -> *mut u8 { self.ptr }
+    pub fn len(&self) -> usize { self.len }
+    pub fn is_empty(&self) -> bool { self.len == 0 }
+    pub fn as_slice(&self) -> &[u8] { unsafe { std::slice::from_raw_parts(self.ptr, self.len) } }
+}
+impl Drop for PageBuf {
+    fn drop(&mut self) { unsafe { std::alloc::dealloc(self.ptr, std::alloc::Layout::from_size_align_unchecked(self.cap, Self::PAGE)); } }
+}
+
+pub struct PackedBundle { pub bytes: PageBuf, pub len: Vec<u32>, pub digests: Vec<u8>, pub esc_index: Vec<u32>, pub esc_cids: Vec<u8>,
                           registered: bool }
 impl PackedBundle {
     pub const STD: [u8; 6] = [0x01, 0x71, 0xa0, 0xe4, 0x02, 0x20];  // CIDv1, dag-cbor, blake2b-256, 32-byte digest
@@ -182,7 +205,7 @@ impl PackedBundle {
                 esc_cids.extend_from_slice(&slot);
             }
         }
-        let mut t = Self { bytes, len, digests, esc_index, esc_cids, registered: false };
+        let mut t = Self { bytes: PageBuf::from_slice(&bytes), len, digests, esc_index, esc_cids, registered: false };
         if register && !t.bytes.is_empty() {
             match unsafe { ipcfp_host_register(t.bytes.as_mut_ptr() as *mut std::ffi::c_void, t.bytes.len() as u64) } {
                 0 => t.registered = true,
