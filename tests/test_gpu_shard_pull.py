@@ -192,6 +192,9 @@ def test_pull_refuses_a_buffer_the_device_cannot_read(engine, tip):
     pk = ipcfp.PackedWitnessTables(tip.data.copy(), tip.off, tip.lens, tip.cids)   # pageable, not registered
     with pytest.raises(ipcfp.EngineError, match="device-readable"):
         engine.witness_shard_pull(pk, tip.parent_cids, tip.child_cid, 2, 0)
+    with pytest.raises(ipcfp.EngineError, match="page boundary"):          # an ingest buffer owns its pages (include/ipcfp.h)
+        ipcfp.host_register(pk.data[1:])
+    pk = ipcfp.PackedWitnessTables(tip.data, tip.off, tip.lens, tip.cids, ingest=True)
     pk.lens = pk.lens.copy()
     pk.lens[7] += 1                                                         # tables that do not add up
     ipcfp.host_register(pk.data)
